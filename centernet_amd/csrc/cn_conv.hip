@@ -1,0 +1,565 @@
+// cn_conv.hip -- im2col-free implicit-GEMM convolution and fused deformable
+// convolution (DCNv2) on the gfx950 fp32 matrix cores.
+//
+// One kernel template, three A-operand producers:
+//   A_DENSE : ordinary convolution, NHWC activations.  Replaces the
+//             Conv2d / BatchNorm2d(eval) / ReLU / residual call sites of the
+//             reference backbones (resnet_dcn.py:38-67,155-177; msra_resnet.py;
+//             pose_dla_dcn.py:147-221; large_hourglass.py:17-74) and, through the
+//             output-scatter arguments, ConvTranspose2d(4,2,1) (resnet_dcn.py:228-235).
+//   A_STEM  : first 7x7/2 convolution reading the user's NCHW 3-channel image
+//             directly (resnet_dcn.py:138-139), K packed as (tap, rgb0).
+//   A_DCN   : modulated deformable convolution.  Replaces dcn_v2_cuda_forward
+//             (DCNv2/src/dcn_v2_cuda.c:10-102) + modulated_deformable_im2col_gpu_kernel
+//             (DCNv2/src/cuda/dcn_v2_im2col_cuda.cu:118-180) + dmcn_im2col_bilinear
+//             (:18-47): offsets/mask are read once per (pixel, tap), the four
+//             bilinear corners are fetched as 16-byte channel vectors (NHWC, so a
+//             corner of 32 channels is one 128-byte line), combined, multiplied
+//             by the mask and written straight into the LDS A tile that feeds
+//             the MFMAs.  No column buffer, no per-sample host loop, bias and
+//             the following BatchNorm+ReLU are the epilogue.
+//
+// GEMM view: D[M = B*Ho*Wo pixels][N = Cout] = A[M][K = taps*Cin] * W[K][N].
+// Matrix instruction: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 cycles).
+// LDS tiles are [rows][32 + 4] floats: the +4 pad makes the 16-lane groups of a
+// ds_read_b128 hit 16 distinct 16-byte slots (row*144 B mod 256), i.e. no bank
+// conflicts, and one b128 read feeds four consecutive MFMAs because K is
+// consumed in the order {k, k+4}: lane half h holds k = 4h..4h+3 of each 8-group
+// for both operands (any fixed K permutation is a valid dot-product order).
+#include "cn_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int BK = 32;
+constexpr int LDT = BK + 4;  // LDS row pitch in floats
+
+enum { A_DENSE = 0, A_STEM = 1, A_DCN = 2 };
+
+struct IgemmArgs {
+    const float *x;
+    const float *w;
+    const float *bias;   // added before scale (DCN bias), may be null
+    const float *scale;  // per-Cout, may be null (=1)
+    const float *shift;  // per-Cout, may be null (=0)
+    const float *residual;
+    float *y;
+    const float *om;  // DCN: NHWC offsets(18) + mask(9) per pixel
+    int om_pitch, mask_sigmoid;
+    int B, H, W, Cin;
+    int Ho, Wo, Cout;
+    int KH, KW, stride, pad_h, pad_w, dil;
+    int in_pitch, out_pitch;
+    int OH, OW, oy_mul, oy_add, ox_mul, ox_add;
+    int relu;
+    int M;         // B*Ho*Wo
+    int cin_pad;   // K extent per tap in the packed weight (multiple of 32)
+    int cout_pad;  // rows per tap in the packed weight (multiple of 32)
+    int nchunk;    // cin_pad / 32
+    int KT;        // taps * nchunk
+};
+
+__device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW>
+__global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
+{
+    static_assert(WM * WN == NT / CN_WAVE, "4 waves");
+    constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
+    constexpr int MB = TM / 32, NB = TN / 32;  // 32x32 MFMA blocks per wave
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be 32-aligned");
+    constexpr int PA = BM / 32;  // A rows per thread per chunk
+    constexpr int PB = BN / 32;  // B rows per thread per chunk
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *As = reinterpret_cast<float *>(smem);  // [2][BM][LDT]
+    float *Bs = As + 2 * BM * LDT;                // [2][BN][LDT]
+    int *rowoff = reinterpret_cast<int *>(Bs + 2 * BN * LDT);  // [BM]
+    // DCN sampling parameters per (row, tap): 4 corner pixel indices, 4 weights, mask
+    int *sidx = rowoff + BM;                               // [BM*9*4]
+    float *swt = reinterpret_cast<float *>(sidx + BM * 36);  // [BM*9*4]
+    float *smk = swt + BM * 36;                            // [BM*9]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int lrow = tid >> 3;  // 0..31: row inside a 32-row pass
+    const int q = tid & 7;      // float4 slot inside the 32-float chunk
+    const int HoWo = a.Ho * a.Wo;
+
+    // ---- per-thread A rows: conv-grid coordinates
+    int a_iy0[PA], a_ix0[PA], a_pix[PA];  // a_pix: b*H*W, or -1 if row >= M
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int m = m0 + p * 32 + lrow;
+        if (m < a.M) {
+            const int b = m / HoWo;
+            const int r = m - b * HoWo;
+            const int oy = r / a.Wo;
+            const int ox = r - oy * a.Wo;
+            a_iy0[p] = oy * a.stride - a.pad_h;
+            a_ix0[p] = ox * a.stride - a.pad_w;
+            a_pix[p] = b * a.H * a.W;
+        } else {
+            a_iy0[p] = 0;
+            a_ix0[p] = 0;
+            a_pix[p] = -1;
+        }
+    }
+    // ---- output pixel index of every tile row (epilogue + residual)
+    for (int r = tid; r < BM; r += NT) {
+        const int m = m0 + r;
+        int off = -1;
+        if (m < a.M) {
+            const int b = m / HoWo;
+            const int rr = m - b * HoWo;
+            const int oy = rr / a.Wo;
+            const int ox = rr - oy * a.Wo;
+            off = (b * a.OH + oy * a.oy_mul + a.oy_add) * a.OW + ox * a.ox_mul + a.ox_add;
+        }
+        rowoff[r] = off;
+    }
+    if (AMODE == A_DCN) {
+        // dcn_v2_im2col_cuda.cu:151-176 and :18-47, evaluated once per (pixel, tap)
+        for (int i = tid; i < BM * 9; i += NT) {
+            const int r = i / 9, tap = i - r * 9;
+            const int m = m0 + r;
+            int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
+            if (m < a.M) {
+                const int b = m / HoWo;
+                const int rr = m - b * HoWo;
+                const int oy = rr / a.Wo;
+                const int ox = rr - oy * a.Wo;
+                const float *om = a.om + (size_t)m * a.om_pitch;
+                const float off_h = om[2 * tap];
+                const float off_w = om[2 * tap + 1];
+                mk = om[18 + tap];
+                if (a.mask_sigmoid) mk = sigmoidf_dev(mk);  // dcn_v2.py:67
+                const int ki = tap / 3, kj = tap - ki * 3;
+                const float h_im = (float)(oy - 1 + ki) + off_h;
+                const float w_im = (float)(ox - 1 + kj) + off_w;
+                const int H = a.H, W = a.W;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int h_low = (int)hf, w_low = (int)wf;
+                    const int h_high = h_low + 1, w_high = w_low + 1;
+                    const float lh = h_im - hf, lw = w_im - wf;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const bool hl_ok = h_low >= 0, wl_ok = w_low >= 0;
+                    const bool hh_ok = h_high <= H - 1, wh_ok = w_high <= W - 1;
+                    w1 = (hl_ok && wl_ok) ? hh * hw : 0.f;
+                    w2 = (hl_ok && wh_ok) ? hh * lw : 0.f;
+                    w3 = (hh_ok && wl_ok) ? lh * hw : 0.f;
+                    w4 = (hh_ok && wh_ok) ? lh * lw : 0.f;
+                    const int yl = max(h_low, 0), yh = min(h_high, H - 1);
+                    const int xl = max(w_low, 0), xh = min(w_high, W - 1);
+                    const int base = b * H * W;
+                    i0 = base + yl * W + xl;
+                    i1 = base + yl * W + xh;
+                    i2 = base + yh * W + xl;
+                    i3 = base + yh * W + xh;
+                }
+            }
+            sidx[i * 4 + 0] = i0;
+            sidx[i * 4 + 1] = i1;
+            sidx[i * 4 + 2] = i2;
+            sidx[i * 4 + 3] = i3;
+            swt[i * 4 + 0] = w1;
+            swt[i * 4 + 1] = w2;
+            swt[i * 4 + 2] = w3;
+            swt[i * 4 + 3] = w4;
+            smk[i] = mk;
+        }
+    }
+    __syncthreads();
+
+    cn_f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int NCORN = (AMODE == A_DCN) ? 4 : 1;
+    cn_f32x4 ra[PA][NCORN];
+    cn_f32x4 rb[PB];
+    const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto load_tiles = [&](int kt) {
+        const int tap = kt / a.nchunk;
+        const int c0 = (kt - tap * a.nchunk) * BK;
+        // ---- B: packed weight [tap][cout_pad][cin_pad]
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int n = n0 + p * 32 + lrow;
+            rb[p] = (n < a.cout_pad)
+                        ? *reinterpret_cast<const cn_f32x4 *>(
+                              a.w + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + c0 + 4 * q))
+                        : zero4;
+        }
+        // ---- A
+        if (AMODE == A_DENSE) {
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+            const int c = c0 + 4 * q;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int iy = a_iy0[p] + ky * a.dil;
+                const int ix = a_ix0[p] + kx * a.dil;
+                const bool ok = a_pix[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W &&
+                                c < a.Cin;
+                ra[p][0] = ok ? *reinterpret_cast<const cn_f32x4 *>(
+                                    a.x + ((size_t)(a_pix[p] + iy * a.W + ix) * a.in_pitch + c))
+                              : zero4;
+            }
+        } else if (AMODE == A_STEM) {
+            // chunk = 8 taps x (r,g,b,0); input NCHW with Cin == 3
+            const int tq = kt * 8 + q;
+            const int ky = tq / a.KW, kx = tq - ky * a.KW;
+            const bool tap_ok = tq < a.KH * a.KW;
+            const int HW = a.H * a.W;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int iy = a_iy0[p] + ky * a.dil;
+                const int ix = a_ix0[p] + kx * a.dil;
+                const bool ok = tap_ok && a_pix[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 &&
+                                ix < a.W;
+                cn_f32x4 v = zero4;
+                if (ok) {
+                    const float *px = a.x + (size_t)a_pix[p] * 3 + (size_t)iy * a.W + ix;
+                    v.x = px[0];
+                    v.y = px[HW];
+                    v.z = px[2 * HW];
+                }
+                ra[p][0] = v;
+            }
+        } else {  // A_DCN: four bilinear corners, each a 16-byte channel vector
+            const int c = c0 + 4 * q;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int r = p * 32 + lrow;
+                const int *si = sidx + (r * 9 + tap) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    ra[p][j] = (c < a.Cin) ? *reinterpret_cast<const cn_f32x4 *>(
+                                                 a.x + ((size_t)si[j] * a.in_pitch + c))
+                                           : zero4;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf, int kt) {
+        float *Ad = As + buf * BM * LDT;
+        float *Bd = Bs + buf * BN * LDT;
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<cn_f32x4 *>(Bd + (p * 32 + lrow) * LDT + 4 * q) = rb[p];
+        if (AMODE == A_DCN) {
+            const int tap = kt / a.nchunk;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int r = p * 32 + lrow;
+                const float *wt = swt + (r * 9 + tap) * 4;
+                const float mk = smk[r * 9 + tap];
+                const float w1 = wt[0], w2 = wt[1], w3 = wt[2], w4 = wt[3];
+                cn_f32x4 v;
+                // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (dcn_v2_im2col_cuda.cu:43-45,174)
+                v = ra[p][0] * w1 + ra[p][1] * w2 + ra[p][2] * w3 + ra[p][3] * w4;
+                v = v * mk;
+                *reinterpret_cast<cn_f32x4 *>(Ad + r * LDT + 4 * q) = v;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < PA; ++p)
+                *reinterpret_cast<cn_f32x4 *>(Ad + (p * 32 + lrow) * LDT + 4 * q) = ra[p][0];
+        }
+    };
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    auto compute = [&](int buf) {
+        const float *Ab = As + buf * BM * LDT + (wm * TM + l31) * LDT + 4 * lh;
+        const float *Bb = Bs + buf * BN * LDT + (wn * TN + l31) * LDT + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            cn_f32x4 af[MB], bf[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                af[i] = *reinterpret_cast<const cn_f32x4 *>(Ab + i * 32 * LDT + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                bf[j] = *reinterpret_cast<const cn_f32x4 *>(Bb + j * 32 * LDT + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        if (OUT_NCHW)  // D rows = cout, cols = pixels
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s],
+                                                                             acc[i][j], 0, 0, 0);
+                        else  // D rows = pixels, cols = cout
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s],
+                                                                             acc[i][j], 0, 0, 0);
+                    }
+        }
+    };
+
+    // ---- main loop: LDS double buffer + register prefetch, one barrier / chunk
+    load_tiles(0);
+    store_tiles(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < a.KT; ++kt) {
+        const int buf = kt & 1;
+        const bool more = (kt + 1) < a.KT;
+        if (more) load_tiles(kt + 1);
+        compute(buf);
+        if (more) store_tiles(buf ^ 1, kt + 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: y = relu?((acc + bias) * scale + shift + residual)
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (!OUT_NCHW) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + wn * TN + j * 32 + l31;
+            const bool n_ok = n < a.Cout;
+            const float bs = (a.bias && n_ok) ? a.bias[n] : 0.f;
+            const float sc = (a.scale && n_ok) ? a.scale[n] : 1.f;
+            const float sf = (a.shift && n_ok) ? a.shift[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int off = rowoff[row];
+                    if (off >= 0 && n_ok) {
+                        float v = (acc[i][j][r] + bs) * sc + sf;
+                        const size_t o = (size_t)off * a.out_pitch + n;
+                        if (a.residual) v += a.residual[o];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        a.y[o] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        const int OHW = a.OH * a.OW;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int off = rowoff[wm * TM + i * 32 + l31];  // this lane's pixel
+            const int b = off >= 0 ? off / OHW : 0;
+            const int rem = off - b * OHW;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wn * TN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (off >= 0 && n < a.Cout) {
+                        const float bs = a.bias ? a.bias[n] : 0.f;
+                        const float sc = a.scale ? a.scale[n] : 1.f;
+                        const float sf = a.shift ? a.shift[n] : 0.f;
+                        float v = (acc[i][j][r] + bs) * sc + sf;
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        a.y[((size_t)b * a.Cout + n) * OHW + rem] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int AMODE>
+constexpr size_t igemm_lds_bytes()
+{
+    return (size_t)(2 * BM * LDT + 2 * BN * LDT) * 4 + BM * 4 +
+           (AMODE == A_DCN ? (size_t)BM * (36 * 4 + 36 * 4 + 9 * 4) : 0);
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW>
+int launch_igemm(const IgemmArgs &a, hipStream_t st)
+{
+    constexpr size_t lds = igemm_lds_bytes<BM, BN, AMODE>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, AMODE, OUT_NCHW>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN));
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, AMODE, OUT_NCHW>), grid, dim3(NT), lds, st, a);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+// ---- weight packing: (Cout,Cin,KH,KW) -> [tap][cout_pad][cin_pad], zero padded
+__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout,
+                                   int Cin, int taps, int cout_pad, int cin_pad)
+{
+    const size_t total = (size_t)taps * cout_pad * cin_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cin_pad);
+        const int n = (int)((i / cin_pad) % cout_pad);
+        const int t = (int)(i / ((size_t)cin_pad * cout_pad));
+        float v = 0.f;
+        if (c < Cin && n < Cout) v = w[((size_t)n * Cin + c) * taps + t];
+        wp[i] = v;
+    }
+}
+// stem: (Cout,3,KH,KW) -> [cout_pad][kpad], k = tap*4 + rgb
+__global__ void pack_stem_weight_kernel(const float *__restrict__ w, float *__restrict__ wp,
+                                        int Cout, int taps, int cout_pad, int kpad)
+{
+    const size_t total = (size_t)cout_pad * kpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % kpad);
+        const int n = (int)(i / kpad);
+        const int t = k >> 2, c = k & 3;
+        float v = 0.f;
+        if (n < Cout && t < taps && c < 3) v = w[((size_t)n * 3 + c) * taps + t];
+        wp[i] = v;
+    }
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline bool is_stem(int Cin, int in_layout) { return in_layout == CN_LAYOUT_NCHW && Cin == 3; }
+
+}  // namespace
+
+extern "C" size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW)
+{
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
+    if (Cin == 3)  // stem form: [cout_pad][round_up(taps*4, 32)]
+        return (size_t)round_up(Cout, 32) * round_up(KH * KW * 4, 32);
+    return (size_t)KH * KW * round_up(Cout, 32) * round_up(Cin, 32);
+}
+
+extern "C" int cn_pack_conv_weight_f32(const float *w_oihw, float *w_packed, int Cout, int Cin,
+                                       int KH, int KW, void *stream)
+{
+    if (!w_oihw || !w_packed) return CN_ERR_NULL;
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return CN_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int taps = KH * KW;
+    const int cout_pad = round_up(Cout, 32);
+    if (Cin == 3) {
+        const int kpad = round_up(taps * 4, 32);
+        const size_t total = (size_t)cout_pad * kpad;
+        hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((unsigned)cn_cdiv((int)total, 256)),
+                           dim3(256), 0, st, w_oihw, w_packed, Cout, taps, cout_pad, kpad);
+    } else {
+        const int cin_pad = round_up(Cin, 32);
+        const size_t total = (size_t)taps * cout_pad * cin_pad;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, w_packed,
+                           Cout, Cin, taps, cout_pad, cin_pad);
+    }
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+static int conv_fill_args(const cn_conv_desc *d, IgemmArgs *a)
+{
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 ||
+        d->KW <= 0 || d->stride <= 0 || d->dil <= 0 || d->Ho <= 0 || d->Wo <= 0)
+        return CN_ERR_SHAPE;
+    // shape rule (same as torch / dcn_v2_cuda.c:40-41)
+    const int ho = (d->H + 2 * d->pad_h - (d->dil * (d->KH - 1) + 1)) / d->stride + 1;
+    const int wo = (d->W + 2 * d->pad_w - (d->dil * (d->KW - 1) + 1)) / d->stride + 1;
+    if (d->oy_mul == 1 && d->ox_mul == 1 && (ho != d->Ho || wo != d->Wo)) return CN_ERR_SHAPE;
+    if ((long)d->B * d->H * d->W * (long)(d->in_layout == CN_LAYOUT_NHWC ? d->in_pitch : d->Cin) >=
+        (1L << 31))
+        return CN_ERR_UNSUPPORTED;
+    if ((long)d->B * d->OH * d->OW * (long)(d->out_layout == CN_LAYOUT_NHWC ? d->out_pitch : d->Cout) >=
+        (1L << 31))
+        return CN_ERR_UNSUPPORTED;
+    a->B = d->B; a->H = d->H; a->W = d->W; a->Cin = d->Cin;
+    a->Ho = d->Ho; a->Wo = d->Wo; a->Cout = d->Cout;
+    a->KH = d->KH; a->KW = d->KW; a->stride = d->stride;
+    a->pad_h = d->pad_h; a->pad_w = d->pad_w; a->dil = d->dil;
+    a->in_pitch = d->in_pitch; a->out_pitch = d->out_pitch;
+    a->OH = d->OH; a->OW = d->OW;
+    a->oy_mul = d->oy_mul; a->oy_add = d->oy_add; a->ox_mul = d->ox_mul; a->ox_add = d->ox_add;
+    a->relu = d->relu;
+    a->M = d->B * d->Ho * d->Wo;
+    a->cout_pad = round_up(d->Cout, 32);
+    if (is_stem(d->Cin, d->in_layout)) {
+        a->cin_pad = round_up(d->KH * d->KW * 4, 32);
+        a->nchunk = a->cin_pad / 32;
+        a->KT = a->nchunk;
+    } else {
+        if (d->in_layout != CN_LAYOUT_NHWC) return CN_ERR_UNSUPPORTED;
+        if ((d->Cin & 3) || (d->in_pitch & 3) || d->in_pitch < d->Cin) return CN_ERR_UNSUPPORTED;
+        a->cin_pad = round_up(d->Cin, 32);
+        a->nchunk = a->cin_pad / 32;
+        a->KT = d->KH * d->KW * a->nchunk;
+    }
+    return CN_OK;
+}
+
+extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float *w_packed,
+                             const float *scale, const float *shift, const float *residual,
+                             float *y, void *stream)
+{
+    if (!d || !x || !w_packed || !y) return CN_ERR_NULL;
+    if (!cn_aligned16(x) || !cn_aligned16(w_packed)) return CN_ERR_ALIGN;
+    IgemmArgs a = {};
+    int rc = conv_fill_args(d, &a);
+    if (rc != CN_OK) return rc;
+    a.x = x; a.w = w_packed; a.bias = nullptr; a.scale = scale; a.shift = shift;
+    a.residual = residual; a.y = y; a.om = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const bool stem = is_stem(d->Cin, d->in_layout);
+    if (d->out_layout == CN_LAYOUT_NCHW) {
+        if (residual || stem) return CN_ERR_UNSUPPORTED;
+        if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, true>(a, st);
+        if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, true>(a, st);
+        return launch_igemm<128, 32, 4, 1, A_DENSE, true>(a, st);
+    }
+    if (stem) {
+        if (d->Cout > 64) return CN_ERR_UNSUPPORTED;
+        return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
+    }
+    if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
+    if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
+    return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);
+}
+
+extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_packed,
+                                          const float *bias, const float *offset_mask_nhwc,
+                                          int om_pitch, const float *scale, const float *shift,
+                                          float *output_nhwc, int B, int Cin, int H, int W,
+                                          int Cout, int mask_sigmoid, int relu, void *stream)
+{
+    if (!input_nhwc || !weight_packed || !offset_mask_nhwc || !output_nhwc) return CN_ERR_NULL;
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return CN_ERR_SHAPE;
+    if (om_pitch < 27) return CN_ERR_SHAPE;
+    if ((Cin & 3) != 0) return CN_ERR_UNSUPPORTED;
+    if (!cn_aligned16(input_nhwc) || !cn_aligned16(weight_packed)) return CN_ERR_ALIGN;
+    if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return CN_ERR_UNSUPPORTED;
+    IgemmArgs a = {};
+    a.x = input_nhwc; a.w = weight_packed; a.bias = bias; a.scale = scale; a.shift = shift;
+    a.residual = nullptr; a.y = output_nhwc; a.om = offset_mask_nhwc; a.om_pitch = om_pitch;
+    a.mask_sigmoid = mask_sigmoid;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = H; a.Wo = W; a.Cout = Cout;
+    a.KH = 3; a.KW = 3; a.stride = 1; a.pad_h = 1; a.pad_w = 1; a.dil = 1;
+    a.in_pitch = Cin; a.out_pitch = Cout;
+    a.OH = H; a.OW = W; a.oy_mul = 1; a.oy_add = 0; a.ox_mul = 1; a.ox_add = 0;
+    a.relu = relu;
+    a.M = B * H * W;
+    a.cin_pad = round_up(Cin, 32);
+    a.cout_pad = round_up(Cout, 32);
+    a.nchunk = a.cin_pad / 32;
+    a.KT = 9 * a.nchunk;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout > 64) return launch_igemm<64, 128, 2, 2, A_DCN, false>(a, st);
+    if (Cout > 32) return launch_igemm<64, 64, 2, 2, A_DCN, false>(a, st);
+    return launch_igemm<128, 32, 4, 1, A_DCN, false>(a, st);
+}

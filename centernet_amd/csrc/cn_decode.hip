@@ -1,0 +1,514 @@
+// cn_decode.hip -- heat-map decode for gfx950: sigmoid -> 3x3 peak test ->
+// exact top-K -> gather -> box assembly.
+//
+// Reference behaviour being replaced (paths relative to /root/reference/src/lib):
+//   hm.sigmoid_()                      detectors/ctdet.py:31
+//   _nms                               models/decode.py:9-15
+//   _topk_channel / _topk              models/decode.py:92-119
+//   _transpose_and_gather_feat         models/utils.py:22-26
+//   ctdet_decode                       models/decode.py:464-495
+//
+// Design (HBM-bound: the heat-map is read exactly once):
+//   kernel 1  nms_topk_kernel   one workgroup per (image, class, row band).  The
+//             band (+1 halo row each side) is staged in LDS after the sigmoid,
+//             every thread keeps its peak-tested values in registers, and an
+//             exact wave/LDS radix select over a 64-bit key (score, ~index)
+//             leaves the band's K best peaks, sorted, as candidates.
+//   kernel 2  merge_topk_kernel one workgroup per image: the same radix select
+//             over the C*bands*K candidates (== torch's second topk over C*K,
+//             decode.py:112), then each of the K winners gathers wh/reg straight
+//             from the NCHW maps (no permute().contiguous() copy, utils.py:23)
+//             and writes its box.
+//
+// Order of equal scores (torch.topk leaves it unspecified): score descending,
+// then class ascending, then spatial index ascending -- the key below makes
+// that a strict total order, so the result is deterministic.
+#include "cn_common.h"
+
+namespace {
+
+constexpr int NT = 256;      // threads per workgroup (4 waves)
+constexpr int KMAX = 128;    // largest supported K
+constexpr int HBINS = 2048;  // radix-select histogram bins (11-bit digits)
+
+typedef unsigned long long u64;
+
+// Order-preserving float -> uint32 map (larger float -> larger key).
+__device__ __forceinline__ uint32_t f2key(float v)
+{
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+constexpr uint32_t KEY_ZERO = 0x80000000u;  // f2key(+0.0f)
+
+struct SelShared {
+    uint32_t hist[HBINS];
+    u64 sel[KMAX];
+    uint32_t wsum[NT / CN_WAVE];
+    uint32_t cnt;
+    uint32_t digit, need, bincount;
+    uint32_t pad_[3];
+};
+static_assert(sizeof(SelShared) % 16 == 0, "keep the LDS carve 16-byte aligned");
+
+__device__ __forceinline__ int pass_shift(int p)
+{
+    // 64-bit key split into digits of 11,11,10 | 11,11,10 bits (msb first)
+    return p == 0 ? 53 : p == 1 ? 42 : p == 2 ? 32 : p == 3 ? 21 : p == 4 ? 10 : 0;
+}
+__device__ __forceinline__ uint32_t pass_dmask(int p) { return (p == 2 || p == 5) ? 1023u : 2047u; }
+
+// Exact selection of the `need0` largest 64-bit keys among the elements that
+// `for_each(f)` enumerates (f(key64, is_plain_zero)); keys must be distinct.
+// On return every thread holds (prefix, mask): an element is selected iff
+// (key & mask) >= prefix.  Elements whose score is exactly +0.0 (the ~89 % of a
+// heat-map that the peak test suppressed) are counted per wave instead of one
+// LDS atomic each, otherwise they would serialise on a single histogram bin.
+template <class ForEach>
+__device__ __forceinline__ void radix_select(ForEach &&for_each, uint32_t need0, SelShared &sh,
+                                             u64 &out_prefix, u64 &out_mask)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & (CN_WAVE - 1);
+    const int wave = tid / CN_WAVE;
+    u64 prefix = 0, mask = 0;
+    uint32_t need = need0;
+    const u64 zkey = (u64)KEY_ZERO << 32;
+#pragma unroll 1
+    for (int pass = 0; pass < 6; ++pass) {
+        const int shift = pass_shift(pass);
+        const uint32_t dmask = pass_dmask(pass);
+        for (int i = tid; i < HBINS; i += NT) sh.hist[i] = 0;
+        __syncthreads();
+        uint32_t zc = 0;
+        for_each([&](u64 k, bool plain_zero) {
+            if ((k & mask) == prefix) {
+                if (plain_zero && pass < 3)
+                    ++zc;
+                else
+                    atomicAdd(&sh.hist[(uint32_t)(k >> shift) & dmask], 1u);
+            }
+        });
+        if (pass < 3) {
+            for (int o = CN_WAVE / 2; o > 0; o >>= 1) zc += __shfl_down(zc, o);
+            if (lane == 0 && zc) atomicAdd(&sh.hist[(uint32_t)(zkey >> shift) & dmask], zc);
+        }
+        __syncthreads();
+        // suffix sums over bins: thread t owns bins [8t, 8t+8)
+        uint32_t p = 0;
+#pragma unroll
+        for (int j = 0; j < HBINS / NT; ++j) p += sh.hist[tid * (HBINS / NT) + j];
+        uint32_t s = p;
+#pragma unroll
+        for (int o = 1; o < CN_WAVE; o <<= 1) {
+            const uint32_t t = __shfl_down(s, o);
+            if (lane + o < CN_WAVE) s += t;
+        }
+        if (lane == 0) sh.wsum[wave] = s;
+        __syncthreads();
+        for (int w = wave + 1; w < NT / CN_WAVE; ++w) s += sh.wsum[w];
+        const uint32_t above = s - p;  // elements in strictly higher bins
+        if (above < need && s >= need) {
+            uint32_t run = above;
+            for (int j = HBINS / NT - 1; j >= 0; --j) {
+                const uint32_t h = sh.hist[tid * (HBINS / NT) + j];
+                if (run + h >= need) {
+                    sh.digit = tid * (HBINS / NT) + j;
+                    sh.need = need - run;
+                    sh.bincount = h;
+                    break;
+                }
+                run += h;
+            }
+        }
+        __syncthreads();
+        prefix |= (u64)sh.digit << shift;
+        mask |= (u64)dmask << shift;
+        need = sh.need;
+        if (sh.bincount == need) break;  // the whole bin is taken: done
+    }
+    out_prefix = prefix;
+    out_mask = mask;
+}
+
+// Collect the selected keys into sh.sel[0..KMAX) and sort them descending.
+template <class ForEach>
+__device__ __forceinline__ void collect_and_sort(ForEach &&for_each, u64 prefix, u64 mask,
+                                                 SelShared &sh)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) sh.cnt = 0;
+    for (int i = tid; i < KMAX; i += NT) sh.sel[i] = 0;  // pad keys sort last
+    __syncthreads();
+    for_each([&](u64 k, bool) {
+        if ((k & mask) >= prefix) {
+            const uint32_t pos = atomicAdd(&sh.cnt, 1u);
+            if (pos < (uint32_t)KMAX) sh.sel[pos] = k;
+        }
+    });
+    __syncthreads();
+    // bitonic sort, descending, KMAX elements
+    for (int k = 2; k <= KMAX; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (tid < KMAX) {
+                const int ixj = tid ^ j;
+                if (ixj > tid) {
+                    const u64 a = sh.sel[tid], b = sh.sel[ixj];
+                    const bool desc = ((tid & k) == 0);
+                    if (desc ? (a < b) : (a > b)) {
+                        sh.sel[tid] = b;
+                        sh.sel[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_ref(float x)
+{
+    // 1 / (1 + exp(-x)) in fp32, IEEE division (detectors/ctdet.py:31)
+    return 1.0f / (1.0f + expf(-x));
+}
+
+// ---------------------------------------------------------------------------
+// kernel 1: per (image, class, row-band): sigmoid + 3x3 peak test + top-K
+// grid (nbands, C, B), block NT, dynamic LDS = sizeof(SelShared) + (R+2)*W*4
+// ---------------------------------------------------------------------------
+template <int EPT>
+__global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ heat, int C, int H,
+                                                      int W, int K, int R, int apply_sigmoid,
+                                                      float *__restrict__ cand_score,
+                                                      int32_t *__restrict__ cand_idx)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SelShared &sh = *reinterpret_cast<SelShared *>(smem);
+    float *tile = reinterpret_cast<float *>(smem + sizeof(SelShared));
+
+    const int tid = threadIdx.x;
+    const int band = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int nbands = gridDim.x;
+    const int r0 = band * R;
+    const int rows = min(R, H - r0);  // rows of this band
+    const int n_band = rows * W;
+    const float *plane = heat + ((size_t)b * C + c) * (size_t)H * W;
+    const float NEG_INF = -__builtin_huge_valf();
+
+    // ---- stage rows r0-1 .. r0+rows (rows+2 rows) into LDS, sigmoid applied once
+    const int trows = rows + 2;
+    if ((W & 3) == 0) {
+        const int w4 = W >> 2;
+        const int nq = trows * w4;
+        for (int q = tid; q < nq; q += NT) {
+            const int tr = q / w4;
+            const int c4 = q - tr * w4;
+            const int gy = r0 - 1 + tr;
+            cn_f32x4 v;
+            if (gy >= 0 && gy < H) {
+                v = *reinterpret_cast<const cn_f32x4 *>(plane + (size_t)gy * W + c4 * 4);
+                if (apply_sigmoid) {
+                    v.x = sigmoidf_ref(v.x);
+                    v.y = sigmoidf_ref(v.y);
+                    v.z = sigmoidf_ref(v.z);
+                    v.w = sigmoidf_ref(v.w);
+                }
+            } else {
+                v.x = v.y = v.z = v.w = NEG_INF;
+            }
+            *reinterpret_cast<cn_f32x4 *>(tile + tr * W + c4 * 4) = v;
+        }
+    } else {
+        const int ne = trows * W;
+        for (int q = tid; q < ne; q += NT) {
+            const int tr = q / W;
+            const int x = q - tr * W;
+            const int gy = r0 - 1 + tr;
+            float v = NEG_INF;
+            if (gy >= 0 && gy < H) {
+                v = plane[(size_t)gy * W + x];
+                if (apply_sigmoid) v = sigmoidf_ref(v);
+            }
+            tile[tr * W + x] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3x3 peak test (decode.py:9-15); results stay in registers as keys
+    uint32_t key[EPT];
+    {
+        int y = tid / W, x = tid - (tid / W) * W;
+        const int dy = NT / W, dx = NT - (NT / W) * W;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = i * NT + tid;
+            uint32_t kk = 0;
+            if (e < n_band) {
+                const float *row = tile + (y + 1) * W + x;
+                const float v = row[0];
+                float m = fmaxf(row[-W], row[W]);
+                m = fmaxf(m, v);
+                if (x > 0) {
+                    m = fmaxf(m, row[-1]);
+                    m = fmaxf(m, row[-W - 1]);
+                    m = fmaxf(m, row[W - 1]);
+                }
+                if (x < W - 1) {
+                    m = fmaxf(m, row[1]);
+                    m = fmaxf(m, row[-W + 1]);
+                    m = fmaxf(m, row[W + 1]);
+                }
+                float val = (m == v) ? v : 0.0f;  // heat * keep
+                val += 0.0f;                       // -0.0 -> +0.0
+                kk = f2key(val);
+            }
+            key[i] = kk;
+            x += dx;
+            y += dy;
+            if (x >= W) {
+                x -= W;
+                ++y;
+            }
+        }
+    }
+
+    const uint32_t base = (uint32_t)(r0 * W);
+    auto for_each = [&](auto &&f) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = i * NT + tid;
+            if (e < n_band)
+                f(((u64)key[i] << 32) | (u64)(0xFFFFFFFFu - (base + (uint32_t)e)), key[i] == KEY_ZERO);
+        }
+    };
+
+    const int kb = min(K, n_band);
+    u64 prefix, mask;
+    radix_select(for_each, (uint32_t)kb, sh, prefix, mask);
+    collect_and_sort(for_each, prefix, mask, sh);
+
+    if (tid < K) {
+        const size_t o = ((((size_t)b * C + c) * nbands) + band) * K + tid;
+        if (tid < kb) {
+            const u64 k = sh.sel[tid];
+            cand_score[o] = key2f((uint32_t)(k >> 32));
+            cand_idx[o] = (int32_t)(0xFFFFFFFFu - (uint32_t)k);
+        } else {
+            cand_score[o] = NEG_INF;
+            cand_idx[o] = -1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernel 2: merge candidate lists of one group into its K best, sorted.
+//   CTDET : group = image; N = C*per_class candidates, class = j / per_class;
+//           output = gathered boxes (decode.py:472-493)
+//   !CTDET: group = (image, channel); output = (scores, inds)  (_topk_channel)
+// ---------------------------------------------------------------------------
+template <bool CTDET>
+__global__ __launch_bounds__(NT) void merge_topk_kernel(
+    const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int N,
+    int per_class, int H, int W, int K, int C, const float *__restrict__ wh,
+    const float *__restrict__ reg, int cat_spec_wh, float *__restrict__ dets, int det_dim,
+    int32_t *__restrict__ inds_out, float *__restrict__ out_scores)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SelShared &sh = *reinterpret_cast<SelShared *>(smem);
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x;
+    const int HW = H * W;
+    const float *cs = cand_score + (size_t)g * N;
+    const int32_t *ci = cand_idx + (size_t)g * N;
+
+    auto for_each = [&](auto &&f) {
+        for (int j = tid; j < N; j += NT) {
+            const int32_t idx = ci[j];
+            if (idx < 0) continue;
+            const uint32_t kk = f2key(cs[j] + 0.0f);
+            const uint32_t fid = CTDET ? (uint32_t)((j / per_class) * HW + idx) : (uint32_t)idx;
+            f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - fid), kk == KEY_ZERO);
+        }
+    };
+    u64 prefix, mask;
+    radix_select(for_each, (uint32_t)K, sh, prefix, mask);
+    collect_and_sort(for_each, prefix, mask, sh);
+
+    if (tid < K) {
+        const u64 k = sh.sel[tid];
+        const float score = key2f((uint32_t)(k >> 32));
+        const uint32_t fid = 0xFFFFFFFFu - (uint32_t)k;
+        if (CTDET) {
+            const int cls = (int)(fid / (uint32_t)HW);
+            const int ind = (int)(fid - (uint32_t)cls * (uint32_t)HW);
+            const int yi = ind / W, xi = ind - yi * W;
+            float xs = (float)xi, ys = (float)yi;
+            const int b = g;
+            if (reg) {  // decode.py:472-476
+                xs = xs + reg[((size_t)b * 2 + 0) * HW + ind];
+                ys = ys + reg[((size_t)b * 2 + 1) * HW + ind];
+            } else {  // decode.py:477-479
+                xs = xs + 0.5f;
+                ys = ys + 0.5f;
+            }
+            const int whC = cat_spec_wh ? 2 * C : 2;
+            const int wc = cat_spec_wh ? 2 * cls : 0;  // decode.py:481-486
+            const float w = wh[((size_t)b * whC + wc + 0) * HW + ind];
+            const float h = wh[((size_t)b * whC + wc + 1) * HW + ind];
+            float *d = dets + ((size_t)b * K + tid) * det_dim;
+            d[0] = xs - w / 2;  // decode.py:489-492
+            d[1] = ys - h / 2;
+            d[2] = xs + w / 2;
+            d[3] = ys + h / 2;
+            d[4] = score;
+            d[det_dim - 1] = (float)cls;
+            if (inds_out) inds_out[(size_t)b * K + tid] = ind;
+        } else {
+            out_scores[(size_t)g * K + tid] = score;
+            inds_out[(size_t)g * K + tid] = (int32_t)fid;
+        }
+    }
+}
+
+struct BandPlan {
+    int ept;     // 16 or 64 register-resident elements per thread
+    int R;       // rows per band
+    int nbands;
+    size_t lds;  // dynamic LDS bytes of kernel 1
+};
+
+// Deterministic function of the shapes only (workspace query == launch).
+bool make_band_plan(int B, int C, int H, int W, int K, BandPlan *bp)
+{
+    if (W <= 0 || H <= 0 || W > 4096) return false;
+    const int r64 = (64 * NT) / W;  // rows that fit 64 elements/thread
+    const int r16 = (16 * NT) / W;
+    int ept = 64, R = r64 < H ? r64 : H;
+    if (R < 1) return false;
+    const long blocks64 = (long)B * C * cn_cdiv(H, R);
+    if (blocks64 < 512 && r16 >= 1) {
+        // not enough workgroups to fill 256 CUs with whole planes: use short bands
+        int R16 = r16 < H ? r16 : H;
+        // a band should still be able to supply K candidates if it can
+        while (R16 < H && R16 * W < K) ++R16;
+        if (R16 * W <= 16 * NT) {
+            ept = 16;
+            R = R16;
+        }
+    }
+    bp->ept = ept;
+    bp->R = R;
+    bp->nbands = cn_cdiv(H, R);
+    bp->lds = sizeof(SelShared) + (size_t)(R + 2) * W * sizeof(float);
+    return bp->lds <= 160 * 1024;
+}
+
+int launch_nms_topk(const float *heat, int B, int C, int H, int W, int K, int apply_sigmoid,
+                    const BandPlan &bp, float *cand_score, int32_t *cand_idx, hipStream_t st)
+{
+    dim3 grid(bp.nbands, C, B), block(NT);
+    if (bp.ept == 64) {
+        static bool attr64 = false;
+        if (!attr64) {
+            (void)hipFuncSetAttribute((const void *)nms_topk_kernel<64>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr64 = true;
+        }
+        hipLaunchKernelGGL(nms_topk_kernel<64>, grid, block, bp.lds, st, heat, C, H, W, K, bp.R,
+                           apply_sigmoid, cand_score, cand_idx);
+    } else {
+        static bool attr16 = false;
+        if (!attr16) {
+            (void)hipFuncSetAttribute((const void *)nms_topk_kernel<16>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr16 = true;
+        }
+        hipLaunchKernelGGL(nms_topk_kernel<16>, grid, block, bp.lds, st, heat, C, H, W, K, bp.R,
+                           apply_sigmoid, cand_score, cand_idx);
+    }
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+}  // namespace
+
+extern "C" size_t cn_ctdet_decode_workspace_bytes(int B, int C, int H, int W, int K)
+{
+    BandPlan bp;
+    if (B <= 0 || C <= 0 || K <= 0 || !make_band_plan(B, C, H, W, K, &bp)) return 0;
+    const size_t n = (size_t)B * C * bp.nbands * K;
+    return cn_align_up(n * sizeof(float), 256) + cn_align_up(n * sizeof(int32_t), 256);
+}
+
+static int decode_checks(const void *heat, int B, int C, int H, int W, int K, BandPlan *bp)
+{
+    if (!heat) return CN_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return CN_ERR_SHAPE;
+    if ((long)K > (long)H * W) return CN_ERR_SHAPE;  // torch.topk: k out of range
+    if (K > KMAX) return CN_ERR_UNSUPPORTED;
+    if ((long)C * H * W >= (1L << 31)) return CN_ERR_UNSUPPORTED;
+    if (!make_band_plan(B, C, H, W, K, bp)) return CN_ERR_UNSUPPORTED;
+    if (((W & 3) == 0) && !cn_aligned16(heat)) return CN_ERR_ALIGN;
+    return CN_OK;
+}
+
+extern "C" int cn_ctdet_decode_f32(const float *heat, const float *wh, const float *reg, int B,
+                                   int C, int H, int W, int K, int cat_spec_wh, int apply_sigmoid,
+                                   float *dets, int32_t *inds, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    BandPlan bp;
+    int rc = decode_checks(heat, B, C, H, W, K, &bp);
+    if (rc != CN_OK) return rc;
+    if (!wh || !dets || !workspace) return CN_ERR_NULL;
+    const size_t need = cn_ctdet_decode_workspace_bytes(B, C, H, W, K);
+    if (workspace_bytes < need) return CN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)B * C * bp.nbands * K;
+    float *cand_score = (float *)workspace;
+    int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
+    rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
+    if (rc != CN_OK) return rc;
+    hipLaunchKernelGGL(merge_topk_kernel<true>, dim3(B), dim3(NT), sizeof(SelShared), st,
+                       cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg,
+                       cat_spec_wh, dets, 6, inds, (float *)nullptr);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_nms_topk_channel_f32(const float *heat, int B, int C, int H, int W, int K,
+                                       int apply_sigmoid, float *scores, int32_t *inds,
+                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    BandPlan bp;
+    int rc = decode_checks(heat, B, C, H, W, K, &bp);
+    if (rc != CN_OK) return rc;
+    if (!scores || !inds) return CN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (bp.nbands == 1) {
+        // one band per plane: kernel 1 already emits the final sorted (B,C,K) lists
+        return launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, scores, inds, st);
+    }
+    if (!workspace) return CN_ERR_NULL;
+    const size_t need = cn_ctdet_decode_workspace_bytes(B, C, H, W, K);
+    if (workspace_bytes < need) return CN_ERR_WORKSPACE;
+    const size_t n = (size_t)B * C * bp.nbands * K;
+    float *cand_score = (float *)workspace;
+    int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
+    rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
+    if (rc != CN_OK) return rc;
+    hipLaunchKernelGGL(merge_topk_kernel<false>, dim3(B * C), dim3(NT), sizeof(SelShared), st,
+                       cand_score, cand_idx, bp.nbands * K, bp.nbands * K, H, W, K, C,
+                       (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0, inds,
+                       scores);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+// ---- multi_pose decode: implemented in cn_pose.hip ------------------------------

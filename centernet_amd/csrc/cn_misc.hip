@@ -1,0 +1,241 @@
+// cn_misc.hip -- memory-bound helpers around the hot path: layout conversion at
+// the API edge, max pooling, and the NCHW (reference-layout) entry point of DCNv2.
+#include "cn_common.h"
+
+namespace {
+
+// (B,C,HW) -> (B,HW,pitch): 32x32 tiles through LDS, both sides coalesced.
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, int C,
+                                    int HW, int pitch)
+{
+    __shared__ float t[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float *xb = x + (size_t)b * C * HW;
+    float *yb = y + (size_t)b * HW * pitch;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        t[i][tx] = (c < C && p < HW) ? xb[(size_t)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        if (p < HW && c < pitch) yb[(size_t)p * pitch + c] = t[tx][i];  // c >= C -> zeros
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ x, float *__restrict__ y, int C,
+                                    int HW, int pitch)
+{
+    __shared__ float t[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float *xb = x + (size_t)b * HW * pitch;
+    float *yb = y + (size_t)b * C * HW;
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        t[i][tx] = (p < HW && c < C) ? xb[(size_t)p * pitch + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        if (c < C && p < HW) yb[(size_t)c * HW + p] = t[tx][i];
+    }
+}
+
+// max pooling, NHWC, -inf padding (torch.nn.MaxPool2d semantics), 4 channels/thread
+__global__ void maxpool_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int H,
+                                    int W, int C, int Ho, int Wo, int k, int s, int pad)
+{
+    const int c4n = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float ninf = -__builtin_huge_valf();
+        cn_f32x4 m = {ninf, ninf, ninf, ninf};
+        for (int dy = 0; dy < k; ++dy) {
+            const int iy = oy * s - pad + dy;
+            if (iy < 0 || iy >= H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int ix = ox * s - pad + dx;
+                if (ix < 0 || ix >= W) continue;
+                const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
+                    x + (((size_t)b * H + iy) * W + ix) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x);
+                m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z);
+                m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<cn_f32x4 *>(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4) = m;
+    }
+}
+
+// offset (B,18,HW) + mask (B,9,HW) NCHW -> om (B,HW,32) NHWC
+__global__ void pack_offset_mask_kernel(const float *__restrict__ offset,
+                                        const float *__restrict__ mask, float *__restrict__ om,
+                                        int HW, size_t total)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i & 31);
+        const size_t bp = i >> 5;
+        const size_t b = bp / HW, p = bp - b * HW;
+        float v = 0.f;
+        if (ch < 18)
+            v = offset[(b * 18 + ch) * HW + p];
+        else if (ch < 27)
+            v = mask[(b * 9 + (ch - 18)) * HW + p];
+        om[i] = v;
+    }
+}
+
+inline int blocks_for(size_t total, int per_block, int cap)
+{
+    size_t b = (total + per_block - 1) / per_block;
+    return (int)(b > (size_t)cap ? cap : (b ? b : 1));
+}
+
+}  // namespace
+
+extern "C" int cn_version(void) { return 100; }  // 0.1.0
+
+extern "C" const char *cn_arch(void) { return "gfx950"; }
+
+extern "C" const char *cn_status_string(int s)
+{
+    switch (s) {
+    case CN_OK: return "ok";
+    case CN_ERR_SHAPE: return "shape mismatch";
+    case CN_ERR_UNSUPPORTED: return "unsupported configuration";
+    case CN_ERR_WORKSPACE: return "workspace too small";
+    case CN_ERR_LAUNCH: return "kernel launch failed";
+    case CN_ERR_NULL: return "null pointer";
+    case CN_ERR_ALIGN: return "pointer not 16-byte aligned";
+    default: return "unknown status";
+    }
+}
+
+extern "C" int cn_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W,
+                                   int out_pitch, void *stream)
+{
+    if (!x || !y) return CN_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || out_pitch < C) return CN_ERR_SHAPE;
+    const int HW = H * W;
+    dim3 grid(cn_cdiv(HW, 32), cn_cdiv(out_pitch, 32), B);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, HW,
+                       out_pitch);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W,
+                                   int in_pitch, void *stream)
+{
+    if (!x || !y) return CN_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || in_pitch < C) return CN_ERR_SHAPE;
+    const int HW = H * W;
+    dim3 grid(cn_cdiv(HW, 32), cn_cdiv(C, 32), B);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, HW,
+                       in_pitch);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_maxpool_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, int k,
+                                   int s, int pad, void *stream)
+{
+    if (!x || !y) return CN_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || pad < 0) return CN_ERR_SHAPE;
+    if (C & 3) return CN_ERR_UNSUPPORTED;
+    if (!cn_aligned16(x) || !cn_aligned16(y)) return CN_ERR_ALIGN;
+    const int Ho = (H + 2 * pad - k) / s + 1, Wo = (W + 2 * pad - k) / s + 1;
+    if (Ho <= 0 || Wo <= 0) return CN_ERR_SHAPE;
+    const size_t total = (size_t)B * Ho * Wo * (C >> 2);
+    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, B, H, W, C, Ho, Wo, k, s, pad);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C,
+                                        void *stream)
+{
+    return cn_maxpool_nhwc_f32(x, y, B, H, W, C, 3, 2, 1, stream);
+}
+
+// ---- reference-layout (NCHW) DCNv2 entry point --------------------------------
+namespace {
+struct DcnWs {
+    size_t x_off, om_off, w_off, y_off, total;
+};
+DcnWs dcn_ws_plan(int B, int Cin, int H, int W, int Cout, int kh, int kw)
+{
+    DcnWs p;
+    const size_t hw = (size_t)B * H * W;
+    size_t o = 0;
+    p.x_off = o;
+    o += cn_align_up(hw * Cin * 4, 256);
+    p.om_off = o;
+    o += cn_align_up(hw * 32 * 4, 256);
+    p.w_off = o;
+    o += cn_align_up(cn_packed_conv_weight_floats(Cout, Cin, kh, kw) * 4, 256);
+    p.y_off = o;
+    o += cn_align_up(hw * Cout * 4, 256);
+    p.total = o;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t cn_dcn_v2_forward_workspace_bytes(int B, int Cin, int H, int W, int Cout,
+                                                    int kernel_h, int kernel_w, int layout)
+{
+    if (layout != CN_LAYOUT_NCHW) return 0;
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    return dcn_ws_plan(B, Cin, H, W, Cout, kernel_h, kernel_w).total;
+}
+
+extern "C" int cn_dcn_v2_forward_f32(const float *input, const float *weight, const float *bias,
+                                     const float *offset, const float *mask, float *output, int B,
+                                     int Cin, int H, int W, int Cout, int kernel_h, int kernel_w,
+                                     int stride_h, int stride_w, int pad_h, int pad_w,
+                                     int dilation_h, int dilation_w, int deformable_group,
+                                     int apply_mask_sigmoid, void *workspace,
+                                     size_t workspace_bytes, void *stream)
+{
+    if (!input || !weight || !bias || !offset || !mask || !output || !workspace) return CN_ERR_NULL;
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return CN_ERR_SHAPE;
+    if (kernel_h != 3 || kernel_w != 3 || stride_h != 1 || stride_w != 1 || pad_h != 1 ||
+        pad_w != 1 || dilation_h != 1 || dilation_w != 1 || deformable_group != 1)
+        return CN_ERR_UNSUPPORTED;
+    if (Cin == 3 || (Cin & 3)) return CN_ERR_UNSUPPORTED;
+    if (!cn_aligned16(workspace)) return CN_ERR_ALIGN;
+    const DcnWs p = dcn_ws_plan(B, Cin, H, W, Cout, 3, 3);
+    if (workspace_bytes < p.total) return CN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *x_nhwc = (float *)(ws + p.x_off);
+    float *om = (float *)(ws + p.om_off);
+    float *wp = (float *)(ws + p.w_off);
+    float *y_nhwc = (float *)(ws + p.y_off);
+    int rc = cn_nchw_to_nhwc_f32(input, x_nhwc, B, Cin, H, W, Cin, stream);
+    if (rc != CN_OK) return rc;
+    const size_t tot = (size_t)B * H * W * 32;
+    hipLaunchKernelGGL(pack_offset_mask_kernel, dim3(blocks_for(tot, 256, 65535)), dim3(256), 0, st,
+                       offset, mask, om, H * W, tot);
+    CN_CHECK_LAUNCH();
+    rc = cn_pack_conv_weight_f32(weight, wp, Cout, Cin, 3, 3, stream);
+    if (rc != CN_OK) return rc;
+    rc = cn_dcn_v2_forward_nhwc_f32(x_nhwc, wp, bias, om, 32, nullptr, nullptr, y_nhwc, B, Cin, H, W,
+                                    Cout, apply_mask_sigmoid, 0, stream);
+    if (rc != CN_OK) return rc;
+    return cn_nhwc_to_nchw_f32(y_nhwc, output, B, Cout, H, W, Cout, stream);
+}

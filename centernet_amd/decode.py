@@ -1,0 +1,99 @@
+"""Heat-map decode entry points (mirror of src/lib/models/decode.py), backed by the
+fused HIP kernels in csrc/cn_decode.hip / cn_pose.hip.
+
+Same callables, same argument meaning, tensors in / tensor out:
+    ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100)      decode.py:464-495
+    multi_pose_decode(heat, wh, kps, reg, hm_hp, hp_offset, K)      decode.py:497-571
+    _nms / _topk / _topk_channel                                    decode.py:9-15, 92-119
+``heat`` is post-sigmoid as in the reference; pass ``apply_sigmoid=True`` with logits
+to fuse ``hm.sigmoid_()`` (detectors/ctdet.py:31) into the same pass over the heat-map.
+"""
+import torch
+
+from . import native
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = str(device)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), device=device, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _prep(*ts):
+    out = []
+    for t in ts:
+        if t is None:
+            out.append(None)
+            continue
+        if not t.is_cuda:
+            raise native.NativeError("decode needs HIP tensors (got %s); there is no CPU path" % t.device)
+        native.require_f32(t)
+        out.append(t.contiguous())
+    return out
+
+
+def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=False,
+                 return_inds=False):
+    heat, wh, reg = _prep(heat, wh, reg)
+    lib = native.lib()
+    B, C, H, W = heat.shape
+    if K > H * W:
+        raise RuntimeError("selected index k out of range")  # torch.topk's error
+    dets = torch.empty((B, K, 6), device=heat.device, dtype=torch.float32)
+    inds = torch.empty((B, K), device=heat.device, dtype=torch.int32)
+    nbytes = lib.cn_ctdet_decode_workspace_bytes(B, C, H, W, K)
+    ws = _workspace(nbytes, heat.device)
+    rc = lib.cn_ctdet_decode_f32(native.ptr(heat), native.ptr(wh), native.ptr(reg), B, C, H, W, K,
+                                 int(bool(cat_spec_wh)), int(bool(apply_sigmoid)),
+                                 native.ptr(dets), native.ptr(inds), native.ptr(ws), ws.numel(),
+                                 native.stream_ptr())
+    native.check(rc, "cn_ctdet_decode_f32")
+    return (dets, inds.long()) if return_inds else dets
+
+
+def _topk_channel(scores, K=40, apply_sigmoid=False, nms=False):
+    """decode.py:92-101.  With ``nms=True`` the 3x3 peak test is fused in front (the only
+    way the reference ever calls it, decode.py:528-533)."""
+    (scores,) = _prep(scores)
+    lib = native.lib()
+    B, C, H, W = scores.shape
+    if K > H * W:
+        raise RuntimeError("selected index k out of range")
+    if not nms:
+        raise native.NativeError("the HIP kernel fuses _nms with _topk_channel; call with nms=True")
+    s = torch.empty((B, C, K), device=scores.device, dtype=torch.float32)
+    i = torch.empty((B, C, K), device=scores.device, dtype=torch.int32)
+    nbytes = lib.cn_ctdet_decode_workspace_bytes(B, C, H, W, K)
+    ws = _workspace(nbytes, scores.device)
+    rc = lib.cn_nms_topk_channel_f32(native.ptr(scores), B, C, H, W, K, int(bool(apply_sigmoid)),
+                                     native.ptr(s), native.ptr(i), native.ptr(ws), ws.numel(),
+                                     native.stream_ptr())
+    native.check(rc, "cn_nms_topk_channel_f32")
+    i = i.long()
+    ys = (i // W).float()
+    xs = (i % W).float()
+    return s, i, ys, xs
+
+
+def multi_pose_decode(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100,
+                      apply_sigmoid=False):
+    heat, wh, kps, reg, hm_hp, hp_offset = _prep(heat, wh, kps, reg, hm_hp, hp_offset)
+    lib = native.lib()
+    B, C, H, W = heat.shape
+    J = kps.shape[1] // 2
+    if K > H * W:
+        raise RuntimeError("selected index k out of range")
+    dets = torch.empty((B, K, 4 + 1 + 2 * J + 1), device=heat.device, dtype=torch.float32)
+    nbytes = lib.cn_multi_pose_decode_workspace_bytes(B, C, H, W, J, K)
+    ws = _workspace(nbytes, heat.device)
+    rc = lib.cn_multi_pose_decode_f32(native.ptr(heat), native.ptr(wh), native.ptr(kps),
+                                      native.ptr(reg), native.ptr(hm_hp), native.ptr(hp_offset),
+                                      B, C, H, W, J, K, int(bool(apply_sigmoid)), native.ptr(dets),
+                                      native.ptr(ws), ws.numel(), native.stream_ptr())
+    native.check(rc, "cn_multi_pose_decode_f32")
+    return dets

@@ -1,0 +1,321 @@
+"""Network plan: turns a CenterNet module tree into a fixed sequence of HIP launches.
+
+The ``nn.Module`` classes under ``centernet_amd/networks`` only *hold parameters*
+(with the reference's state-dict names, so zoo checkpoints load).  Their forward
+pass is not a chain of torch ops: each network describes itself once to a
+``PlanBuilder`` (conv+BN+ReLU(+residual) -> one implicit-GEMM launch, DCN+BN+ReLU ->
+one fused deformable launch, ...), weights are re-packed for the MFMA kernels, BN
+(eval) is folded to a per-channel fp32 scale/shift epilogue, activations live in
+NHWC, and the resulting launch list is replayed per batch on the current HIP stream
+(optionally captured in a HIP graph).
+
+Reference call sites being replaced: ``self.model(images)[-1]``
+(src/lib/detectors/ctdet.py:30) and everything below it
+(src/lib/models/networks/*.py ``forward``).
+"""
+import ctypes
+
+import torch
+
+from . import native
+from .native import ConvDesc, LAYOUT_NCHW, LAYOUT_NHWC
+
+
+def _out_size(n, k, s, p, d=1):
+    return (n + 2 * p - (d * (k - 1) + 1)) // s + 1
+
+
+class Act:
+    """An activation: NHWC fp32 tensor ``t`` of shape (B,H,W,pitch) using channels
+    [c_off, c_off + C).  For NCHW tensors (network input, head outputs) ``nchw`` is set."""
+    __slots__ = ("t", "B", "H", "W", "C", "pitch", "c_off", "nchw")
+
+    def __init__(self, t, B, H, W, C, pitch=None, c_off=0, nchw=False):
+        self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+        self.pitch = C if pitch is None else pitch
+        self.c_off = c_off
+        self.nchw = nchw
+
+    def ptr(self):
+        return ctypes.c_void_p(self.t.data_ptr() + 4 * self.c_off)
+
+
+def fold_bn(conv_bias, bn, cout, device):
+    """BatchNorm2d(eval) [+ conv bias] -> per-channel (scale, shift), fp32.
+
+    y = (acc + bias - mean) * gamma / sqrt(var + eps) + beta
+      =  acc * scale + shift
+    """
+    if bn is None:
+        if conv_bias is None:
+            return None, None
+        return None, conv_bias.detach().to(device=device, dtype=torch.float32).contiguous()
+    g = bn.weight.detach().float() if bn.weight is not None else torch.ones(cout)
+    b = bn.bias.detach().float() if bn.bias is not None else torch.zeros(cout)
+    mean = bn.running_mean.detach().float()
+    var = bn.running_var.detach().float()
+    scale = g / torch.sqrt(var + bn.eps)
+    shift = b - mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach().float() * scale
+    return (scale.to(device).contiguous(), shift.to(device).contiguous())
+
+
+class PlanBuilder:
+    """Records launches for one (B, H, W) input shape."""
+
+    def __init__(self, device, B, H, W):
+        self.device = device
+        self.B, self.H, self.W = B, H, W
+        self.lib = native.lib()
+        self.ops = []          # list of zero-arg callables
+        self.keep = []         # tensors that must stay alive (weights, descriptors)
+        self.flops = 0         # algorithmic conv/DCN FLOPs per forward (2*MACs)
+        self.input = None
+
+    # ---- helpers -------------------------------------------------------------
+    def _new(self, B, H, W, C, pitch=None):
+        pitch = C if pitch is None else pitch
+        t = torch.empty((B, H, W, pitch), device=self.device, dtype=torch.float32)
+        return Act(t, B, H, W, C, pitch)
+
+    def _pack(self, w_oihw):
+        w = w_oihw.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        co, ci, kh, kw = w.shape
+        n = self.lib.cn_packed_conv_weight_floats(co, ci, kh, kw)
+        wp = torch.empty(n, device=self.device, dtype=torch.float32)
+        native.check(self.lib.cn_pack_conv_weight_f32(native.ptr(w), native.ptr(wp), co, ci, kh, kw,
+                                                      native.stream_ptr()), "cn_pack_conv_weight_f32")
+        torch.cuda.current_stream().synchronize()
+        self.keep.append(wp)
+        return wp
+
+    def set_input(self, C=3):
+        """Network input: user NCHW image batch, bound at run time."""
+        self.input = Act(None, self.B, self.H, self.W, C, nchw=True)
+        return self.input
+
+    # ---- ops -------------------------------------------------------------------
+    def conv(self, x, weight, bias=None, bn=None, relu=False, residual=None, stride=1,
+             padding=0, dilation=1, out_nchw=False, out=None):
+        """conv2d (+bias) (+BN eval) (+residual) (+ReLU) as one implicit-GEMM launch."""
+        co, ci, kh, kw = weight.shape
+        assert ci == x.C, (ci, x.C)
+        Ho = _out_size(x.H, kh, stride, padding, dilation)
+        Wo = _out_size(x.W, kw, stride, padding, dilation)
+        wp = self._pack(weight)
+        scale, shift = fold_bn(bias, bn, co, self.device)
+        self.keep += [scale, shift]
+        if out is None:
+            if out_nchw:
+                t = torch.empty((x.B, co, Ho, Wo), device=self.device, dtype=torch.float32)
+                out = Act(t, x.B, Ho, Wo, co, nchw=True)
+            else:
+                out = self._new(x.B, Ho, Wo, co)
+        d = ConvDesc(B=x.B, H=x.H, W=x.W, Cin=ci, Ho=Ho, Wo=Wo, Cout=co, KH=kh, KW=kw,
+                     stride=stride, pad_h=padding, pad_w=padding, dil=dilation,
+                     in_layout=LAYOUT_NCHW if x.nchw else LAYOUT_NHWC, in_pitch=x.pitch,
+                     out_layout=LAYOUT_NCHW if out.nchw else LAYOUT_NHWC, out_pitch=out.pitch,
+                     OH=Ho, OW=Wo, oy_mul=1, oy_add=0, ox_mul=1, ox_add=0, relu=int(relu))
+        self._emit_conv(d, x, wp, scale, shift, residual, out)
+        self.flops += 2 * x.B * Ho * Wo * co * ci * kh * kw
+        return out
+
+    def _emit_conv(self, d, x, wp, scale, shift, residual, out):
+        lib = self.lib
+        self.keep.append(d)
+        is_input = x is self.input
+        sp, hp = native.ptr(scale), native.ptr(shift)
+        rp = residual.ptr() if residual is not None else None
+        wpp, op = native.ptr(wp), out.ptr()
+        dref = ctypes.byref(d)
+
+        def run():
+            xp = ctypes.c_void_p(self.input.t.data_ptr()) if is_input else x.ptr()
+            rc = lib.cn_conv2d_f32(dref, xp, wpp, sp, hp, rp, op, native.stream_ptr())
+            if rc:
+                native.check(rc, "cn_conv2d_f32")
+        self.ops.append(run)
+
+    def conv_transpose4x4s2(self, x, weight, bn=None, relu=False):
+        """ConvTranspose2d(k=4, s=2, p=1, bias=False) as four parity-class 2x2 convolutions
+        (reference: resnet_dcn.py:228-235, msra_resnet.py deconv layers)."""
+        ci, co, kh, kw = weight.shape
+        assert (kh, kw) == (4, 4) and ci == x.C
+        out = self._new(x.B, 2 * x.H, 2 * x.W, co)
+        scale, shift = fold_bn(None, bn, co, self.device)
+        self.keep += [scale, shift]
+        w = weight.detach().to(device=self.device, dtype=torch.float32)
+        ktab = ((3, 1), (2, 0))  # kernel row used by tap t of output parity p
+        for py in range(2):
+            for px in range(2):
+                sub = torch.empty((co, ci, 2, 2), device=self.device, dtype=torch.float32)
+                for ty in range(2):
+                    for tx in range(2):
+                        sub[:, :, ty, tx] = w[:, :, ktab[py][ty], ktab[px][tx]].t()
+                wp = self._pack(sub)
+                d = ConvDesc(B=x.B, H=x.H, W=x.W, Cin=ci, Ho=x.H, Wo=x.W, Cout=co, KH=2, KW=2,
+                             stride=1, pad_h=1 - py, pad_w=1 - px, dil=1,
+                             in_layout=LAYOUT_NHWC, in_pitch=x.pitch, out_layout=LAYOUT_NHWC,
+                             out_pitch=out.pitch, OH=2 * x.H, OW=2 * x.W, oy_mul=2, oy_add=py,
+                             ox_mul=2, ox_add=px, relu=int(relu))
+                self._emit_conv(d, x, wp, scale, shift, None, out)
+        self.flops += 2 * x.B * (2 * x.H) * (2 * x.W) * co * ci * 4
+        return out
+
+    def maxpool(self, x, k, s, pad):
+        Ho, Wo = _out_size(x.H, k, s, pad), _out_size(x.W, k, s, pad)
+        out = self._new(x.B, Ho, Wo, x.C)
+        lib = self.lib
+        assert x.pitch == x.C and x.c_off == 0
+
+        def run():
+            rc = lib.cn_maxpool_nhwc_f32(x.ptr(), out.ptr(), x.B, x.H, x.W, x.C, k, s, pad,
+                                         native.stream_ptr())
+            if rc:
+                native.check(rc, "cn_maxpool_nhwc_f32")
+        self.ops.append(run)
+        return out
+
+    def dcn(self, x, dcn_mod, bn=None, relu=False):
+        """DCN (DCNv2/dcn_v2.py:44-70) [+ BatchNorm + ReLU]: conv_offset_mask as an
+        implicit-GEMM launch writing 27 channels at pitch 32, then the fused deformable
+        kernel (gather + MFMA contraction + bias/BN/ReLU epilogue)."""
+        assert tuple(dcn_mod.kernel_size) == (3, 3) and dcn_mod.stride == 1 and \
+            dcn_mod.padding == 1 and dcn_mod.dilation == 1 and dcn_mod.deformable_groups == 1, \
+            "only the 3x3/s1/p1/d1/dg1 DCN that CenterNet instantiates is supported"
+        com = dcn_mod.conv_offset_mask
+        om = self._new(x.B, x.H, x.W, 27, pitch=32)
+        self.conv(x, com.weight, bias=com.bias, stride=1, padding=1, out=om)
+        co, ci = dcn_mod.weight.shape[0], dcn_mod.weight.shape[1]
+        wp = self._pack(dcn_mod.weight)
+        bias = dcn_mod.bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        scale, shift = fold_bn(None, bn, co, self.device)
+        self.keep += [bias, scale, shift]
+        out = self._new(x.B, x.H, x.W, co)
+        lib = self.lib
+        assert x.pitch == x.C and x.c_off == 0
+        bp, sp, hp, wpp = native.ptr(bias), native.ptr(scale), native.ptr(shift), native.ptr(wp)
+
+        def run():
+            rc = lib.cn_dcn_v2_forward_nhwc_f32(x.ptr(), wpp, bp, om.ptr(), om.pitch, sp, hp,
+                                                out.ptr(), x.B, ci, x.H, x.W, co, 1, int(relu),
+                                                native.stream_ptr())
+            if rc:
+                native.check(rc, "cn_dcn_v2_forward_nhwc_f32")
+        self.ops.append(run)
+        self.flops += 2 * x.B * x.H * x.W * co * ci * 9
+        return out
+
+    def heads(self, x, head_modules):
+        """Per head: conv3x3(F->head_conv)+ReLU+conv1x1(head_conv->classes)
+        (resnet_dcn.py:155-177).  The 3x3 convolutions of all heads read the same
+        feature map, so they run as ONE launch with concatenated output channels; each
+        1x1 then reads its channel slice and writes the NCHW map the decode consumes."""
+        names = list(head_modules.keys())
+        outs = {}
+        seqs = [head_modules[n] for n in names]
+        if all(isinstance(s, torch.nn.Sequential) for s in seqs):
+            w = torch.cat([s[0].weight.detach() for s in seqs], 0)
+            b = torch.cat([s[0].bias.detach() for s in seqs], 0)
+            k = seqs[0][0].kernel_size[0]
+            mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2)
+            off = 0
+            for n, s in zip(names, seqs):
+                hc = s[0].weight.shape[0]
+                sl = Act(mid.t, mid.B, mid.H, mid.W, hc, pitch=mid.pitch, c_off=off)
+                last = s[-1]
+                outs[n] = self.conv(sl, last.weight, bias=last.bias, stride=1,
+                                    padding=last.kernel_size[0] // 2, out_nchw=True)
+                off += hc
+        else:
+            for n, s in zip(names, seqs):
+                outs[n] = self.conv(x, s.weight, bias=s.bias, stride=1,
+                                    padding=s.kernel_size[0] // 2, out_nchw=True)
+        return outs
+
+
+class Plan:
+    """A compiled forward pass for one input shape."""
+
+    def __init__(self, builder, outputs):
+        self.b = builder
+        self.outputs = outputs  # name -> Act (NCHW)
+        self.graph = None
+        self._static_in = None
+
+    @property
+    def flops(self):
+        return self.b.flops
+
+    def run(self, images):
+        if not images.is_cuda:
+            raise native.NativeError("input batch must be on a HIP device; there is no CPU path")
+        native.require_f32(images)
+        images = images.contiguous()
+        assert tuple(images.shape) == (self.b.B, self.b.input.C, self.b.H, self.b.W), images.shape
+        if self.graph is not None:
+            self._static_in.copy_(images)
+            self.graph.replay()
+        else:
+            self.b.input.t = images
+            for op in self.b.ops:
+                op()
+        return {k: v.t for k, v in self.outputs.items()}
+
+    def capture(self):
+        """Capture the launch list in a HIP graph (launch-bound small batches)."""
+        self._static_in = torch.zeros((self.b.B, self.b.input.C, self.b.H, self.b.W),
+                                      device=self.b.device, dtype=torch.float32)
+        self.b.input.t = self._static_in
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):  # warm-up outside capture (attribute calls, lazy loads)
+                for op in self.b.ops:
+                    op()
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for op in self.b.ops:
+                op()
+        self.graph = g
+        return self
+
+
+class PlannedModule(torch.nn.Module):
+    """Base class of the network modules: ``forward`` replays a cached Plan."""
+
+    def describe(self, pb, x):  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def plan_for(self, B, H, W, device):
+        cache = self.__dict__.setdefault("_plans", {})
+        key = (B, H, W, str(device))
+        if key not in cache:
+            native.lib()  # raises if the HIP library is missing
+            with torch.no_grad():
+                pb = PlanBuilder(device, B, H, W)
+                x = pb.set_input(3)
+                outs = self.describe(pb, x)
+            cache[key] = Plan(pb, outs)
+        return cache[key]
+
+    def invalidate_plans(self):
+        self.__dict__["_plans"] = {}
+
+    def load_state_dict(self, *a, **kw):
+        r = super().load_state_dict(*a, **kw)
+        self.invalidate_plans()
+        return r
+
+    def forward(self, x):
+        if self.training:
+            raise native.NativeError("centernet_amd implements the inference path only; call .eval()")
+        if not x.is_cuda:
+            raise native.NativeError(
+                "centernet_amd runs on MI355X only (input is on %s). There is no CPU path: the "
+                "CPU restatement under oracle/ is test infrastructure." % x.device)
+        B, C, H, W = x.shape
+        plan = self.plan_for(B, H, W, x.device)
+        return [plan.run(x)]

@@ -1,0 +1,125 @@
+"""ctypes binding of libcenternet_amd.so -- the C ABI declared in include/centernet_amd.h.
+
+There is no fallback: if the HIP library has not been built (``python -c
+"import __graft_entry__ as g; g.build()"`` or ``make -C centernet_amd/csrc``) every
+entry point raises.  PyTorch is used only for device memory and streams; tensors
+cross this boundary as raw device pointers.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcenternet_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+CN_OK = 0
+LAYOUT_NCHW = 0
+LAYOUT_NHWC = 1
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``cn_conv_desc`` (include/centernet_amd.h)."""
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad_h", "pad_w",
+        "dil", "in_layout", "in_pitch", "out_layout", "out_pitch", "OH", "OW", "oy_mul",
+        "oy_add", "ox_mul", "ox_add", "relu")]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(args, stdout=out)
+    if not os.path.exists(LIB_PATH):
+        raise NativeError("build did not produce %s" % LIB_PATH)
+    return LIB_PATH
+
+
+def _declare(lib):
+    vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    lib.cn_version.restype = i
+    lib.cn_status_string.restype = ctypes.c_char_p
+    lib.cn_status_string.argtypes = [i]
+    lib.cn_arch.restype = ctypes.c_char_p
+    lib.cn_dcn_v2_forward_workspace_bytes.restype = sz
+    lib.cn_dcn_v2_forward_workspace_bytes.argtypes = [i] * 8
+    lib.cn_dcn_v2_forward_f32.restype = i
+    lib.cn_dcn_v2_forward_f32.argtypes = [vp] * 6 + [i] * 15 + [vp, sz, vp]
+    lib.cn_dcn_v2_forward_nhwc_f32.restype = i
+    lib.cn_dcn_v2_forward_nhwc_f32.argtypes = [vp, vp, vp, vp, i, vp, vp, vp] + [i] * 7 + [vp]
+    lib.cn_packed_conv_weight_floats.restype = sz
+    lib.cn_packed_conv_weight_floats.argtypes = [i] * 4
+    lib.cn_pack_conv_weight_f32.restype = i
+    lib.cn_pack_conv_weight_f32.argtypes = [vp, vp, i, i, i, i, vp]
+    lib.cn_conv2d_f32.restype = i
+    lib.cn_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
+    lib.cn_maxpool3x3s2_nhwc_f32.restype = i
+    lib.cn_maxpool3x3s2_nhwc_f32.argtypes = [vp, vp, i, i, i, i, vp]
+    lib.cn_maxpool_nhwc_f32.restype = i
+    lib.cn_maxpool_nhwc_f32.argtypes = [vp, vp, i, i, i, i, i, i, i, vp]
+    lib.cn_nchw_to_nhwc_f32.restype = i
+    lib.cn_nchw_to_nhwc_f32.argtypes = [vp, vp, i, i, i, i, i, vp]
+    lib.cn_nhwc_to_nchw_f32.restype = i
+    lib.cn_nhwc_to_nchw_f32.argtypes = [vp, vp, i, i, i, i, i, vp]
+    lib.cn_ctdet_decode_workspace_bytes.restype = sz
+    lib.cn_ctdet_decode_workspace_bytes.argtypes = [i] * 5
+    lib.cn_ctdet_decode_f32.restype = i
+    lib.cn_ctdet_decode_f32.argtypes = [vp, vp, vp] + [i] * 7 + [vp, vp, vp, sz, vp]
+    lib.cn_nms_topk_channel_f32.restype = i
+    lib.cn_nms_topk_channel_f32.argtypes = [vp] + [i] * 6 + [vp, vp, vp, sz, vp]
+    lib.cn_multi_pose_decode_workspace_bytes.restype = sz
+    lib.cn_multi_pose_decode_workspace_bytes.argtypes = [i] * 6
+    lib.cn_multi_pose_decode_f32.restype = i
+    lib.cn_multi_pose_decode_f32.argtypes = [vp] * 6 + [i] * 7 + [vp, vp, sz, vp]
+
+
+def lib():
+    """Load the HIP library; raise loudly if it is missing (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "%s is missing: build it with `make -C %s` (hipcc, gfx950). "
+                "centernet_amd has no CPU or PyTorch fallback." % (LIB_PATH, CSRC))
+        l = ctypes.CDLL(LIB_PATH)
+        _declare(l)
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != CN_OK:
+        raise NativeError("%s failed: %s (%d)" % (what, lib().cn_status_string(rc).decode(), rc))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Raw device pointer of a CUDA/HIP fp32/int32 tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NativeError("centernet_amd kernels need tensors on a HIP device (got %s); "
+                          "there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise NativeError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise NativeError("fp32 tensors required, got %s" % t.dtype)

@@ -1,0 +1,116 @@
+"""Deterministic synthetic weights and inputs (no checkpoints or datasets exist offline).
+
+Everything is drawn from ``numpy.random.RandomState`` (a frozen legacy stream), so the
+same seed gives the same bits here, on the GPU box and inside
+``tests/golden/gen_golden.py`` -- independent of torch's initialisers.
+
+Recipe: He-normal conv weights; BatchNorm made non-trivial
+(gamma ~ U(0.5,1.5), beta, running_mean ~ N(0,0.1), running_var ~ U(0.5,1.5));
+``conv_offset_mask`` -- zero in the reference (DCNv2/dcn_v2.py:60-62) -- gets weights so
+that offsets spread over a few pixels and masks vary, otherwise the deformable gather
+would never leave the regular grid; ``hm`` output bias = -2.19 (resnet_dcn.py:165-166).
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def fill_state_dict_(module, seed=317):
+    """Overwrite every parameter / buffer of ``module`` in place; returns the module."""
+    rng = np.random.RandomState(seed)
+    sd = module.state_dict()
+    keys = sorted(sd.keys())  # canonical order: independent of module registration order
+    new = {}
+    for k in keys:
+        v = sd[k]
+        if k.endswith("num_batches_tracked"):
+            continue
+        shape = tuple(v.shape)
+        prefix = k.rsplit(".", 1)[0] if "." in k else ""
+        leaf = k.rsplit(".", 1)[-1]
+        is_bn = (prefix + ".running_mean") in sd if prefix else ("running_mean" in sd)
+        if leaf == "running_mean":
+            a = rng.standard_normal(shape) * 0.1
+        elif leaf == "running_var":
+            a = rng.uniform(0.5, 1.5, size=shape)
+        elif is_bn and leaf == "weight":
+            a = rng.uniform(0.5, 1.5, size=shape)
+        elif is_bn and leaf == "bias":
+            a = rng.standard_normal(shape) * 0.1
+        elif v.dim() == 4:
+            if "conv_offset_mask" in k:
+                fan_in = shape[1] * shape[2] * shape[3]
+                a = rng.standard_normal(shape) * (1.5 / math.sqrt(fan_in))
+            elif ".up_" in k or _is_transposed(module, prefix):
+                # ConvTranspose2d weight is (Cin, Cout/groups, kh, kw)
+                fan_in = max(1, shape[0] * shape[2] * shape[3] // 4) if shape[1] > 1 else 4
+                a = rng.standard_normal(shape) * math.sqrt(2.0 / fan_in)
+            else:
+                fan_in = shape[1] * shape[2] * shape[3]
+                a = rng.standard_normal(shape) * math.sqrt(2.0 / fan_in)
+        elif leaf == "bias":
+            if "conv_offset_mask" in k:
+                a = rng.standard_normal(shape)
+            elif _is_hm_out(k, sd):
+                a = np.full(shape, -2.19)
+            else:
+                a = rng.standard_normal(shape) * 0.1
+        else:
+            a = rng.standard_normal(shape) * 0.1
+        new[k] = torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(shape)
+    with torch.no_grad():
+        for k, t in new.items():
+            sd[k].copy_(t)
+    if hasattr(module, "invalidate_plans"):
+        module.invalidate_plans()
+    return module
+
+
+def _is_transposed(module, prefix):
+    try:
+        m = module.get_submodule(prefix) if prefix else module
+    except Exception:
+        return False
+    return isinstance(m, torch.nn.ConvTranspose2d)
+
+
+def _is_hm_out(key, sd):
+    # last conv of a head whose name contains 'hm' (hm, hm_hp): 'hm.2.bias' or 'hm.bias'
+    parts = key.split(".")
+    if "hm" not in parts[0]:
+        return False
+    if len(parts) == 2:
+        return True
+    if len(parts) == 3 and parts[1].isdigit():
+        nxt = "%s.%d.weight" % (parts[0], int(parts[1]) + 1)
+        later = [k for k in sd if k.startswith(parts[0] + ".") and k.endswith(".weight")
+                 and k.split(".")[1].isdigit() and int(k.split(".")[1]) > int(parts[1])]
+        return nxt not in sd and not later
+    return False
+
+
+def images(B, H=512, W=512, seed=0):
+    """Already-normalised synthetic input batch, (B,3,H,W) fp32, CPU."""
+    rng = np.random.RandomState(seed)
+    return torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32))
+
+
+def heatmap(shape, seed=0):
+    """Post-sigmoid-like scores in (0,1) built with exact arithmetic only: u^2 * v^2.
+    Mostly small values with a sparse upper tail, so the top-K scores are well separated
+    (no float32 ties among them) the way a trained heat-map's peaks are."""
+    rng = np.random.RandomState(seed)
+    u = rng.random_sample(shape).astype(np.float32)
+    v = rng.random_sample(shape).astype(np.float32)
+    return (u * u) * (v * v)
+
+
+def uniform(shape, lo, hi, seed):
+    rng = np.random.RandomState(seed)
+    return (rng.random_sample(shape) * (hi - lo) + lo).astype(np.float32)
+
+
+def normal(shape, std, seed, mean=0.0):
+    rng = np.random.RandomState(seed)
+    return (rng.standard_normal(shape) * std + mean).astype(np.float32)

@@ -1,0 +1,205 @@
+/*
+ * centernet_amd.h -- C ABI of libcenternet_amd.so (gfx950 / MI355X only).
+ *
+ * This is the drop-in boundary for the CenterNet inference hot path
+ * (SURVEY.md section 8b).  Every entry point:
+ *   - takes plain device pointers, sizes and a hipStream_t passed as void*;
+ *   - never allocates, frees or synchronises: the caller owns every buffer,
+ *     including the workspace, and the call is stream-ordered and asynchronous;
+ *   - returns CN_OK (0) or a negative cn_status; nothing longjmps or prints
+ *     (the reference raises THError, DCNv2/src/dcn_v2_cuda.c:33-38, and only
+ *     printf()s launch errors, dcn_v2_im2col_cuda.cu:331-335);
+ *   - is thread-safe per stream (no hidden global scratch, unlike the
+ *     per-Function `ones`/`columns` buffers of DCNv2/dcn_v2_func.py:28).
+ *
+ * All tensors are fp32.  "NCHW" is the reference's layout; "NHWC" is the
+ * native layout of this library (channel vectors contiguous so that the four
+ * bilinear taps of the deformable gather are 128-byte coalesced reads).
+ *
+ * Citations are relative to /root/reference.
+ */
+#ifndef CENTERNET_AMD_H
+#define CENTERNET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cn_status {
+    CN_OK = 0,
+    CN_ERR_SHAPE = -1,     /* shapes / kernel sizes do not match (THError in the reference) */
+    CN_ERR_UNSUPPORTED = -2,
+    CN_ERR_WORKSPACE = -3, /* workspace too small; query with the *_workspace_bytes call */
+    CN_ERR_LAUNCH = -4,    /* hipGetLastError() != hipSuccess after a launch */
+    CN_ERR_NULL = -5,
+    CN_ERR_ALIGN = -6      /* a pointer is not 16-byte aligned */
+} cn_status;
+
+#define CN_LAYOUT_NCHW 0
+#define CN_LAYOUT_NHWC 1
+
+/* Library / ABI version (major*10000 + minor*100 + patch). */
+int cn_version(void);
+/* Human-readable text for a cn_status. */
+const char *cn_status_string(int status);
+/* Architecture the device code was compiled for ("gfx950"). */
+const char *cn_arch(void);
+
+/* ------------------------------------------------------------------------
+ * Deformable convolution v2, forward.
+ *
+ * Replaces: void dcn_v2_cuda_forward(THCudaTensor *input, *weight, *bias,
+ *   *ones, *offset, *mask, *output, *columns, int kernel_h, int kernel_w,
+ *   stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+ *   deformable_group)          -- DCNv2/src/dcn_v2_cuda.h:9-17,
+ *                                 impl DCNv2/src/dcn_v2_cuda.c:10-102,
+ *                                 called from DCNv2/dcn_v2_func.py:29-37.
+ * Differences at the boundary: no `ones`/`columns` scratch (the column buffer
+ * is never materialised; bias is an epilogue), the batch is one launch (no
+ * per-sample host loop, dcn_v2_cuda.c:61), errors are return codes.
+ *
+ *   y[b,o,h,w] = bias[o] + sum_{c,k} W[o,c,k] * m[b,k,h,w] *
+ *                bilinear(x[b,c], h*s-p+i*d+dy[b,k,h,w], w*s-p+j*d+dx[b,k,h,w])
+ * with the reference's sampling-window rule (dcn_v2_im2col_cuda.cu:165) and
+ * per-corner zeroing (:30-41).  offset channel 2k = dy, 2k+1 = dx of tap k.
+ *
+ * layout = CN_LAYOUT_NCHW: input (B,Cin,H,W), offset (B,dg*2*kh*kw,Ho,Wo),
+ *   mask (B,dg*kh*kw,Ho,Wo), output (B,Cout,Ho,Wo) -- exactly the reference.
+ * layout = CN_LAYOUT_NHWC: input (B,H,W,Cin), offset_mask (B,Ho,Wo,om_pitch)
+ *   holding [2*kh*kw offsets | kh*kw mask] per pixel (mask pointer ignored,
+ *   om_pitch >= 3*kh*kw given through cn_dcn_v2_forward_nhwc_f32 below).
+ *
+ * weight is always the reference's (Cout,Cin,kh,kw) tensor here; use
+ * cn_pack_conv_weight_f32 + the *_packed entry points to skip the repack.
+ * Supported: kh=kw=3, stride 1, dilation 1, pad 1, deformable_group 1
+ * (the only configuration CenterNet instantiates: resnet_dcn.py:221-223,
+ * pose_dla_dcn.py:352); anything else returns CN_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------ */
+size_t cn_dcn_v2_forward_workspace_bytes(int B, int Cin, int H, int W, int Cout,
+                                         int kernel_h, int kernel_w, int layout);
+
+int cn_dcn_v2_forward_f32(const float *input, const float *weight, const float *bias,
+                          const float *offset, const float *mask, float *output,
+                          int B, int Cin, int H, int W, int Cout,
+                          int kernel_h, int kernel_w, int stride_h, int stride_w,
+                          int pad_h, int pad_w, int dilation_h, int dilation_w,
+                          int deformable_group, int apply_mask_sigmoid,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Native form used by the network plan: NHWC activations, packed weight
+ * ([tap][Cout_pad][Cin], see cn_pack_conv_weight_f32), offsets and mask logits
+ * interleaved per pixel as produced by the conv_offset_mask convolution
+ * (DCNv2/dcn_v2.py:64-68: channels 0..17 offsets, 18..26 mask logits; the
+ * sigmoid of :67 is applied inside when mask_sigmoid != 0), and a fused
+ * epilogue  y = relu?( (acc + bias) * scale + shift )  that folds the
+ * BatchNorm + ReLU following every DCN in resnet_dcn.py:237-239 /
+ * pose_dla_dcn.py:345-357.  scale/shift may be NULL (identity).
+ */
+int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_packed,
+                               const float *bias, const float *offset_mask_nhwc,
+                               int om_pitch, const float *scale, const float *shift,
+                               float *output_nhwc, int B, int Cin, int H, int W,
+                               int Cout, int mask_sigmoid, int relu, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Dense convolution as an implicit GEMM on fp32 MFMA (no im2col buffer).
+ *
+ * Replaces the torch.nn.Conv2d / BatchNorm2d(eval) / ReLU / residual-add call
+ * sites of the backbones (resnet_dcn.py:38-67,138-142,155-177;
+ * msra_resnet.py; pose_dla_dcn.py:147-221; large_hourglass.py:17-74) and, with
+ * the output-scatter arguments, the four parity classes of
+ * ConvTranspose2d(k=4,s=2,p=1) (resnet_dcn.py:228-235).
+ *
+ *   y = relu?( conv(x, w) * scale + shift + residual? )
+ *
+ * x: NHWC with pixel pitch in_pitch floats (>= Cin; lets a layer read a channel
+ * slice of a wider tensor), or NCHW3 for the stem (in_layout = NCHW, Cin = 3).
+ * w: packed by cn_pack_conv_weight_f32.  y: NHWC (pitch out_pitch) or NCHW.
+ * Output pixel (oy,ox) of the conv grid (Ho,Wo) is written to
+ * (oy*oy_mul+oy_add, ox*ox_mul+ox_add) of a (B,OH,OW) map.
+ * ------------------------------------------------------------------------ */
+typedef struct cn_conv_desc {
+    int B, H, W, Cin;       /* input */
+    int Ho, Wo, Cout;       /* conv output grid */
+    int KH, KW;
+    int stride, pad_h, pad_w, dil;
+    int in_layout, in_pitch; /* pitch in floats per pixel (NHWC) */
+    int out_layout, out_pitch;
+    int OH, OW, oy_mul, oy_add, ox_mul, ox_add;
+    int relu;
+} cn_conv_desc;
+
+/* Number of floats of the packed weight for (Cout,Cin,KH,KW). */
+size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
+/* (Cout,Cin,KH,KW) fp32 device tensor -> packed [KH*KW][Cout_pad32][Cin_pad] */
+int cn_pack_conv_weight_f32(const float *w_oihw, float *w_packed, int Cout, int Cin,
+                            int KH, int KW, void *stream);
+
+int cn_conv2d_f32(const cn_conv_desc *desc, const float *x, const float *w_packed,
+                  const float *scale, const float *shift, const float *residual,
+                  float *y, void *stream);
+
+/* 3x3 / stride-2 / pad-1 max pooling, NHWC (resnet_dcn.py:142). */
+int cn_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C,
+                             void *stream);
+/* generic k x k / stride s max pooling NHWC (pose_dla_dcn.py:200 uses 2x2 s2) */
+int cn_maxpool_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, int k,
+                        int s, int pad, void *stream);
+
+/* Layout conversion at the API edge. */
+int cn_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W,
+                        int out_pitch, void *stream);
+int cn_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W,
+                        int in_pitch, void *stream);
+
+/* ------------------------------------------------------------------------
+ * ctdet decode: sigmoid -> 3x3 peak test -> per-class top-K -> global top-K
+ *               -> wh/reg gather -> box assembly.
+ *
+ * Replaces: ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100)
+ *   (models/decode.py:464-495) together with hm.sigmoid_() of
+ *   detectors/ctdet.py:31 when apply_sigmoid != 0, i.e. _nms (decode.py:9-15),
+ *   _topk (:103-119) and _transpose_and_gather_feat (models/utils.py:22-26).
+ *
+ * heat (B,C,H,W) NCHW: logits when apply_sigmoid, else post-sigmoid scores
+ *   (what the reference function receives).
+ * wh (B,2,H,W) or (B,2C,H,W) if cat_spec_wh; reg (B,2,H,W) or NULL.
+ * dets (B,K,6) = [x1,y1,x2,y2,score,cls] sorted by score descending.
+ * inds (B,K) int32 spatial index of each detection, may be NULL.
+ * Tie order (unspecified by torch.topk): score desc, class asc, index asc.
+ * Requires K <= 128 and K <= H*W (torch.topk raises for K > H*W).
+ * ------------------------------------------------------------------------ */
+size_t cn_ctdet_decode_workspace_bytes(int B, int C, int H, int W, int K);
+
+int cn_ctdet_decode_f32(const float *heat, const float *wh, const float *reg,
+                        int B, int C, int H, int W, int K, int cat_spec_wh,
+                        int apply_sigmoid, float *dets, int32_t *inds,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* _nms + _topk_channel (models/decode.py:9-15, 92-101) as one kernel: per
+ * (b,c) plane the K best peaks; scores (B,C,K) desc, inds (B,C,K) int32. */
+int cn_nms_topk_channel_f32(const float *heat, int B, int C, int H, int W, int K,
+                            int apply_sigmoid, float *scores, int32_t *inds,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------
+ * multi_pose decode.
+ * Replaces: multi_pose_decode(heat, wh, kps, reg, hm_hp, hp_offset, K)
+ *   (models/decode.py:497-571).  dets (B,K,4+1+2J+1).
+ * ------------------------------------------------------------------------ */
+size_t cn_multi_pose_decode_workspace_bytes(int B, int C, int H, int W, int J, int K);
+
+int cn_multi_pose_decode_f32(const float *heat, const float *wh, const float *kps,
+                             const float *reg, const float *hm_hp,
+                             const float *hp_offset, int B, int C, int H, int W,
+                             int J, int K, int apply_sigmoid, float *dets,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CENTERNET_AMD_H */

@@ -1,0 +1,177 @@
+"""ctypes binding of oracle/libcn_oracle.so (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+numpy in, numpy out; every function mirrors one reference callable:
+
+    dcn_v2_forward      <- DCNv2Function.forward   (DCNv2/dcn_v2_func.py:22-38)
+    nms                 <- _nms                    (models/decode.py:9-15)
+    topk / topk_channel <- _topk / _topk_channel   (models/decode.py:92-119)
+    ctdet_decode        <- ctdet_decode            (models/decode.py:464-495)
+    multi_pose_decode   <- multi_pose_decode       (models/decode.py:497-571)
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcn_oracle.so")
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("dcn_v2_oracle.c", "decode_oracle.c")]
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libcn_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_dcn_v2_forward.restype = ctypes.c_int
+        _lib.oracle_dcn_v2_im2col.restype = ctypes.c_int
+        _lib.oracle_topk_channel.restype = ctypes.c_int
+        _lib.oracle_topk.restype = ctypes.c_int
+        _lib.oracle_ctdet_decode.restype = ctypes.c_int
+        _lib.oracle_multi_pose_decode.restype = ctypes.c_int
+        _lib.oracle_nms3x3.restype = None
+        _lib.oracle_transpose_and_gather_feat.restype = None
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _optf(a):
+    if a is None:
+        return None, None
+    return _f(a)
+
+
+def out_hw(H, W, kh, kw, stride, pad, dil):
+    """Output shape rule, DCNv2/src/dcn_v2_cuda.c:40-41."""
+    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    return Ho, Wo
+
+
+def dcn_v2_forward(x, offset, mask, weight, bias, stride=1, pad=1, dil=1, dg=1,
+                   acc_mode=0):
+    x, xp = _f(x)
+    offset, op = _f(offset)
+    mask, mp = _f(mask)
+    weight, wp = _f(weight)
+    bias, bp = _f(bias)
+    B, Cin, H, W = x.shape
+    Cout, Cin_w, kh, kw = weight.shape
+    if Cin_w != Cin:
+        raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (Cin, Cin_w))
+    Ho, Wo = out_hw(H, W, kh, kw, stride, pad, dil)
+    assert offset.shape == (B, dg * 2 * kh * kw, Ho, Wo), offset.shape
+    assert mask.shape == (B, dg * kh * kw, Ho, Wo), mask.shape
+    out = np.empty((B, Cout, Ho, Wo), dtype=np.float32)
+    rc = lib().oracle_dcn_v2_forward(
+        xp, wp, bp, op, mp, out.ctypes.data_as(_f32p),
+        B, Cin, H, W, Cout, kh, kw, stride, stride, pad, pad, dil, dil, dg, acc_mode)
+    if rc != 0:
+        raise RuntimeError("oracle_dcn_v2_forward failed: %d" % rc)
+    return out
+
+
+def dcn_v2_im2col(x, offset, mask, kh=3, kw=3, stride=1, pad=1, dil=1, dg=1):
+    """One sample: x (Cin,H,W) -> columns (Cin*kh*kw, Ho, Wo)."""
+    x, xp = _f(x)
+    offset, op = _f(offset)
+    mask, mp = _f(mask)
+    Cin, H, W = x.shape
+    Ho, Wo = out_hw(H, W, kh, kw, stride, pad, dil)
+    cols = np.empty((Cin * kh * kw, Ho, Wo), dtype=np.float32)
+    rc = lib().oracle_dcn_v2_im2col(xp, op, mp, cols.ctypes.data_as(_f32p), Cin, H, W,
+                                    kh, kw, stride, stride, pad, pad, dil, dil, dg)
+    if rc != 0:
+        raise RuntimeError("oracle_dcn_v2_im2col failed: %d" % rc)
+    return cols
+
+
+def nms(heat):
+    heat, hp = _f(heat)
+    B, C, H, W = heat.shape
+    out = np.empty_like(heat)
+    lib().oracle_nms3x3(hp, out.ctypes.data_as(_f32p), B * C, H, W)
+    return out
+
+
+def topk_channel(scores, K):
+    scores, sp = _f(scores)
+    B, C, H, W = scores.shape
+    s = np.empty((B, C, K), np.float32)
+    i = np.empty((B, C, K), np.int64)
+    y = np.empty((B, C, K), np.float32)
+    x = np.empty((B, C, K), np.float32)
+    rc = lib().oracle_topk_channel(sp, B, C, H, W, K, s.ctypes.data_as(_f32p),
+                                   i.ctypes.data_as(_i64p), y.ctypes.data_as(_f32p),
+                                   x.ctypes.data_as(_f32p))
+    if rc != 0:
+        raise RuntimeError("selected index k out of range")
+    return s, i, y, x
+
+
+def topk(scores, K):
+    scores, sp = _f(scores)
+    B, C, H, W = scores.shape
+    s = np.empty((B, K), np.float32)
+    i = np.empty((B, K), np.int64)
+    c = np.empty((B, K), np.int32)
+    y = np.empty((B, K), np.float32)
+    x = np.empty((B, K), np.float32)
+    rc = lib().oracle_topk(sp, B, C, H, W, K, s.ctypes.data_as(_f32p),
+                           i.ctypes.data_as(_i64p), c.ctypes.data_as(_i32p),
+                           y.ctypes.data_as(_f32p), x.ctypes.data_as(_f32p))
+    if rc != 0:
+        raise RuntimeError("selected index k out of range")
+    return s, i, c, y, x
+
+
+def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100, return_inds=False):
+    """heat is POST-sigmoid, as in the reference (models/decode.py:467)."""
+    heat, hp = _f(heat)
+    wh, wp = _f(wh)
+    reg, rp = _optf(reg)
+    B, C, H, W = heat.shape
+    dets = np.empty((B, K, 6), np.float32)
+    inds = np.empty((B, K), np.int64)
+    rc = lib().oracle_ctdet_decode(hp, wp, rp, B, C, H, W, K, int(bool(cat_spec_wh)),
+                                   dets.ctypes.data_as(_f32p), inds.ctypes.data_as(_i64p))
+    if rc != 0:
+        raise RuntimeError("selected index k out of range")
+    return (dets, inds) if return_inds else dets
+
+
+def multi_pose_decode(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100):
+    heat, hp = _f(heat)
+    wh, wp = _f(wh)
+    kps, kp = _f(kps)
+    reg, rp = _optf(reg)
+    hm_hp, hhp = _optf(hm_hp)
+    hp_offset, hop = _optf(hp_offset)
+    B, C, H, W = heat.shape
+    J = kps.shape[1] // 2
+    dets = np.empty((B, K, 4 + 1 + 2 * J + 1), np.float32)
+    rc = lib().oracle_multi_pose_decode(hp, wp, kp, rp, hhp, hop, B, C, H, W, J, K,
+                                        dets.ctypes.data_as(_f32p))
+    if rc != 0:
+        raise RuntimeError("selected index k out of range")
+    return dets
