@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/s of the CenterNet ctdet hot path (network + decode) on
+512x512 synthetic input, ResNet-18-DCN, batch 32 per GPU, fp32.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = detector.run_batch(images): backbone + DCN + heads + fused sigmoid/decode over
+one device-resident batch.  Images shard over ranks (weak scaling, no collective in the
+loop); rank 0 broadcasts the flat weight buffer once at start-up over RCCL.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+F32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    p.add_argument("--arch", default="resdcn_18")
+    p.add_argument("--res", type=int, default=512)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-images", type=int, default=16)
+    p.add_argument("--per-op", action="store_true", help="print per-launch timings to stderr")
+    return p.parse_args()
+
+
+def cpu_baseline(arch, state_dict, heads, res, n_images):
+    """The CPU restatement of the same path (oracle/: torch-CPU dense ops, i.e. the
+    reference's own arithmetic, + C DCNv2 + C decode) timed on the host cores."""
+    from centernet_amd import synth
+    from oracle import net_oracle, cref
+    cref.lib()
+    cores = min(os.cpu_count() or 1, 64)   # more threads than this slows batch-1 convs down
+    torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    x = synth.images(1, res, res, seed=1)
+    net_oracle.ctdet_process(arch, state_dict, x, heads)  # warm-up
+    t0 = time.time()
+    done = 0
+    while done < n_images and (time.time() - t0) < 20.0:   # bounded sample: <= ~20 s of CPU work
+        net_oracle.ctdet_process(arch, state_dict, synth.images(1, res, res, seed=2 + done), heads)
+        done += 1
+    dt = time.time() - t0
+    return {"value": done / dt, "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "%d images %dx%d batch 1, oracle/net_oracle.ctdet_process (torch-CPU convs "
+                      "+ C DCNv2 + C decode), %.1f s" % (done, res, res, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=dev)
+
+    from centernet_amd import synth
+    from centernet_amd.opts import opts
+    from centernet_amd.detectors import detector_factory
+    from centernet_amd.sharding import broadcast_weights
+
+    opt = opts().init(["ctdet", "--arch", a.arch, "--input_res", str(a.res)])
+    det = detector_factory[opt.task](opt)
+    if rank == 0:
+        synth.fill_state_dict_(det.model, 317)
+    if world > 1:
+        broadcast_weights(det.model, src=0)      # one flat RCCL broadcast, then no collectives
+    det.model.invalidate_plans()
+    B = a.batch
+    images = synth.images(B, a.res, a.res, seed=100 + rank).to(dev)
+
+    for _ in range(max(a.warmup, 1)):
+        dets = det.run_batch(images)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    plan = det.model.plan_for(B, a.res, a.res, dev)
+    ev_all = []
+    e_dec0, e_dec1 = [], []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        evs = []
+        with torch.no_grad():
+            out = plan.run(images, events=evs)
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            from centernet_amd.decode import ctdet_decode
+            dets = ctdet_decode(out["hm"], out["wh"], reg=out["reg"], K=opt.K, apply_sigmoid=True)
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        ev_all.append(evs); e_dec0.append(e0); e_dec1.append(e1)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # ---- per-kernel-class time from the HIP events recorded inside the timed region
+        kinds = {}
+        for evs in ev_all:
+            for i, m in enumerate(plan.b.meta):
+                ms = evs[i].elapsed_time(evs[i + 1])
+                k = kinds.setdefault(m["kind"], {"ms": 0.0, "flops": 0, "bytes": 0, "launches": 0})
+                k["ms"] += ms; k["flops"] += m["flops"]; k["bytes"] += m["bytes"]; k["launches"] += 1
+        if a.per_op:
+            for i, m in enumerate(plan.b.meta):
+                ms = sum(evs[i].elapsed_time(evs[i + 1]) for evs in ev_all) / a.steps
+                kind, act = plan.b.trace[i]
+                print("op %2d %-7s out(B,H,W,C)=(%d,%d,%d,%d) %8.3f ms  %7.2f TF/s  %7.1f GB/s" % (
+                    i, kind, act.B, act.H, act.W, act.C, ms, m["flops"] / ms / 1e9 if ms else 0,
+                    m["bytes"] / ms / 1e6 if ms else 0), file=sys.stderr)
+        dec_ms = sum(s.elapsed_time(e) for s, e in zip(e_dec0, e_dec1))
+        C, Ho = opt.num_classes, a.res // 4
+        dec_bytes = B * (C * Ho * Ho * 4 + 2 * 2 * Ho * Ho * 4 + opt.K * 6 * 4)
+        kinds["decode"] = {"ms": dec_ms, "flops": 0, "bytes": dec_bytes * a.steps,
+                           "launches": 2 * a.steps}
+        dom = max(kinds, key=lambda k: kinds[k]["ms"])
+
+        def mfma_roof(k):
+            s = kinds[k]
+            ach = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
+            return {"kernel": k, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TF, "traffic": None,
+                    "avg_launch_ms": s["ms"] / max(s["launches"], 1), "launches_per_step": s["launches"] // a.steps}
+
+        def hbm_roof(k):
+            s = kinds[k]
+            ach = s["bytes"] / (s["ms"] * 1e-3) / 1e9 if s["ms"] > 0 else 0.0
+            return {"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": s["ms"] / max(s["launches"], 1), "launches_per_step": s["launches"] // a.steps}
+
+        roofline = mfma_roof(dom) if kinds[dom]["flops"] > 0 else hbm_roof(dom)
+        total_imgs = B * a.steps * world
+        res = {
+            "metric": "images/sec whole-node, 512x512 ctdet", "value": total_imgs / dt,
+            "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ctdet %s %dx%d, batch %d per GPU (BASELINE configs[1]), "
+                                   "network + fused sigmoid/peak-NMS/top-K decode, K=%d"
+                                   % (a.arch, a.res, a.res, B, opt.K),
+                       "global_batch": B * world, "parallelism": "image-sharded x%d" % world,
+                       "gflop_per_image": plan.flops / B / 1e9},
+            "roofline": roofline,
+            "roofline_dcn_mfma": mfma_roof("dcn") if "dcn" in kinds else None,
+            "roofline_dcn_hbm": hbm_roof("dcn") if "dcn" in kinds else None,
+            "roofline_decode_hbm": hbm_roof("decode"),
+            "time_share": {k: round(v["ms"] / (dt * 1e3), 4) for k, v in kinds.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            sd = {k: v.detach().cpu() for k, v in det.model.state_dict().items()}
+            res["cpu_baseline"] = cpu_baseline(a.arch, sd, list(opt.heads), a.res, a.cpu_images)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

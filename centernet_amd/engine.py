@@ -69,9 +69,11 @@ class PlanBuilder:
         self.B, self.H, self.W = B, H, W
         self.lib = native.lib()
         self.ops = []          # list of zero-arg callables
+        self.meta = []         # per op: dict(kind, flops, bytes) -- algorithmic work
         self.keep = []         # tensors that must stay alive (weights, descriptors)
         self.flops = 0         # algorithmic conv/DCN FLOPs per forward (2*MACs)
         self.input = None
+        self.trace = []        # (kind, Act) of every op output, in launch order (debugging)
 
     # ---- helpers -------------------------------------------------------------
     def _new(self, B, H, W, C, pitch=None):
@@ -117,11 +119,14 @@ class PlanBuilder:
                      in_layout=LAYOUT_NCHW if x.nchw else LAYOUT_NHWC, in_pitch=x.pitch,
                      out_layout=LAYOUT_NCHW if out.nchw else LAYOUT_NHWC, out_pitch=out.pitch,
                      OH=Ho, OW=Wo, oy_mul=1, oy_add=0, ox_mul=1, ox_add=0, relu=int(relu))
-        self._emit_conv(d, x, wp, scale, shift, residual, out)
-        self.flops += 2 * x.B * Ho * Wo * co * ci * kh * kw
+        fl = 2 * x.B * Ho * Wo * co * ci * kh * kw
+        by = 4 * (x.B * x.H * x.W * ci + x.B * Ho * Wo * co * (2 if residual is not None else 1)
+                  + co * ci * kh * kw)
+        self._emit_conv(d, x, wp, scale, shift, residual, out, dict(kind="conv", flops=fl, bytes=by))
+        self.flops += fl
         return out
 
-    def _emit_conv(self, d, x, wp, scale, shift, residual, out):
+    def _emit_conv(self, d, x, wp, scale, shift, residual, out, meta):
         lib = self.lib
         self.keep.append(d)
         is_input = x is self.input
@@ -136,6 +141,8 @@ class PlanBuilder:
             if rc:
                 native.check(rc, "cn_conv2d_f32")
         self.ops.append(run)
+        self.meta.append(meta)
+        self.trace.append((meta["kind"], out))
 
     def conv_transpose4x4s2(self, x, weight, bn=None, relu=False):
         """ConvTranspose2d(k=4, s=2, p=1, bias=False) as four parity-class 2x2 convolutions
@@ -159,8 +166,11 @@ class PlanBuilder:
                              in_layout=LAYOUT_NHWC, in_pitch=x.pitch, out_layout=LAYOUT_NHWC,
                              out_pitch=out.pitch, OH=2 * x.H, OW=2 * x.W, oy_mul=2, oy_add=py,
                              ox_mul=2, ox_add=px, relu=int(relu))
-                self._emit_conv(d, x, wp, scale, shift, None, out)
-        self.flops += 2 * x.B * (2 * x.H) * (2 * x.W) * co * ci * 4
+                fl = 2 * x.B * x.H * x.W * co * ci * 4
+                by = 4 * (x.B * x.H * x.W * (ci + co) + co * ci * 4)
+                self._emit_conv(d, x, wp, scale, shift, None, out,
+                                dict(kind="deconv", flops=fl, bytes=by))
+                self.flops += fl
         return out
 
     def maxpool(self, x, k, s, pad):
@@ -175,6 +185,9 @@ class PlanBuilder:
             if rc:
                 native.check(rc, "cn_maxpool_nhwc_f32")
         self.ops.append(run)
+        self.meta.append(dict(kind="maxpool", flops=0,
+                              bytes=4 * x.B * x.C * (x.H * x.W + Ho * Wo)))
+        self.trace.append(("maxpool", out))
         return out
 
     def dcn(self, x, dcn_mod, bn=None, relu=False):
@@ -204,7 +217,12 @@ class PlanBuilder:
             if rc:
                 native.check(rc, "cn_dcn_v2_forward_nhwc_f32")
         self.ops.append(run)
-        self.flops += 2 * x.B * x.H * x.W * co * ci * 9
+        fl = 2 * x.B * x.H * x.W * co * ci * 9
+        # activations 4*(Cin + 27 + Cout)*HW per image + weights once per launch
+        by = 4 * (x.B * x.H * x.W * (ci + 27 + co) + co * ci * 9 + co)
+        self.meta.append(dict(kind="dcn", flops=fl, bytes=by, samples=x.B * x.H * x.W * 9 * ci))
+        self.trace.append(("dcn", out))
+        self.flops += fl
         return out
 
     def heads(self, x, head_modules):
@@ -248,7 +266,9 @@ class Plan:
     def flops(self):
         return self.b.flops
 
-    def run(self, images):
+    def run(self, images, events=None):
+        """Replay the launch list.  ``events``: optional list that receives one
+        torch.cuda.Event per op boundary (len(ops)+1), recorded on the launch stream."""
         if not images.is_cuda:
             raise native.NativeError("input batch must be on a HIP device; there is no CPU path")
         native.require_f32(images)
@@ -259,8 +279,18 @@ class Plan:
             self.graph.replay()
         else:
             self.b.input.t = images
-            for op in self.b.ops:
-                op()
+            if events is None:
+                for op in self.b.ops:
+                    op()
+            else:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                events.append(e)
+                for op in self.b.ops:
+                    op()
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    events.append(e)
         return {k: v.t for k, v in self.outputs.items()}
 
     def capture(self):

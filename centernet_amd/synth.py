@@ -5,7 +5,8 @@ same seed gives the same bits here, on the GPU box and inside
 ``tests/golden/gen_golden.py`` -- independent of torch's initialisers.
 
 Recipe: He-normal conv weights; BatchNorm made non-trivial
-(gamma ~ U(0.5,1.5), beta, running_mean ~ N(0,0.1), running_var ~ U(0.5,1.5));
+(gamma ~ U(0.5,1.5) -- U(0.1,0.4) on the closing BN of a residual branch so the trunk
+stays O(1) -- beta, running_mean ~ N(0,0.1), running_var ~ U(0.5,1.5));
 ``conv_offset_mask`` -- zero in the reference (DCNv2/dcn_v2.py:60-62) -- gets weights so
 that offsets spread over a few pixels and masks vary, otherwise the deformable gather
 would never leave the regular grid; ``hm`` output bias = -2.19 (resnet_dcn.py:165-166).
@@ -35,20 +36,32 @@ def fill_state_dict_(module, seed=317):
         elif leaf == "running_var":
             a = rng.uniform(0.5, 1.5, size=shape)
         elif is_bn and leaf == "weight":
-            a = rng.uniform(0.5, 1.5, size=shape)
+            # the last BN of a residual branch is damped (as zero-init-residual training
+            # leaves it) so that activations stay O(1) through the trunk: with O(100)
+            # activations the offset convolution would throw every deformable sample
+            # hundreds of pixels outside the map and the network becomes chaotic in its
+            # inputs, which no real checkpoint is.
+            tail = prefix.rsplit(".", 1)[-1]
+            if tail in ("bn2", "bn3"):
+                a = rng.uniform(0.1, 0.4, size=shape)
+            else:
+                a = rng.uniform(0.5, 1.5, size=shape)
         elif is_bn and leaf == "bias":
             a = rng.standard_normal(shape) * 0.1
         elif v.dim() == 4:
             if "conv_offset_mask" in k:
                 fan_in = shape[1] * shape[2] * shape[3]
-                a = rng.standard_normal(shape) * (1.5 / math.sqrt(fan_in))
+                a = rng.standard_normal(shape) * (0.4 / math.sqrt(fan_in))
             elif ".up_" in k or _is_transposed(module, prefix):
                 # ConvTranspose2d weight is (Cin, Cout/groups, kh, kw)
                 fan_in = max(1, shape[0] * shape[2] * shape[3] // 4) if shape[1] > 1 else 4
                 a = rng.standard_normal(shape) * math.sqrt(2.0 / fan_in)
             else:
                 fan_in = shape[1] * shape[2] * shape[3]
-                a = rng.standard_normal(shape) * math.sqrt(2.0 / fan_in)
+                gain = 2.0 if _is_dcn(module, prefix) else 1.0  # mask ~0.5 halves the signal
+                if _is_head_out(k, sd):
+                    gain = 0.15  # logits std ~1 around the -2.19 bias: no saturated scores
+                a = rng.standard_normal(shape) * (gain * math.sqrt(2.0 / fan_in))
         elif leaf == "bias":
             if "conv_offset_mask" in k:
                 a = rng.standard_normal(shape)
@@ -67,6 +80,14 @@ def fill_state_dict_(module, seed=317):
     return module
 
 
+def _is_dcn(module, prefix):
+    try:
+        m = module.get_submodule(prefix) if prefix else module
+    except Exception:
+        return False
+    return hasattr(m, "conv_offset_mask")
+
+
 def _is_transposed(module, prefix):
     try:
         m = module.get_submodule(prefix) if prefix else module
@@ -75,11 +96,27 @@ def _is_transposed(module, prefix):
     return isinstance(m, torch.nn.ConvTranspose2d)
 
 
+_TRUNK = ("conv", "bn", "layer", "deconv", "base", "dla_up", "ida_up", "pre", "kps", "cnvs",
+          "inters", "cnvs_", "inters_")
+
+
+def _is_head_out(key, sd):
+    """weight/bias of the LAST conv of a head module ('hm.2.weight', 'wh.bias', ...)."""
+    parts = key.split(".")
+    if parts[0].startswith(_TRUNK):
+        return False
+    return _is_last_of_head(parts, sd)
+
+
 def _is_hm_out(key, sd):
     # last conv of a head whose name contains 'hm' (hm, hm_hp): 'hm.2.bias' or 'hm.bias'
     parts = key.split(".")
     if "hm" not in parts[0]:
         return False
+    return _is_last_of_head(parts, sd)
+
+
+def _is_last_of_head(parts, sd):
     if len(parts) == 2:
         return True
     if len(parts) == 3 and parts[1].isdigit():

@@ -38,14 +38,23 @@ def dcn(x, sd, p):
     return torch.from_numpy(y)
 
 
+TRACE = None  # set to a list to record intermediate activations (debugging aid)
+
+
+def _t(name, x):
+    if TRACE is not None:
+        TRACE.append((name, x))
+    return x
+
+
 def _basic_block(x, sd, p, stride):
     res = x
-    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1), sd, p + ".bn1"))
-    out = _bn(F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".bn2")
     if (p + ".downsample.0.weight") in sd:
-        res = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride, 0), sd,
-                  p + ".downsample.1")
-    return F.relu(out + res)
+        res = _t(p + ".ds", _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride, 0), sd,
+                                p + ".downsample.1"))
+    out = _t(p + ".c1", F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1), sd, p + ".bn1")))
+    out = _bn(F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".bn2")
+    return _t(p + ".out", F.relu(out + res))
 
 
 def _bottleneck(x, sd, p, stride):
@@ -81,8 +90,8 @@ def resnet_forward(sd, x, num_layers, heads, dcn_up):
     kind, layers = _SPEC[num_layers]
     block = _basic_block if kind == "basic" else _bottleneck
     with torch.no_grad():
-        x = F.relu(_bn(F.conv2d(x, sd["conv1.weight"], None, 2, 3), sd, "bn1"))
-        x = F.max_pool2d(x, 3, 2, 1)
+        x = _t("stem", F.relu(_bn(F.conv2d(x, sd["conv1.weight"], None, 2, 3), sd, "bn1")))
+        x = _t("pool", F.max_pool2d(x, 3, 2, 1))
         for li, n in enumerate(layers):
             for bi in range(n):
                 stride = 2 if (li > 0 and bi == 0) else 1
@@ -90,14 +99,15 @@ def resnet_forward(sd, x, num_layers, heads, dcn_up):
         if dcn_up:  # resnet_dcn.py:209-246: [DCN, BN, ReLU, ConvT, BN, ReLU] x 3
             for i in range(3):
                 b = 6 * i
-                x = F.relu(_bn(dcn(x, sd, "deconv_layers.%d" % b), sd, "deconv_layers.%d" % (b + 1)))
+                x = _t("dcn%d" % i, F.relu(_bn(dcn(x, sd, "deconv_layers.%d" % b), sd,
+                                               "deconv_layers.%d" % (b + 1))))
                 x = F.conv_transpose2d(x, sd["deconv_layers.%d.weight" % (b + 3)], None, 2, 1, 0)
-                x = F.relu(_bn(x, sd, "deconv_layers.%d" % (b + 4)))
+                x = _t("up%d" % i, F.relu(_bn(x, sd, "deconv_layers.%d" % (b + 4))))
         else:  # msra_resnet.py: [ConvT, BN, ReLU] x 3
             for i in range(3):
                 b = 3 * i
                 x = F.conv_transpose2d(x, sd["deconv_layers.%d.weight" % b], None, 2, 1, 0)
-                x = F.relu(_bn(x, sd, "deconv_layers.%d" % (b + 1)))
+                x = _t("up%d" % i, F.relu(_bn(x, sd, "deconv_layers.%d" % (b + 1))))
         return {h: _head(x, sd, h) for h in heads}
 
 

@@ -1,0 +1,62 @@
+"""The C-ABI shared library builds for gfx950, loads, and exports every symbol that
+include/centernet_amd.h declares (no compute: this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "centernet_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from centernet_amd import native
+    path = native.build()
+    lib = ctypes.CDLL(path)
+    names = _declared()
+    assert len(names) >= 15
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_version_status_strings_and_arch():
+    from centernet_amd import native
+    lib = native.lib()
+    assert lib.cn_version() >= 100
+    assert lib.cn_arch() == b"gfx950"
+    assert lib.cn_status_string(0) == b"ok"
+    assert b"workspace" in lib.cn_status_string(-3)
+
+
+def test_device_code_is_gfx950_only():
+    """The shared object carries exactly one offload target: gfx950."""
+    from centernet_amd import native
+    blob = open(native.build(), "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_shape_queries_without_gpu():
+    """Pure host-side entry points work without a device."""
+    from centernet_amd import native
+    lib = native.lib()
+    assert lib.cn_packed_conv_weight_floats(64, 64, 3, 3) == 9 * 64 * 64
+    assert lib.cn_packed_conv_weight_floats(27, 512, 3, 3) == 9 * 32 * 512
+    assert lib.cn_packed_conv_weight_floats(64, 3, 7, 7) == 64 * 224
+    n = lib.cn_ctdet_decode_workspace_bytes(32, 80, 128, 128, 100)
+    assert n >= 2 * 4 * 32 * 80 * 100
+    assert lib.cn_ctdet_decode_workspace_bytes(1, 80, 128, 128, 100) > 0
+    assert lib.cn_dcn_v2_forward_workspace_bytes(2, 64, 16, 16, 64, 3, 3, 0) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import pytest
+    from centernet_amd import native
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(native.NativeError):
+        native.lib()

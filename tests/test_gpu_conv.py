@@ -1,0 +1,121 @@
+"""Implicit-GEMM conv / conv-transpose / max-pool kernels (through the plan builder, i.e.
+the C ABI) vs torch CPU fp32 (the reference's third-party arithmetic).  Tolerance:
+|diff| <= 2e-5 * (1 + |ref|)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from centernet_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _check(y, ref):
+    err = (y - ref).abs() / (1 + ref.abs())
+    assert float(err.max()) < TOL, float(err.max())
+
+
+def _nhwc_act(x, dev):
+    from centernet_amd.engine import Act
+    B, C, H, W = x.shape
+    return Act(x.permute(0, 2, 3, 1).contiguous().to(dev), B, H, W, C)
+
+
+def _run(pb):
+    for op in pb.ops:
+        op()
+    torch.cuda.synchronize()
+
+
+def _bn(C, seed):
+    bn = torch.nn.BatchNorm2d(C)
+    synth.fill_state_dict_(bn, seed)
+    return bn.eval()
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, Cin, H, W, Cout, k, stride, pad, bias, bn, relu, residual
+    (2, 64, 32, 32, 64, 3, 1, 1, False, True, True, True),
+    (2, 64, 32, 32, 128, 3, 2, 1, False, True, True, False),
+    (1, 64, 17, 19, 128, 1, 2, 0, False, True, False, False),
+    (2, 256, 16, 16, 512, 3, 1, 1, False, True, True, True),
+    (1, 512, 16, 16, 27, 3, 1, 1, True, False, False, False),
+    (3, 36, 9, 11, 40, 3, 1, 1, True, False, True, False),
+    (1, 64, 128, 128, 192, 3, 1, 1, True, False, True, False),
+    (2, 128, 8, 8, 256, 1, 1, 0, False, True, True, True),
+])
+def test_conv_bn_relu_residual(dev, cfg):
+    from centernet_amd.engine import PlanBuilder
+    B, Cin, H, W, Cout, k, s, p, use_bias, use_bn, relu, use_res = cfg
+    x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1))
+    w = torch.from_numpy(synth.normal((Cout, Cin, k, k), (2.0 / (Cin * k * k)) ** 0.5, 2))
+    bias = torch.from_numpy(synth.normal((Cout,), 0.3, 3)) if use_bias else None
+    bn = _bn(Cout, 4) if use_bn else None
+    ref = F.conv2d(x, w, bias, s, p)
+    if bn is not None:
+        ref = bn(ref)
+    res = None
+    if use_res:
+        res = torch.from_numpy(synth.normal(tuple(ref.shape), 1.0, 5))
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    pb = PlanBuilder(dev, B, H, W)
+    y = pb.conv(_nhwc_act(x, dev), w, bias=bias, bn=bn, relu=relu,
+                residual=_nhwc_act(res, dev) if use_res else None, stride=s, padding=p)
+    _run(pb)
+    _check(y.t.permute(0, 3, 1, 2).cpu(), ref.detach())
+
+
+def test_stem_conv_nchw_input(dev):
+    from centernet_amd.engine import PlanBuilder
+    B, H, W = 2, 64, 96
+    x = synth.images(B, H, W, 3)
+    w = torch.from_numpy(synth.normal((64, 3, 7, 7), (2.0 / 147) ** 0.5, 2))
+    bn = _bn(64, 4)
+    ref = F.relu(bn(F.conv2d(x, w, None, 2, 3))).detach()
+    pb = PlanBuilder(dev, B, H, W)
+    xin = pb.set_input(3)
+    y = pb.conv(xin, w, bn=bn, relu=True, stride=2, padding=3)
+    pb.input.t = x.to(dev)
+    _run(pb)
+    _check(y.t.permute(0, 3, 1, 2).cpu(), ref)
+    pooled = F.max_pool2d(ref, 3, 2, 1)
+    pb2 = PlanBuilder(dev, B, H, W)
+    z = pb2.maxpool(_nhwc_act(ref, dev), 3, 2, 1)
+    _run(pb2)
+    assert torch.equal(z.t.permute(0, 3, 1, 2).cpu(), pooled)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 64), (1, 256, 16, 16, 256), (1, 128, 9, 7, 64)])
+def test_conv_transpose_4x4_s2(dev, cfg):
+    from centernet_amd.engine import PlanBuilder
+    B, Cin, H, W, Cout = cfg
+    x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1))
+    w = torch.from_numpy(synth.normal((Cin, Cout, 4, 4), (2.0 / (Cin * 4)) ** 0.5, 2))
+    bn = _bn(Cout, 3)
+    ref = F.relu(bn(F.conv_transpose2d(x, w, None, 2, 1, 0))).detach()
+    pb = PlanBuilder(dev, B, H, W)
+    y = pb.conv_transpose4x4s2(_nhwc_act(x, dev), w, bn=bn, relu=True)
+    _run(pb)
+    _check(y.t.permute(0, 3, 1, 2).cpu(), ref)
+
+
+def test_heads_fused_nchw_outputs(dev):
+    from centernet_amd.engine import PlanBuilder
+    B, F_, H, W = 2, 64, 32, 32
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    mods = {}
+    for i, (h, c) in enumerate(heads.items()):
+        seq = torch.nn.Sequential(torch.nn.Conv2d(F_, 64, 3, padding=1), torch.nn.ReLU(),
+                                  torch.nn.Conv2d(64, c, 1))
+        synth.fill_state_dict_(seq, 10 + i)
+        mods[h] = seq.eval()
+    x = torch.from_numpy(synth.normal((B, F_, H, W), 1.0, 1))
+    pb = PlanBuilder(dev, B, H, W)
+    outs = pb.heads(_nhwc_act(x, dev), mods)
+    _run(pb)
+    for h in heads:
+        _check(outs[h].t.cpu(), mods[h](x).detach())

@@ -1,0 +1,130 @@
+"""HIP decode (through the C ABI) vs the reference goldens and the C oracle."""
+import numpy as np
+import pytest
+import torch
+
+from centernet_amd import synth
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(a, dev):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("name", ["ctdet_coco", "ctdet_small_catspec", "ctdet_rect", "ctdet_odd"])
+def test_ctdet_decode_bit_exact_vs_reference_golden(dev, gen, decode_golden, name):
+    from centernet_amd.decode import ctdet_decode
+    z, _ = decode_golden
+    heat, wh, reg, K, cat = gen.decode_inputs(name)
+    dets, inds = ctdet_decode(_gpu(heat, dev), _gpu(wh, dev), _gpu(reg, dev), cat_spec_wh=cat, K=K,
+                              return_inds=True)
+    dets, inds = dets.cpu().numpy(), inds.cpu().numpy()
+    ref = z[name + "/dets"]
+    assert np.array_equal(inds, z[name + "/topk_inds"]), "box indices differ from the reference"
+    assert np.array_equal(dets.view(np.uint32), ref.view(np.uint32)), np.abs(dets - ref).max()
+
+
+@pytest.mark.parametrize("shape", [(1, 80, 128, 128, 100), (4, 80, 128, 128, 100), (32, 80, 128, 128, 100),
+                                   (2, 1, 128, 128, 100), (1, 3, 152, 100, 40), (3, 2, 7, 9, 5),
+                                   (1, 2, 10, 13, 128), (2, 20, 96, 320, 100)])
+def test_ctdet_decode_vs_oracle(dev, shape):
+    from centernet_amd.decode import ctdet_decode
+    B, C, H, W, K = shape
+    heat = synth.heatmap((B, C, H, W), 11 + B + C)
+    wh = synth.uniform((B, 2, H, W), 0, 40, 5)
+    reg = synth.uniform((B, 2, H, W), 0, 1, 6)
+    ref, ref_inds = cref.ctdet_decode(heat, wh, reg, K=K, return_inds=True)
+    dets, inds = ctdet_decode(_gpu(heat, dev), _gpu(wh, dev), _gpu(reg, dev), K=K, return_inds=True)
+    assert np.array_equal(inds.cpu().numpy(), ref_inds)
+    assert np.array_equal(dets.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_fused_sigmoid_matches_oracle(dev):
+    """apply_sigmoid=True (logits in): scores within 1e-6 of torch's sigmoid, same boxes
+    wherever the oracle's own score gap exceeds 1e-6."""
+    from centernet_amd.decode import ctdet_decode
+    B, C, H, W, K = 4, 80, 128, 128, 100
+    logits = synth.normal((B, C, H, W), 2.0, 3, mean=-2.19)
+    wh = synth.uniform((B, 2, H, W), 0, 40, 5)
+    reg = synth.uniform((B, 2, H, W), 0, 1, 6)
+    heat = torch.from_numpy(logits.copy()).sigmoid_().numpy()
+    ref, ref_inds = cref.ctdet_decode(heat, wh, reg, K=K, return_inds=True)
+    dets, inds = ctdet_decode(_gpu(logits, dev), _gpu(wh, dev), _gpu(reg, dev), K=K,
+                              apply_sigmoid=True, return_inds=True)
+    dets, inds = dets.cpu().numpy(), inds.cpu().numpy()
+    assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-6
+    gap = np.minimum(np.abs(np.diff(ref[..., 4], axis=1, prepend=np.inf)),
+                     np.abs(np.diff(ref[..., 4], axis=1, append=-np.inf)))
+    safe = gap > 1e-6
+    assert safe.mean() > 0.9
+    assert np.array_equal(inds[safe], ref_inds[safe])
+    assert np.abs(dets[safe] - ref[safe]).max() < 1e-4
+
+
+def test_ties_and_degenerate_maps(dev):
+    from centernet_amd.decode import ctdet_decode
+    # constant map: every cell is a peak and all scores tie -> (class, index) order
+    heat = np.full((2, 3, 16, 16), 0.25, np.float32)
+    wh = synth.uniform((2, 2, 16, 16), 0, 4, 1)
+    ref, ri = cref.ctdet_decode(heat, wh, None, K=100, return_inds=True)
+    d, i = ctdet_decode(_gpu(heat, dev), _gpu(wh, dev), None, K=100, return_inds=True)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # fewer than K peaks: a single bump per plane, the rest of the top-K are zeros
+    heat = np.zeros((1, 2, 12, 12), np.float32)
+    heat[0, 0, 5, 6] = 0.9
+    heat[0, 1, 2, 3] = 0.8
+    heat[0, 1, 2, 4] = 0.8   # equal neighbours: both survive the == test
+    ref, ri = cref.ctdet_decode(heat, wh[:1, :, :12, :12].copy(), None, K=20, return_inds=True)
+    d, i = ctdet_decode(_gpu(heat, dev), _gpu(wh[:1, :, :12, :12].copy(), dev), None, K=20,
+                        return_inds=True)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # negative "heat" (the function accepts any floats)
+    heat = synth.normal((1, 4, 9, 9), 1.0, 2)
+    ref, ri = cref.ctdet_decode(heat, wh[:1, :, :9, :9].copy(), None, K=30, return_inds=True)
+    d, i = ctdet_decode(_gpu(heat, dev), _gpu(wh[:1, :, :9, :9].copy(), dev), None, K=30,
+                        return_inds=True)
+    assert np.array_equal(d.cpu().numpy()[..., 4], ref[..., 4])
+    assert np.array_equal(i.cpu().numpy(), ri)
+
+
+def test_k_out_of_range_and_cpu_tensor_raise(dev):
+    from centernet_amd.decode import ctdet_decode
+    from centernet_amd.native import NativeError
+    heat = torch.zeros((1, 1, 2, 2), device=dev)
+    with pytest.raises(RuntimeError):
+        ctdet_decode(heat, torch.zeros((1, 2, 2, 2), device=dev), K=5)
+    with pytest.raises(NativeError):
+        ctdet_decode(torch.zeros((1, 1, 8, 8)), torch.zeros((1, 2, 8, 8)), K=5)
+
+
+def test_full_size_properties(dev):
+    """BASELINE config size (B=32): size-independent properties -- sorted scores, every
+    box is a true local maximum, idempotent under re-decode, permutation of the batch."""
+    from centernet_amd.decode import ctdet_decode
+    B, C, H, W, K = 32, 80, 128, 128, 100
+    g = torch.Generator(device="cpu").manual_seed(0)
+    logits = (2 * torch.randn((B, C, H, W), generator=g) - 2.19).to(dev)
+    wh = (40 * torch.rand((B, 2, H, W), generator=g)).to(dev)
+    reg = torch.rand((B, 2, H, W), generator=g).to(dev)
+    dets, inds = ctdet_decode(logits, wh, reg, K=K, apply_sigmoid=True, return_inds=True)
+    s = dets[..., 4]
+    assert bool((s[:, 1:] <= s[:, :-1]).all())
+    heat = logits.sigmoid()
+    hmax = torch.nn.functional.max_pool2d(heat, 3, 1, 1)
+    cls = dets[..., 5].long()
+    b = torch.arange(B, device=dev)[:, None].expand(B, K)
+    y, x = inds // W, inds % W
+    assert bool((hmax[b, cls, y, x] == heat[b, cls, y, x]).all())
+    assert float((heat[b, cls, y, x] - s).abs().max()) < 1e-6
+    # the K-th score bounds every non-selected peak
+    peaks = torch.where(hmax == heat, heat, torch.zeros_like(heat)).view(B, -1)
+    kth = torch.topk(peaks, K, dim=1).values[:, -1]
+    assert float((kth - s[:, -1]).abs().max()) < 1e-6
+    perm = torch.randperm(B, generator=g).to(dev)
+    d2 = ctdet_decode(logits[perm].contiguous(), wh[perm].contiguous(), reg[perm].contiguous(),
+                      K=K, apply_sigmoid=True)
+    assert torch.equal(d2, dets[perm])
