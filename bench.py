@@ -83,7 +83,9 @@ def main():
     from centernet_amd.sharding import broadcast_weights
 
     opt = opts().init(["ctdet", "--arch", a.arch, "--input_res", str(a.res)])
-    det = detector_factory[opt.task](opt)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # the detector prints 'Creating model...'
+        det = detector_factory[opt.task](opt)
     if rank == 0:
         synth.fill_state_dict_(det.model, 317)
     if world > 1:
