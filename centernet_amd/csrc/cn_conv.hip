@@ -57,6 +57,9 @@ struct IgemmArgs {
     int cout_pad;  // rows per tap in the packed weight (multiple of 32)
     int nchunk;    // cin_pad / 32
     int KT;        // taps * nchunk
+    int zparity;   // ConvTranspose 4x4/s2: blockIdx.z = output parity class (py*2+px)
+    int w_zstride; // floats between the packed weights of two parity classes
+    int vec_out;   // NHWC output base/pitch allow 16-byte stores
 };
 
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -89,6 +92,18 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     const int lrow = tid >> 3;  // 0..31: row inside a 32-row pass
     const int q = tid & 7;      // float4 slot inside the 32-float chunk
     const int HoWo = a.Ho * a.Wo;
+    // ConvTranspose2d(4,2,1): output parity (py,px) is a 2x2 convolution with its own
+    // weights, padding (1-py, 1-px) and output offset (py,px)
+    int pad_h = a.pad_h, pad_w = a.pad_w, oy_add = a.oy_add, ox_add = a.ox_add;
+    const float *wbase = a.w;
+    if (a.zparity) {
+        const int py = blockIdx.z >> 1, px = blockIdx.z & 1;
+        pad_h = 1 - py;
+        pad_w = 1 - px;
+        oy_add = py;
+        ox_add = px;
+        wbase += (size_t)blockIdx.z * a.w_zstride;
+    }
 
     // ---- per-thread A rows: conv-grid coordinates
     int a_iy0[PA], a_ix0[PA], a_pix[PA];  // a_pix: b*H*W, or -1 if row >= M
@@ -100,8 +115,8 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
             const int r = m - b * HoWo;
             const int oy = r / a.Wo;
             const int ox = r - oy * a.Wo;
-            a_iy0[p] = oy * a.stride - a.pad_h;
-            a_ix0[p] = ox * a.stride - a.pad_w;
+            a_iy0[p] = oy * a.stride - pad_h;
+            a_ix0[p] = ox * a.stride - pad_w;
             a_pix[p] = b * a.H * a.W;
         } else {
             a_iy0[p] = 0;
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
             const int rr = m - b * HoWo;
             const int oy = rr / a.Wo;
             const int ox = rr - oy * a.Wo;
-            off = (b * a.OH + oy * a.oy_mul + a.oy_add) * a.OW + ox * a.ox_mul + a.ox_add;
+            off = (b * a.OH + oy * a.oy_mul + oy_add) * a.OW + ox * a.ox_mul + ox_add;
         }
         rowoff[r] = off;
     }
@@ -196,11 +211,10 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         // ---- B: packed weight [tap][cout_pad][cin_pad]
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int n = n0 + p * 32 + lrow;
-            rb[p] = (n < a.cout_pad)
-                        ? *reinterpret_cast<const cn_f32x4 *>(
-                              a.w + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + c0 + 4 * q))
-                        : zero4;
+            // rows past cout_pad are clamped: their columns are never stored
+            const int n = min(n0 + p * 32 + lrow, a.cout_pad - 1);
+            rb[p] = *reinterpret_cast<const cn_f32x4 *>(
+                wbase + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + c0 + 4 * q));
         }
         // ---- A
         if (AMODE == A_DENSE) {
@@ -212,9 +226,10 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 const int ix = a_ix0[p] + kx * a.dil;
                 const bool ok = a_pix[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W &&
                                 c < a.Cin;
-                ra[p][0] = ok ? *reinterpret_cast<const cn_f32x4 *>(
-                                    a.x + ((size_t)(a_pix[p] + iy * a.W + ix) * a.in_pitch + c))
-                              : zero4;
+                // always load from a valid address, then select: no exec-mask branches
+                const size_t off = ok ? ((size_t)(a_pix[p] + iy * a.W + ix) * a.in_pitch + c) : 0;
+                const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(a.x + off);
+                ra[p][0] = ok ? v : zero4;
             }
         } else if (AMODE == A_STEM) {
             // chunk = 8 taps x (r,g,b,0); input NCHW with Cin == 3
@@ -228,14 +243,13 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 const int ix = a_ix0[p] + kx * a.dil;
                 const bool ok = tap_ok && a_pix[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 &&
                                 ix < a.W;
-                cn_f32x4 v = zero4;
-                if (ok) {
-                    const float *px = a.x + (size_t)a_pix[p] * 3 + (size_t)iy * a.W + ix;
-                    v.x = px[0];
-                    v.y = px[HW];
-                    v.z = px[2 * HW];
-                }
-                ra[p][0] = v;
+                const float *px = a.x + (ok ? ((size_t)a_pix[p] * 3 + (size_t)iy * a.W + ix) : 0);
+                cn_f32x4 v;
+                v.x = px[0];
+                v.y = px[HW];
+                v.z = px[2 * HW];
+                v.w = 0.f;
+                ra[p][0] = ok ? v : zero4;
             }
         } else {  // A_DCN: four bilinear corners, each a 16-byte channel vector
             const int c = c0 + 4 * q;
@@ -244,10 +258,11 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 const int r = p * 32 + lrow;
                 const int *si = sidx + (r * 9 + tap) * 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    ra[p][j] = (c < a.Cin) ? *reinterpret_cast<const cn_f32x4 *>(
-                                                 a.x + ((size_t)si[j] * a.in_pitch + c))
-                                           : zero4;
+                for (int j = 0; j < 4; ++j) {
+                    const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
+                        a.x + ((size_t)si[j] * a.in_pitch + (c < a.Cin ? c : 0)));
+                    ra[p][j] = (c < a.Cin) ? v : zero4;
+                }
             }
         }
     };
@@ -324,26 +339,65 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     // ---- epilogue: y = relu?((acc + bias) * scale + shift + residual)
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (!OUT_NCHW) {
+        // Stage the tile through LDS (As/Bs are free after the loop's last barrier) so that
+        // residual loads and output stores are 16-byte, row-contiguous accesses.
+        constexpr int LDC = BN + 4;
+        float *Cs = reinterpret_cast<float *>(smem);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int n = n0 + wn * TN + j * 32 + l31;
-            const bool n_ok = n < a.Cout;
-            const float bs = (a.bias && n_ok) ? a.bias[n] : 0.f;
-            const float sc = (a.scale && n_ok) ? a.scale[n] : 1.f;
-            const float sf = (a.shift && n_ok) ? a.shift[n] : 0.f;
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int i = 0; i < MB; ++i) {
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int off = rowoff[row];
-                    if (off >= 0 && n_ok) {
-                        float v = (acc[i][j][r] + bs) * sc + sf;
-                        const size_t o = (size_t)off * a.out_pitch + n;
-                        if (a.residual) v += a.residual[o];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        a.y[o] = v;
-                    }
+                    Cs[row * LDC + wn * TN + j * 32 + l31] = acc[i][j][r];
+                }
+        __syncthreads();
+        constexpr int C4 = BN / 4;    // float4 columns per tile row
+        constexpr int RPI = NT / C4;  // tile rows covered per pass
+        const int c4 = tid % C4, r0 = tid / C4;
+        const int n = n0 + c4 * 4;
+        float bs[4], sc[4], sf[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = (n + e) < a.Cout;
+            bs[e] = (a.bias && ok) ? a.bias[n + e] : 0.f;
+            sc[e] = (a.scale && ok) ? a.scale[n + e] : 1.f;
+            sf[e] = (a.shift && ok) ? a.shift[n + e] : 0.f;
+        }
+        const bool vec = a.vec_out && (n + 4 <= a.Cout);
+        if (vec) {
+            cn_f32x4 res[BM / RPI];
+            int offs[BM / RPI];
+#pragma unroll
+            for (int it = 0; it < BM / RPI; ++it) {
+                offs[it] = rowoff[it * RPI + r0];
+                if (a.residual) {
+                    const size_t o = (size_t)(offs[it] >= 0 ? offs[it] : 0) * a.out_pitch + n;
+                    res[it] = *reinterpret_cast<const cn_f32x4 *>(a.residual + o);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < BM / RPI; ++it) {
+                if (offs[it] < 0) continue;
+                cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(Cs + (it * RPI + r0) * LDC + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = (v[e] + bs[e]) * sc[e] + sf[e];
+                    if (a.residual) t += res[it][e];
+                    v[e] = a.relu ? fmaxf(t, 0.f) : t;
+                }
+                *reinterpret_cast<cn_f32x4 *>(a.y + (size_t)offs[it] * a.out_pitch + n) = v;
+            }
+        } else if (n < a.Cout) {
+            for (int it = 0; it < BM / RPI; ++it) {
+                const int off = rowoff[it * RPI + r0];
+                if (off < 0) continue;
+                for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
+                    const size_t o = (size_t)off * a.out_pitch + n + e;
+                    float t = (Cs[(it * RPI + r0) * LDC + c4 * 4 + e] + bs[e]) * sc[e] + sf[e];
+                    if (a.residual) t += a.residual[o];
+                    a.y[o] = a.relu ? fmaxf(t, 0.f) : t;
                 }
             }
         }
@@ -390,7 +444,7 @@ int launch_igemm(const IgemmArgs &a, hipStream_t st)
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN));
+    dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : 1);
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, AMODE, OUT_NCHW>), grid, dim3(NT), lds, st, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
@@ -515,6 +569,8 @@ extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float 
     if (rc != CN_OK) return rc;
     a.x = x; a.w = w_packed; a.bias = nullptr; a.scale = scale; a.shift = shift;
     a.residual = residual; a.y = y; a.om = nullptr;
+    a.vec_out = (d->out_layout == CN_LAYOUT_NHWC && (d->out_pitch & 3) == 0 && cn_aligned16(y) &&
+                 (!residual || cn_aligned16(residual))) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool stem = is_stem(d->Cin, d->in_layout);
     if (d->out_layout == CN_LAYOUT_NCHW) {
@@ -524,8 +580,9 @@ extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float 
         return launch_igemm<128, 32, 4, 1, A_DENSE, true>(a, st);
     }
     if (stem) {
-        if (d->Cout > 64) return CN_ERR_UNSUPPORTED;
-        return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
+        if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_STEM, false>(a, st);
+        if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
+        return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
     }
     if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
     if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
@@ -558,8 +615,85 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
     a.cout_pad = round_up(Cout, 32);
     a.nchunk = a.cin_pad / 32;
     a.KT = 9 * a.nchunk;
+    a.vec_out = ((Cout & 3) == 0 && cn_aligned16(output_nhwc)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (Cout > 64) return launch_igemm<64, 128, 2, 2, A_DCN, false>(a, st);
     if (Cout > 32) return launch_igemm<64, 64, 2, 2, A_DCN, false>(a, st);
     return launch_igemm<128, 32, 4, 1, A_DCN, false>(a, st);
+}
+
+// ---- ConvTranspose2d(kernel 4, stride 2, padding 1, no output padding) -----------------
+// out[2q+py, 2r+px] = sum_{ty,tx,ci} in[q - (1-py) + ty, r - (1-px) + tx, ci] * w[ci, co, ky(py,ty), kx(px,tx)]
+// with ky(0,.) = {3,1}, ky(1,.) = {2,0}: four 2x2 convolutions, one launch (blockIdx.z).
+namespace {
+__global__ void pack_deconv_weight_kernel(const float *__restrict__ w, float *__restrict__ wp,
+                                          int Cin, int Cout, int cout_pad, int cin_pad)
+{
+    const size_t total = (size_t)16 * cout_pad * cin_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cin_pad);
+        const int n = (int)((i / cin_pad) % cout_pad);
+        const int t = (int)((i / ((size_t)cin_pad * cout_pad)) % 4);
+        const int z = (int)(i / ((size_t)cin_pad * cout_pad * 4));
+        const int py = z >> 1, px = z & 1, ty = t >> 1, tx = t & 1;
+        const int ky = py ? (ty ? 0 : 2) : (ty ? 1 : 3);
+        const int kx = px ? (tx ? 0 : 2) : (tx ? 1 : 3);
+        float v = 0.f;
+        if (c < Cin && n < Cout) v = w[(((size_t)c * Cout + n) * 4 + ky) * 4 + kx];
+        wp[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" size_t cn_packed_deconv4x4s2_weight_floats(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)16 * round_up(Cout, 32) * round_up(Cin, 32);
+}
+
+extern "C" int cn_pack_deconv4x4s2_weight_f32(const float *w_iohw, float *w_packed, int Cin,
+                                              int Cout, void *stream)
+{
+    if (!w_iohw || !w_packed) return CN_ERR_NULL;
+    if (Cin <= 0 || Cout <= 0) return CN_ERR_SHAPE;
+    const size_t total = cn_packed_deconv4x4s2_weight_floats(Cin, Cout);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_deconv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       w_iohw, w_packed, Cin, Cout, round_up(Cout, 32), round_up(Cin, 32));
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_packed,
+                                          const float *scale, const float *shift, float *y_nhwc,
+                                          int B, int H, int W, int Cin, int Cout, int in_pitch,
+                                          int out_pitch, int relu, void *stream)
+{
+    if (!x_nhwc || !w_packed || !y_nhwc) return CN_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CN_ERR_SHAPE;
+    if ((Cin & 3) || (in_pitch & 3) || in_pitch < Cin || out_pitch < Cout) return CN_ERR_UNSUPPORTED;
+    if (!cn_aligned16(x_nhwc) || !cn_aligned16(w_packed)) return CN_ERR_ALIGN;
+    if ((long)B * H * W * 4 * (long)out_pitch >= (1L << 31) || (long)B * H * W * (long)in_pitch >= (1L << 31))
+        return CN_ERR_UNSUPPORTED;
+    IgemmArgs a = {};
+    a.x = x_nhwc; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y_nhwc;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = H; a.Wo = W; a.Cout = Cout;
+    a.KH = 2; a.KW = 2; a.stride = 1; a.pad_h = 1; a.pad_w = 1; a.dil = 1;
+    a.in_pitch = in_pitch; a.out_pitch = out_pitch;
+    a.OH = 2 * H; a.OW = 2 * W; a.oy_mul = 2; a.ox_mul = 2; a.oy_add = 0; a.ox_add = 0;
+    a.relu = relu;
+    a.M = B * H * W;
+    a.cin_pad = round_up(Cin, 32);
+    a.cout_pad = round_up(Cout, 32);
+    a.nchunk = a.cin_pad / 32;
+    a.KT = 4 * a.nchunk;
+    a.zparity = 1;
+    a.w_zstride = 4 * a.cout_pad * a.cin_pad;
+    a.vec_out = ((out_pitch & 3) == 0 && cn_aligned16(y_nhwc)) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
+    if (Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
+    return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);
 }

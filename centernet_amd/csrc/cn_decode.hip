@@ -312,13 +312,17 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
 //           output = gathered boxes (decode.py:472-493)
 //   !CTDET: group = (image, channel); output = (scores, inds)  (_topk_channel)
 // ---------------------------------------------------------------------------
-template <bool CTDET>
+enum { MODE_CTDET = 0, MODE_CHANNEL = 1, MODE_POSE = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(NT) void merge_topk_kernel(
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int N,
     int per_class, int H, int W, int K, int C, const float *__restrict__ wh,
     const float *__restrict__ reg, int cat_spec_wh, float *__restrict__ dets, int det_dim,
-    int32_t *__restrict__ inds_out, float *__restrict__ out_scores)
+    int32_t *__restrict__ inds_out, float *__restrict__ out_scores,
+    const float *__restrict__ kps_map, int J)
 {
+    constexpr bool CTDET = (MODE != MODE_CHANNEL);  // group = image, class from position
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SelShared &sh = *reinterpret_cast<SelShared *>(smem);
     const int tid = threadIdx.x;
@@ -368,6 +372,14 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(
             d[3] = ys + h / 2;
             d[4] = score;
             d[det_dim - 1] = (float)cls;
+            if (MODE == MODE_POSE) {
+                // decode.py:506-509: kps = hps[ind] + (xs, ys) with the un-offset centre
+                const float x0 = (float)xi, y0 = (float)yi;
+                for (int j = 0; j < J; ++j) {
+                    d[5 + 2 * j] = kps_map[((size_t)b * 2 * J + 2 * j) * HW + ind] + x0;
+                    d[5 + 2 * j + 1] = kps_map[((size_t)b * 2 * J + 2 * j + 1) * HW + ind] + y0;
+                }
+            }
             if (inds_out) inds_out[(size_t)b * K + tid] = ind;
         } else {
             out_scores[(size_t)g * K + tid] = score;
@@ -475,9 +487,9 @@ extern "C" int cn_ctdet_decode_f32(const float *heat, const float *wh, const flo
     int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
     rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
     if (rc != CN_OK) return rc;
-    hipLaunchKernelGGL(merge_topk_kernel<true>, dim3(B), dim3(NT), sizeof(SelShared), st,
+    hipLaunchKernelGGL(merge_topk_kernel<MODE_CTDET>, dim3(B), dim3(NT), sizeof(SelShared), st,
                        cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg,
-                       cat_spec_wh, dets, 6, inds, (float *)nullptr);
+                       cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr, 0);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -503,12 +515,158 @@ extern "C" int cn_nms_topk_channel_f32(const float *heat, int B, int C, int H, i
     int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
     rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
     if (rc != CN_OK) return rc;
-    hipLaunchKernelGGL(merge_topk_kernel<false>, dim3(B * C), dim3(NT), sizeof(SelShared), st,
-                       cand_score, cand_idx, bp.nbands * K, bp.nbands * K, H, W, K, C,
+    hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * C), dim3(NT), sizeof(SelShared),
+                       st, cand_score, cand_idx, bp.nbands * K, bp.nbands * K, H, W, K, C,
                        (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0, inds,
-                       scores);
+                       scores, (const float *)nullptr, 0);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
 
-// ---- multi_pose decode: implemented in cn_pose.hip ------------------------------
+
+// ---------------------------------------------------------------------------
+// multi_pose decode (models/decode.py:497-571)
+//   stage A  nms_topk + merge<MODE_POSE>: boxes, scores, regression keypoints
+//   stage B  nms_topk (+ channel merge) on hm_hp: K candidates per joint (_topk_channel)
+//   stage C  pose_match_kernel: nearest candidate per (detection, joint), reject rule, blend
+// Arithmetic is kept in the reference's association (no FMA contraction) so the result
+// is bit-identical to torch on CPU: the argmin and the threshold tests are discontinuous.
+// ---------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(KMAX) void pose_match_kernel(
+    const float *__restrict__ hp_scores, const int32_t *__restrict__ hp_inds,
+    const float *__restrict__ hp_offset, float *__restrict__ dets, int J, int K, int H, int W,
+    int det_dim)
+{
+    __shared__ float cs[KMAX], cx[KMAX], cy[KMAX];
+    const int j = blockIdx.x, b = blockIdx.y;
+    const int q = threadIdx.x;
+    const int HW = H * W;
+    const float thresh = 0.1f;
+    if (q < K) {
+        const size_t o = ((size_t)b * J + j) * K + q;
+        float s = hp_scores[o];
+        const int ind = hp_inds[o];
+        const int yi = ind / W, xi = ind - yi * W;
+        float x = (float)xi, y = (float)yi;
+        if (hp_offset) {  // decode.py:534-539
+            x = __fadd_rn(x, hp_offset[((size_t)b * 2 + 0) * HW + ind]);
+            y = __fadd_rn(y, hp_offset[((size_t)b * 2 + 1) * HW + ind]);
+        } else {
+            x = __fadd_rn(x, 0.5f);
+            y = __fadd_rn(y, 0.5f);
+        }
+        const float m = (s > thresh) ? 1.0f : 0.0f;  // decode.py:544-547
+        const float im = __fsub_rn(1.0f, m);
+        cs[q] = __fadd_rn(__fmul_rn(im, -1.0f), __fmul_rn(m, s));
+        cy[q] = __fadd_rn(__fmul_rn(im, -10000.0f), __fmul_rn(m, y));
+        cx[q] = __fadd_rn(__fmul_rn(im, -10000.0f), __fmul_rn(m, x));
+    }
+    __syncthreads();
+    if (q < K) {
+        float *d = dets + ((size_t)b * K + q) * det_dim;
+        const float rx = d[5 + 2 * j], ry = d[5 + 2 * j + 1];
+        float best = 0.f;
+        int bi = -1;
+        for (int c = 0; c < K; ++c) {  // decode.py:550-551, first minimum
+            const float dx = __fsub_rn(rx, cx[c]);
+            const float dy = __fsub_rn(ry, cy[c]);
+            const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+            if (bi < 0 || dist < best) {
+                best = dist;
+                bi = c;
+            }
+        }
+        const float sc = cs[bi], kx = cx[bi], ky = cy[bi];
+        const float l = d[0], t = d[1], r = d[2], bt = d[3];
+        const float bh = __fsub_rn(bt, t), bw = __fsub_rn(r, l);
+        const float mx = __fmul_rn(fmaxf(bh, bw), 0.3f);
+        const bool reject = (kx < l) || (kx > r) || (ky < t) || (ky > bt) || (sc < thresh) ||
+                            (best > mx);  // decode.py:562-565
+        const float m = reject ? 1.0f : 0.0f;
+        const float im = __fsub_rn(1.0f, m);
+        d[5 + 2 * j] = __fadd_rn(__fmul_rn(im, kx), __fmul_rn(m, rx));  // decode.py:566
+        d[5 + 2 * j + 1] = __fadd_rn(__fmul_rn(im, ky), __fmul_rn(m, ry));
+    }
+}
+
+struct PoseWs {
+    size_t cand_s, cand_i, hp_s, hp_i, total;
+};
+bool pose_ws_plan(int B, int C, int H, int W, int J, int K, PoseWs *p, BandPlan *bp_hm,
+                  BandPlan *bp_hp)
+{
+    if (!make_band_plan(B, C, H, W, K, bp_hm) || !make_band_plan(B, J > 0 ? J : 1, H, W, K, bp_hp))
+        return false;
+    const size_t n_hm = (size_t)B * C * bp_hm->nbands * K;
+    const size_t n_hp = (size_t)B * J * bp_hp->nbands * K;
+    const size_t n = n_hm > n_hp ? n_hm : n_hp;  // candidate buffers are reused by both stages
+    size_t o = 0;
+    p->cand_s = o; o += cn_align_up(n * 4, 256);
+    p->cand_i = o; o += cn_align_up(n * 4, 256);
+    p->hp_s = o;   o += cn_align_up((size_t)B * J * K * 4, 256);
+    p->hp_i = o;   o += cn_align_up((size_t)B * J * K * 4, 256);
+    p->total = o;
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t cn_multi_pose_decode_workspace_bytes(int B, int C, int H, int W, int J, int K)
+{
+    PoseWs p;
+    BandPlan a, b;
+    if (B <= 0 || C <= 0 || J <= 0 || K <= 0 || !pose_ws_plan(B, C, H, W, J, K, &p, &a, &b)) return 0;
+    return p.total;
+}
+
+extern "C" int cn_multi_pose_decode_f32(const float *heat, const float *wh, const float *kps,
+                                        const float *reg, const float *hm_hp,
+                                        const float *hp_offset, int B, int C, int H, int W, int J,
+                                        int K, int apply_sigmoid, float *dets, void *workspace,
+                                        size_t workspace_bytes, void *stream)
+{
+    BandPlan bp, bph;
+    int rc = decode_checks(heat, B, C, H, W, K, &bp);
+    if (rc != CN_OK) return rc;
+    if (!wh || !kps || !dets || !workspace) return CN_ERR_NULL;
+    if (J <= 0) return CN_ERR_SHAPE;
+    PoseWs p;
+    if (!pose_ws_plan(B, C, H, W, J, K, &p, &bp, &bph)) return CN_ERR_UNSUPPORTED;
+    if (workspace_bytes < p.total) return CN_ERR_WORKSPACE;
+    if (hm_hp && ((W & 3) == 0) && !cn_aligned16(hm_hp)) return CN_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *cand_s = (float *)(ws + p.cand_s);
+    int32_t *cand_i = (int32_t *)(ws + p.cand_i);
+    float *hp_s = (float *)(ws + p.hp_s);
+    int32_t *hp_i = (int32_t *)(ws + p.hp_i);
+    const int D = 4 + 1 + 2 * J + 1;
+    // stage A
+    rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_s, cand_i, st);
+    if (rc != CN_OK) return rc;
+    hipLaunchKernelGGL(merge_topk_kernel<MODE_POSE>, dim3(B), dim3(NT), sizeof(SelShared), st,
+                       cand_s, cand_i, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg, 0,
+                       dets, D, (int32_t *)nullptr, (float *)nullptr, kps, J);
+    CN_CHECK_LAUNCH();
+    if (!hm_hp) return CN_OK;
+    // stage B: per-joint top-K of the keypoint heat-map
+    if (bph.nbands == 1) {
+        rc = launch_nms_topk(hm_hp, B, J, H, W, K, apply_sigmoid, bph, hp_s, hp_i, st);
+        if (rc != CN_OK) return rc;
+    } else {
+        rc = launch_nms_topk(hm_hp, B, J, H, W, K, apply_sigmoid, bph, cand_s, cand_i, st);
+        if (rc != CN_OK) return rc;
+        hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * J), dim3(NT),
+                           sizeof(SelShared), st, cand_s, cand_i, bph.nbands * K, bph.nbands * K, H,
+                           W, K, J, (const float *)nullptr, (const float *)nullptr, 0,
+                           (float *)nullptr, 0, hp_i, hp_s, (const float *)nullptr, 0);
+        CN_CHECK_LAUNCH();
+    }
+    // stage C
+    hipLaunchKernelGGL(pose_match_kernel, dim3(J, B), dim3(KMAX), 0, st, hp_s, hp_i, hp_offset,
+                       dets, J, K, H, W, D);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}

@@ -98,6 +98,88 @@ __global__ void pack_offset_mask_kernel(const float *__restrict__ offset,
     }
 }
 
+// depthwise ConvTranspose2d(C, C, kernel 2f, stride f, padding f/2, groups=C), NHWC,
+// optionally fused with the element-wise add that follows it in IDAUp.forward
+// (pose_dla_dcn.py:370-373, 381-386).  Each output pixel receives 2x2 taps.
+__global__ void dw_deconv_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                 const float *__restrict__ add, float *__restrict__ y, int B, int H,
+                                 int W, int C, int f)
+{
+    const int c4n = C >> 2;
+    const int OH = H * f, OW = W * f, K2 = 2 * f, pad = f / 2;
+    const size_t total = (size_t)B * OH * OW * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        const int ky0 = (oy + pad) % f, kx0 = (ox + pad) % f;
+        const int iy0 = (oy + pad - ky0) / f, ix0 = (ox + pad - kx0) / f;
+        cn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty) {
+            const int iy = iy0 - ty, ky = ky0 + ty * f;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx) {
+                const int ix = ix0 - tx, kx = kx0 + tx * f;
+                if (ix < 0 || ix >= W) continue;
+                const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
+                    x + (((size_t)b * H + iy) * W + ix) * C + c4 * 4);
+                const cn_f32x4 wv =
+                    *reinterpret_cast<const cn_f32x4 *>(w + (size_t)(ky * K2 + kx) * C + c4 * 4);
+                acc += v * wv;
+            }
+        }
+        const size_t o = (((size_t)b * OH + oy) * OW + ox) * C + c4 * 4;
+        if (add) acc += *reinterpret_cast<const cn_f32x4 *>(add + o);
+        *reinterpret_cast<cn_f32x4 *>(y + o) = acc;
+    }
+}
+
+// copy C channels of npix pixels between two NHWC tensors with different pitches
+// (torch.cat(x, 1) of Root.forward, pose_dla_dcn.py:159, without a permute)
+__global__ void copy_channels_kernel(const float *__restrict__ src, int src_pitch,
+                                     float *__restrict__ dst, int dst_pitch, size_t npix, int C)
+{
+    const int c4n = C >> 2;
+    const size_t total = npix * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const size_t p = i / c4n;
+        *reinterpret_cast<cn_f32x4 *>(dst + p * dst_pitch + c4 * 4) =
+            *reinterpret_cast<const cn_f32x4 *>(src + p * src_pitch + c4 * 4);
+    }
+}
+
+// nearest-neighbour x2 up-sampling (nn.Upsample(scale_factor=2), large_hourglass.py:102-103)
+// fused with the add of the skip branch (merge layer, :104-109)
+__global__ void upsample2x_add_kernel(const float *__restrict__ x, const float *__restrict__ add,
+                                      float *__restrict__ y, int B, int H, int W, int C)
+{
+    const int c4n = C >> 2;
+    const int OH = 2 * H, OW = 2 * W;
+    const size_t total = (size_t)B * OH * OW * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
+            x + (((size_t)b * H + (oy >> 1)) * W + (ox >> 1)) * C + c4 * 4);
+        const size_t o = (((size_t)b * OH + oy) * OW + ox) * C + c4 * 4;
+        if (add) v += *reinterpret_cast<const cn_f32x4 *>(add + o);
+        *reinterpret_cast<cn_f32x4 *>(y + o) = v;
+    }
+}
+
 inline int blocks_for(size_t total, int per_block, int cap)
 {
     size_t b = (total + per_block - 1) / per_block;
@@ -238,4 +320,47 @@ extern "C" int cn_dcn_v2_forward_f32(const float *input, const float *weight, co
                                     Cout, apply_mask_sigmoid, 0, stream);
     if (rc != CN_OK) return rc;
     return cn_nhwc_to_nchw_f32(y_nhwc, output, B, Cout, H, W, Cout, stream);
+}
+
+extern "C" int cn_dw_conv_transpose_f32(const float *x, const float *w_taps, const float *add,
+                                        float *y, int B, int H, int W, int C, int f, void *stream)
+{
+    if (!x || !w_taps || !y) return CN_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || f < 2 || (f & 1)) return CN_ERR_SHAPE;
+    if (C & 3) return CN_ERR_UNSUPPORTED;
+    if (!cn_aligned16(x) || !cn_aligned16(w_taps) || !cn_aligned16(y) || (add && !cn_aligned16(add)))
+        return CN_ERR_ALIGN;
+    const size_t total = (size_t)B * H * f * W * f * (C >> 2);
+    hipLaunchKernelGGL(dw_deconv_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, x, w_taps, add, y, B, H, W, C, f);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_copy_channels_f32(const float *src, int src_pitch, float *dst, int dst_pitch,
+                                    size_t npix, int C, void *stream)
+{
+    if (!src || !dst) return CN_ERR_NULL;
+    if (C <= 0 || src_pitch < C || dst_pitch < C) return CN_ERR_SHAPE;
+    if ((C & 3) || (src_pitch & 3) || (dst_pitch & 3)) return CN_ERR_UNSUPPORTED;
+    if (!cn_aligned16(src) || !cn_aligned16(dst)) return CN_ERR_ALIGN;
+    const size_t total = npix * (C >> 2);
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, src, src_pitch, dst, dst_pitch, npix, C);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_upsample2x_add_f32(const float *x, const float *add, float *y, int B, int H,
+                                     int W, int C, void *stream)
+{
+    if (!x || !y) return CN_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return CN_ERR_SHAPE;
+    if (C & 3) return CN_ERR_UNSUPPORTED;
+    if (!cn_aligned16(x) || !cn_aligned16(y) || (add && !cn_aligned16(add))) return CN_ERR_ALIGN;
+    const size_t total = (size_t)B * 4 * H * W * (C >> 2);
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, x, add, y, B, H, W, C);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
 }

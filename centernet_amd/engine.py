@@ -145,32 +145,35 @@ class PlanBuilder:
         self.trace.append((meta["kind"], out))
 
     def conv_transpose4x4s2(self, x, weight, bn=None, relu=False):
-        """ConvTranspose2d(k=4, s=2, p=1, bias=False) as four parity-class 2x2 convolutions
-        (reference: resnet_dcn.py:228-235, msra_resnet.py deconv layers)."""
+        """ConvTranspose2d(k=4, s=2, p=1, bias=False) [+BN+ReLU]: the four output-parity
+        2x2 convolutions in one launch (reference: resnet_dcn.py:228-235)."""
         ci, co, kh, kw = weight.shape
         assert (kh, kw) == (4, 4) and ci == x.C
         out = self._new(x.B, 2 * x.H, 2 * x.W, co)
         scale, shift = fold_bn(None, bn, co, self.device)
-        self.keep += [scale, shift]
-        w = weight.detach().to(device=self.device, dtype=torch.float32)
-        ktab = ((3, 1), (2, 0))  # kernel row used by tap t of output parity p
-        for py in range(2):
-            for px in range(2):
-                sub = torch.empty((co, ci, 2, 2), device=self.device, dtype=torch.float32)
-                for ty in range(2):
-                    for tx in range(2):
-                        sub[:, :, ty, tx] = w[:, :, ktab[py][ty], ktab[px][tx]].t()
-                wp = self._pack(sub)
-                d = ConvDesc(B=x.B, H=x.H, W=x.W, Cin=ci, Ho=x.H, Wo=x.W, Cout=co, KH=2, KW=2,
-                             stride=1, pad_h=1 - py, pad_w=1 - px, dil=1,
-                             in_layout=LAYOUT_NHWC, in_pitch=x.pitch, out_layout=LAYOUT_NHWC,
-                             out_pitch=out.pitch, OH=2 * x.H, OW=2 * x.W, oy_mul=2, oy_add=py,
-                             ox_mul=2, ox_add=px, relu=int(relu))
-                fl = 2 * x.B * x.H * x.W * co * ci * 4
-                by = 4 * (x.B * x.H * x.W * (ci + co) + co * ci * 4)
-                self._emit_conv(d, x, wp, scale, shift, None, out,
-                                dict(kind="deconv", flops=fl, bytes=by))
-                self.flops += fl
+        w = weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        lib = self.lib
+        wp = torch.empty(lib.cn_packed_deconv4x4s2_weight_floats(ci, co), device=self.device,
+                         dtype=torch.float32)
+        native.check(lib.cn_pack_deconv4x4s2_weight_f32(native.ptr(w), native.ptr(wp), ci, co,
+                                                        native.stream_ptr()),
+                     "cn_pack_deconv4x4s2_weight_f32")
+        torch.cuda.current_stream().synchronize()
+        self.keep += [scale, shift, wp]
+        sp, hp, wpp = native.ptr(scale), native.ptr(shift), native.ptr(wp)
+
+        def run():
+            rc = lib.cn_conv_transpose4x4s2_f32(x.ptr(), wpp, sp, hp, out.ptr(), x.B, x.H, x.W, ci,
+                                                co, x.pitch, out.pitch, int(relu),
+                                                native.stream_ptr())
+            if rc:
+                native.check(rc, "cn_conv_transpose4x4s2_f32")
+        self.ops.append(run)
+        fl = 2 * x.B * (2 * x.H) * (2 * x.W) * co * ci * 4
+        by = 4 * (x.B * x.H * x.W * (ci + 4 * co) + co * ci * 16)
+        self.meta.append(dict(kind="deconv", flops=fl, bytes=by))
+        self.trace.append(("deconv", out))
+        self.flops += fl
         return out
 
     def maxpool(self, x, k, s, pad):
@@ -188,6 +191,70 @@ class PlanBuilder:
         self.meta.append(dict(kind="maxpool", flops=0,
                               bytes=4 * x.B * x.C * (x.H * x.W + Ho * Wo)))
         self.trace.append(("maxpool", out))
+        return out
+
+    def _emit_simple(self, fn, kind, out, nbytes):
+        self.ops.append(fn)
+        self.meta.append(dict(kind=kind, flops=0, bytes=nbytes))
+        self.trace.append((kind, out))
+
+    def concat(self, acts):
+        """torch.cat(acts, 1) (Root.forward, pose_dla_dcn.py:159): channel-slice copies into
+        one NHWC buffer."""
+        a0 = acts[0]
+        C = sum(a.C for a in acts)
+        out = self._new(a0.B, a0.H, a0.W, C)
+        lib = self.lib
+        npix = a0.B * a0.H * a0.W
+        off = 0
+        for a in acts:
+            assert (a.B, a.H, a.W) == (a0.B, a0.H, a0.W) and not a.nchw
+            dst = Act(out.t, out.B, out.H, out.W, a.C, pitch=C, c_off=off)
+
+            def run(a=a, dst=dst):
+                rc = lib.cn_copy_channels_f32(a.ptr(), a.pitch, dst.ptr(), C, npix, a.C,
+                                              native.stream_ptr())
+                if rc:
+                    native.check(rc, "cn_copy_channels_f32")
+            self._emit_simple(run, "copy", dst, 8 * npix * a.C)
+            off += a.C
+        return out
+
+    def dw_deconv(self, x, weight, f, add=None):
+        """Depthwise ConvTranspose2d(C, C, 2f, stride f, padding f//2, groups=C) + add
+        (IDAUp, pose_dla_dcn.py:370-373, 381-386)."""
+        C = x.C
+        assert tuple(weight.shape) == (C, 1, 2 * f, 2 * f) and x.pitch == C and x.c_off == 0
+        wt = weight.detach().to(device=self.device, dtype=torch.float32)
+        wt = wt[:, 0].permute(1, 2, 0).reshape(4 * f * f, C).contiguous()
+        self.keep.append(wt)
+        out = self._new(x.B, x.H * f, x.W * f, C)
+        lib = self.lib
+        wp = native.ptr(wt)
+        if add is not None:
+            assert (add.H, add.W, add.C, add.pitch, add.c_off) == (out.H, out.W, C, C, 0)
+
+        def run():
+            rc = lib.cn_dw_conv_transpose_f32(x.ptr(), wp, add.ptr() if add is not None else None,
+                                              out.ptr(), x.B, x.H, x.W, C, f, native.stream_ptr())
+            if rc:
+                native.check(rc, "cn_dw_conv_transpose_f32")
+        self._emit_simple(run, "dwdeconv", out,
+                          4 * x.B * C * (x.H * x.W + (2 if add is not None else 1) * out.H * out.W))
+        return out
+
+    def upsample2x_add(self, x, add=None):
+        """nn.Upsample(scale_factor=2) (nearest) + skip add (large_hourglass.py:102-109)."""
+        assert x.pitch == x.C and x.c_off == 0
+        out = self._new(x.B, 2 * x.H, 2 * x.W, x.C)
+        lib = self.lib
+
+        def run():
+            rc = lib.cn_upsample2x_add_f32(x.ptr(), add.ptr() if add is not None else None,
+                                           out.ptr(), x.B, x.H, x.W, x.C, native.stream_ptr())
+            if rc:
+                native.check(rc, "cn_upsample2x_add_f32")
+        self._emit_simple(run, "upsample", out, 4 * x.B * x.C * x.H * x.W * (1 + 4 + (4 if add is not None else 0)))
         return out
 
     def dcn(self, x, dcn_mod, bn=None, relu=False):

@@ -64,10 +64,22 @@ def _declare(lib):
     lib.cn_pack_conv_weight_f32.argtypes = [vp, vp, i, i, i, i, vp]
     lib.cn_conv2d_f32.restype = i
     lib.cn_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
+    lib.cn_packed_deconv4x4s2_weight_floats.restype = sz
+    lib.cn_packed_deconv4x4s2_weight_floats.argtypes = [i, i]
+    lib.cn_pack_deconv4x4s2_weight_f32.restype = i
+    lib.cn_pack_deconv4x4s2_weight_f32.argtypes = [vp, vp, i, i, vp]
+    lib.cn_conv_transpose4x4s2_f32.restype = i
+    lib.cn_conv_transpose4x4s2_f32.argtypes = [vp] * 5 + [i] * 8 + [vp]
     lib.cn_maxpool3x3s2_nhwc_f32.restype = i
     lib.cn_maxpool3x3s2_nhwc_f32.argtypes = [vp, vp, i, i, i, i, vp]
     lib.cn_maxpool_nhwc_f32.restype = i
     lib.cn_maxpool_nhwc_f32.argtypes = [vp, vp, i, i, i, i, i, i, i, vp]
+    lib.cn_dw_conv_transpose_f32.restype = i
+    lib.cn_dw_conv_transpose_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp]
+    lib.cn_copy_channels_f32.restype = i
+    lib.cn_copy_channels_f32.argtypes = [vp, i, vp, i, sz, i, vp]
+    lib.cn_upsample2x_add_f32.restype = i
+    lib.cn_upsample2x_add_f32.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.cn_nchw_to_nhwc_f32.restype = i
     lib.cn_nchw_to_nhwc_f32.argtypes = [vp, vp, i, i, i, i, i, vp]
     lib.cn_nhwc_to_nchw_f32.restype = i

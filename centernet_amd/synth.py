@@ -5,8 +5,8 @@ same seed gives the same bits here, on the GPU box and inside
 ``tests/golden/gen_golden.py`` -- independent of torch's initialisers.
 
 Recipe: He-normal conv weights; BatchNorm made non-trivial
-(gamma ~ U(0.5,1.5) -- U(0.1,0.4) on the closing BN of a residual branch so the trunk
-stays O(1) -- beta, running_mean ~ N(0,0.1), running_var ~ U(0.5,1.5));
+(gamma ~ U(0.75,1.25) -- U(0.15,0.35) on the closing BN of a residual branch so the trunk
+stays O(1) -- beta, running_mean ~ N(0,0.1), running_var ~ U(0.8,1.25));
 ``conv_offset_mask`` -- zero in the reference (DCNv2/dcn_v2.py:60-62) -- gets weights so
 that offsets spread over a few pixels and masks vary, otherwise the deformable gather
 would never leave the regular grid; ``hm`` output bias = -2.19 (resnet_dcn.py:165-166).
@@ -19,14 +19,17 @@ import torch
 
 def fill_state_dict_(module, seed=317):
     """Overwrite every parameter / buffer of ``module`` in place; returns the module."""
-    rng = np.random.RandomState(seed)
+    import zlib
     sd = module.state_dict()
-    keys = sorted(sd.keys())  # canonical order: independent of module registration order
+    keys = sorted(sd.keys())
     new = {}
     for k in keys:
         v = sd[k]
         if k.endswith("num_batches_tracked"):
             continue
+        # one stream per tensor, keyed by (seed, name): independent of registration order
+        # and of which other tensors exist (e.g. the unused base.fc of DLA checkpoints)
+        rng = np.random.RandomState((seed * 1000003 + zlib.crc32(k.encode())) & 0x7FFFFFFF)
         shape = tuple(v.shape)
         prefix = k.rsplit(".", 1)[0] if "." in k else ""
         leaf = k.rsplit(".", 1)[-1]
@@ -34,7 +37,7 @@ def fill_state_dict_(module, seed=317):
         if leaf == "running_mean":
             a = rng.standard_normal(shape) * 0.1
         elif leaf == "running_var":
-            a = rng.uniform(0.5, 1.5, size=shape)
+            a = rng.uniform(0.8, 1.25, size=shape)
         elif is_bn and leaf == "weight":
             # the last BN of a residual branch is damped (as zero-init-residual training
             # leaves it) so that activations stay O(1) through the trunk: with O(100)
@@ -43,24 +46,40 @@ def fill_state_dict_(module, seed=317):
             # inputs, which no real checkpoint is.
             tail = prefix.rsplit(".", 1)[-1]
             if tail in ("bn2", "bn3"):
-                a = rng.uniform(0.1, 0.4, size=shape)
+                a = rng.uniform(0.15, 0.35, size=shape)
+            elif ".actf." in k:
+                # BN after a DCN whose input is a sum of two maps (IDAUp node): keep the
+                # up-sampling pyramid from doubling its variance at every node
+                a = rng.uniform(0.45, 0.75, size=shape)
             else:
-                a = rng.uniform(0.5, 1.5, size=shape)
+                a = rng.uniform(0.75, 1.25, size=shape)
         elif is_bn and leaf == "bias":
             a = rng.standard_normal(shape) * 0.1
         elif v.dim() == 4:
             if "conv_offset_mask" in k:
                 fan_in = shape[1] * shape[2] * shape[3]
-                a = rng.standard_normal(shape) * (0.4 / math.sqrt(fan_in))
+                a = rng.standard_normal(shape) * (0.3 / math.sqrt(fan_in))
+            elif shape[1] == 1 and (".up_" in k or _is_transposed(module, prefix)):
+                # depthwise up-sampling (IDAUp): bilinear kernel (what fill_up_weights,
+                # pose_dla_dcn.py:329-338, initialises and training keeps close to) x jitter
+                kk = shape[2]
+                f = int(math.ceil(kk / 2))
+                c = (2 * f - 1 - f % 2) / (2.0 * f)
+                g = np.array([1 - abs(i / f - c) for i in range(kk)])
+                a = (g[:, None] * g[None, :])[None, None] * rng.uniform(0.8, 1.2, size=shape)
             elif ".up_" in k or _is_transposed(module, prefix):
                 # ConvTranspose2d weight is (Cin, Cout/groups, kh, kw)
-                fan_in = max(1, shape[0] * shape[2] * shape[3] // 4) if shape[1] > 1 else 4
+                fan_in = max(1, shape[0] * shape[2] * shape[3] // 4)
                 a = rng.standard_normal(shape) * math.sqrt(2.0 / fan_in)
             else:
                 fan_in = shape[1] * shape[2] * shape[3]
-                gain = 2.0 if _is_dcn(module, prefix) else 1.0  # mask ~0.5 halves the signal
+                gain = 1.6 if _is_dcn(module, prefix) else 1.0  # mask ~0.5 halves the signal
                 if _is_head_out(k, sd):
-                    gain = 0.15  # logits std ~1 around the -2.19 bias: no saturated scores
+                    # logits std ~1 around the -2.19 bias for every arch (no saturated, tied
+                    # scores): scale by the head's input width F and hidden width hc
+                    first = sd.get(k.split(".")[0] + ".0.weight")
+                    F_in = first.shape[1] if first is not None and first.dim() == 4 else shape[1]
+                    gain = 0.5 * (64.0 / F_in) ** 0.66 * (shape[1] / 64.0) ** 0.8
                 a = rng.standard_normal(shape) * (gain * math.sqrt(2.0 / fan_in))
         elif leaf == "bias":
             if "conv_offset_mask" in k:

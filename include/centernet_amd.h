@@ -143,12 +143,41 @@ int cn_conv2d_f32(const cn_conv_desc *desc, const float *x, const float *w_packe
                   const float *scale, const float *shift, const float *residual,
                   float *y, void *stream);
 
+/* ------------------------------------------------------------------------
+ * ConvTranspose2d(kernel 4, stride 2, padding 1, bias=False) + BN(eval) + ReLU.
+ * Replaces the up-sampling layers of resnet_dcn.py:228-235 / msra_resnet.py
+ * (_make_deconv_layer).  Executed as the four output-parity 2x2 convolutions in
+ * ONE launch.  w_iohw is torch's (Cin,Cout,4,4) ConvTranspose2d weight.
+ * x (B,H,W,in_pitch) NHWC -> y (B,2H,2W,out_pitch) NHWC.
+ * ------------------------------------------------------------------------ */
+size_t cn_packed_deconv4x4s2_weight_floats(int Cin, int Cout);
+int cn_pack_deconv4x4s2_weight_f32(const float *w_iohw, float *w_packed, int Cin, int Cout,
+                                   void *stream);
+int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_packed, const float *scale,
+                               const float *shift, float *y_nhwc, int B, int H, int W, int Cin,
+                               int Cout, int in_pitch, int out_pitch, int relu, void *stream);
+
 /* 3x3 / stride-2 / pad-1 max pooling, NHWC (resnet_dcn.py:142). */
 int cn_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C,
                              void *stream);
 /* generic k x k / stride s max pooling NHWC (pose_dla_dcn.py:200 uses 2x2 s2) */
 int cn_maxpool_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, int k,
                         int s, int pad, void *stream);
+
+/* Depthwise ConvTranspose2d(C, C, kernel 2f, stride f, padding f/2, groups=C, bias=False)
+ * -- the up-sampling of IDAUp (pose_dla_dcn.py:370-373) -- fused with the element-wise
+ * add that follows it (IDAUp.forward, :385-386: node(layers[i] + layers[i-1])).
+ * x (B,H,W,C) NHWC; w_taps [(2f)*(2f)][C] (tap-major: w_taps[ky*2f+kx][c] = w[c,0,ky,kx]);
+ * add (B,fH,fW,C) or NULL; y (B,fH,fW,C). */
+int cn_dw_conv_transpose_f32(const float *x, const float *w_taps, const float *add, float *y,
+                             int B, int H, int W, int C, int f, void *stream);
+/* Channel-slice copy between NHWC tensors of different pitch (torch.cat(.., 1) of
+ * Root.forward, pose_dla_dcn.py:159). */
+int cn_copy_channels_f32(const float *src, int src_pitch, float *dst, int dst_pitch,
+                         size_t npix, int C, void *stream);
+/* Nearest x2 up-sampling + add of the skip branch (large_hourglass.py:102-109, 163-174). */
+int cn_upsample2x_add_f32(const float *x, const float *add, float *y, int B, int H, int W,
+                          int C, void *stream);
 
 /* Layout conversion at the API edge. */
 int cn_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W,

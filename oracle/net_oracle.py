@@ -111,6 +111,83 @@ def resnet_forward(sd, x, num_layers, heads, dcn_up):
         return {h: _head(x, sd, h) for h in heads}
 
 
+# ----------------------------------------------------------------------------- DLA-34
+# pose_dla_dcn.py: BasicBlock :31-62, Root :147-165, Tree :168-221, DLA :224-286,
+# DeformConv :345-357, IDAUp :360-386, DLAUp :390-413, DLASeg.forward :470-482
+_DLA_LEVELS = [1, 1, 1, 2, 2, 1]
+_DLA_CH = [16, 32, 64, 128, 256, 512]
+
+
+def _dla_block(x, sd, p, stride, residual=None):
+    if residual is None:
+        residual = x
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1), sd, p + ".bn1"))
+    out = _bn(F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".bn2")
+    return F.relu(out + residual)
+
+
+def _dla_tree(x, sd, p, levels, stride, level_root, residual=None, children=None):
+    children = [] if children is None else children
+    bottom = F.max_pool2d(x, stride, stride) if stride > 1 else x
+    if (p + ".project.0.weight") in sd:
+        residual = _t(p + ".project", _bn(F.conv2d(bottom, sd[p + ".project.0.weight"]), sd,
+                                          p + ".project.1"))
+    else:
+        residual = bottom
+    if level_root:
+        children.append(bottom)
+    if levels == 1:
+        x1 = _dla_block(x, sd, p + ".tree1", stride, residual)
+        x2 = _dla_block(x1, sd, p + ".tree2", 1)
+        cat = torch.cat([x2, x1] + children, 1)
+        y = _bn(F.conv2d(cat, sd[p + ".root.conv.weight"]), sd, p + ".root.bn")
+        return _t(p + ".root", F.relu(y))  # root_residual is False for dla34 (:310-312)
+    x1 = _dla_tree(x, sd, p + ".tree1", levels - 1, stride, False, residual)
+    children.append(x1)
+    return _dla_tree(x1, sd, p + ".tree2", levels - 1, 1, False, children=children)
+
+
+def _deform_conv(x, sd, p):
+    return F.relu(_bn(dcn(x, sd, p + ".conv"), sd, p + ".actf.0"))
+
+
+def _ida_up(layers, sd, p, startp, endp):
+    for i in range(startp + 1, endp):
+        k = str(i - startp)
+        w = sd[p + ".up_" + k + ".weight"]
+        f = w.shape[2] // 2
+        y = _deform_conv(layers[i], sd, p + ".proj_" + k)
+        y = F.conv_transpose2d(y, w, None, stride=f, padding=f // 2, output_padding=0,
+                               groups=w.shape[0])
+        layers[i] = _t(p + ".node_" + k, _deform_conv(y + layers[i - 1], sd, p + ".node_" + k))
+
+
+def dla34_forward(sd, x, heads, down_ratio=4, last_level=5):
+    sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+    first_level = {2: 1, 4: 2, 8: 3, 16: 4}[down_ratio]
+    with torch.no_grad():
+        x = F.relu(_bn(F.conv2d(x, sd["base.base_layer.0.weight"], None, 1, 3), sd,
+                       "base.base_layer.1"))
+        y = []
+        for i in range(6):
+            p = "base.level%d" % i
+            if i < 2:
+                x = F.relu(_bn(F.conv2d(x, sd[p + ".0.weight"], None, 2 if i == 1 else 1, 1), sd,
+                               p + ".1"))
+            else:
+                x = _dla_tree(x, sd, p, _DLA_LEVELS[i], 2, i >= 3)
+            y.append(_t("level%d" % i, x))
+        # DLAUp.forward
+        layers = list(y)
+        out = [layers[-1]]
+        for i in range(len(layers) - first_level - 1):
+            _ida_up(layers, sd, "dla_up.ida_%d" % i, len(layers) - i - 2, len(layers))
+            out.insert(0, layers[-1])
+        z = [out[i].clone() for i in range(last_level - first_level)]
+        _ida_up(z, sd, "ida_up", 0, len(z))
+        return {h: _head(z[-1], sd, h) for h in heads}
+
+
 def forward(arch, sd, x, heads):
     """arch string as in the reference's create_model ('res_18', 'resdcn_18', ...)."""
     name, _, n = arch.partition("_")
@@ -119,6 +196,8 @@ def forward(arch, sd, x, heads):
         return resnet_forward(sd, x, n, heads, dcn_up=False)
     if name == "resdcn":
         return resnet_forward(sd, x, n, heads, dcn_up=True)
+    if name == "dla" and n == 34:
+        return dla34_forward(sd, x, heads)
     raise NotImplementedError(arch)
 
 

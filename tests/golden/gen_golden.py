@@ -133,6 +133,7 @@ def gen_decode(ref_decode):
 
 # --------------------------------------------------------------------------- networks
 NET_HEADS = {"hm": 80, "wh": 2, "reg": 2}
+POSE_HEADS = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
 NET_INPUT = (1, 128, 128)  # B, H, W  (small so the fixture stays small)
 NET_SEED = 317             # reference default seed, src/lib/opts.py:43-44
 
@@ -181,6 +182,22 @@ def gen_nets():
         with torch.no_grad():
             ret = net(x)[-1]
         for h in NET_HEADS:
+            out["%s/%s" % (arch, h)] = ret[h].numpy()
+        sd = net.state_dict()
+        meta[arch] = {"keys": {k: list(v.shape) for k, v in sd.items()},
+                      "weights_sha": sha(*[sd[k].numpy() for k in sorted(sd)
+                                           if not k.endswith("num_batches_tracked")])}
+    # DLA-34 (pose_dla_dcn.DLASeg built directly, pretrained=False: no download), ctdet heads
+    # and multi_pose heads (opts.py:321-330), head_conv 256 (opts.py:246)
+    from models.networks import pose_dla_dcn
+    for arch, heads in (("dla_34", NET_HEADS), ("dla_34_pose", POSE_HEADS)):
+        net = pose_dla_dcn.DLASeg("dla34", dict(heads), pretrained=False, down_ratio=4,
+                                  final_kernel=1, last_level=5, head_conv=256)
+        synth.fill_state_dict_(net, NET_SEED)
+        net.eval()
+        with torch.no_grad():
+            ret = net(x)[-1]
+        for h in heads:
             out["%s/%s" % (arch, h)] = ret[h].numpy()
         sd = net.state_dict()
         meta[arch] = {"keys": {k: list(v.shape) for k, v in sd.items()},

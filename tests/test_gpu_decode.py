@@ -128,3 +128,33 @@ def test_full_size_properties(dev):
     d2 = ctdet_decode(logits[perm].contiguous(), wh[perm].contiguous(), reg[perm].contiguous(),
                       K=K, apply_sigmoid=True)
     assert torch.equal(d2, dets[perm])
+
+
+@pytest.mark.parametrize("name", ["pose_full", "pose_no_hm_hp", "pose_no_offsets"])
+def test_multi_pose_decode_bit_exact_vs_reference_golden(dev, gen, decode_golden, name):
+    from centernet_amd.decode import multi_pose_decode
+    z, _ = decode_golden
+    heat, wh, kps, reg, hm_hp, hp_offset, K = gen.pose_inputs(name)
+    dets = multi_pose_decode(_gpu(heat, dev), _gpu(wh, dev), _gpu(kps, dev), _gpu(reg, dev),
+                             _gpu(hm_hp, dev), _gpu(hp_offset, dev), K=K).cpu().numpy()
+    ref = z[name + "/dets"]
+    bad = dets.view(np.uint32) != ref.view(np.uint32)
+    assert not bad.any(), "%d mismatches, max abs %g" % (bad.sum(), np.abs(dets - ref).max())
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 128, 100), (1, 96, 160, 64), (3, 17, 23, 9)])
+def test_multi_pose_decode_vs_oracle(dev, shape):
+    from centernet_amd.decode import multi_pose_decode
+    B, H, W, K = shape
+    J = 17
+    heat = synth.heatmap((B, 1, H, W), 3)
+    wh = synth.uniform((B, 2, H, W), 0, 60, 4)
+    kps = synth.normal((B, 2 * J, H, W), 8.0, 5)
+    reg = synth.uniform((B, 2, H, W), 0, 1, 6)
+    hm_hp = np.sqrt(np.sqrt(synth.heatmap((B, J, H, W), 7))).astype(np.float32) * synth.heatmap((B, J, H, W), 8)
+    hp_offset = synth.uniform((B, 2, H, W), 0, 1, 9)
+    ref = cref.multi_pose_decode(heat, wh, kps, reg, hm_hp, hp_offset, K)
+    dets = multi_pose_decode(_gpu(heat, dev), _gpu(wh, dev), _gpu(kps, dev), _gpu(reg, dev),
+                             _gpu(hm_hp, dev), _gpu(hp_offset, dev), K=K).cpu().numpy()
+    bad = dets.view(np.uint32) != ref.view(np.uint32)
+    assert not bad.any(), "%d mismatches, max abs %g" % (bad.sum(), np.abs(dets - ref).max())

@@ -13,21 +13,23 @@ pytestmark = pytest.mark.gpu
 
 def _model(arch, heads, seed, dev):
     from centernet_amd.model import create_model
-    m = create_model(arch, dict(heads), 64)
+    m = create_model(arch, dict(heads), 256 if arch.startswith("dla") else 64)
     synth.fill_state_dict_(m, seed)
     return m.to(dev).eval()
 
 
-@pytest.mark.parametrize("arch", ["res_18", "resdcn_18"])
-def test_heads_match_reference_golden(dev, gen, net_golden, arch):
+@pytest.mark.parametrize("case", ["res_18", "resdcn_18", "dla_34", "dla_34_pose"])
+def test_heads_match_reference_golden(dev, gen, net_golden, case):
     z, meta = net_golden
-    m = _model(arch, gen.NET_HEADS, gen.NET_SEED, dev)
+    heads = gen.POSE_HEADS if case.endswith("_pose") else gen.NET_HEADS
+    arch = case.replace("_pose", "")
+    m = _model(arch, heads, gen.NET_SEED, dev)
     B, H, W = gen.NET_INPUT
     x = synth.images(B, H, W, seed=0)
     with torch.no_grad():
         out = m(x.to(dev))[-1]
-    for h in gen.NET_HEADS:
-        ref = z["%s/%s" % (arch, h)]
+    for h in heads:
+        ref = z["%s/%s" % (case, h)]
         got = out[h].cpu().numpy()
         assert got.shape == ref.shape
         # fp32 tolerance relative to the map's scale (north_star: 1e-4 fp32)
@@ -36,7 +38,7 @@ def test_heads_match_reference_golden(dev, gen, net_golden, arch):
         assert err < 1e-4, (h, err)
 
 
-@pytest.mark.parametrize("arch,B", [("resdcn_18", 2), ("res_18", 1)])
+@pytest.mark.parametrize("arch,B", [("resdcn_18", 2), ("res_18", 1), ("dla_34", 1)])
 def test_end_to_end_boxes_512(dev, arch, B):
     """512x512 input: network + fused sigmoid/decode vs oracle process()."""
     from centernet_amd.decode import ctdet_decode
