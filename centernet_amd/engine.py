@@ -294,29 +294,36 @@ class PlanBuilder:
 
     def heads(self, x, head_modules):
         """Per head: conv3x3(F->head_conv)+ReLU+conv1x1(head_conv->classes)
-        (resnet_dcn.py:155-177).  The 3x3 convolutions of all heads read the same
-        feature map, so they run as ONE launch with concatenated output channels; each
-        1x1 then reads its channel slice and writes the NCHW map the decode consumes."""
-        names = list(head_modules.keys())
+        (resnet_dcn.py:155-177, pose_dla_dcn.py:446-468) or a single 1x1 when head_conv=0."""
+        seqs = {n: m for n, m in head_modules.items()}
+        if all(isinstance(s, torch.nn.Sequential) for s in seqs.values()):
+            return self.heads_from_convs(x, {n: (s[0], s[-1]) for n, s in seqs.items()})
         outs = {}
-        seqs = [head_modules[n] for n in names]
-        if all(isinstance(s, torch.nn.Sequential) for s in seqs):
-            w = torch.cat([s[0].weight.detach() for s in seqs], 0)
-            b = torch.cat([s[0].bias.detach() for s in seqs], 0)
-            k = seqs[0][0].kernel_size[0]
-            mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2)
-            off = 0
-            for n, s in zip(names, seqs):
-                hc = s[0].weight.shape[0]
-                sl = Act(mid.t, mid.B, mid.H, mid.W, hc, pitch=mid.pitch, c_off=off)
-                last = s[-1]
-                outs[n] = self.conv(sl, last.weight, bias=last.bias, stride=1,
-                                    padding=last.kernel_size[0] // 2, out_nchw=True)
-                off += hc
-        else:
-            for n, s in zip(names, seqs):
-                outs[n] = self.conv(x, s.weight, bias=s.bias, stride=1,
-                                    padding=s.kernel_size[0] // 2, out_nchw=True)
+        for n, s in seqs.items():
+            outs[n] = self.conv(x, s.weight, bias=s.bias, stride=1, padding=s.kernel_size[0] // 2,
+                                out_nchw=True)
+        return outs
+
+    def heads_from_convs(self, x, pairs):
+        """``pairs``: name -> (first conv kxk + ReLU, last conv).  The first convolutions of
+        all heads read the same feature map, so they run as ONE launch with concatenated
+        output channels; each last conv then reads its channel slice and writes the NCHW
+        map the decode consumes."""
+        names = list(pairs.keys())
+        firsts = [pairs[n][0] for n in names]
+        w = torch.cat([c.weight.detach() for c in firsts], 0)
+        b = torch.cat([c.bias.detach() for c in firsts], 0)
+        k = firsts[0].kernel_size[0]
+        mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2)
+        outs = {}
+        off = 0
+        for n in names:
+            first, last = pairs[n]
+            hc = first.weight.shape[0]
+            sl = Act(mid.t, mid.B, mid.H, mid.W, hc, pitch=mid.pitch, c_off=off)
+            outs[n] = self.conv(sl, last.weight, bias=last.bias, stride=1,
+                                padding=last.kernel_size[0] // 2, out_nchw=True)
+            off += hc
         return outs
 
 

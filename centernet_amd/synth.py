@@ -47,6 +47,10 @@ def fill_state_dict_(module, seed=317):
             tail = prefix.rsplit(".", 1)[-1]
             if tail in ("bn2", "bn3"):
                 a = rng.uniform(0.15, 0.35, size=shape)
+            elif k.startswith(("cnvs.", "cnvs_.", "inters_.")):
+                # hourglass: each stack multiplies the activation scale by ~6 (identity
+                # skips + five merge adds); the BN that closes a stack brings it back to O(1)
+                a = rng.uniform(0.1, 0.2, size=shape)
             elif ".actf." in k:
                 # BN after a DCN whose input is a sum of two maps (IDAUp node): keep the
                 # up-sampling pyramid from doubling its variance at every node
@@ -136,14 +140,21 @@ def _is_hm_out(key, sd):
 
 
 def _is_last_of_head(parts, sd):
-    if len(parts) == 2:
+    """True if the key belongs to the LAST conv of its head: 'hm.weight', 'hm.2.weight'
+    (resnet/dla heads), 'hm.1.1.weight' (hourglass: head[stack][1])."""
+    path = parts[:-1]
+    if len(path) == 1:
         return True
-    if len(parts) == 3 and parts[1].isdigit():
-        nxt = "%s.%d.weight" % (parts[0], int(parts[1]) + 1)
-        later = [k for k in sd if k.startswith(parts[0] + ".") and k.endswith(".weight")
-                 and k.split(".")[1].isdigit() and int(k.split(".")[1]) > int(parts[1])]
-        return nxt not in sd and not later
-    return False
+    if not path[-1].isdigit():
+        return False
+    prefix = ".".join(path[:-1]) + "."
+    idx = int(path[-1])
+    for k in sd:
+        if k.startswith(prefix):
+            rest = k[len(prefix):].split(".")
+            if rest[0].isdigit() and int(rest[0]) > idx:
+                return False
+    return True
 
 
 def images(B, H=512, W=512, seed=0):

@@ -188,6 +188,69 @@ def dla34_forward(sd, x, heads, down_ratio=4, last_level=5):
         return {h: _head(z[-1], sd, h) for h in heads}
 
 
+# ----------------------------------------------------------------------------- Hourglass-104
+# large_hourglass.py: convolution :17-30, residual :48-74, kp_module.forward :163-174,
+# exkp.forward :250-274, HourglassNet :283-296
+_HG_MODULES = [2, 2, 2, 2, 2, 4]
+
+
+def _hg_conv(x, sd, p, k, stride=1, with_bn=True):
+    y = F.conv2d(x, sd[p + ".conv.weight"], sd.get(p + ".conv.bias"), stride, (k - 1) // 2)
+    if with_bn:
+        y = _bn(y, sd, p + ".bn")
+    return F.relu(y)
+
+
+def _hg_res(x, sd, p, stride=1):
+    y = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1), sd, p + ".bn1"))
+    y = _bn(F.conv2d(y, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".bn2")
+    skip = x
+    if (p + ".skip.0.weight") in sd:
+        skip = _bn(F.conv2d(x, sd[p + ".skip.0.weight"], None, stride, 0), sd, p + ".skip.1")
+    return F.relu(y + skip)
+
+
+def _hg_seq(x, sd, p, n, first_stride=1):
+    for i in range(n):
+        x = _hg_res(x, sd, "%s.%d" % (p, i), first_stride if i == 0 else 1)
+    return x
+
+
+def _hg_kp(x, sd, p, n, mods):
+    up1 = _hg_seq(x, sd, p + ".up1", mods[0])
+    low1 = _hg_seq(x, sd, p + ".low1", mods[0], first_stride=2)   # max1 is an empty Sequential
+    if n > 1:
+        low2 = _hg_kp(low1, sd, p + ".low2", n - 1, mods[1:])
+    else:
+        low2 = _hg_seq(low1, sd, p + ".low2", mods[1])
+    low3 = _hg_seq(low2, sd, p + ".low3", mods[0])
+    up2 = F.interpolate(low3, scale_factor=2, mode="nearest")       # nn.Upsample(scale_factor=2)
+    return _t(p, up1 + up2)
+
+
+def hourglass_forward(sd, x, heads, nstack=2, all_stacks=False):
+    sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        inter = _hg_conv(x, sd, "pre.0", 7, 2)
+        inter = _t("pre", _hg_res(inter, sd, "pre.1", 2))
+        outs = []
+        for ind in range(nstack):
+            kp = _hg_kp(inter, sd, "kps.%d" % ind, 5, _HG_MODULES)
+            cnv = _t("cnv%d" % ind, _hg_conv(kp, sd, "cnvs.%d" % ind, 3))
+            if all_stacks or ind == nstack - 1:
+                out = {}
+                for h in heads:
+                    y = _hg_conv(cnv, sd, "%s.%d.0" % (h, ind), 3, with_bn=False)
+                    out[h] = F.conv2d(y, sd["%s.%d.1.weight" % (h, ind)], sd["%s.%d.1.bias" % (h, ind)])
+                outs.append(out)
+            if ind < nstack - 1:
+                a = _bn(F.conv2d(inter, sd["inters_.%d.0.weight" % ind]), sd, "inters_.%d.1" % ind)
+                b = _bn(F.conv2d(cnv, sd["cnvs_.%d.0.weight" % ind]), sd, "cnvs_.%d.1" % ind)
+                inter = F.relu(a + b)
+                inter = _t("inter%d" % ind, _hg_res(inter, sd, "inters.%d" % ind))
+        return outs if all_stacks else outs[-1]
+
+
 def forward(arch, sd, x, heads):
     """arch string as in the reference's create_model ('res_18', 'resdcn_18', ...)."""
     name, _, n = arch.partition("_")
@@ -198,6 +261,8 @@ def forward(arch, sd, x, heads):
         return resnet_forward(sd, x, n, heads, dcn_up=True)
     if name == "dla" and n == 34:
         return dla34_forward(sd, x, heads)
+    if name == "hourglass":
+        return hourglass_forward(sd, x, heads)
     raise NotImplementedError(arch)
 
 

@@ -203,6 +203,19 @@ def gen_nets():
         meta[arch] = {"keys": {k: list(v.shape) for k, v in sd.items()},
                       "weights_sha": sha(*[sd[k].numpy() for k in sorted(sd)
                                            if not k.endswith("num_batches_tracked")])}
+    # Hourglass-104 (large_hourglass.HourglassNet, 2 stacks); the detector uses outs[-1]
+    from models.networks import large_hourglass
+    net = large_hourglass.HourglassNet(dict(NET_HEADS), 2)
+    synth.fill_state_dict_(net, NET_SEED)
+    net.eval()
+    with torch.no_grad():
+        ret = net(x)[-1]
+    for h in NET_HEADS:
+        out["hourglass/%s" % h] = ret[h].numpy()
+    sd = net.state_dict()
+    meta["hourglass"] = {"keys": {k: list(v.shape) for k, v in sd.items()},
+                         "weights_sha": sha(*[sd[k].numpy() for k in sorted(sd)
+                                              if not k.endswith("num_batches_tracked")])}
     np.savez_compressed(os.path.join(HERE, "net_golden.npz"), **out)
     with open(os.path.join(HERE, "net_golden.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

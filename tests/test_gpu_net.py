@@ -18,7 +18,7 @@ def _model(arch, heads, seed, dev):
     return m.to(dev).eval()
 
 
-@pytest.mark.parametrize("case", ["res_18", "resdcn_18", "dla_34", "dla_34_pose"])
+@pytest.mark.parametrize("case", ["res_18", "resdcn_18", "dla_34", "dla_34_pose", "hourglass"])
 def test_heads_match_reference_golden(dev, gen, net_golden, case):
     z, meta = net_golden
     heads = gen.POSE_HEADS if case.endswith("_pose") else gen.NET_HEADS
