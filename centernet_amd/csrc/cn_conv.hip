@@ -64,9 +64,10 @@ struct IgemmArgs {
 
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW>
+template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
 __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 {
+    static_assert(NBUF == 1 || NBUF == 2, "LDS tile buffers");
     static_assert(WM * WN == NT / CN_WAVE, "4 waves");
     constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
     constexpr int MB = TM / 32, NB = TN / 32;  // 32x32 MFMA blocks per wave
@@ -75,9 +76,13 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     constexpr int PB = BN / 32;  // B rows per thread per chunk
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *As = reinterpret_cast<float *>(smem);  // [2][BM][LDT]
-    float *Bs = As + 2 * BM * LDT;                // [2][BN][LDT]
-    int *rowoff = reinterpret_cast<int *>(Bs + 2 * BN * LDT);  // [BM]
+    // layout: [tiles | epilogue staging] (union), then rowoff, then the DCN records
+    constexpr int TILE_FLOATS = NBUF * (BM + BN) * LDT;
+    constexpr int CS_FLOATS = OUT_NCHW ? 0 : (BM / WM) * (BN + 4);
+    constexpr int UNION_FLOATS = TILE_FLOATS > CS_FLOATS ? TILE_FLOATS : CS_FLOATS;
+    float *As = reinterpret_cast<float *>(smem);  // [NBUF][BM][LDT]
+    float *Bs = As + NBUF * BM * LDT;             // [NBUF][BN][LDT]
+    int *rowoff = reinterpret_cast<int *>(As + UNION_FLOATS);  // [BM]
     // DCN sampling parameters per (row, tap): 4 corner pixel indices, 4 weights, mask
     int *sidx = rowoff + BM;                               // [BM*9*4]
     float *swt = reinterpret_cast<float *>(sidx + BM * 36);  // [BM*9*4]
@@ -323,38 +328,39 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         }
     };
 
-    // ---- main loop: LDS double buffer + register prefetch, one barrier / chunk
+    // ---- main loop: register prefetch of chunk k+1 during the MFMAs of chunk k.
+    // NBUF=2: LDS double buffer, one barrier per chunk.  NBUF=1: half the LDS (more
+    // workgroups per CU hide the second barrier), two barriers per chunk.
     load_tiles(0);
     store_tiles(0, 0);
     __syncthreads();
     for (int kt = 0; kt < a.KT; ++kt) {
-        const int buf = kt & 1;
         const bool more = (kt + 1) < a.KT;
         if (more) load_tiles(kt + 1);
-        compute(buf);
-        if (more) store_tiles(buf ^ 1, kt + 1);
-        __syncthreads();
+        if (NBUF == 2) {
+            const int buf = kt & 1;
+            compute(buf);
+            if (more) store_tiles(buf ^ 1, kt + 1);
+            __syncthreads();
+        } else {
+            compute(0);
+            __syncthreads();
+            if (more) store_tiles(0, kt + 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: y = relu?((acc + bias) * scale + shift + residual)
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (!OUT_NCHW) {
         // Stage the tile through LDS (As/Bs are free after the loop's last barrier) so that
-        // residual loads and output stores are 16-byte, row-contiguous accesses.
+        // residual loads and output stores are 16-byte, row-contiguous accesses.  One pass
+        // per wave-row (TM rows) keeps the staging buffer at TM x (BN+4) floats.
         constexpr int LDC = BN + 4;
         float *Cs = reinterpret_cast<float *>(smem);
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    Cs[row * LDC + wn * TN + j * 32 + l31] = acc[i][j][r];
-                }
-        __syncthreads();
         constexpr int C4 = BN / 4;    // float4 columns per tile row
-        constexpr int RPI = NT / C4;  // tile rows covered per pass
+        constexpr int RPI = NT / C4;  // tile rows covered per pass of the block
+        constexpr int ITERS = (TM + RPI - 1) / RPI;
         const int c4 = tid % C4, r0 = tid / C4;
         const int n = n0 + c4 * 4;
         float bs[4], sc[4], sf[4];
@@ -366,38 +372,59 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
             sf[e] = (a.shift && ok) ? a.shift[n + e] : 0.f;
         }
         const bool vec = a.vec_out && (n + 4 <= a.Cout);
-        if (vec) {
-            cn_f32x4 res[BM / RPI];
-            int offs[BM / RPI];
+#pragma unroll 1
+        for (int pass = 0; pass < WM; ++pass) {
+            if (pass) __syncthreads();  // previous pass fully read
+            if (wm == pass) {
 #pragma unroll
-            for (int it = 0; it < BM / RPI; ++it) {
-                offs[it] = rowoff[it * RPI + r0];
-                if (a.residual) {
-                    const size_t o = (size_t)(offs[it] >= 0 ? offs[it] : 0) * a.out_pitch + n;
-                    res[it] = *reinterpret_cast<const cn_f32x4 *>(a.residual + o);
-                }
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            Cs[row * LDC + wn * TN + j * 32 + l31] = acc[i][j][r];
+                        }
             }
+            __syncthreads();
+            const int rbase = pass * TM;  // tile row of staging row 0
+            if (vec) {
+                cn_f32x4 res[ITERS];
+                int offs[ITERS];
 #pragma unroll
-            for (int it = 0; it < BM / RPI; ++it) {
-                if (offs[it] < 0) continue;
-                cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(Cs + (it * RPI + r0) * LDC + c4 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = (v[e] + bs[e]) * sc[e] + sf[e];
-                    if (a.residual) t += res[it][e];
-                    v[e] = a.relu ? fmaxf(t, 0.f) : t;
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lr = it * RPI + r0;
+                    offs[it] = (lr < TM) ? rowoff[rbase + lr] : -1;
+                    if (a.residual) {
+                        const size_t o = (size_t)(offs[it] >= 0 ? offs[it] : 0) * a.out_pitch + n;
+                        res[it] = *reinterpret_cast<const cn_f32x4 *>(a.residual + o);
+                    }
                 }
-                *reinterpret_cast<cn_f32x4 *>(a.y + (size_t)offs[it] * a.out_pitch + n) = v;
-            }
-        } else if (n < a.Cout) {
-            for (int it = 0; it < BM / RPI; ++it) {
-                const int off = rowoff[it * RPI + r0];
-                if (off < 0) continue;
-                for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
-                    const size_t o = (size_t)off * a.out_pitch + n + e;
-                    float t = (Cs[(it * RPI + r0) * LDC + c4 * 4 + e] + bs[e]) * sc[e] + sf[e];
-                    if (a.residual) t += a.residual[o];
-                    a.y[o] = a.relu ? fmaxf(t, 0.f) : t;
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    if (offs[it] < 0) continue;
+                    cn_f32x4 v =
+                        *reinterpret_cast<const cn_f32x4 *>(Cs + (it * RPI + r0) * LDC + c4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = (v[e] + bs[e]) * sc[e] + sf[e];
+                        if (a.residual) t += res[it][e];
+                        v[e] = a.relu ? fmaxf(t, 0.f) : t;
+                    }
+                    *reinterpret_cast<cn_f32x4 *>(a.y + (size_t)offs[it] * a.out_pitch + n) = v;
+                }
+            } else if (n < a.Cout) {
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lr = it * RPI + r0;
+                    if (lr >= TM) continue;
+                    const int off = rowoff[rbase + lr];
+                    if (off < 0) continue;
+                    for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
+                        const size_t o = (size_t)off * a.out_pitch + n + e;
+                        float t = (Cs[lr * LDC + c4 * 4 + e] + bs[e]) * sc[e] + sf[e];
+                        if (a.residual) t += a.residual[o];
+                        a.y[o] = a.relu ? fmaxf(t, 0.f) : t;
+                    }
                 }
             }
         }
@@ -427,27 +454,48 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     }
 }
 
-template <int BM, int BN, int AMODE>
+template <int BM, int BN, int WM, int AMODE, bool OUT_NCHW, int NBUF>
 constexpr size_t igemm_lds_bytes()
 {
-    return (size_t)(2 * BM * LDT + 2 * BN * LDT) * 4 + BM * 4 +
+    constexpr size_t tiles = (size_t)NBUF * (BM + BN) * LDT;
+    constexpr size_t cs = OUT_NCHW ? 0 : (size_t)(BM / WM) * (BN + 4);
+    return (tiles > cs ? tiles : cs) * 4 + BM * 4 +
            (AMODE == A_DCN ? (size_t)BM * (36 * 4 + 36 * 4 + 9 * 4) : 0);
+}
+
+int g_tune_nbuf = 0;  // 0 = per-shape default, 1 / 2 = force (cn_set_tuning key 1)
+int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-wide tiles
+
+template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
+int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
+{
+    constexpr size_t lds = igemm_lds_bytes<BM, BN, WM, AMODE, OUT_NCHW, NBUF>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(
+            (const void *)igemm_kernel<BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>,
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : 1);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), grid, dim3(NT), lds,
+                       st, a);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
 }
 
 template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW>
 int launch_igemm(const IgemmArgs &a, hipStream_t st)
 {
-    constexpr size_t lds = igemm_lds_bytes<BM, BN, AMODE>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, AMODE, OUT_NCHW>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    // measured on MI355X (tools/bench_kernels.py, profiles/): single-buffered LDS (more
+    // workgroups per CU) wins for stride-1 layers, double-buffered for strided gathers
+    int nbuf = g_tune_nbuf ? g_tune_nbuf : (a.stride == 1 ? 1 : 2);
+    if (AMODE != A_DENSE || OUT_NCHW) nbuf = 2;  // only the dense NHWC kernels carry both forms
+    if (nbuf == 1) {
+        if constexpr (AMODE == A_DENSE && !OUT_NCHW)
+            return launch_igemm_n<BM, BN, WM, WN, AMODE, OUT_NCHW, 1>(a, st);
     }
-    dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : 1);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, AMODE, OUT_NCHW>), grid, dim3(NT), lds, st, a);
-    CN_CHECK_LAUNCH();
-    return CN_OK;
+    return launch_igemm_n<BM, BN, WM, WN, AMODE, OUT_NCHW, 2>(a, st);
 }
 
 // ---- weight packing: (Cout,Cin,KH,KW) -> [tap][cout_pad][cin_pad], zero padded
@@ -584,7 +632,11 @@ extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float 
         if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
         return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
     }
-    if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
+    // 128-wide N tiles unless their padding wastes a whole 64-wide tile (e.g. Cout = 192)
+    const int waste128 = cn_cdiv(d->Cout, 128) * 128 - d->Cout;
+    const int waste64 = cn_cdiv(d->Cout, 64) * 64 - d->Cout;
+    const bool narrow = !g_tune_narrow && (waste128 - waste64 >= 64);
+    if (d->Cout > 64 && !narrow) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
     if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
     return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);
 }
@@ -696,4 +748,17 @@ extern "C" int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_pa
     if (Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
     if (Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
     return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);
+}
+
+extern "C" int cn_set_tuning(int key, int value)
+{
+    if (key == 1 && value >= 0 && value <= 2) {
+        g_tune_nbuf = value;
+        return CN_OK;
+    }
+    if (key == 2 && (value == 0 || value == 1)) {
+        g_tune_narrow = value;
+        return CN_OK;
+    }
+    return CN_ERR_UNSUPPORTED;
 }

@@ -46,12 +46,15 @@ __device__ __forceinline__ float key2f(uint32_t k)
 }
 constexpr uint32_t KEY_ZERO = 0x80000000u;  // f2key(+0.0f)
 
+constexpr int MAXW = 16;  // waves of the largest workgroup that uses SelShared (1024 threads)
+
 struct SelShared {
     uint32_t hist[HBINS];
     u64 sel[KMAX];
-    uint32_t wsum[NT / CN_WAVE];
+    uint32_t wsum[MAXW];
     uint32_t cnt;
     uint32_t digit, need, bincount;
+    uint32_t ncand;
     uint32_t pad_[3];
 };
 static_assert(sizeof(SelShared) % 16 == 0, "keep the LDS carve 16-byte aligned");
@@ -69,10 +72,12 @@ __device__ __forceinline__ uint32_t pass_dmask(int p) { return (p == 2 || p == 5
 // (key & mask) >= prefix.  Elements whose score is exactly +0.0 (the ~89 % of a
 // heat-map that the peak test suppressed) are counted per wave instead of one
 // LDS atomic each, otherwise they would serialise on a single histogram bin.
-template <class ForEach>
+template <int TB, class ForEach>
 __device__ __forceinline__ void radix_select(ForEach &&for_each, uint32_t need0, SelShared &sh,
                                              u64 &out_prefix, u64 &out_mask)
 {
+    static_assert(HBINS % TB == 0 && TB / CN_WAVE <= MAXW, "block size");
+    constexpr int BPT = HBINS / TB;  // histogram bins owned by a thread
     const int tid = threadIdx.x;
     const int lane = tid & (CN_WAVE - 1);
     const int wave = tid / CN_WAVE;
@@ -83,7 +88,7 @@ __device__ __forceinline__ void radix_select(ForEach &&for_each, uint32_t need0,
     for (int pass = 0; pass < 6; ++pass) {
         const int shift = pass_shift(pass);
         const uint32_t dmask = pass_dmask(pass);
-        for (int i = tid; i < HBINS; i += NT) sh.hist[i] = 0;
+        for (int i = tid; i < HBINS; i += TB) sh.hist[i] = 0;
         __syncthreads();
         uint32_t zc = 0;
         for_each([&](u64 k, bool plain_zero) {
@@ -99,10 +104,10 @@ __device__ __forceinline__ void radix_select(ForEach &&for_each, uint32_t need0,
             if (lane == 0 && zc) atomicAdd(&sh.hist[(uint32_t)(zkey >> shift) & dmask], zc);
         }
         __syncthreads();
-        // suffix sums over bins: thread t owns bins [8t, 8t+8)
+        // suffix sums over bins: thread t owns bins [BPT*t, BPT*t + BPT)
         uint32_t p = 0;
 #pragma unroll
-        for (int j = 0; j < HBINS / NT; ++j) p += sh.hist[tid * (HBINS / NT) + j];
+        for (int j = 0; j < BPT; ++j) p += sh.hist[tid * BPT + j];
         uint32_t s = p;
 #pragma unroll
         for (int o = 1; o < CN_WAVE; o <<= 1) {
@@ -111,14 +116,14 @@ __device__ __forceinline__ void radix_select(ForEach &&for_each, uint32_t need0,
         }
         if (lane == 0) sh.wsum[wave] = s;
         __syncthreads();
-        for (int w = wave + 1; w < NT / CN_WAVE; ++w) s += sh.wsum[w];
+        for (int w = wave + 1; w < TB / CN_WAVE; ++w) s += sh.wsum[w];
         const uint32_t above = s - p;  // elements in strictly higher bins
         if (above < need && s >= need) {
             uint32_t run = above;
-            for (int j = HBINS / NT - 1; j >= 0; --j) {
-                const uint32_t h = sh.hist[tid * (HBINS / NT) + j];
+            for (int j = BPT - 1; j >= 0; --j) {
+                const uint32_t h = sh.hist[tid * BPT + j];
                 if (run + h >= need) {
-                    sh.digit = tid * (HBINS / NT) + j;
+                    sh.digit = tid * BPT + j;
                     sh.need = need - run;
                     sh.bincount = h;
                     break;
@@ -136,15 +141,17 @@ __device__ __forceinline__ void radix_select(ForEach &&for_each, uint32_t need0,
     out_mask = mask;
 }
 
-// Collect the selected keys into sh.sel[0..KMAX) and sort them descending.
-template <class ForEach>
+// Collect the selected keys into sh.sel[0..KMAX) and sort them descending.  The sort is a
+// 128-element bitonic network run by ONE wave (two keys per lane, cross-lane exchange by
+// shuffles): no workgroup barriers inside the network.
+template <int TB, class ForEach>
 __device__ __forceinline__ void collect_and_sort(ForEach &&for_each, u64 prefix, u64 mask,
                                                  SelShared &sh)
 {
     const int tid = threadIdx.x;
     __syncthreads();
     if (tid == 0) sh.cnt = 0;
-    for (int i = tid; i < KMAX; i += NT) sh.sel[i] = 0;  // pad keys sort last
+    for (int i = tid; i < KMAX; i += TB) sh.sel[i] = 0;  // pad keys sort last
     __syncthreads();
     for_each([&](u64 k, bool) {
         if ((k & mask) >= prefix) {
@@ -153,36 +160,56 @@ __device__ __forceinline__ void collect_and_sort(ForEach &&for_each, u64 prefix,
         }
     });
     __syncthreads();
-    // bitonic sort, descending, KMAX elements
-    for (int k = 2; k <= KMAX; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (tid < KMAX) {
-                const int ixj = tid ^ j;
-                if (ixj > tid) {
-                    const u64 a = sh.sel[tid], b = sh.sel[ixj];
-                    const bool desc = ((tid & k) == 0);
-                    if (desc ? (a < b) : (a > b)) {
-                        sh.sel[tid] = b;
-                        sh.sel[ixj] = a;
+    if (tid < CN_WAVE) {
+        const int lane = tid;
+        u64 v[2] = {sh.sel[lane], sh.sel[lane + CN_WAVE]};
+        for (int k = 2; k <= KMAX; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j == CN_WAVE) {  // partner = the lane's other slot (only when k == 128)
+                    const u64 hi = v[0] > v[1] ? v[0] : v[1];
+                    const u64 lo = v[0] > v[1] ? v[1] : v[0];
+                    v[0] = hi;
+                    v[1] = lo;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int i = s * CN_WAVE + lane;
+                        const uint32_t olo = __shfl_xor((uint32_t)v[s], j);
+                        const uint32_t ohi = __shfl_xor((uint32_t)(v[s] >> 32), j);
+                        const u64 o = ((u64)ohi << 32) | olo;
+                        const bool desc = (i & k) == 0;
+                        const bool lower = (i & j) == 0;
+                        const bool take_max = (lower == desc);
+                        v[s] = take_max ? (v[s] > o ? v[s] : o) : (v[s] > o ? o : v[s]);
                     }
                 }
             }
-            __syncthreads();
         }
+        sh.sel[lane] = v[0];
+        sh.sel[lane + CN_WAVE] = v[1];
     }
+    __syncthreads();
 }
 
 __device__ __forceinline__ float sigmoidf_ref(float x)
 {
-    // 1 / (1 + exp(-x)) in fp32, IEEE division (detectors/ctdet.py:31)
-    return 1.0f / (1.0f + expf(-x));
+    // 1 / (1 + exp(-x)) (detectors/ctdet.py:31): v_exp_f32 + v_rcp_f32, ~1e-7 of torch's value
+    return __frcp_rn(1.0f + __expf(-x));
 }
+
+constexpr int CAND_CAP = 4096;  // compacted positive peaks per band (uint16 tile offsets)
 
 // ---------------------------------------------------------------------------
 // kernel 1: per (image, class, row-band): sigmoid + 3x3 peak test + top-K
-// grid (nbands, C, B), block NT, dynamic LDS = sizeof(SelShared) + (R+2)*W*4
+// grid (nbands, C, B), block NT, dynamic LDS = SelShared | tile (R+2)*W floats | peak list
+//
+// Fast path: the peak test (four cells per step, horizontal 3-max shared between the three
+// rows) appends the tile offsets of the POSITIVE peaks -- about a ninth of the cells -- to a
+// compact LDS list with one wave-aggregated atomic per step; the exact radix select then
+// touches only that list.  If a band holds fewer than K positive peaks, or more than the
+// list can hold (constant maps, tiny maps, negative "heat"), the kernel falls back to a
+// full scan that re-evaluates the peak test per element, so every input is still exact.
 // ---------------------------------------------------------------------------
-template <int EPT>
 __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ heat, int C, int H,
                                                       int W, int K, int R, int apply_sigmoid,
                                                       float *__restrict__ cand_score,
@@ -193,36 +220,61 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
     float *tile = reinterpret_cast<float *>(smem + sizeof(SelShared));
 
     const int tid = threadIdx.x;
+    const int lane = tid & (CN_WAVE - 1);
     const int band = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
     const int nbands = gridDim.x;
     const int r0 = band * R;
     const int rows = min(R, H - r0);  // rows of this band
     const int n_band = rows * W;
+    const int trows = rows + 2;
+    uint16_t *clist = reinterpret_cast<uint16_t *>(tile + (size_t)(R + 2) * W);
     const float *plane = heat + ((size_t)b * C + c) * (size_t)H * W;
     const float NEG_INF = -__builtin_huge_valf();
+    // ablation bits for tools/bench_decode.py (never set through the Python API)
+    const bool dbg_noselect = (apply_sigmoid & 256) != 0;
+    const bool dbg_nonms = (apply_sigmoid & 512) != 0;
+    const bool dbg_slow = (apply_sigmoid & 1024) != 0;
+    apply_sigmoid &= 1;
+    if (tid == 0) sh.ncand = 0;
 
     // ---- stage rows r0-1 .. r0+rows (rows+2 rows) into LDS, sigmoid applied once
-    const int trows = rows + 2;
-    if ((W & 3) == 0) {
+    const bool vec = (W & 3) == 0;
+    if (vec) {
         const int w4 = W >> 2;
         const int nq = trows * w4;
-        for (int q = tid; q < nq; q += NT) {
-            const int tr = q / w4;
-            const int c4 = q - tr * w4;
-            const int gy = r0 - 1 + tr;
-            cn_f32x4 v;
-            if (gy >= 0 && gy < H) {
-                v = *reinterpret_cast<const cn_f32x4 *>(plane + (size_t)gy * W + c4 * 4);
-                if (apply_sigmoid) {
-                    v.x = sigmoidf_ref(v.x);
-                    v.y = sigmoidf_ref(v.y);
-                    v.z = sigmoidf_ref(v.z);
-                    v.w = sigmoidf_ref(v.w);
+        constexpr int U = 8;  // global loads in flight per thread before the first use
+        for (int q0 = tid; q0 < nq; q0 += U * NT) {
+            cn_f32x4 v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NT;
+                dst[u] = -1;
+                v[u].x = v[u].y = v[u].z = v[u].w = NEG_INF;
+                if (q < nq) {
+                    const int tr = q / w4;
+                    const int c4 = q - tr * w4;
+                    const int gy = r0 - 1 + tr;
+                    dst[u] = tr * W + c4 * 4;
+                    if (gy >= 0 && gy < H) {
+                        v[u] = *reinterpret_cast<const cn_f32x4 *>(plane + (size_t)gy * W + c4 * 4);
+                    } else {
+                        dst[u] |= 0x40000000;  // halo row outside the image: keep -inf
+                    }
                 }
-            } else {
-                v.x = v.y = v.z = v.w = NEG_INF;
             }
-            *reinterpret_cast<cn_f32x4 *>(tile + tr * W + c4 * 4) = v;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (dst[u] < 0) continue;
+                cn_f32x4 t = v[u];
+                if (apply_sigmoid && !(dst[u] & 0x40000000)) {
+                    t.x = sigmoidf_ref(t.x);
+                    t.y = sigmoidf_ref(t.y);
+                    t.z = sigmoidf_ref(t.z);
+                    t.w = sigmoidf_ref(t.w);
+                }
+                *reinterpret_cast<cn_f32x4 *>(tile + (dst[u] & 0x3FFFFFFF)) = t;
+            }
         }
     } else {
         const int ne = trows * W;
@@ -240,58 +292,108 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
     }
     __syncthreads();
 
-    // ---- 3x3 peak test (decode.py:9-15); results stay in registers as keys
-    uint32_t key[EPT];
-    {
-        int y = tid / W, x = tid - (tid / W) * W;
-        const int dy = NT / W, dx = NT - (NT / W) * W;
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int e = i * NT + tid;
-            uint32_t kk = 0;
-            if (e < n_band) {
-                const float *row = tile + (y + 1) * W + x;
-                const float v = row[0];
-                float m = fmaxf(row[-W], row[W]);
-                m = fmaxf(m, v);
-                if (x > 0) {
-                    m = fmaxf(m, row[-1]);
-                    m = fmaxf(m, row[-W - 1]);
-                    m = fmaxf(m, row[W - 1]);
-                }
-                if (x < W - 1) {
-                    m = fmaxf(m, row[1]);
-                    m = fmaxf(m, row[-W + 1]);
-                    m = fmaxf(m, row[W + 1]);
-                }
-                float val = (m == v) ? v : 0.0f;  // heat * keep
-                val += 0.0f;                       // -0.0 -> +0.0
-                kk = f2key(val);
+    // peak test of one cell (decode.py:9-15); t = offset of the cell in the tile
+    auto nms_val = [&](int t, int x) -> float {
+        const float *row = tile + t;
+        const float v = row[0];
+        float m = fmaxf(fmaxf(row[-W], row[W]), v);
+        if (x > 0) m = fmaxf(fmaxf(m, row[-1]), fmaxf(row[-W - 1], row[W - 1]));
+        if (x < W - 1) m = fmaxf(fmaxf(m, row[1]), fmaxf(row[-W + 1], row[W + 1]));
+        if (dbg_nonms) m = v;
+        return ((m == v) ? v : 0.0f) + 0.0f;  // heat * keep, -0.0 -> +0.0
+    };
+    // append the tile offset of a positive peak; one LDS atomic per wave per call
+    auto append = [&](bool is, int t) {
+        const u64 bal = __ballot(is);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&sh.ncand, (uint32_t)__popcll(bal));
+            base = __shfl(base, leader);
+            if (is) {
+                const uint32_t pos =
+                    base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (pos < (uint32_t)CAND_CAP) clist[pos] = (uint16_t)t;
             }
-            key[i] = kk;
-            x += dx;
-            y += dy;
-            if (x >= W) {
-                x -= W;
-                ++y;
-            }
-        }
-    }
-
-    const uint32_t base = (uint32_t)(r0 * W);
-    auto for_each = [&](auto &&f) {
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const int e = i * NT + tid;
-            if (e < n_band)
-                f(((u64)key[i] << 32) | (u64)(0xFFFFFFFFu - (base + (uint32_t)e)), key[i] == KEY_ZERO);
         }
     };
 
+    if (vec) {
+        const int w4 = W >> 2;
+        const int nq = rows * w4;
+        const int nqr = (nq + NT - 1) / NT * NT;  // whole waves take part in the ballots
+        for (int q = tid; q < nqr; q += NT) {
+            bool pk[4] = {false, false, false, false};
+            int t0 = 0;
+            if (q < nq) {
+                const int y = q / w4;
+                const int x4 = q - y * w4;
+                t0 = (y + 1) * W + x4 * 4;
+                float hm[4] = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+                cn_f32x4 ctr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dr = -1; dr <= 1; ++dr) {
+                    const float *row = tile + t0 + dr * W;
+                    const cn_f32x4 cv = *reinterpret_cast<const cn_f32x4 *>(row);
+                    const float l = (x4 > 0) ? row[-1] : NEG_INF;
+                    const float r = (x4 < w4 - 1) ? row[4] : NEG_INF;
+                    hm[0] = fmaxf(hm[0], fmaxf(fmaxf(l, cv.x), cv.y));
+                    hm[1] = fmaxf(hm[1], fmaxf(fmaxf(cv.x, cv.y), cv.z));
+                    hm[2] = fmaxf(hm[2], fmaxf(fmaxf(cv.y, cv.z), cv.w));
+                    hm[3] = fmaxf(hm[3], fmaxf(fmaxf(cv.z, cv.w), r));
+                    if (dr == 0) ctr = cv;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (dbg_nonms || hm[e] == ctr[e]) && ctr[e] > 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) append(pk[e], t0 + e);
+        }
+    } else {
+        const int nr = (n_band + NT - 1) / NT * NT;
+        for (int e = tid; e < nr; e += NT) {
+            bool is = false;
+            int t = 0;
+            if (e < n_band) {
+                const int y = e / W, x = e - y * W;
+                t = (y + 1) * W + x;
+                is = nms_val(t, x) > 0.0f;
+            }
+            append(is, t);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t base = (uint32_t)(r0 * W);
     const int kb = min(K, n_band);
+    const uint32_t npos = sh.ncand;
+    const bool fast = !dbg_slow && npos >= (uint32_t)kb && npos <= (uint32_t)CAND_CAP;
     u64 prefix, mask;
-    radix_select(for_each, (uint32_t)kb, sh, prefix, mask);
-    collect_and_sort(for_each, prefix, mask, sh);
+    if (dbg_noselect) {
+        if (tid < KMAX) sh.sel[tid] = npos;
+        __syncthreads();
+    } else if (fast) {
+        auto for_each = [&](auto &&f) {
+            for (uint32_t j = tid; j < npos; j += NT) {
+                const uint32_t t = clist[j];
+                f(((u64)f2key(tile[t]) << 32) | (u64)(0xFFFFFFFFu - (base + t - (uint32_t)W)), false);
+            }
+        };
+        radix_select<NT>(for_each, (uint32_t)kb, sh, prefix, mask);
+        collect_and_sort<NT>(for_each, prefix, mask, sh);
+    } else {
+        // exact fallback: every cell takes part (zeros from suppressed cells included)
+        auto for_each = [&](auto &&f) {
+            for (int e = tid; e < n_band; e += NT) {
+                const int y = e / W, x = e - y * W;
+                const uint32_t kk = f2key(nms_val((y + 1) * W + x, x));
+                f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - (base + (uint32_t)e)), kk == KEY_ZERO);
+            }
+        };
+        radix_select<NT>(for_each, (uint32_t)kb, sh, prefix, mask);
+        collect_and_sort<NT>(for_each, prefix, mask, sh);
+    }
 
     if (tid < K) {
         const size_t o = ((((size_t)b * C + c) * nbands) + band) * K + tid;
@@ -314,8 +416,10 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------------------
 enum { MODE_CTDET = 0, MODE_CHANNEL = 1, MODE_POSE = 2 };
 
+constexpr int NTM = 1024;  // the merge runs one workgroup per image: make it a big one
+
 template <int MODE>
-__global__ __launch_bounds__(NT) void merge_topk_kernel(
+__global__ __launch_bounds__(NTM) void merge_topk_kernel(
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int N,
     int per_class, int H, int W, int K, int C, const float *__restrict__ wh,
     const float *__restrict__ reg, int cat_spec_wh, float *__restrict__ dets, int det_dim,
@@ -332,7 +436,7 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(
     const int32_t *ci = cand_idx + (size_t)g * N;
 
     auto for_each = [&](auto &&f) {
-        for (int j = tid; j < N; j += NT) {
+        for (int j = tid; j < N; j += NTM) {
             const int32_t idx = ci[j];
             if (idx < 0) continue;
             const uint32_t kk = f2key(cs[j] + 0.0f);
@@ -341,8 +445,8 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(
         }
     };
     u64 prefix, mask;
-    radix_select(for_each, (uint32_t)K, sh, prefix, mask);
-    collect_and_sort(for_each, prefix, mask, sh);
+    radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
+    collect_and_sort<NTM>(for_each, prefix, mask, sh);
 
     if (tid < K) {
         const u64 k = sh.sel[tid];
@@ -389,35 +493,26 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(
 }
 
 struct BandPlan {
-    int ept;     // 16 or 64 register-resident elements per thread
     int R;       // rows per band
     int nbands;
     size_t lds;  // dynamic LDS bytes of kernel 1
 };
 
 // Deterministic function of the shapes only (workspace query == launch).
+// Bands of <= 8192 cells: tile + list + select state stay under ~52 KB, so three
+// workgroups share a CU and their load / peak-test / select phases overlap.
 bool make_band_plan(int B, int C, int H, int W, int K, BandPlan *bp)
 {
+    (void)B; (void)C;
     if (W <= 0 || H <= 0 || W > 4096) return false;
-    const int r64 = (64 * NT) / W;  // rows that fit 64 elements/thread
-    const int r16 = (16 * NT) / W;
-    int ept = 64, R = r64 < H ? r64 : H;
-    if (R < 1) return false;
-    const long blocks64 = (long)B * C * cn_cdiv(H, R);
-    if (blocks64 < 512 && r16 >= 1) {
-        // not enough workgroups to fill 256 CUs with whole planes: use short bands
-        int R16 = r16 < H ? r16 : H;
-        // a band should still be able to supply K candidates if it can
-        while (R16 < H && R16 * W < K) ++R16;
-        if (R16 * W <= 16 * NT) {
-            ept = 16;
-            R = R16;
-        }
-    }
-    bp->ept = ept;
+    int R = 8192 / W;
+    if (R < 1) R = 1;
+    if (R > H) R = H;
+    while (R < H && R * W < K) ++R;  // a band should be able to supply K candidates
+    if ((long)R * W > 16384) return false;
     bp->R = R;
     bp->nbands = cn_cdiv(H, R);
-    bp->lds = sizeof(SelShared) + (size_t)(R + 2) * W * sizeof(float);
+    bp->lds = sizeof(SelShared) + (size_t)(R + 2) * W * sizeof(float) + CAND_CAP * sizeof(uint16_t);
     return bp->lds <= 160 * 1024;
 }
 
@@ -425,25 +520,14 @@ int launch_nms_topk(const float *heat, int B, int C, int H, int W, int K, int ap
                     const BandPlan &bp, float *cand_score, int32_t *cand_idx, hipStream_t st)
 {
     dim3 grid(bp.nbands, C, B), block(NT);
-    if (bp.ept == 64) {
-        static bool attr64 = false;
-        if (!attr64) {
-            (void)hipFuncSetAttribute((const void *)nms_topk_kernel<64>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr64 = true;
-        }
-        hipLaunchKernelGGL(nms_topk_kernel<64>, grid, block, bp.lds, st, heat, C, H, W, K, bp.R,
-                           apply_sigmoid, cand_score, cand_idx);
-    } else {
-        static bool attr16 = false;
-        if (!attr16) {
-            (void)hipFuncSetAttribute((const void *)nms_topk_kernel<16>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr16 = true;
-        }
-        hipLaunchKernelGGL(nms_topk_kernel<16>, grid, block, bp.lds, st, heat, C, H, W, K, bp.R,
-                           apply_sigmoid, cand_score, cand_idx);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)nms_topk_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
     }
+    hipLaunchKernelGGL(nms_topk_kernel, grid, block, bp.lds, st, heat, C, H, W, K, bp.R,
+                       apply_sigmoid, cand_score, cand_idx);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -487,7 +571,7 @@ extern "C" int cn_ctdet_decode_f32(const float *heat, const float *wh, const flo
     int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
     rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
     if (rc != CN_OK) return rc;
-    hipLaunchKernelGGL(merge_topk_kernel<MODE_CTDET>, dim3(B), dim3(NT), sizeof(SelShared), st,
+    hipLaunchKernelGGL(merge_topk_kernel<MODE_CTDET>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg,
                        cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr, 0);
     CN_CHECK_LAUNCH();
@@ -515,7 +599,7 @@ extern "C" int cn_nms_topk_channel_f32(const float *heat, int B, int C, int H, i
     int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
     rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
     if (rc != CN_OK) return rc;
-    hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * C), dim3(NT), sizeof(SelShared),
+    hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * C), dim3(NTM), sizeof(SelShared),
                        st, cand_score, cand_idx, bp.nbands * K, bp.nbands * K, H, W, K, C,
                        (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0, inds,
                        scores, (const float *)nullptr, 0);
@@ -646,7 +730,7 @@ extern "C" int cn_multi_pose_decode_f32(const float *heat, const float *wh, cons
     // stage A
     rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_s, cand_i, st);
     if (rc != CN_OK) return rc;
-    hipLaunchKernelGGL(merge_topk_kernel<MODE_POSE>, dim3(B), dim3(NT), sizeof(SelShared), st,
+    hipLaunchKernelGGL(merge_topk_kernel<MODE_POSE>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_s, cand_i, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg, 0,
                        dets, D, (int32_t *)nullptr, (float *)nullptr, kps, J);
     CN_CHECK_LAUNCH();
@@ -658,7 +742,7 @@ extern "C" int cn_multi_pose_decode_f32(const float *heat, const float *wh, cons
     } else {
         rc = launch_nms_topk(hm_hp, B, J, H, W, K, apply_sigmoid, bph, cand_s, cand_i, st);
         if (rc != CN_OK) return rc;
-        hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * J), dim3(NT),
+        hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * J), dim3(NTM),
                            sizeof(SelShared), st, cand_s, cand_i, bph.nbands * K, bph.nbands * K, H,
                            W, K, J, (const float *)nullptr, (const float *)nullptr, 0,
                            (float *)nullptr, 0, hp_i, hp_s, (const float *)nullptr, 0);

@@ -38,7 +38,7 @@ def _prep(*ts):
 
 
 def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=False,
-                 return_inds=False):
+                 return_inds=False, _debug_flags=0):
     heat, wh, reg = _prep(heat, wh, reg)
     lib = native.lib()
     B, C, H, W = heat.shape
@@ -49,7 +49,7 @@ def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=Fal
     nbytes = lib.cn_ctdet_decode_workspace_bytes(B, C, H, W, K)
     ws = _workspace(nbytes, heat.device)
     rc = lib.cn_ctdet_decode_f32(native.ptr(heat), native.ptr(wh), native.ptr(reg), B, C, H, W, K,
-                                 int(bool(cat_spec_wh)), int(bool(apply_sigmoid)),
+                                 int(bool(cat_spec_wh)), int(bool(apply_sigmoid)) | int(_debug_flags),
                                  native.ptr(dets), native.ptr(inds), native.ptr(ws), ws.numel(),
                                  native.stream_ptr())
     native.check(rc, "cn_ctdet_decode_f32")

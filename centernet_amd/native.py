@@ -52,6 +52,8 @@ def _declare(lib):
     lib.cn_status_string.restype = ctypes.c_char_p
     lib.cn_status_string.argtypes = [i]
     lib.cn_arch.restype = ctypes.c_char_p
+    lib.cn_set_tuning.restype = i
+    lib.cn_set_tuning.argtypes = [i, i]
     lib.cn_dcn_v2_forward_workspace_bytes.restype = sz
     lib.cn_dcn_v2_forward_workspace_bytes.argtypes = [i] * 8
     lib.cn_dcn_v2_forward_f32.restype = i

@@ -126,7 +126,7 @@ _TRUNK = ("conv", "bn", "layer", "deconv", "base", "dla_up", "ida_up", "pre", "k
 def _is_head_out(key, sd):
     """weight/bias of the LAST conv of a head module ('hm.2.weight', 'wh.bias', ...)."""
     parts = key.split(".")
-    if parts[0].startswith(_TRUNK):
+    if len(parts) < 2 or parts[0].startswith(_TRUNK):
         return False
     return _is_last_of_head(parts, sd)
 
@@ -143,6 +143,8 @@ def _is_last_of_head(parts, sd):
     """True if the key belongs to the LAST conv of its head: 'hm.weight', 'hm.2.weight'
     (resnet/dla heads), 'hm.1.1.weight' (hourglass: head[stack][1])."""
     path = parts[:-1]
+    if len(path) == 0:
+        return False
     if len(path) == 1:
         return True
     if not path[-1].isdigit():

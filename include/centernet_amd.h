@@ -47,6 +47,11 @@ int cn_version(void);
 const char *cn_status_string(int status);
 /* Architecture the device code was compiled for ("gfx950"). */
 const char *cn_arch(void);
+/* Kernel-selection knobs for benchmarking (process-wide; not needed for correctness).
+ * key 1: LDS tile buffers of the dense implicit-GEMM kernels, 0 = default, 1 or 2.
+ * key 2: 1 = never pick 64-wide N tiles for Cout > 64 (default 0 = pick them when they
+ *        avoid a half-empty 128-wide tile). */
+int cn_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------
  * Deformable convolution v2, forward.

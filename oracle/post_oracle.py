@@ -1,0 +1,101 @@
+"""oracle/post_oracle.py -- TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+NumPy restatement of the host tail of the path, following the reference statement by
+statement (including its per-point Python loop):
+  transform_preds / get_affine_transform / affine_transform   utils/image.py:19-66
+  ctdet_post_process                                           utils/post_process.py:83-100
+  CtdetDetector.post_process / merge_outputs                   detectors/ctdet.py:47-73
+cv2.getAffineTransform (third-party, absent here) is restated as the exact solution of the
+3-point system in float64, which is what OpenCV computes; the closed-form cases in
+tests/test_host.py pin it (parity otherwise unpinned: no reference test covers it).
+"""
+import numpy as np
+
+
+def _get_dir(src_point, rot_rad):
+    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
+    return [src_point[0] * cs - src_point[1] * sn, src_point[0] * sn + src_point[1] * cs]
+
+
+def _third(a, b):
+    d = a - b
+    return b + np.array([-d[1], d[0]], dtype=np.float32)
+
+
+def _cv_get_affine(src, dst):
+    # 6x6 system exactly as OpenCV sets it up (imgwarp.cpp getAffineTransform)
+    A = np.zeros((6, 6), np.float64)
+    b = np.zeros(6, np.float64)
+    for i in range(3):
+        A[i, 0:3] = [src[i][0], src[i][1], 1]
+        A[i + 3, 3:6] = [src[i][0], src[i][1], 1]
+        b[i] = dst[i][0]
+        b[i + 3] = dst[i][1]
+    return np.linalg.solve(A, b).reshape(2, 3)
+
+
+def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0], dtype=np.float32),
+                         inv=0):
+    if not isinstance(scale, np.ndarray) and not isinstance(scale, list):
+        scale = np.array([scale, scale], dtype=np.float32)
+    src_w = scale[0]
+    dst_w, dst_h = output_size[0], output_size[1]
+    rot_rad = np.pi * rot / 180
+    src_dir = _get_dir([0, src_w * -0.5], rot_rad)
+    dst_dir = np.array([0, dst_w * -0.5], np.float32)
+    src = np.zeros((3, 2), dtype=np.float32)
+    dst = np.zeros((3, 2), dtype=np.float32)
+    src[0, :] = center + scale * shift
+    src[1, :] = center + src_dir + scale * shift
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + dst_dir
+    src[2:, :] = _third(src[0, :], src[1, :])
+    dst[2:, :] = _third(dst[0, :], dst[1, :])
+    return _cv_get_affine(np.float32(dst), np.float32(src)) if inv else \
+        _cv_get_affine(np.float32(src), np.float32(dst))
+
+
+def affine_transform(pt, t):
+    new_pt = np.array([pt[0], pt[1], 1.], dtype=np.float32).T
+    return np.dot(t, new_pt)[:2]
+
+
+def transform_preds(coords, center, scale, output_size):
+    target = np.zeros(coords.shape)
+    trans = get_affine_transform(center, scale, 0, output_size, inv=1)
+    for p in range(coords.shape[0]):
+        target[p, 0:2] = affine_transform(coords[p, 0:2], trans)
+    return target
+
+
+def ctdet_post_process(dets, c, s, h, w, num_classes):
+    ret = []
+    for i in range(dets.shape[0]):
+        top_preds = {}
+        dets[i, :, :2] = transform_preds(dets[i, :, 0:2], c[i], s[i], (w, h))
+        dets[i, :, 2:4] = transform_preds(dets[i, :, 2:4], c[i], s[i], (w, h))
+        classes = dets[i, :, -1]
+        for j in range(num_classes):
+            inds = (classes == j)
+            top_preds[j + 1] = np.concatenate(
+                [dets[i, inds, :4].astype(np.float32), dets[i, inds, 4:5].astype(np.float32)],
+                axis=1).tolist()
+        ret.append(top_preds)
+    return ret
+
+
+def ctdet_results(dets, meta, num_classes, scale=1, max_per_image=100):
+    """detectors/ctdet.py:47-73 for one image, single scale, no NMS."""
+    d = dets.reshape(1, -1, dets.shape[2]).copy()
+    d = ctdet_post_process(d, [meta['c']], [meta['s']], meta['out_height'], meta['out_width'],
+                           num_classes)[0]
+    for j in range(1, num_classes + 1):
+        d[j] = np.array(d[j], dtype=np.float32).reshape(-1, 5)
+        d[j][:, :4] /= scale
+    scores = np.hstack([d[j][:, 4] for j in range(1, num_classes + 1)])
+    if len(scores) > max_per_image:
+        kth = len(scores) - max_per_image
+        thresh = np.partition(scores, kth)[kth]
+        for j in range(1, num_classes + 1):
+            d[j] = d[j][d[j][:, 4] >= thresh]
+    return d

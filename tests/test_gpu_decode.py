@@ -158,3 +158,15 @@ def test_multi_pose_decode_vs_oracle(dev, shape):
                              _gpu(hm_hp, dev), _gpu(hp_offset, dev), K=K).cpu().numpy()
     bad = dets.view(np.uint32) != ref.view(np.uint32)
     assert not bad.any(), "%d mismatches, max abs %g" % (bad.sum(), np.abs(dets - ref).max())
+
+
+def test_full_scan_fallback_equals_compacted_path(dev):
+    """The kernel's exact fallback (taken for degenerate maps) and its compacted-peak fast
+    path must agree bit for bit on ordinary data (debug flag 1024 forces the fallback)."""
+    from centernet_amd.decode import ctdet_decode
+    B, C, H, W, K = 3, 20, 128, 128, 100
+    heat = torch.from_numpy(synth.heatmap((B, C, H, W), 5)).to(dev)
+    wh = torch.from_numpy(synth.uniform((B, 2, H, W), 0, 40, 6)).to(dev)
+    a, ia = ctdet_decode(heat, wh, None, K=K, return_inds=True)
+    b, ib = ctdet_decode(heat, wh, None, K=K, return_inds=True, _debug_flags=1024)
+    assert torch.equal(ia, ib) and torch.equal(a, b)

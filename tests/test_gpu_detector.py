@@ -1,0 +1,66 @@
+"""The reference's public API on the HIP path: opts().init -> detector_factory[task](opt)
+-> run(img) (README.md:101-116) and the prefetch-dict branch of test.py:35-42,70."""
+import numpy as np
+import pytest
+import torch
+
+from centernet_amd import synth
+from oracle import net_oracle, post_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _detector(arch, extra=()):
+    from centernet_amd.detectors import detector_factory
+    from centernet_amd.opts import opts
+    opt = opts().init(["ctdet", "--arch", arch] + list(extra))
+    det = detector_factory[opt.task](opt)
+    synth.fill_state_dict_(det.model, 317)
+    return det, opt
+
+
+def test_run_on_image_matches_oracle_pipeline(dev):
+    det, opt = _detector("resdcn_18")
+    rs = np.random.RandomState(0)
+    image = rs.randint(0, 256, (512, 512, 3)).astype(np.uint8)       # BGR uint8, like cv2.imread
+    ret = det.run(image)
+    assert set(ret) == {"results", "tot", "load", "pre", "net", "dec", "post", "merge"}
+    res = ret["results"]
+    assert sorted(res) == list(range(1, 81))
+    assert all(v.dtype == np.float32 and v.ndim == 2 and v.shape[1] == 5 for v in res.values())
+    assert sum(len(v) for v in res.values()) == 100
+    # oracle: same pre-processed tensor through the CPU restatement of the whole path
+    images, meta = det.pre_process(image, 1.0)
+    _, dets = net_oracle.ctdet_process("resdcn_18", det.model.state_dict(), images, list(opt.heads), K=opt.K)
+    ref = post_oracle.ctdet_results(dets, meta, opt.num_classes)
+    n_same = 0
+    for j in range(1, 81):
+        if len(ref[j]) == len(res[j]) and len(ref[j]):
+            a = res[j][np.argsort(-res[j][:, 4])]
+            b = ref[j][np.argsort(-ref[j][:, 4])]
+            assert np.abs(a[:, 4] - b[:, 4]).max() < 1e-4
+            assert np.abs(a[:, :4] - b[:, :4]).max() < 2e-3       # image pixels (x4 the grid)
+            n_same += len(a)
+    assert n_same >= 95
+
+
+def test_prefetch_dict_branch_and_flip_test(dev):
+    det, opt = _detector("resdcn_18", ["--flip_test"])
+    image = np.random.RandomState(1).randint(0, 256, (512, 512, 3)).astype(np.uint8)
+    images, meta = det.pre_process(image, 1.0)
+    assert tuple(images.shape) == (2, 3, 512, 512)               # flip_test doubles the batch
+    pre = {"images": {1.0: images[None]}, "image": torch.from_numpy(image)[None],
+           "meta": {1.0: {k: torch.from_numpy(np.asarray(v))[None] for k, v in meta.items()}}}
+    r1 = det.run(pre)["results"]
+    r2 = det.run(image)["results"]
+    for j in range(1, 81):
+        assert np.array_equal(r1[j], r2[j])
+
+
+def test_run_batch(dev):
+    det, opt = _detector("resdcn_18")
+    x = synth.images(4, 512, 512, seed=2).to(dev)
+    d = det.run_batch(x)
+    assert tuple(d.shape) == (4, 100, 6)
+    one = det.run_batch(x[1:2].contiguous())
+    assert torch.equal(one[0], d[1])

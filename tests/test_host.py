@@ -1,0 +1,84 @@
+"""Host-side mirror of the reference interface: opts, geometry, post-process (CPU only)."""
+import numpy as np
+import pytest
+
+from centernet_amd import image as img
+from centernet_amd.opts import opts
+from centernet_amd.post_process import ctdet_post_process, multi_pose_post_process
+from oracle import post_oracle
+
+
+def test_opts_init_ctdet_defaults():
+    o = opts().init(["ctdet", "--arch", "resdcn_18"])
+    assert o.heads == {"hm": 80, "wh": 2, "reg": 2} and o.head_conv == 64
+    assert (o.input_h, o.input_w, o.output_h, o.output_w) == (512, 512, 128, 128)
+    assert o.K == 100 and o.gpus == [0] and o.test_scales == [1.0] and o.fix_res
+    assert o.mean == [0.408, 0.447, 0.470] and o.num_classes == 80 and o.down_ratio == 4
+    o = opts().init(["ctdet", "--arch", "dla_34", "--cat_spec_wh", "--not_reg_offset", "--gpus", "-1"])
+    assert o.heads == {"hm": 80, "wh": 160} and o.head_conv == 256 and o.gpus == [-1]
+    o = opts().init(["multi_pose", "--arch", "hourglass", "--keep_res", "--test_scales", "0.5,1,2"])
+    assert o.heads == {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
+    assert o.pad == 127 and o.num_stacks == 2 and not o.fix_res and o.test_scales == [0.5, 1.0, 2.0]
+    with pytest.raises(NotImplementedError):
+        opts().init(["ddd"])
+
+
+def test_affine_identity_for_benchmark_configuration():
+    """512x512 input with fix_res: c=(256,256), s=512 -> input warp is the identity and the
+    output-grid -> image map is x4 (SURVEY.md section 7 'No cv2')."""
+    c = np.array([256., 256.], np.float32)
+    t = img.get_affine_transform(c, 512.0, 0, [512, 512])
+    assert np.allclose(t, [[1, 0, 0], [0, 1, 0]], atol=1e-9)
+    ti = img.get_affine_transform(c, 512.0, 0, [128, 128], inv=1)
+    assert np.allclose(ti, [[4, 0, 0], [0, 4, 0]], atol=1e-9)
+
+
+@pytest.mark.parametrize("case", [((640., 480.), 640.0, (128, 128)), ((333., 250.), 500.0, (128, 96)),
+                                  ((320., 240.), np.array([672., 512.], np.float32), (168, 128))])
+def test_transform_preds_matches_oracle(case):
+    (w, h), s, out = case
+    c = np.array([w / 2, h / 2], np.float32)
+    pts = np.random.RandomState(0).uniform(0, 120, (50, 2)).astype(np.float32)
+    got = img.transform_preds(pts, c, s, out)
+    ref = post_oracle.transform_preds(pts, c, s, out)
+    assert np.allclose(got, ref, rtol=0, atol=1e-4)
+
+
+def test_ctdet_post_process_matches_oracle():
+    rs = np.random.RandomState(1)
+    dets = np.concatenate([rs.uniform(0, 128, (2, 100, 4)), rs.uniform(0, 1, (2, 100, 1)),
+                           rs.randint(0, 80, (2, 100, 1))], axis=2).astype(np.float32)
+    c = [np.array([250., 187.5], np.float32)] * 2
+    s = [500.0] * 2
+    got = ctdet_post_process(dets.copy(), c, s, 128, 128, 80)
+    ref = post_oracle.ctdet_post_process(dets.copy(), c, s, 128, 128, 80)
+    for g, r in zip(got, ref):
+        assert set(g) == set(range(1, 81))
+        for j in range(1, 81):
+            assert np.allclose(np.array(g[j]).reshape(-1, 5), np.array(r[j]).reshape(-1, 5), atol=1e-4)
+
+
+def test_multi_pose_post_process_shapes():
+    rs = np.random.RandomState(2)
+    dets = rs.uniform(0, 128, (1, 100, 40)).astype(np.float32)
+    out = multi_pose_post_process(dets.copy(), [np.array([256., 256.], np.float32)], [512.0], 128, 128)
+    assert list(out[0].keys()) == [1] and np.array(out[0][1]).shape == (100, 39)
+    assert np.allclose(np.array(out[0][1])[:, :4], dets[0, :, :4] * 4, atol=1e-3)
+
+
+def test_warp_affine_identity_and_shift():
+    rs = np.random.RandomState(3)
+    im = rs.randint(0, 255, (40, 60, 3)).astype(np.uint8)
+    assert np.array_equal(img.warp_affine(im, np.array([[1, 0, 0], [0, 1, 0.]]), (60, 40)), im)
+    sh = img.warp_affine(im, np.array([[1, 0, 2.], [0, 1, 3.]]), (60, 40))
+    assert np.array_equal(sh[3:, 2:], im[:-3, :-2]) and sh[:3].max() == 0
+    up = img.resize_bilinear(im, (120, 80))
+    assert up.shape == (80, 120, 3)
+
+
+def test_detector_rejects_cpu_mode():
+    from centernet_amd.detectors import detector_factory
+    from centernet_amd.native import NativeError
+    o = opts().init(["ctdet", "--arch", "res_18", "--gpus", "-1"])
+    with pytest.raises(NativeError):
+        detector_factory[o.task](o)
