@@ -37,13 +37,13 @@ constexpr int LDT = BK + 4;  // LDS row pitch in floats
 enum { A_DENSE = 0, A_STEM = 1, A_DCN = 2 };
 
 struct IgemmArgs {
-    const float *x;
-    const float *w;
+    const void *x;       // activations, element type T (fp32 or fp16); fp32 NCHW for the stem
+    const void *w;       // packed weights, element type T
     const float *bias;   // added before scale (DCN bias), may be null
     const float *scale;  // per-Cout, may be null (=1)
     const float *shift;  // per-Cout, may be null (=0)
-    const float *residual;
-    float *y;
+    const void *residual;  // element type T
+    void *y;               // element type T (NHWC) or fp32 (NCHW head outputs)
     const float *om;  // DCN: NHWC offsets(18) + mask(9) per pixel
     int om_pitch, mask_sigmoid;
     int B, H, W, Cin;
@@ -64,9 +64,39 @@ struct IgemmArgs {
 
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
+typedef _Float16 cn_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cn_f16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int EPV = 4; };
+template <> struct ElemTraits<_Float16> { static constexpr int EPV = 8; };
+
+__device__ __forceinline__ cn_f32x4 load4_as_f32(const float *p) { return *reinterpret_cast<const cn_f32x4 *>(p); }
+__device__ __forceinline__ cn_f32x4 load4_as_f32(const _Float16 *p)
+{
+    const cn_f16x4 h = *reinterpret_cast<const cn_f16x4 *>(p);
+    cn_f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return r;
+}
+__device__ __forceinline__ void store4_from_f32(float *p, cn_f32x4 v) { *reinterpret_cast<cn_f32x4 *>(p) = v; }
+__device__ __forceinline__ void store4_from_f32(_Float16 *p, cn_f32x4 v)
+{
+    cn_f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    *reinterpret_cast<cn_f16x4 *>(p) = h;
+}
+
+// T = float : v_mfma_f32_32x32x2_f32, chunk = 32 channels
+// T = fp16  : v_mfma_f32_32x32x16_f16 (fp32 accumulate), chunk = 64 channels.  Both use the
+//             same 128-byte LDS rows and the same ds_read_b128 addresses: lane half h of a
+//             32-row block reads bytes [32*kk + 16*h, +16) of its row, which is k = 4h..4h+3
+//             of an 8-group in fp32 (four MFMAs) and k = 16*kk + 8h..8h+7 in fp16 (one MFMA).
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
 __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 {
+    constexpr int EPV = ElemTraits<T>::EPV;  // elements per 16-byte vector
+    constexpr int BKE = 8 * EPV;             // channels per chunk (one 128-byte LDS row)
+    constexpr bool F16 = (EPV == 8);
+    static_assert(!(F16 && AMODE == A_DCN), "the deformable kernel is fp32 only");
     static_assert(NBUF == 1 || NBUF == 2, "LDS tile buffers");
     static_assert(WM * WN == NT / CN_WAVE, "4 waves");
     constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
@@ -100,7 +130,8 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     // ConvTranspose2d(4,2,1): output parity (py,px) is a 2x2 convolution with its own
     // weights, padding (1-py, 1-px) and output offset (py,px)
     int pad_h = a.pad_h, pad_w = a.pad_w, oy_add = a.oy_add, ox_add = a.ox_add;
-    const float *wbase = a.w;
+    const T *wbase = reinterpret_cast<const T *>(a.w);
+    const T *xT = reinterpret_cast<const T *>(a.x);
     if (a.zparity) {
         const int py = blockIdx.z >> 1, px = blockIdx.z & 1;
         pad_h = 1 - py;
@@ -212,19 +243,19 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 
     auto load_tiles = [&](int kt) {
         const int tap = kt / a.nchunk;
-        const int c0 = (kt - tap * a.nchunk) * BK;
+        const int c0 = (kt - tap * a.nchunk) * BKE;
         // ---- B: packed weight [tap][cout_pad][cin_pad]
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             // rows past cout_pad are clamped: their columns are never stored
             const int n = min(n0 + p * 32 + lrow, a.cout_pad - 1);
             rb[p] = *reinterpret_cast<const cn_f32x4 *>(
-                wbase + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + c0 + 4 * q));
+                wbase + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + c0 + EPV * q));
         }
         // ---- A
         if (AMODE == A_DENSE) {
             const int ky = tap / a.KW, kx = tap - ky * a.KW;
-            const int c = c0 + 4 * q;
+            const int c = c0 + EPV * q;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int iy = a_iy0[p] + ky * a.dil;
@@ -233,31 +264,36 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                                 c < a.Cin;
                 // always load from a valid address, then select: no exec-mask branches
                 const size_t off = ok ? ((size_t)(a_pix[p] + iy * a.W + ix) * a.in_pitch + c) : 0;
-                const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(a.x + off);
+                const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(xT + off);
                 ra[p][0] = ok ? v : zero4;
             }
         } else if (AMODE == A_STEM) {
-            // chunk = 8 taps x (r,g,b,0); input NCHW with Cin == 3
-            const int tq = kt * 8 + q;
-            const int ky = tq / a.KW, kx = tq - ky * a.KW;
-            const bool tap_ok = tq < a.KH * a.KW;
+            // one 16-byte vector = EPV/4 taps x (r,g,b,0); the image is fp32 NCHW, Cin == 3
+            constexpr int TPV = EPV / 4;
+            const float *xin = reinterpret_cast<const float *>(a.x);
             const int HW = a.H * a.W;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
-                const int iy = a_iy0[p] + ky * a.dil;
-                const int ix = a_ix0[p] + kx * a.dil;
-                const bool ok = tap_ok && a_pix[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 &&
-                                ix < a.W;
-                const float *px = a.x + (ok ? ((size_t)a_pix[p] * 3 + (size_t)iy * a.W + ix) : 0);
-                cn_f32x4 v;
-                v.x = px[0];
-                v.y = px[HW];
-                v.z = px[2 * HW];
-                v.w = 0.f;
-                ra[p][0] = ok ? v : zero4;
+                T vals[EPV];
+#pragma unroll
+                for (int t = 0; t < TPV; ++t) {
+                    const int tq = (kt * 8 + q) * TPV + t;
+                    const int ky = tq / a.KW, kx = tq - ky * a.KW;
+                    const int iy = a_iy0[p] + ky * a.dil;
+                    const int ix = a_ix0[p] + kx * a.dil;
+                    const bool ok = tq < a.KH * a.KW && a_pix[p] >= 0 && iy >= 0 && iy < a.H &&
+                                    ix >= 0 && ix < a.W;
+                    const float *px = xin + (ok ? ((size_t)a_pix[p] * 3 + (size_t)iy * a.W + ix) : 0);
+                    const float r = px[0], g = px[HW], bl = px[2 * HW];
+                    vals[4 * t + 0] = ok ? (T)r : (T)0.f;
+                    vals[4 * t + 1] = ok ? (T)g : (T)0.f;
+                    vals[4 * t + 2] = ok ? (T)bl : (T)0.f;
+                    vals[4 * t + 3] = (T)0.f;
+                }
+                ra[p][0] = *reinterpret_cast<const cn_f32x4 *>(vals);
             }
         } else {  // A_DCN: four bilinear corners, each a 16-byte channel vector
-            const int c = c0 + 4 * q;
+            const int c = c0 + EPV * q;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int r = p * 32 + lrow;
@@ -265,7 +301,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
-                        a.x + ((size_t)si[j] * a.in_pitch + (c < a.Cin ? c : 0)));
+                        xT + ((size_t)si[j] * a.in_pitch + (c < a.Cin ? c : 0)));
                     ra[p][j] = (c < a.Cin) ? v : zero4;
                 }
             }
@@ -312,19 +348,33 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
             for (int j = 0; j < NB; ++j)
                 bf[j] = *reinterpret_cast<const cn_f32x4 *>(Bb + j * 32 * LDT + kk * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
+            if constexpr (F16) {
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
-                        if (OUT_NCHW)  // D rows = cout, cols = pixels
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s],
-                                                                             acc[i][j], 0, 0, 0);
-                        else  // D rows = pixels, cols = cout
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s],
-                                                                             acc[i][j], 0, 0, 0);
+                        const cn_f16x8 a8 = __builtin_bit_cast(cn_f16x8, af[i]);
+                        const cn_f16x8 b8 = __builtin_bit_cast(cn_f16x8, bf[j]);
+                        if (OUT_NCHW)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b8, a8, acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, b8, acc[i][j], 0, 0, 0);
                     }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            if (OUT_NCHW)  // D rows = cout, cols = pixels
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
+                            else  // D rows = pixels, cols = cout
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        }
+            }
         }
     };
 
@@ -397,7 +447,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                     offs[it] = (lr < TM) ? rowoff[rbase + lr] : -1;
                     if (a.residual) {
                         const size_t o = (size_t)(offs[it] >= 0 ? offs[it] : 0) * a.out_pitch + n;
-                        res[it] = *reinterpret_cast<const cn_f32x4 *>(a.residual + o);
+                        res[it] = load4_as_f32(reinterpret_cast<const T *>(a.residual) + o);
                     }
                 }
 #pragma unroll
@@ -411,7 +461,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                         if (a.residual) t += res[it][e];
                         v[e] = a.relu ? fmaxf(t, 0.f) : t;
                     }
-                    *reinterpret_cast<cn_f32x4 *>(a.y + (size_t)offs[it] * a.out_pitch + n) = v;
+                    store4_from_f32(reinterpret_cast<T *>(a.y) + (size_t)offs[it] * a.out_pitch + n, v);
                 }
             } else if (n < a.Cout) {
                 for (int it = 0; it < ITERS; ++it) {
@@ -422,8 +472,8 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                     for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
                         const size_t o = (size_t)off * a.out_pitch + n + e;
                         float t = (Cs[lr * LDC + c4 * 4 + e] + bs[e]) * sc[e] + sf[e];
-                        if (a.residual) t += a.residual[o];
-                        a.y[o] = a.relu ? fmaxf(t, 0.f) : t;
+                        if (a.residual) t += (float)reinterpret_cast<const T *>(a.residual)[o];
+                        reinterpret_cast<T *>(a.y)[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
                     }
                 }
             }
@@ -446,7 +496,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                         const float sf = a.shift ? a.shift[n] : 0.f;
                         float v = (acc[i][j][r] + bs) * sc + sf;
                         if (a.relu) v = fmaxf(v, 0.f);
-                        a.y[((size_t)b * a.Cout + n) * OHW + rem] = v;
+                        reinterpret_cast<float *>(a.y)[((size_t)b * a.Cout + n) * OHW + rem] = v;
                     }
                 }
             }
@@ -466,22 +516,32 @@ constexpr size_t igemm_lds_bytes()
 int g_tune_nbuf = 0;  // 0 = per-shape default, 1 / 2 = force (cn_set_tuning key 1)
 int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-wide tiles
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
+template <typename T, int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
 int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
 {
     constexpr size_t lds = igemm_lds_bytes<BM, BN, WM, AMODE, OUT_NCHW, NBUF>();
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(
-            (const void *)igemm_kernel<BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>,
+            (const void *)igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>,
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : 1);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), grid, dim3(NT), lds,
-                       st, a);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), grid, dim3(NT),
+                       lds, st, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
+}
+
+// fp16 activations/weights (fp32 accumulate): dense + stem forms only
+template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW>
+int launch_igemm_h(const IgemmArgs &a, hipStream_t st)
+{
+    static_assert(AMODE != A_DCN, "fp16 DCN is not built");
+    if (!OUT_NCHW && AMODE == A_DENSE && a.stride == 1)
+        return launch_igemm_n<_Float16, BM, BN, WM, WN, AMODE, OUT_NCHW, 1>(a, st);
+    return launch_igemm_n<_Float16, BM, BN, WM, WN, AMODE, OUT_NCHW, 2>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW>
@@ -493,13 +553,14 @@ int launch_igemm(const IgemmArgs &a, hipStream_t st)
     if (AMODE != A_DENSE || OUT_NCHW) nbuf = 2;  // only the dense NHWC kernels carry both forms
     if (nbuf == 1) {
         if constexpr (AMODE == A_DENSE && !OUT_NCHW)
-            return launch_igemm_n<BM, BN, WM, WN, AMODE, OUT_NCHW, 1>(a, st);
+            return launch_igemm_n<float, BM, BN, WM, WN, AMODE, OUT_NCHW, 1>(a, st);
     }
-    return launch_igemm_n<BM, BN, WM, WN, AMODE, OUT_NCHW, 2>(a, st);
+    return launch_igemm_n<float, BM, BN, WM, WN, AMODE, OUT_NCHW, 2>(a, st);
 }
 
 // ---- weight packing: (Cout,Cin,KH,KW) -> [tap][cout_pad][cin_pad], zero padded
-__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout,
+template <typename T>
+__global__ void pack_weight_kernel(const float *__restrict__ w, T *__restrict__ wp, int Cout,
                                    int Cin, int taps, int cout_pad, int cin_pad)
 {
     const size_t total = (size_t)taps * cout_pad * cin_pad;
@@ -510,11 +571,12 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
         const int t = (int)(i / ((size_t)cin_pad * cout_pad));
         float v = 0.f;
         if (c < Cin && n < Cout) v = w[((size_t)n * Cin + c) * taps + t];
-        wp[i] = v;
+        wp[i] = (T)v;
     }
 }
 // stem: (Cout,3,KH,KW) -> [cout_pad][kpad], k = tap*4 + rgb
-__global__ void pack_stem_weight_kernel(const float *__restrict__ w, float *__restrict__ wp,
+template <typename T>
+__global__ void pack_stem_weight_kernel(const float *__restrict__ w, T *__restrict__ wp,
                                         int Cout, int taps, int cout_pad, int kpad)
 {
     const size_t total = (size_t)cout_pad * kpad;
@@ -525,7 +587,7 @@ __global__ void pack_stem_weight_kernel(const float *__restrict__ w, float *__re
         const int t = k >> 2, c = k & 3;
         float v = 0.f;
         if (n < Cout && t < taps && c < 3) v = w[((size_t)n * 3 + c) * taps + t];
-        wp[i] = v;
+        wp[i] = (T)v;
     }
 }
 
@@ -534,37 +596,62 @@ inline bool is_stem(int Cin, int in_layout) { return in_layout == CN_LAYOUT_NCHW
 
 }  // namespace
 
-extern "C" size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW)
+static size_t packed_elems(int Cout, int Cin, int KH, int KW, int bke)
 {
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
-    if (Cin == 3)  // stem form: [cout_pad][round_up(taps*4, 32)]
-        return (size_t)round_up(Cout, 32) * round_up(KH * KW * 4, 32);
-    return (size_t)KH * KW * round_up(Cout, 32) * round_up(Cin, 32);
+    if (Cin == 3)  // stem form: [cout_pad][round_up(taps*4, chunk)]
+        return (size_t)round_up(Cout, 32) * round_up(KH * KW * 4, bke);
+    return (size_t)KH * KW * round_up(Cout, 32) * round_up(Cin, bke);
+}
+
+extern "C" size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW)
+{
+    return packed_elems(Cout, Cin, KH, KW, 32);
+}
+
+extern "C" size_t cn_packed_conv_weight_elems(int Cout, int Cin, int KH, int KW, int dtype)
+{
+    return packed_elems(Cout, Cin, KH, KW, dtype == CN_DTYPE_F16 ? 64 : 32);
+}
+
+template <typename T>
+static int pack_conv_weight_t(const float *w_oihw, void *w_packed, int Cout, int Cin, int KH,
+                              int KW, int bke, hipStream_t st)
+{
+    const int taps = KH * KW;
+    const int cout_pad = round_up(Cout, 32);
+    if (Cin == 3) {
+        const int kpad = round_up(taps * 4, bke);
+        const size_t total = (size_t)cout_pad * kpad;
+        hipLaunchKernelGGL(pack_stem_weight_kernel<T>, dim3((unsigned)cn_cdiv((int)total, 256)),
+                           dim3(256), 0, st, w_oihw, (T *)w_packed, Cout, taps, cout_pad, kpad);
+    } else {
+        const int cin_pad = round_up(Cin, bke);
+        const size_t total = (size_t)taps * cout_pad * cin_pad;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, st, w_oihw,
+                           (T *)w_packed, Cout, Cin, taps, cout_pad, cin_pad);
+    }
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_pack_conv_weight(const float *w_oihw, void *w_packed, int Cout, int Cin, int KH,
+                                   int KW, int dtype, void *stream)
+{
+    if (!w_oihw || !w_packed) return CN_ERR_NULL;
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return CN_ERR_SHAPE;
+    if (dtype == CN_DTYPE_F16)
+        return pack_conv_weight_t<_Float16>(w_oihw, w_packed, Cout, Cin, KH, KW, 64, (hipStream_t)stream);
+    if (dtype != CN_DTYPE_F32) return CN_ERR_UNSUPPORTED;
+    return pack_conv_weight_t<float>(w_oihw, w_packed, Cout, Cin, KH, KW, 32, (hipStream_t)stream);
 }
 
 extern "C" int cn_pack_conv_weight_f32(const float *w_oihw, float *w_packed, int Cout, int Cin,
                                        int KH, int KW, void *stream)
 {
-    if (!w_oihw || !w_packed) return CN_ERR_NULL;
-    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return CN_ERR_SHAPE;
-    hipStream_t st = (hipStream_t)stream;
-    const int taps = KH * KW;
-    const int cout_pad = round_up(Cout, 32);
-    if (Cin == 3) {
-        const int kpad = round_up(taps * 4, 32);
-        const size_t total = (size_t)cout_pad * kpad;
-        hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((unsigned)cn_cdiv((int)total, 256)),
-                           dim3(256), 0, st, w_oihw, w_packed, Cout, taps, cout_pad, kpad);
-    } else {
-        const int cin_pad = round_up(Cin, 32);
-        const size_t total = (size_t)taps * cout_pad * cin_pad;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, w_packed,
-                           Cout, Cin, taps, cout_pad, cin_pad);
-    }
-    CN_CHECK_LAUNCH();
-    return CN_OK;
+    return cn_pack_conv_weight(w_oihw, w_packed, Cout, Cin, KH, KW, CN_DTYPE_F32, stream);
 }
 
 static int conv_fill_args(const cn_conv_desc *d, IgemmArgs *a)
@@ -592,23 +679,26 @@ static int conv_fill_args(const cn_conv_desc *d, IgemmArgs *a)
     a->relu = d->relu;
     a->M = d->B * d->Ho * d->Wo;
     a->cout_pad = round_up(d->Cout, 32);
+    const int f16 = (d->dtype == CN_DTYPE_F16);
+    if (d->dtype != CN_DTYPE_F32 && !f16) return CN_ERR_UNSUPPORTED;
+    const int bke = f16 ? 64 : 32, epv = f16 ? 8 : 4;
     if (is_stem(d->Cin, d->in_layout)) {
-        a->cin_pad = round_up(d->KH * d->KW * 4, 32);
-        a->nchunk = a->cin_pad / 32;
+        a->cin_pad = round_up(d->KH * d->KW * 4, bke);
+        a->nchunk = a->cin_pad / bke;
         a->KT = a->nchunk;
     } else {
         if (d->in_layout != CN_LAYOUT_NHWC) return CN_ERR_UNSUPPORTED;
-        if ((d->Cin & 3) || (d->in_pitch & 3) || d->in_pitch < d->Cin) return CN_ERR_UNSUPPORTED;
-        a->cin_pad = round_up(d->Cin, 32);
-        a->nchunk = a->cin_pad / 32;
+        if ((d->Cin % epv) || (d->in_pitch % epv) || d->in_pitch < d->Cin) return CN_ERR_UNSUPPORTED;
+        a->cin_pad = round_up(d->Cin, bke);
+        a->nchunk = a->cin_pad / bke;
         a->KT = d->KH * d->KW * a->nchunk;
     }
     return CN_OK;
 }
 
-extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float *w_packed,
-                             const float *scale, const float *shift, const float *residual,
-                             float *y, void *stream)
+extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_packed,
+                         const float *scale, const float *shift, const void *residual, void *y,
+                         void *stream)
 {
     if (!d || !x || !w_packed || !y) return CN_ERR_NULL;
     if (!cn_aligned16(x) || !cn_aligned16(w_packed)) return CN_ERR_ALIGN;
@@ -617,28 +707,55 @@ extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float 
     if (rc != CN_OK) return rc;
     a.x = x; a.w = w_packed; a.bias = nullptr; a.scale = scale; a.shift = shift;
     a.residual = residual; a.y = y; a.om = nullptr;
-    a.vec_out = (d->out_layout == CN_LAYOUT_NHWC && (d->out_pitch & 3) == 0 && cn_aligned16(y) &&
-                 (!residual || cn_aligned16(residual))) ? 1 : 0;
+    const bool f16 = (d->dtype == CN_DTYPE_F16);
+    const size_t valign = f16 ? 8 : 16;  // 4 output elements per store
+    a.vec_out = (d->out_layout == CN_LAYOUT_NHWC && (d->out_pitch & 3) == 0 &&
+                 (((uintptr_t)y) % valign) == 0 &&
+                 (!residual || (((uintptr_t)residual) % valign) == 0)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool stem = is_stem(d->Cin, d->in_layout);
-    if (d->out_layout == CN_LAYOUT_NCHW) {
-        if (residual || stem) return CN_ERR_UNSUPPORTED;
-        if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, true>(a, st);
-        if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, true>(a, st);
-        return launch_igemm<128, 32, 4, 1, A_DENSE, true>(a, st);
-    }
-    if (stem) {
-        if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_STEM, false>(a, st);
-        if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
-        return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
-    }
     // 128-wide N tiles unless their padding wastes a whole 64-wide tile (e.g. Cout = 192)
     const int waste128 = cn_cdiv(d->Cout, 128) * 128 - d->Cout;
     const int waste64 = cn_cdiv(d->Cout, 64) * 64 - d->Cout;
     const bool narrow = !g_tune_narrow && (waste128 - waste64 >= 64);
-    if (d->Cout > 64 && !narrow) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
-    if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
+    const int cls = (d->Cout > 64 && !narrow) ? 2 : (d->Cout > 32 ? 1 : 0);  // 128 / 64 / 32 wide
+    if (d->out_layout == CN_LAYOUT_NCHW) {
+        if (residual || stem) return CN_ERR_UNSUPPORTED;
+        if (f16) {
+            if (cls == 2) return launch_igemm_h<128, 128, 2, 2, A_DENSE, true>(a, st);
+            if (cls == 1) return launch_igemm_h<128, 64, 2, 2, A_DENSE, true>(a, st);
+            return launch_igemm_h<128, 32, 4, 1, A_DENSE, true>(a, st);
+        }
+        if (cls == 2) return launch_igemm<128, 128, 2, 2, A_DENSE, true>(a, st);
+        if (cls == 1) return launch_igemm<128, 64, 2, 2, A_DENSE, true>(a, st);
+        return launch_igemm<128, 32, 4, 1, A_DENSE, true>(a, st);
+    }
+    if (stem) {
+        if (f16) {
+            if (d->Cout > 64) return launch_igemm_h<128, 128, 2, 2, A_STEM, false>(a, st);
+            if (d->Cout > 32) return launch_igemm_h<128, 64, 2, 2, A_STEM, false>(a, st);
+            return launch_igemm_h<128, 32, 4, 1, A_STEM, false>(a, st);
+        }
+        if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_STEM, false>(a, st);
+        if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
+        return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
+    }
+    if (f16) {
+        if (cls == 2) return launch_igemm_h<128, 128, 2, 2, A_DENSE, false>(a, st);
+        if (cls == 1) return launch_igemm_h<128, 64, 2, 2, A_DENSE, false>(a, st);
+        return launch_igemm_h<128, 32, 4, 1, A_DENSE, false>(a, st);
+    }
+    if (cls == 2) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
+    if (cls == 1) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
     return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);
+}
+
+extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float *w_packed,
+                             const float *scale, const float *shift, const float *residual,
+                             float *y, void *stream)
+{
+    if (d && d->dtype != CN_DTYPE_F32) return CN_ERR_UNSUPPORTED;
+    return cn_conv2d(d, x, w_packed, scale, shift, residual, y, stream);
 }
 
 extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_packed,

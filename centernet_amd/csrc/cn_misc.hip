@@ -364,3 +364,44 @@ extern "C" int cn_upsample2x_add_f32(const float *x, const float *add, float *y,
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
+
+namespace {
+// fp16 variant: 8 channels (16 bytes) per thread
+__global__ void upsample2x_add_f16_kernel(const _Float16 *__restrict__ x,
+                                          const _Float16 *__restrict__ add,
+                                          _Float16 *__restrict__ y, int B, int H, int W, int C)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int c8n = C >> 3;
+    const int OH = 2 * H, OW = 2 * W;
+    const size_t total = (size_t)B * OH * OW * c8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        size_t r = i / c8n;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        h8 v = *reinterpret_cast<const h8 *>(x + (((size_t)b * H + (oy >> 1)) * W + (ox >> 1)) * C + c8 * 8);
+        const size_t o = (((size_t)b * OH + oy) * OW + ox) * C + c8 * 8;
+        if (add) v += *reinterpret_cast<const h8 *>(add + o);
+        *reinterpret_cast<h8 *>(y + o) = v;
+    }
+}
+}  // namespace
+
+extern "C" int cn_upsample2x_add_f16(const void *x, const void *add, void *y, int B, int H, int W,
+                                     int C, void *stream)
+{
+    if (!x || !y) return CN_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return CN_ERR_SHAPE;
+    if (C & 7) return CN_ERR_UNSUPPORTED;
+    if (!cn_aligned16(x) || !cn_aligned16(y) || (add && !cn_aligned16(add))) return CN_ERR_ALIGN;
+    const size_t total = (size_t)B * 4 * H * W * (C >> 3);
+    hipLaunchKernelGGL(upsample2x_add_f16_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, (const _Float16 *)x, (const _Float16 *)add,
+                       (_Float16 *)y, B, H, W, C);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}

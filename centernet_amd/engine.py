@@ -18,7 +18,7 @@ import ctypes
 import torch
 
 from . import native
-from .native import ConvDesc, LAYOUT_NCHW, LAYOUT_NHWC
+from .native import ConvDesc, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTYPE_F32
 
 
 def _out_size(n, k, s, p, d=1):
@@ -37,7 +37,7 @@ class Act:
         self.nchw = nchw
 
     def ptr(self):
-        return ctypes.c_void_p(self.t.data_ptr() + 4 * self.c_off)
+        return ctypes.c_void_p(self.t.data_ptr() + self.t.element_size() * self.c_off)
 
 
 def fold_bn(conv_bias, bn, cout, device):
@@ -64,8 +64,11 @@ def fold_bn(conv_bias, bn, cout, device):
 class PlanBuilder:
     """Records launches for one (B, H, W) input shape."""
 
-    def __init__(self, device, B, H, W):
+    def __init__(self, device, B, H, W, dtype=torch.float32):
+        assert dtype in (torch.float32, torch.float16)
         self.device = device
+        self.dtype = dtype           # element type of NHWC activations and packed weights
+        self.cdtype = DTYPE_F16 if dtype == torch.float16 else DTYPE_F32
         self.B, self.H, self.W = B, H, W
         self.lib = native.lib()
         self.ops = []          # list of zero-arg callables
@@ -78,16 +81,17 @@ class PlanBuilder:
     # ---- helpers -------------------------------------------------------------
     def _new(self, B, H, W, C, pitch=None):
         pitch = C if pitch is None else pitch
-        t = torch.empty((B, H, W, pitch), device=self.device, dtype=torch.float32)
+        t = torch.empty((B, H, W, pitch), device=self.device, dtype=self.dtype)
         return Act(t, B, H, W, C, pitch)
 
     def _pack(self, w_oihw):
         w = w_oihw.detach().to(device=self.device, dtype=torch.float32).contiguous()
         co, ci, kh, kw = w.shape
-        n = self.lib.cn_packed_conv_weight_floats(co, ci, kh, kw)
-        wp = torch.empty(n, device=self.device, dtype=torch.float32)
-        native.check(self.lib.cn_pack_conv_weight_f32(native.ptr(w), native.ptr(wp), co, ci, kh, kw,
-                                                      native.stream_ptr()), "cn_pack_conv_weight_f32")
+        n = self.lib.cn_packed_conv_weight_elems(co, ci, kh, kw, self.cdtype)
+        wp = torch.empty(n, device=self.device, dtype=self.dtype)
+        native.check(self.lib.cn_pack_conv_weight(native.ptr(w), native.ptr(wp), co, ci, kh, kw,
+                                                  self.cdtype, native.stream_ptr()),
+                     "cn_pack_conv_weight")
         torch.cuda.current_stream().synchronize()
         self.keep.append(wp)
         return wp
@@ -118,7 +122,8 @@ class PlanBuilder:
                      stride=stride, pad_h=padding, pad_w=padding, dil=dilation,
                      in_layout=LAYOUT_NCHW if x.nchw else LAYOUT_NHWC, in_pitch=x.pitch,
                      out_layout=LAYOUT_NCHW if out.nchw else LAYOUT_NHWC, out_pitch=out.pitch,
-                     OH=Ho, OW=Wo, oy_mul=1, oy_add=0, ox_mul=1, ox_add=0, relu=int(relu))
+                     OH=Ho, OW=Wo, oy_mul=1, oy_add=0, ox_mul=1, ox_add=0, relu=int(relu),
+                     dtype=self.cdtype)
         fl = 2 * x.B * Ho * Wo * co * ci * kh * kw
         by = 4 * (x.B * x.H * x.W * ci + x.B * Ho * Wo * co * (2 if residual is not None else 1)
                   + co * ci * kh * kw)
@@ -137,9 +142,9 @@ class PlanBuilder:
 
         def run():
             xp = ctypes.c_void_p(self.input.t.data_ptr()) if is_input else x.ptr()
-            rc = lib.cn_conv2d_f32(dref, xp, wpp, sp, hp, rp, op, native.stream_ptr())
+            rc = lib.cn_conv2d(dref, xp, wpp, sp, hp, rp, op, native.stream_ptr())
             if rc:
-                native.check(rc, "cn_conv2d_f32")
+                native.check(rc, "cn_conv2d")
         self.ops.append(run)
         self.meta.append(meta)
         self.trace.append((meta["kind"], out))
@@ -149,6 +154,7 @@ class PlanBuilder:
         2x2 convolutions in one launch (reference: resnet_dcn.py:228-235)."""
         ci, co, kh, kw = weight.shape
         assert (kh, kw) == (4, 4) and ci == x.C
+        assert self.dtype == torch.float32, "ConvTranspose is built for fp32 only"
         out = self._new(x.B, 2 * x.H, 2 * x.W, co)
         scale, shift = fold_bn(None, bn, co, self.device)
         w = weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -177,6 +183,7 @@ class PlanBuilder:
         return out
 
     def maxpool(self, x, k, s, pad):
+        assert self.dtype == torch.float32, "max-pool is built for fp32 only"
         Ho, Wo = _out_size(x.H, k, s, pad), _out_size(x.W, k, s, pad)
         out = self._new(x.B, Ho, Wo, x.C)
         lib = self.lib
@@ -249,11 +256,13 @@ class PlanBuilder:
         out = self._new(x.B, 2 * x.H, 2 * x.W, x.C)
         lib = self.lib
 
+        fn = lib.cn_upsample2x_add_f16 if self.dtype == torch.float16 else lib.cn_upsample2x_add_f32
+
         def run():
-            rc = lib.cn_upsample2x_add_f32(x.ptr(), add.ptr() if add is not None else None,
-                                           out.ptr(), x.B, x.H, x.W, x.C, native.stream_ptr())
+            rc = fn(x.ptr(), add.ptr() if add is not None else None, out.ptr(), x.B, x.H, x.W, x.C,
+                    native.stream_ptr())
             if rc:
-                native.check(rc, "cn_upsample2x_add_f32")
+                native.check(rc, "cn_upsample2x_add")
         self._emit_simple(run, "upsample", out, 4 * x.B * x.C * x.H * x.W * (1 + 4 + (4 if add is not None else 0)))
         return out
 
@@ -264,6 +273,7 @@ class PlanBuilder:
         assert tuple(dcn_mod.kernel_size) == (3, 3) and dcn_mod.stride == 1 and \
             dcn_mod.padding == 1 and dcn_mod.dilation == 1 and dcn_mod.deformable_groups == 1, \
             "only the 3x3/s1/p1/d1/dg1 DCN that CenterNet instantiates is supported"
+        assert self.dtype == torch.float32, "the deformable kernel is fp32 only"
         com = dcn_mod.conv_offset_mask
         om = self._new(x.B, x.H, x.W, 27, pitch=32)
         self.conv(x, com.weight, bias=com.bias, stride=1, padding=1, out=om)
@@ -393,13 +403,22 @@ class PlannedModule(torch.nn.Module):
     def describe(self, pb, x):  # pragma: no cover - interface
         raise NotImplementedError
 
+    compute_dtype = torch.float32   # set to torch.float16 with .half_compute() (hourglass)
+
+    def half_compute(self, enable=True):
+        """fp16 activations/weights with fp32 accumulation (BASELINE configs[4]); parameters
+        stay fp32 in the module, only the packed plan copies are fp16."""
+        self.compute_dtype = torch.float16 if enable else torch.float32
+        self.invalidate_plans()
+        return self
+
     def plan_for(self, B, H, W, device):
         cache = self.__dict__.setdefault("_plans", {})
-        key = (B, H, W, str(device))
+        key = (B, H, W, str(device), self.compute_dtype)
         if key not in cache:
             native.lib()  # raises if the HIP library is missing
             with torch.no_grad():
-                pb = PlanBuilder(device, B, H, W)
+                pb = PlanBuilder(device, B, H, W, dtype=self.compute_dtype)
                 x = pb.set_input(3)
                 outs = self.describe(pb, x)
             cache[key] = Plan(pb, outs)

@@ -18,6 +18,8 @@ CSRC = os.path.join(_HERE, "csrc")
 CN_OK = 0
 LAYOUT_NCHW = 0
 LAYOUT_NHWC = 1
+DTYPE_F32 = 0
+DTYPE_F16 = 1
 
 _lib = None
 
@@ -31,7 +33,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad_h", "pad_w",
         "dil", "in_layout", "in_pitch", "out_layout", "out_pitch", "OH", "OW", "oy_mul",
-        "oy_add", "ox_mul", "ox_add", "relu")]
+        "oy_add", "ox_mul", "ox_add", "relu", "dtype")]
 
 
 def build(force=False, verbose=False):
@@ -66,6 +68,14 @@ def _declare(lib):
     lib.cn_pack_conv_weight_f32.argtypes = [vp, vp, i, i, i, i, vp]
     lib.cn_conv2d_f32.restype = i
     lib.cn_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
+    lib.cn_packed_conv_weight_elems.restype = sz
+    lib.cn_packed_conv_weight_elems.argtypes = [i] * 5
+    lib.cn_pack_conv_weight.restype = i
+    lib.cn_pack_conv_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
+    lib.cn_conv2d.restype = i
+    lib.cn_conv2d.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
+    lib.cn_upsample2x_add_f16.restype = i
+    lib.cn_upsample2x_add_f16.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.cn_packed_deconv4x4s2_weight_floats.restype = sz
     lib.cn_packed_deconv4x4s2_weight_floats.argtypes = [i, i]
     lib.cn_pack_deconv4x4s2_weight_f32.restype = i

@@ -41,6 +41,12 @@ typedef enum cn_status {
 #define CN_LAYOUT_NCHW 0
 #define CN_LAYOUT_NHWC 1
 
+/* Element type of activations / packed weights.  fp32 is the parity path; fp16 (fp32
+ * accumulate, v_mfma_f32_32x32x16_f16) exists for BASELINE configs[4] (Hourglass-104 fp16),
+ * a surface the reference does not have. */
+#define CN_DTYPE_F32 0
+#define CN_DTYPE_F16 1
+
 /* Library / ABI version (major*10000 + minor*100 + patch). */
 int cn_version(void);
 /* Human-readable text for a cn_status. */
@@ -136,6 +142,7 @@ typedef struct cn_conv_desc {
     int out_layout, out_pitch;
     int OH, OW, oy_mul, oy_add, ox_mul, ox_add;
     int relu;
+    int dtype;              /* CN_DTYPE_F32 / CN_DTYPE_F16 (x, w, residual, NHWC y) */
 } cn_conv_desc;
 
 /* Number of floats of the packed weight for (Cout,Cin,KH,KW). */
@@ -147,6 +154,13 @@ int cn_pack_conv_weight_f32(const float *w_oihw, float *w_packed, int Cout, int 
 int cn_conv2d_f32(const cn_conv_desc *desc, const float *x, const float *w_packed,
                   const float *scale, const float *shift, const float *residual,
                   float *y, void *stream);
+/* dtype-generic forms (desc->dtype selects fp32 / fp16; NCHW head outputs and the stem's
+ * NCHW image are always fp32; scale/shift are always fp32). */
+size_t cn_packed_conv_weight_elems(int Cout, int Cin, int KH, int KW, int dtype);
+int cn_pack_conv_weight(const float *w_oihw, void *w_packed, int Cout, int Cin, int KH, int KW,
+                        int dtype, void *stream);
+int cn_conv2d(const cn_conv_desc *desc, const void *x, const void *w_packed, const float *scale,
+              const float *shift, const void *residual, void *y, void *stream);
 
 /* ------------------------------------------------------------------------
  * ConvTranspose2d(kernel 4, stride 2, padding 1, bias=False) + BN(eval) + ReLU.
@@ -183,6 +197,8 @@ int cn_copy_channels_f32(const float *src, int src_pitch, float *dst, int dst_pi
 /* Nearest x2 up-sampling + add of the skip branch (large_hourglass.py:102-109, 163-174). */
 int cn_upsample2x_add_f32(const float *x, const float *add, float *y, int B, int H, int W,
                           int C, void *stream);
+int cn_upsample2x_add_f16(const void *x, const void *add, void *y, int B, int H, int W, int C,
+                          void *stream);
 
 /* Layout conversion at the API edge. */
 int cn_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W,

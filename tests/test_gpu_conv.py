@@ -119,3 +119,57 @@ def test_heads_fused_nchw_outputs(dev):
     _run(pb)
     for h in heads:
         _check(outs[h].t.cpu(), mods[h](x).detach())
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 32, 32, 64, 3, 1, 1, True, True), (2, 256, 16, 16, 384, 3, 2, 1, True, False),
+    (1, 128, 17, 19, 256, 1, 1, 0, False, True), (1, 384, 8, 8, 384, 3, 1, 1, True, True),
+])
+def test_fp16_conv_vs_fp32_reference(dev, cfg):
+    """fp16 operands / fp32 accumulate (configs[4]): against torch fp32 on the SAME
+    fp16-rounded inputs and weights, so only accumulation order and the final fp16 rounding
+    differ: |diff| <= 2e-3 * (1 + |ref|)."""
+    from centernet_amd.engine import PlanBuilder, Act
+    B, Cin, H, W, Cout, k, s, p, relu, use_res = cfg
+    x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1)).half()
+    w = torch.from_numpy(synth.normal((Cout, Cin, k, k), (2.0 / (Cin * k * k)) ** 0.5, 2)).half()
+    bn = _bn(Cout, 4)
+    ref = bn(F.conv2d(x.float(), w.float(), None, s, p))
+    res = None
+    if use_res:
+        res = torch.from_numpy(synth.normal(tuple(ref.shape), 1.0, 5)).half()
+        ref = ref + res.float()
+    if relu:
+        ref = F.relu(ref)
+    pb = PlanBuilder(dev, B, H, W, dtype=torch.float16)
+    xa = Act(x.permute(0, 2, 3, 1).contiguous().to(dev), B, H, W, Cin)
+    ra = Act(res.permute(0, 2, 3, 1).contiguous().to(dev), B, ref.shape[2], ref.shape[3], Cout) if use_res else None
+    y = pb.conv(xa, w.float(), bn=bn, relu=relu, residual=ra, stride=s, padding=p)
+    _run(pb)
+    got = y.t.permute(0, 3, 1, 2).float().cpu()
+    err = (got - ref.detach()).abs() / (1 + ref.detach().abs())
+    assert float(err.max()) < 2e-3, float(err.max())
+
+
+def test_fp16_stem_and_nchw_head(dev):
+    from centernet_amd.engine import PlanBuilder, Act
+    B, H, W = 1, 64, 64
+    x = synth.images(B, H, W, 3)
+    w = torch.from_numpy(synth.normal((128, 3, 7, 7), (2.0 / 147) ** 0.5, 2))
+    bn = _bn(128, 4)
+    ref = F.relu(bn(F.conv2d(x.half().float(), w.half().float(), None, 2, 3))).detach()
+    pb = PlanBuilder(dev, B, H, W, dtype=torch.float16)
+    xin = pb.set_input(3)
+    y = pb.conv(xin, w, bn=bn, relu=True, stride=2, padding=3)
+    w2 = torch.from_numpy(synth.normal((80, 128, 1, 1), 0.1, 7))
+    b2 = torch.from_numpy(synth.normal((80,), 0.1, 8))
+    z = pb.conv(y, w2, bias=b2, out_nchw=True)
+    pb.input.t = x.to(dev)
+    _run(pb)
+    got = y.t.permute(0, 3, 1, 2).float().cpu()
+    err = (got - ref).abs() / (1 + ref.abs())
+    assert float(err.max()) < 3e-3, float(err.max())
+    assert z.t.dtype == torch.float32
+    ref2 = F.conv2d(got.half().float(), w2.half().float(), b2)
+    err2 = (z.t.cpu() - ref2).abs() / (1 + ref2.abs())
+    assert float(err2.max()) < 2e-3, float(err2.max())
