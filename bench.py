@@ -24,6 +24,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+F16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -34,6 +35,8 @@ def parse():
     p.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     p.add_argument("--arch", default="resdcn_18")
     p.add_argument("--res", type=int, default=512)
+    p.add_argument("--fp16", action="store_true",
+                   help="fp16 activations/weights, fp32 accumulate (configs[4], hourglass only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-images", type=int, default=16)
     p.add_argument("--per-op", action="store_true", help="print per-launch timings to stderr")
@@ -91,6 +94,8 @@ def main():
     if world > 1:
         broadcast_weights(det.model, src=0)      # one flat RCCL broadcast, then no collectives
     det.model.invalidate_plans()
+    if a.fp16:
+        det.model.half_compute()
     B = a.batch
     images = synth.images(B, a.res, a.res, seed=100 + rank).to(dev)
 
@@ -149,8 +154,9 @@ def main():
         def mfma_roof(k):
             s = kinds[k]
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
-            return {"kernel": k, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TF, "traffic": None,
+            peak = F16_MFMA_PEAK_TF if a.fp16 else F32_MFMA_PEAK_TF
+            return {"kernel": k, "bound": "mfma", "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                     "avg_launch_ms": s["ms"] / max(s["launches"], 1), "launches_per_step": s["launches"] // a.steps}
 
         def hbm_roof(k):
@@ -166,7 +172,7 @@ def main():
             "metric": "images/sec whole-node, 512x512 ctdet", "value": total_imgs / dt,
             "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if a.fp16 else "f32", "data": "synthetic",
             "config": {"workload": "ctdet %s %dx%d, batch %d per GPU (BASELINE configs[1]), "
                                    "network + fused sigmoid/peak-NMS/top-K decode, K=%d"
                                    % (a.arch, a.res, a.res, B, opt.K),
