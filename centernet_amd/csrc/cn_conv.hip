@@ -113,10 +113,11 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     float *As = reinterpret_cast<float *>(smem);  // [NBUF][BM][LDT]
     float *Bs = As + NBUF * BM * LDT;             // [NBUF][BN][LDT]
     int *rowoff = reinterpret_cast<int *>(As + UNION_FLOATS);  // [BM]
-    // DCN sampling parameters per (row, tap): 4 corner pixel indices, 4 weights, mask
-    int *sidx = rowoff + BM;                               // [BM*9*4]
-    float *swt = reinterpret_cast<float *>(sidx + BM * 36);  // [BM*9*4]
-    float *smk = swt + BM * 36;                            // [BM*9]
+    // DCN sampling records of ONE tap per row (4 corner pixel indices, 4 weights, mask),
+    // double-buffered by tap parity: the records of tap t+1 are written while tap t runs
+    int *sidx = rowoff + BM;                                  // [2][BM][4]
+    float *swt = reinterpret_cast<float *>(sidx + 2 * BM * 4);  // [2][BM][4]
+    float *smk = swt + 2 * BM * 4;                            // [2][BM]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -173,10 +174,10 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         }
         rowoff[r] = off;
     }
-    if (AMODE == A_DCN) {
-        // dcn_v2_im2col_cuda.cu:151-176 and :18-47, evaluated once per (pixel, tap)
-        for (int i = tid; i < BM * 9; i += NT) {
-            const int r = i / 9, tap = i - r * 9;
+    // dcn_v2_im2col_cuda.cu:151-176 and :18-47, evaluated once per (pixel, tap)
+    auto dcn_records = [&](int tap) {
+        const int pb = tap & 1;
+        for (int r = tid; r < BM; r += NT) {
             const int m = m0 + r;
             int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
             float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
@@ -215,16 +216,16 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                     i3 = base + yh * W + xh;
                 }
             }
-            sidx[i * 4 + 0] = i0;
-            sidx[i * 4 + 1] = i1;
-            sidx[i * 4 + 2] = i2;
-            sidx[i * 4 + 3] = i3;
-            swt[i * 4 + 0] = w1;
-            swt[i * 4 + 1] = w2;
-            swt[i * 4 + 2] = w3;
-            swt[i * 4 + 3] = w4;
-            smk[i] = mk;
+            int *si = sidx + (pb * BM + r) * 4;
+            float *sw = swt + (pb * BM + r) * 4;
+            si[0] = i0; si[1] = i1; si[2] = i2; si[3] = i3;
+            sw[0] = w1; sw[1] = w2; sw[2] = w3; sw[3] = w4;
+            smk[pb * BM + r] = mk;
         }
+    };
+    if (AMODE == A_DCN) {
+        dcn_records(0);
+        dcn_records(1);
     }
     __syncthreads();
 
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int r = p * 32 + lrow;
-                const int *si = sidx + (r * 9 + tap) * 4;
+                const int *si = sidx + ((tap & 1) * BM + r) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int r = p * 32 + lrow;
-                const float *wt = swt + (r * 9 + tap) * 4;
-                const float mk = smk[r * 9 + tap];
+                const float *wt = swt + ((tap & 1) * BM + r) * 4;
+                const float mk = smk[(tap & 1) * BM + r];
                 const float w1 = wt[0], w2 = wt[1], w3 = wt[2], w4 = wt[3];
                 cn_f32x4 v;
                 // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (dcn_v2_im2col_cuda.cu:43-45,174)
@@ -387,15 +388,22 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     for (int kt = 0; kt < a.KT; ++kt) {
         const bool more = (kt + 1) < a.KT;
         if (more) load_tiles(kt + 1);
+        // DCN: the records of tap t (t >= 2) are first read by load_tiles(t*nchunk) in
+        // iteration t*nchunk-1; their buffer (parity of t) was last read in iteration
+        // (t-1)*nchunk-2, so iteration t*nchunk-2 is the safe place to write them.
+        const bool rec = (AMODE == A_DCN) && ((kt + 2) % a.nchunk == 0) &&
+                         ((kt + 2) / a.nchunk >= 2) && ((kt + 2) / a.nchunk < 9);
         if (NBUF == 2) {
             const int buf = kt & 1;
             compute(buf);
             if (more) store_tiles(buf ^ 1, kt + 1);
+            if (rec) dcn_records((kt + 2) / a.nchunk);
             __syncthreads();
         } else {
             compute(0);
             __syncthreads();
             if (more) store_tiles(0, kt + 1);
+            if (rec) dcn_records((kt + 2) / a.nchunk);
             __syncthreads();
         }
     }
@@ -510,11 +518,13 @@ constexpr size_t igemm_lds_bytes()
     constexpr size_t tiles = (size_t)NBUF * (BM + BN) * LDT;
     constexpr size_t cs = OUT_NCHW ? 0 : (size_t)(BM / WM) * (BN + 4);
     return (tiles > cs ? tiles : cs) * 4 + BM * 4 +
-           (AMODE == A_DCN ? (size_t)BM * (36 * 4 + 36 * 4 + 9 * 4) : 0);
+           (AMODE == A_DCN ? (size_t)2 * BM * (4 * 4 + 4 * 4 + 4) : 0);
 }
 
 int g_tune_nbuf = 0;  // 0 = per-shape default, 1 / 2 = force (cn_set_tuning key 1)
 int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-wide tiles
+int g_tune_dcn_tile = 0; // cn_set_tuning key 3: 0 = default, 64 / 128 = force the DCN pixel tile
+int g_tune_bm = 0;       // cn_set_tuning key 4: 0 = default, 64 / 128 = force the dense pixel tile
 
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
 int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
@@ -550,9 +560,9 @@ int launch_igemm(const IgemmArgs &a, hipStream_t st)
     // measured on MI355X (tools/bench_kernels.py, profiles/): single-buffered LDS (more
     // workgroups per CU) wins for stride-1 layers, double-buffered for strided gathers
     int nbuf = g_tune_nbuf ? g_tune_nbuf : (a.stride == 1 ? 1 : 2);
-    if (AMODE != A_DENSE || OUT_NCHW) nbuf = 2;  // only the dense NHWC kernels carry both forms
+    if (AMODE == A_STEM || OUT_NCHW) nbuf = 2;  // only the NHWC dense / DCN kernels carry both forms
     if (nbuf == 1) {
-        if constexpr (AMODE == A_DENSE && !OUT_NCHW)
+        if constexpr (AMODE != A_STEM && !OUT_NCHW)
             return launch_igemm_n<float, BM, BN, WM, WN, AMODE, OUT_NCHW, 1>(a, st);
     }
     return launch_igemm_n<float, BM, BN, WM, WN, AMODE, OUT_NCHW, 2>(a, st);
@@ -745,7 +755,13 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         if (cls == 1) return launch_igemm_h<128, 64, 2, 2, A_DENSE, false>(a, st);
         return launch_igemm_h<128, 32, 4, 1, A_DENSE, false>(a, st);
     }
-    if (cls == 2) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
+    if (cls == 2) {
+        // fewer than two workgroups per CU with 128-pixel tiles: halve the pixel tile
+        const long wgs128 = (long)cn_cdiv(a.M, 128) * cn_cdiv(d->Cout, 128) * (a.zparity ? 4 : 1);
+        const bool bm64 = g_tune_bm ? (g_tune_bm == 64) : (wgs128 < 1024);
+        if (bm64) return launch_igemm<64, 128, 2, 2, A_DENSE, false>(a, st);
+        return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
+    }
     if (cls == 1) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
     return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);
 }
@@ -786,8 +802,17 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
     a.KT = 9 * a.nchunk;
     a.vec_out = ((Cout & 3) == 0 && cn_aligned16(output_nhwc)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (Cout > 64) return launch_igemm<64, 128, 2, 2, A_DCN, false>(a, st);
-    if (Cout > 32) return launch_igemm<64, 64, 2, 2, A_DCN, false>(a, st);
+    // 128-pixel tiles amortise the gather over more MFMAs; 64-pixel tiles when the layer
+    // would otherwise not fill the 256 CUs (cn_set_tuning key 3 forces one or the other)
+    const long tiles128 = (long)cn_cdiv(a.M, 128) * cn_cdiv(Cout, Cout > 64 ? 128 : 64);
+    (void)tiles128;  // measured (tools/bench_dcn.py): 64-pixel tiles win at every CenterNet shape
+    const bool small = g_tune_dcn_tile ? (g_tune_dcn_tile == 64) : true;
+    if (Cout > 64)
+        return small ? launch_igemm<64, 128, 2, 2, A_DCN, false>(a, st)
+                     : launch_igemm<128, 128, 2, 2, A_DCN, false>(a, st);
+    if (Cout > 32)
+        return small ? launch_igemm<64, 64, 2, 2, A_DCN, false>(a, st)
+                     : launch_igemm<128, 64, 2, 2, A_DCN, false>(a, st);
     return launch_igemm<128, 32, 4, 1, A_DCN, false>(a, st);
 }
 
@@ -875,6 +900,14 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 2 && (value == 0 || value == 1)) {
         g_tune_narrow = value;
+        return CN_OK;
+    }
+    if (key == 3 && (value == 0 || value == 64 || value == 128)) {
+        g_tune_dcn_tile = value;
+        return CN_OK;
+    }
+    if (key == 4 && (value == 0 || value == 64 || value == 128)) {
+        g_tune_bm = value;
         return CN_OK;
     }
     return CN_ERR_UNSUPPORTED;

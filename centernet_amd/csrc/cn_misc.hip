@@ -405,3 +405,62 @@ extern "C" int cn_upsample2x_add_f16(const void *x, const void *add, void *y, in
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
+
+// ---- soft-NMS on a small host array (merge_outputs, detectors/ctdet.py:63-64) -------------
+// Host-side, in place, same greedy/swap/discard order as src/lib/external/nms.pyx:77-170
+// (soft_nms) and :172-275 (soft_nms_39): `stride` floats per row, box in [0..3], score in [4];
+// rows swap as a whole.  Returns the number of boxes kept (the rows [0, N) at exit); rows
+// beyond N keep their decayed scores, exactly like the reference's in-place array.
+extern "C" int cn_soft_nms_f32(float *boxes, int n, int stride, float sigma, float Nt,
+                               float threshold, int method)
+{
+    if (!boxes || n < 0 || stride < 5) return CN_ERR_SHAPE;
+    int N = n;
+    float *tmp = (float *)alloca(sizeof(float) * (size_t)stride);
+    for (int i = 0; i < n; ++i) {  // the reference iterates over the ORIGINAL count
+        if (i >= N) break;         // rows past N are only self-swapped there: no effect
+        float *bi = boxes + (size_t)i * stride;
+        float maxscore = bi[4];
+        int maxpos = i;
+        for (int pos = i + 1; pos < N; ++pos)
+            if (maxscore < boxes[(size_t)pos * stride + 4]) {
+                maxscore = boxes[(size_t)pos * stride + 4];
+                maxpos = pos;
+            }
+        float *bm = boxes + (size_t)maxpos * stride;
+        for (int c = 0; c < stride; ++c) tmp[c] = bi[c];
+        for (int c = 0; c < stride; ++c) bi[c] = bm[c];
+        for (int c = 0; c < stride; ++c) bm[c] = tmp[c];
+        const float tx1 = bi[0], ty1 = bi[1], tx2 = bi[2], ty2 = bi[3];
+        int pos = i + 1;
+        while (pos < N) {
+            float *bp = boxes + (size_t)pos * stride;
+            const float x1 = bp[0], y1 = bp[1], x2 = bp[2], y2 = bp[3];
+            const float area = (x2 - x1 + 1) * (y2 - y1 + 1);
+            const float iw = (fminf(tx2, x2) - fmaxf(tx1, x1) + 1);
+            if (iw > 0) {
+                const float ih = (fminf(ty2, y2) - fmaxf(ty1, y1) + 1);
+                if (ih > 0) {
+                    const float ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih;
+                    const float ov = iw * ih / ua;
+                    float weight;
+                    if (method == 1)
+                        weight = ov > Nt ? 1 - ov : 1;
+                    else if (method == 2)
+                        weight = (float)exp((double)(-(ov * ov) / sigma));  // np.exp on a C float
+                    else
+                        weight = ov > Nt ? 0 : 1;
+                    bp[4] = weight * bp[4];
+                    if (bp[4] < threshold) {
+                        float *bl = boxes + (size_t)(N - 1) * stride;
+                        for (int c = 0; c < stride; ++c) bp[c] = bl[c];
+                        N = N - 1;
+                        pos = pos - 1;
+                    }
+                }
+            }
+            pos = pos + 1;
+        }
+    }
+    return N;
+}

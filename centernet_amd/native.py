@@ -92,6 +92,8 @@ def _declare(lib):
     lib.cn_copy_channels_f32.argtypes = [vp, i, vp, i, sz, i, vp]
     lib.cn_upsample2x_add_f32.restype = i
     lib.cn_upsample2x_add_f32.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    lib.cn_soft_nms_f32.restype = i
+    lib.cn_soft_nms_f32.argtypes = [vp, i, i, ctypes.c_float, ctypes.c_float, ctypes.c_float, i]
     lib.cn_nchw_to_nhwc_f32.restype = i
     lib.cn_nchw_to_nhwc_f32.argtypes = [vp, vp, i, i, i, i, i, vp]
     lib.cn_nhwc_to_nchw_f32.restype = i

@@ -56,7 +56,9 @@ const char *cn_arch(void);
 /* Kernel-selection knobs for benchmarking (process-wide; not needed for correctness).
  * key 1: LDS tile buffers of the dense implicit-GEMM kernels, 0 = default, 1 or 2.
  * key 2: 1 = never pick 64-wide N tiles for Cout > 64 (default 0 = pick them when they
- *        avoid a half-empty 128-wide tile). */
+ *        avoid a half-empty 128-wide tile).
+ * key 3: pixel tile of the deformable kernel, 0 = default, 64 or 128.
+ * key 4: pixel tile of the dense kernels for Cout > 64, 0 = default, 64 or 128. */
 int cn_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------
@@ -199,6 +201,13 @@ int cn_upsample2x_add_f32(const float *x, const float *add, float *y, int B, int
                           int C, void *stream);
 int cn_upsample2x_add_f16(const void *x, const void *add, void *y, int B, int H, int W, int C,
                           void *stream);
+
+/* Soft-NMS on a HOST array, in place (rows of `stride` floats: x1,y1,x2,y2,score,...).
+ * Replaces external.nms.soft_nms / soft_nms_39 (src/lib/external/nms.pyx:77-275), used by
+ * merge_outputs when --nms or multi-scale testing is on (detectors/ctdet.py:63-64).
+ * method 0 = hard NMS, 1 = linear, 2 = gaussian.  Returns the kept count (>= 0) or < 0. */
+int cn_soft_nms_f32(float *boxes_host, int n, int stride, float sigma, float Nt,
+                    float threshold, int method);
 
 /* Layout conversion at the API edge. */
 int cn_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W,

@@ -99,3 +99,51 @@ def ctdet_results(dets, meta, num_classes, scale=1, max_per_image=100):
         for j in range(1, num_classes + 1):
             d[j] = d[j][d[j][:, 4] >= thresh]
     return d
+
+
+def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """external/nms.pyx:77-170 (and :172-275 for 39-column rows), statement by statement;
+    ``boxes`` float32 (N, 5|39) modified in place; returns the kept indices.  The reference's
+    Cython source does not compile against NumPy 2 (np.int / np.float), so this restatement
+    is pinned only by hand-checked cases in tests/test_host.py."""
+    f = np.float32
+    N = boxes.shape[0]
+    ncol = boxes.shape[1]
+    for i in range(boxes.shape[0]):
+        if i >= N:
+            break
+        maxscore = boxes[i, 4]
+        maxpos = i
+        tmp = boxes[i].copy()
+        pos = i + 1
+        while pos < N:
+            if maxscore < boxes[pos, 4]:
+                maxscore = boxes[pos, 4]
+                maxpos = pos
+            pos += 1
+        boxes[i, :ncol] = boxes[maxpos, :ncol]
+        boxes[maxpos, :ncol] = tmp
+        tx1, ty1, tx2, ty2 = boxes[i, 0], boxes[i, 1], boxes[i, 2], boxes[i, 3]
+        pos = i + 1
+        while pos < N:
+            x1, y1, x2, y2 = boxes[pos, 0], boxes[pos, 1], boxes[pos, 2], boxes[pos, 3]
+            area = f(f(x2 - x1 + f(1)) * f(y2 - y1 + f(1)))
+            iw = f(min(tx2, x2) - max(tx1, x1) + f(1))
+            if iw > 0:
+                ih = f(min(ty2, y2) - max(ty1, y1) + f(1))
+                if ih > 0:
+                    ua = f(f(f(tx2 - tx1 + f(1)) * f(ty2 - ty1 + f(1))) + area - f(iw * ih))
+                    ov = f(f(iw * ih) / ua)
+                    if method == 1:
+                        weight = f(1) - ov if ov > Nt else f(1)
+                    elif method == 2:
+                        weight = f(np.exp(float(f(-f(ov * ov) / f(sigma)))))
+                    else:
+                        weight = f(0) if ov > Nt else f(1)
+                    boxes[pos, 4] = f(weight * boxes[pos, 4])
+                    if boxes[pos, 4] < threshold:
+                        boxes[pos, :ncol] = boxes[N - 1, :ncol]
+                        N -= 1
+                        pos -= 1
+            pos += 1
+    return list(range(N))

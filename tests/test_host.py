@@ -82,3 +82,35 @@ def test_detector_rejects_cpu_mode():
     o = opts().init(["ctdet", "--arch", "res_18", "--gpus", "-1"])
     with pytest.raises(NativeError):
         detector_factory[o.task](o)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("ncol", [5, 39])
+def test_soft_nms_matches_restatement(method, ncol):
+    from centernet_amd.soft_nms import soft_nms, soft_nms_39
+    rs = np.random.RandomState(method * 7 + ncol)
+    n = 60
+    xy = rs.uniform(0, 200, (n, 2))
+    wh = rs.uniform(10, 80, (n, 2))
+    boxes = np.zeros((n, ncol), np.float32)
+    boxes[:, 0:2] = xy
+    boxes[:, 2:4] = xy + wh
+    boxes[:, 4] = rs.uniform(0.001, 1, n)
+    if ncol == 39:
+        boxes[:, 5:] = rs.uniform(0, 200, (n, 34))
+    a, b = boxes.copy(), boxes.copy()
+    keep_a = (soft_nms if ncol == 5 else soft_nms_39)(a, Nt=0.5, method=method)
+    keep_b = post_oracle.soft_nms(b, Nt=0.5, method=method)
+    assert keep_a == keep_b
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_soft_nms_known_answer():
+    """Two identical boxes, hard NMS: the second is discarded; gaussian: decayed by e^-2."""
+    from centernet_amd.soft_nms import soft_nms
+    b = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 9, 0.8], [100, 100, 109, 109, 0.7]], np.float32)
+    a = b.copy()
+    assert soft_nms(a, Nt=0.5, method=0) == [0, 1] and a[0, 4] == np.float32(0.9) and a[1, 4] == np.float32(0.7)
+    g = b.copy()
+    assert soft_nms(g, Nt=0.5, method=2) == [0, 1, 2]
+    assert abs(g[np.argmin(np.abs(g[:, 4] - 0.8 * np.exp(-2.0))), 4] - 0.8 * np.exp(-2.0)) < 1e-6

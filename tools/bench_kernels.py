@@ -35,12 +35,12 @@ def time_ops(pb, iters=20):
     return s.elapsed_time(e) / iters
 
 
-knobs = [(1, 2), (1, 1)]
+knobs = [(4, 128), (4, 64)]
 if os.environ.get('ONLY'):
     SHAPES = [SHAPES[int(i)] for i in os.environ['ONLY'].split(',')]
 if os.environ.get('NBUF'):
     knobs = [(1, int(os.environ['NBUF']))]
-print("%-34s" % "shape (Cin,H,W,Cout,k,s)", *["nbuf=%d" % v for _, v in knobs])
+print("%-34s" % "shape (Cin,H,W,Cout,k,s)", *["key%d=%d" % kv for kv in knobs])
 for (ci, H, W, co, k, s) in SHAPES:
     x = Act(torch.randn((B, H, W, ci), device=dev), B, H, W, ci)
     w = torch.randn((co, ci, k, k)) * 0.05
@@ -52,4 +52,4 @@ for (ci, H, W, co, k, s) in SHAPES:
         ms = time_ops(pb)
         row.append("%6.3f ms %6.1f TF" % (ms, pb.flops / ms / 1e9))
     print("%-34s" % str((ci, H, W, co, k, s)), *row)
-lib.cn_set_tuning(1, 0)
+lib.cn_set_tuning(1, 0); lib.cn_set_tuning(4, 0)
