@@ -60,6 +60,8 @@ struct IgemmArgs {
     int zparity;   // ConvTranspose 4x4/s2: blockIdx.z = output parity class (py*2+px)
     int w_zstride; // floats between the packed weights of two parity classes
     int vec_out;   // NHWC output base/pitch allow 16-byte stores
+    int ksplit;    // split-K: blockIdx.z owns chunks [z*KT/ksplit, (z+1)*KT/ksplit)
+    float *partial; // split-K: raw fp32 partial sums [ksplit][M][cout_pad]
 };
 
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -382,11 +384,16 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     // ---- main loop: register prefetch of chunk k+1 during the MFMAs of chunk k.
     // NBUF=2: LDS double buffer, one barrier per chunk.  NBUF=1: half the LDS (more
     // workgroups per CU hide the second barrier), two barriers per chunk.
-    load_tiles(0);
-    store_tiles(0, 0);
+    int kt0 = 0, kt1 = a.KT;
+    if (a.ksplit > 1) {  // small-M / deep-K layers: several workgroups share one output tile
+        kt0 = (int)((long)blockIdx.z * a.KT / a.ksplit);
+        kt1 = (int)((long)(blockIdx.z + 1) * a.KT / a.ksplit);
+    }
+    load_tiles(kt0);
+    store_tiles(0, kt0);
     __syncthreads();
-    for (int kt = 0; kt < a.KT; ++kt) {
-        const bool more = (kt + 1) < a.KT;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = (kt + 1) < kt1;
         if (more) load_tiles(kt + 1);
         // DCN: the records of tap t (t >= 2) are first read by load_tiles(t*nchunk) in
         // iteration t*nchunk-1; their buffer (parity of t) was last read in iteration
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         const bool rec = (AMODE == A_DCN) && ((kt + 2) % a.nchunk == 0) &&
                          ((kt + 2) / a.nchunk >= 2) && ((kt + 2) / a.nchunk < 9);
         if (NBUF == 2) {
-            const int buf = kt & 1;
+            const int buf = (kt - kt0) & 1;
             compute(buf);
             if (more) store_tiles(buf ^ 1, kt + 1);
             if (rec) dcn_records((kt + 2) / a.nchunk);
@@ -430,6 +437,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
             sf[e] = (a.shift && ok) ? a.shift[n + e] : 0.f;
         }
         const bool vec = a.vec_out && (n + 4 <= a.Cout);
+        const bool raw = a.ksplit > 1;  // partial sums: no epilogue, fp32, row index = m
 #pragma unroll 1
         for (int pass = 0; pass < WM; ++pass) {
             if (pass) __syncthreads();  // previous pass fully read
@@ -446,7 +454,17 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
             }
             __syncthreads();
             const int rbase = pass * TM;  // tile row of staging row 0
-            if (vec) {
+            if (raw) {
+                float *pz = a.partial + (size_t)blockIdx.z * a.M * a.cout_pad;
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int lr = it * RPI + r0;
+                    const int m = m0 + rbase + lr;
+                    if (lr < TM && m < a.M && n < a.cout_pad)
+                        *reinterpret_cast<cn_f32x4 *>(pz + (size_t)m * a.cout_pad + n) =
+                            *reinterpret_cast<const cn_f32x4 *>(Cs + lr * LDC + c4 * 4);
+                }
+            } else if (vec) {
                 cn_f32x4 res[ITERS];
                 int offs[ITERS];
 #pragma unroll
@@ -525,6 +543,7 @@ int g_tune_nbuf = 0;  // 0 = per-shape default, 1 / 2 = force (cn_set_tuning key
 int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-wide tiles
 int g_tune_dcn_tile = 0; // cn_set_tuning key 3: 0 = default, 64 / 128 = force the DCN pixel tile
 int g_tune_bm = 0;       // cn_set_tuning key 4: 0 = default, 64 / 128 = force the dense pixel tile
+int g_tune_nosplit = 0;  // cn_set_tuning key 5: 1 = never split K
 
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
 int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
@@ -537,7 +556,7 @@ int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : 1);
+    dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : (a.ksplit > 1 ? a.ksplit : 1));
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), grid, dim3(NT),
                        lds, st, a);
     CN_CHECK_LAUNCH();
@@ -602,6 +621,55 @@ __global__ void pack_stem_weight_kernel(const float *__restrict__ w, T *__restri
 }
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// split-K second stage: sum the partial tiles, then the usual epilogue
+// y = relu?((sum + bias) * scale + shift + residual), NHWC (element type T)
+template <typename T>
+__global__ void splitk_reduce_kernel(const IgemmArgs a)
+{
+    const int n4 = a.cout_pad >> 2;
+    const size_t total = (size_t)a.M * n4;
+    const int HoWo = a.Ho * a.Wo;
+    const size_t zstride = (size_t)a.M * a.cout_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % n4);
+        const int m = (int)(i / n4);
+        const int n = c4 * 4;
+        if (n >= a.Cout) continue;
+        cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(a.partial + (size_t)m * a.cout_pad + n);
+        for (int z = 1; z < a.ksplit; ++z)
+            v += *reinterpret_cast<const cn_f32x4 *>(a.partial + z * zstride + (size_t)m * a.cout_pad + n);
+        const int b = m / HoWo;
+        const int rr = m - b * HoWo;
+        const int oy = rr / a.Wo;
+        const int ox = rr - oy * a.Wo;
+        const size_t off = (size_t)((b * a.OH + oy * a.oy_mul + a.oy_add) * a.OW + ox * a.ox_mul + a.ox_add);
+        const T *res = reinterpret_cast<const T *>(a.residual);
+        T *y = reinterpret_cast<T *>(a.y);
+        for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
+            const float bs = a.bias ? a.bias[n + e] : 0.f;
+            const float sc = a.scale ? a.scale[n + e] : 1.f;
+            const float sf = a.shift ? a.shift[n + e] : 0.f;
+            float t = (v[e] + bs) * sc + sf;
+            const size_t o = off * a.out_pitch + n + e;
+            if (res) t += (float)res[o];
+            y[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
+        }
+    }
+}
+
+// How many K-splits a dense NHWC layer gets: enough workgroups to put ~2 on every CU,
+// at least 8 chunks of K per split, only when the plain grid is badly under-filled.
+inline int plan_ksplit(int M, int Cout, int KT, int bm, int bn)
+{
+    const long wgs = (long)cn_cdiv(M, bm) * cn_cdiv(Cout, bn);
+    if (wgs >= 256 || KT < 16) return 1;
+    int s = (int)((512 + wgs - 1) / wgs);
+    if (s > KT / 8) s = KT / 8;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
 inline bool is_stem(int Cin, int in_layout) { return in_layout == CN_LAYOUT_NCHW && Cin == 3; }
 
 }  // namespace
@@ -706,9 +774,42 @@ static int conv_fill_args(const cn_conv_desc *d, IgemmArgs *a)
     return CN_OK;
 }
 
+// tile class of a dense layer: N tile 128 / 64 / 32 wide, pixel tile 128 or 64
+static void dense_tile_class(const cn_conv_desc *d, const IgemmArgs &a, int *cls, bool *bm64)
+{
+    // 128-wide N tiles unless their padding wastes a whole 64-wide tile (e.g. Cout = 192)
+    const int waste128 = cn_cdiv(d->Cout, 128) * 128 - d->Cout;
+    const int waste64 = cn_cdiv(d->Cout, 64) * 64 - d->Cout;
+    const bool narrow = !g_tune_narrow && (waste128 - waste64 >= 64);
+    *cls = (d->Cout > 64 && !narrow) ? 2 : (d->Cout > 32 ? 1 : 0);
+    // fewer than four workgroups per CU with 128-pixel tiles: halve the pixel tile
+    const long wgs128 = (long)cn_cdiv(a.M, 128) * cn_cdiv(d->Cout, 128) * (a.zparity ? 4 : 1);
+    *bm64 = (*cls == 2) && (g_tune_bm ? (g_tune_bm == 64) : (wgs128 < 1024));
+}
+
+static int dense_ksplit(const cn_conv_desc *d, const IgemmArgs &a)
+{
+    if (g_tune_nosplit || d->out_layout != CN_LAYOUT_NHWC || is_stem(d->Cin, d->in_layout) ||
+        a.zparity)
+        return 1;
+    int cls;
+    bool bm64;
+    dense_tile_class(d, a, &cls, &bm64);
+    const int bm = bm64 ? 64 : 128, bn = cls == 2 ? 128 : (cls == 1 ? 64 : 32);
+    return plan_ksplit(a.M, d->Cout, a.KT, bm, bn);
+}
+
+extern "C" size_t cn_conv2d_workspace_bytes(const cn_conv_desc *d)
+{
+    IgemmArgs a = {};
+    if (!d || conv_fill_args(d, &a) != CN_OK) return 0;
+    const int s = dense_ksplit(d, a);
+    return s > 1 ? (size_t)s * a.M * a.cout_pad * sizeof(float) : 0;
+}
+
 extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_packed,
                          const float *scale, const float *shift, const void *residual, void *y,
-                         void *stream)
+                         void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!d || !x || !w_packed || !y) return CN_ERR_NULL;
     if (!cn_aligned16(x) || !cn_aligned16(w_packed)) return CN_ERR_ALIGN;
@@ -724,11 +825,17 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
                  (!residual || (((uintptr_t)residual) % valign) == 0)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool stem = is_stem(d->Cin, d->in_layout);
-    // 128-wide N tiles unless their padding wastes a whole 64-wide tile (e.g. Cout = 192)
-    const int waste128 = cn_cdiv(d->Cout, 128) * 128 - d->Cout;
-    const int waste64 = cn_cdiv(d->Cout, 64) * 64 - d->Cout;
-    const bool narrow = !g_tune_narrow && (waste128 - waste64 >= 64);
-    const int cls = (d->Cout > 64 && !narrow) ? 2 : (d->Cout > 32 ? 1 : 0);  // 128 / 64 / 32 wide
+    int cls;
+    bool bm64;
+    dense_tile_class(d, a, &cls, &bm64);
+    // split-K for under-filled grids (needs the caller's workspace; skipped without it)
+    a.ksplit = 1;
+    const int want = dense_ksplit(d, a);
+    if (want > 1 && workspace && cn_aligned16(workspace) &&
+        workspace_bytes >= (size_t)want * a.M * a.cout_pad * sizeof(float)) {
+        a.ksplit = want;
+        a.partial = (float *)workspace;
+    }
     if (d->out_layout == CN_LAYOUT_NCHW) {
         if (residual || stem) return CN_ERR_UNSUPPORTED;
         if (f16) {
@@ -751,19 +858,32 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
     }
     if (f16) {
-        if (cls == 2) return launch_igemm_h<128, 128, 2, 2, A_DENSE, false>(a, st);
-        if (cls == 1) return launch_igemm_h<128, 64, 2, 2, A_DENSE, false>(a, st);
-        return launch_igemm_h<128, 32, 4, 1, A_DENSE, false>(a, st);
+        if (cls == 2)
+            rc = bm64 ? launch_igemm_h<64, 128, 2, 2, A_DENSE, false>(a, st)
+                      : launch_igemm_h<128, 128, 2, 2, A_DENSE, false>(a, st);
+        else if (cls == 1)
+            rc = launch_igemm_h<128, 64, 2, 2, A_DENSE, false>(a, st);
+        else
+            rc = launch_igemm_h<128, 32, 4, 1, A_DENSE, false>(a, st);
+    } else {
+        if (cls == 2)
+            rc = bm64 ? launch_igemm<64, 128, 2, 2, A_DENSE, false>(a, st)
+                      : launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
+        else if (cls == 1)
+            rc = launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
+        else
+            rc = launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);
     }
-    if (cls == 2) {
-        // fewer than two workgroups per CU with 128-pixel tiles: halve the pixel tile
-        const long wgs128 = (long)cn_cdiv(a.M, 128) * cn_cdiv(d->Cout, 128) * (a.zparity ? 4 : 1);
-        const bool bm64 = g_tune_bm ? (g_tune_bm == 64) : (wgs128 < 1024);
-        if (bm64) return launch_igemm<64, 128, 2, 2, A_DENSE, false>(a, st);
-        return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
-    }
-    if (cls == 1) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
-    return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);
+    if (rc != CN_OK || a.ksplit == 1) return rc;
+    const size_t total = (size_t)a.M * (a.cout_pad >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (f16)
+        hipLaunchKernelGGL(splitk_reduce_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
 }
 
 extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float *w_packed,
@@ -771,7 +891,7 @@ extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float 
                              float *y, void *stream)
 {
     if (d && d->dtype != CN_DTYPE_F32) return CN_ERR_UNSUPPORTED;
-    return cn_conv2d(d, x, w_packed, scale, shift, residual, y, stream);
+    return cn_conv2d(d, x, w_packed, scale, shift, residual, y, nullptr, 0, stream);
 }
 
 extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_packed,
@@ -908,6 +1028,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 4 && (value == 0 || value == 64 || value == 128)) {
         g_tune_bm = value;
+        return CN_OK;
+    }
+    if (key == 5 && (value == 0 || value == 1)) {
+        g_tune_nosplit = value;
         return CN_OK;
     }
     return CN_ERR_UNSUPPORTED;

@@ -77,6 +77,8 @@ class PlanBuilder:
         self.flops = 0         # algorithmic conv/DCN FLOPs per forward (2*MACs)
         self.input = None
         self.trace = []        # (kind, Act) of every op output, in launch order (debugging)
+        self.ws = None         # split-K scratch shared by all launches (stream-ordered)
+        self.ws_bytes = 0
 
     # ---- helpers -------------------------------------------------------------
     def _new(self, B, H, W, C, pitch=None):
@@ -139,10 +141,16 @@ class PlanBuilder:
         rp = residual.ptr() if residual is not None else None
         wpp, op = native.ptr(wp), out.ptr()
         dref = ctypes.byref(d)
+        need = lib.cn_conv2d_workspace_bytes(dref)
+        if need > self.ws_bytes:   # grow the shared scratch (ops read self.ws at run time)
+            self.ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+            self.ws_bytes = need
 
         def run():
             xp = ctypes.c_void_p(self.input.t.data_ptr()) if is_input else x.ptr()
-            rc = lib.cn_conv2d(dref, xp, wpp, sp, hp, rp, op, native.stream_ptr())
+            wsp = ctypes.c_void_p(self.ws.data_ptr()) if self.ws is not None else None
+            rc = lib.cn_conv2d(dref, xp, wpp, sp, hp, rp, op, wsp, self.ws_bytes,
+                               native.stream_ptr())
             if rc:
                 native.check(rc, "cn_conv2d")
         self.ops.append(run)

@@ -72,8 +72,10 @@ def _declare(lib):
     lib.cn_packed_conv_weight_elems.argtypes = [i] * 5
     lib.cn_pack_conv_weight.restype = i
     lib.cn_pack_conv_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
+    lib.cn_conv2d_workspace_bytes.restype = sz
+    lib.cn_conv2d_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.cn_conv2d.restype = i
-    lib.cn_conv2d.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
+    lib.cn_conv2d.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.cn_upsample2x_add_f16.restype = i
     lib.cn_upsample2x_add_f16.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.cn_packed_deconv4x4s2_weight_floats.restype = sz

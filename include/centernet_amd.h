@@ -58,7 +58,8 @@ const char *cn_arch(void);
  * key 2: 1 = never pick 64-wide N tiles for Cout > 64 (default 0 = pick them when they
  *        avoid a half-empty 128-wide tile).
  * key 3: pixel tile of the deformable kernel, 0 = default, 64 or 128.
- * key 4: pixel tile of the dense kernels for Cout > 64, 0 = default, 64 or 128. */
+ * key 4: pixel tile of the dense kernels for Cout > 64, 0 = default, 64 or 128.
+ * key 5: 1 = never split K. */
 int cn_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------
@@ -161,8 +162,13 @@ int cn_conv2d_f32(const cn_conv_desc *desc, const float *x, const float *w_packe
 size_t cn_packed_conv_weight_elems(int Cout, int Cin, int KH, int KW, int dtype);
 int cn_pack_conv_weight(const float *w_oihw, void *w_packed, int Cout, int Cin, int KH, int KW,
                         int dtype, void *stream);
+/* workspace: optional scratch for split-K (layers whose plain grid would leave most of the
+ * 256 CUs idle: small maps with deep K); query with cn_conv2d_workspace_bytes, NULL/0 = never
+ * split.  The split is deterministic (fixed partition, second-stage reduce, no atomics). */
+size_t cn_conv2d_workspace_bytes(const cn_conv_desc *desc);
 int cn_conv2d(const cn_conv_desc *desc, const void *x, const void *w_packed, const float *scale,
-              const float *shift, const void *residual, void *y, void *stream);
+              const float *shift, const void *residual, void *y, void *workspace,
+              size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * ConvTranspose2d(kernel 4, stride 2, padding 1, bias=False) + BN(eval) + ReLU.

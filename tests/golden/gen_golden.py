@@ -174,9 +174,10 @@ def gen_nets():
     x = synth.images(B, H, W, seed=0)
     out = {}
     meta = {"input_sha": sha(x.numpy())}
-    for arch, mod in (("res_18", msra_resnet), ("resdcn_18", resnet_dcn)):
+    for arch, mod in (("res_18", msra_resnet), ("resdcn_18", resnet_dcn), ("resdcn_101", resnet_dcn)):
         torch.manual_seed(NET_SEED)
-        net = mod.PoseResNet(mod.BasicBlock, [2, 2, 2, 2], dict(NET_HEADS), head_conv=64)
+        block, layers = mod.resnet_spec[int(arch.split("_")[1])]
+        net = mod.PoseResNet(block, layers, dict(NET_HEADS), head_conv=64)
         synth.fill_state_dict_(net, NET_SEED)
         net.eval()
         with torch.no_grad():

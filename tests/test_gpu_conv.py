@@ -45,6 +45,11 @@ def _bn(C, seed):
     (3, 36, 9, 11, 40, 3, 1, 1, True, False, True, False),
     (1, 64, 128, 128, 192, 3, 1, 1, True, False, True, False),
     (2, 128, 8, 8, 256, 1, 1, 0, False, True, True, True),
+    # small maps with deep K: the split-K path (several workgroups per output tile + reduce)
+    (1, 512, 16, 16, 512, 3, 1, 1, False, True, True, True),
+    (2, 512, 8, 8, 27, 3, 1, 1, True, False, False, False),
+    (1, 384, 4, 4, 384, 3, 1, 1, False, True, True, False),
+    (2, 256, 16, 16, 128, 3, 2, 1, False, True, True, False),
 ])
 def test_conv_bn_relu_residual(dev, cfg):
     from centernet_amd.engine import PlanBuilder
@@ -124,6 +129,7 @@ def test_heads_fused_nchw_outputs(dev):
 @pytest.mark.parametrize("cfg", [
     (2, 64, 32, 32, 64, 3, 1, 1, True, True), (2, 256, 16, 16, 384, 3, 2, 1, True, False),
     (1, 128, 17, 19, 256, 1, 1, 0, False, True), (1, 384, 8, 8, 384, 3, 1, 1, True, True),
+    (1, 512, 4, 4, 512, 3, 1, 1, True, True),
 ])
 def test_fp16_conv_vs_fp32_reference(dev, cfg):
     """fp16 operands / fp32 accumulate (configs[4]): against torch fp32 on the SAME

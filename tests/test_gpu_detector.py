@@ -36,8 +36,9 @@ def test_run_on_image_matches_oracle_pipeline(dev):
     n_same = 0
     for j in range(1, 81):
         if len(ref[j]) == len(res[j]) and len(ref[j]):
-            a = res[j][np.argsort(-res[j][:, 4])]
-            b = ref[j][np.argsort(-ref[j][:, 4])]
+            # pair boxes by position (two boxes of a class can have near-equal scores)
+            a = res[j][np.lexsort((res[j][:, 1], np.round(res[j][:, 0])))]
+            b = ref[j][np.lexsort((ref[j][:, 1], np.round(ref[j][:, 0])))]
             assert np.abs(a[:, 4] - b[:, 4]).max() < 1e-4
             assert np.abs(a[:, :4] - b[:, :4]).max() < 2e-3       # image pixels (x4 the grid)
             n_same += len(a)
@@ -63,4 +64,21 @@ def test_run_batch(dev):
     d = det.run_batch(x)
     assert tuple(d.shape) == (4, 100, 6)
     one = det.run_batch(x[1:2].contiguous())
-    assert torch.equal(one[0], d[1])
+    # kernels pick tile / split-K shapes per batch size, so a different batch size may round
+    # differently: same detections within fp32 noise (scores 1e-5), not bit-identical
+    assert torch.equal(one[0, :, 5], d[1, :, 5])
+    assert float((one[0] - d[1]).abs().max()) < 1e-3 and float((one[0, :, 4] - d[1, :, 4]).abs().max()) < 1e-5
+    assert torch.equal(det.run_batch(x), d)            # same batch: bit-identical replay
+
+
+def test_multi_scale_with_soft_nms(dev):
+    """--test_scales 1,0.75 --nms: two passes at different resolutions, detections merged per
+    class and decayed by the native soft-NMS (detectors/ctdet.py:58-73)."""
+    det, opt = _detector("resdcn_18", ["--test_scales", "1,0.75", "--nms"])
+    image = np.random.RandomState(3).randint(0, 256, (384, 512, 3)).astype(np.uint8)
+    res = det.run(image)["results"]
+    assert sorted(res) == list(range(1, 81))
+    n = sum(len(v) for v in res.values())
+    assert 100 <= n <= 200          # top-100 threshold keeps ties, at most 2x100 candidates
+    allb = np.concatenate([v for v in res.values() if len(v)], 0)
+    assert np.isfinite(allb).all() and (allb[:, 4] > 0).all() and (allb[:, 4] <= 1).all()

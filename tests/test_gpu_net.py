@@ -18,7 +18,7 @@ def _model(arch, heads, seed, dev):
     return m.to(dev).eval()
 
 
-@pytest.mark.parametrize("case", ["res_18", "resdcn_18", "dla_34", "dla_34_pose", "hourglass"])
+@pytest.mark.parametrize("case", ["res_18", "resdcn_18", "resdcn_101", "dla_34", "dla_34_pose", "hourglass"])
 def test_heads_match_reference_golden(dev, gen, net_golden, case):
     z, meta = net_golden
     heads = gen.POSE_HEADS if case.endswith("_pose") else gen.NET_HEADS
@@ -77,7 +77,8 @@ def test_end_to_end_boxes_512(dev, arch, B):
 
 def test_batch_independence_and_graph_replay(dev):
     """Images are independent (the path shards over images): a batch equals its images run
-    one by one, and a HIP-graph replay equals the eager launch list."""
+    one by one (to fp32 rounding: tile and split-K shapes are chosen per batch size), and a
+    HIP-graph replay is bit-identical to the eager launch list."""
     heads = {"hm": 80, "wh": 2, "reg": 2}
     m = _model("resdcn_18", heads, 317, dev)
     x = synth.images(3, 256, 256, seed=4).to(dev)
@@ -86,7 +87,8 @@ def test_batch_independence_and_graph_replay(dev):
         for b in range(3):
             one = m(x[b:b + 1].contiguous())[-1]
             for k in heads:
-                assert torch.equal(one[k][0], full[k][b]), (k, b)
+                scale = max(1.0, float(full[k].pow(2).mean().sqrt()))
+                assert float((one[k][0] - full[k][b]).abs().max()) < 1e-4 * scale, (k, b)
         plan = m.plan_for(3, 256, 256, x.device)
         plan.capture()
         rep = plan.run(x)

@@ -9,7 +9,7 @@ from centernet_amd import synth
 from oracle import net_oracle
 
 
-CASES = ["res_18", "resdcn_18", "dla_34", "dla_34_pose", "hourglass"]
+CASES = ["res_18", "resdcn_18", "resdcn_101", "dla_34", "dla_34_pose", "hourglass"]
 
 
 def _model(case, gen):
