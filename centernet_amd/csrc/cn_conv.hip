@@ -35,6 +35,7 @@ constexpr int BK = 32;
 constexpr int LDT = BK + 4;  // LDS row pitch in floats
 
 enum { A_DENSE = 0, A_STEM = 1, A_DCN = 2 };
+constexpr int STEM_KMAX = 512;  // largest padded K of a 3-channel stem (11x11 -> 363 -> 384)
 
 struct IgemmArgs {
     const void *x;       // activations, element type T (fp32 or fp16); fp32 NCHW for the stem
@@ -117,6 +118,8 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     int *rowoff = reinterpret_cast<int *>(As + UNION_FLOATS);  // [BM]
     // DCN sampling records of ONE tap per row (4 corner pixel indices, 4 weights, mask),
     // double-buffered by tap parity: the records of tap t+1 are written while tap t runs
+    // stem: k -> (plane offset, ky, kx) table, k = tap*3 + rgb  [STEM_KMAX] x 2 ints
+    int *ktab = rowoff + BM;
     int *sidx = rowoff + BM;                                  // [2][BM][4]
     float *swt = reinterpret_cast<float *>(sidx + 2 * BM * 4);  // [2][BM][4]
     float *smk = swt + 2 * BM * 4;                            // [2][BM]
@@ -229,6 +232,16 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         dcn_records(0);
         dcn_records(1);
     }
+    if (AMODE == A_STEM) {
+        const int taps = a.KH * a.KW;
+        for (int k = tid; k < a.cin_pad; k += NT) {
+            const int tap = k / 3, c = k - tap * 3;
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+            const bool ok = tap < taps;
+            ktab[2 * k] = ok ? (c * a.H * a.W + ky * a.dil * a.W + kx * a.dil) : 0;
+            ktab[2 * k + 1] = ok ? ((ky * a.dil) << 16 | (kx * a.dil)) : 0x7fff7fff;  // fails the bounds test
+        }
+    }
     __syncthreads();
 
     cn_f32x16 acc[MB][NB];
@@ -271,27 +284,24 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 ra[p][0] = ok ? v : zero4;
             }
         } else if (AMODE == A_STEM) {
-            // one 16-byte vector = EPV/4 taps x (r,g,b,0); the image is fp32 NCHW, Cin == 3
-            constexpr int TPV = EPV / 4;
+            // K is packed densely as k = tap*3 + rgb (147 -> 160 for 7x7, not 196 -> 224);
+            // the image is fp32 NCHW; (offset, ky, kx) of every k come from the LDS table
             const float *xin = reinterpret_cast<const float *>(a.x);
-            const int HW = a.H * a.W;
+            const int kbase = (kt * 8 + q) * EPV;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 T vals[EPV];
+                const size_t img = (size_t)(a_pix[p] >= 0 ? a_pix[p] : 0) * 3 +
+                                   (size_t)a_iy0[p] * a.W + a_ix0[p];  // may point before the
+                                                                       // image: only used when ok
 #pragma unroll
-                for (int t = 0; t < TPV; ++t) {
-                    const int tq = (kt * 8 + q) * TPV + t;
-                    const int ky = tq / a.KW, kx = tq - ky * a.KW;
-                    const int iy = a_iy0[p] + ky * a.dil;
-                    const int ix = a_ix0[p] + kx * a.dil;
-                    const bool ok = tq < a.KH * a.KW && a_pix[p] >= 0 && iy >= 0 && iy < a.H &&
-                                    ix >= 0 && ix < a.W;
-                    const float *px = xin + (ok ? ((size_t)a_pix[p] * 3 + (size_t)iy * a.W + ix) : 0);
-                    const float r = px[0], g = px[HW], bl = px[2 * HW];
-                    vals[4 * t + 0] = ok ? (T)r : (T)0.f;
-                    vals[4 * t + 1] = ok ? (T)g : (T)0.f;
-                    vals[4 * t + 2] = ok ? (T)bl : (T)0.f;
-                    vals[4 * t + 3] = (T)0.f;
+                for (int e = 0; e < EPV; ++e) {
+                    const int off = ktab[2 * (kbase + e)];
+                    const int kk = ktab[2 * (kbase + e) + 1];
+                    const int iy = a_iy0[p] + (kk >> 16), ix = a_ix0[p] + (kk & 0xffff);
+                    const bool ok = a_pix[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    const float v = xin[ok ? (img + off) : 0];
+                    vals[e] = ok ? (T)v : (T)0.f;
                 }
                 ra[p][0] = *reinterpret_cast<const cn_f32x4 *>(vals);
             }
@@ -536,7 +546,8 @@ constexpr size_t igemm_lds_bytes()
     constexpr size_t tiles = (size_t)NBUF * (BM + BN) * LDT;
     constexpr size_t cs = OUT_NCHW ? 0 : (size_t)(BM / WM) * (BN + 4);
     return (tiles > cs ? tiles : cs) * 4 + BM * 4 +
-           (AMODE == A_DCN ? (size_t)2 * BM * (4 * 4 + 4 * 4 + 4) : 0);
+           (AMODE == A_DCN ? (size_t)2 * BM * (4 * 4 + 4 * 4 + 4) : 0) +
+           (AMODE == A_STEM ? (size_t)STEM_KMAX * 8 : 0);
 }
 
 int g_tune_nbuf = 0;  // 0 = per-shape default, 1 / 2 = force (cn_set_tuning key 1)
@@ -603,7 +614,7 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, T *__restrict__ 
         wp[i] = (T)v;
     }
 }
-// stem: (Cout,3,KH,KW) -> [cout_pad][kpad], k = tap*4 + rgb
+// stem: (Cout,3,KH,KW) -> [cout_pad][kpad], k = tap*3 + rgb
 template <typename T>
 __global__ void pack_stem_weight_kernel(const float *__restrict__ w, T *__restrict__ wp,
                                         int Cout, int taps, int cout_pad, int kpad)
@@ -613,9 +624,9 @@ __global__ void pack_stem_weight_kernel(const float *__restrict__ w, T *__restri
          i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % kpad);
         const int n = (int)(i / kpad);
-        const int t = k >> 2, c = k & 3;
+        const int t = k / 3, c = k - t * 3;
         float v = 0.f;
-        if (n < Cout && t < taps && c < 3) v = w[((size_t)n * 3 + c) * taps + t];
+        if (n < Cout && t < taps) v = w[((size_t)n * 3 + c) * taps + t];
         wp[i] = (T)v;
     }
 }
@@ -677,8 +688,8 @@ inline bool is_stem(int Cin, int in_layout) { return in_layout == CN_LAYOUT_NCHW
 static size_t packed_elems(int Cout, int Cin, int KH, int KW, int bke)
 {
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
-    if (Cin == 3)  // stem form: [cout_pad][round_up(taps*4, chunk)]
-        return (size_t)round_up(Cout, 32) * round_up(KH * KW * 4, bke);
+    if (Cin == 3)  // stem form: [cout_pad][round_up(taps*3, chunk)]
+        return (size_t)round_up(Cout, 32) * round_up(KH * KW * 3, bke);
     return (size_t)KH * KW * round_up(Cout, 32) * round_up(Cin, bke);
 }
 
@@ -699,7 +710,7 @@ static int pack_conv_weight_t(const float *w_oihw, void *w_packed, int Cout, int
     const int taps = KH * KW;
     const int cout_pad = round_up(Cout, 32);
     if (Cin == 3) {
-        const int kpad = round_up(taps * 4, bke);
+        const int kpad = round_up(taps * 3, bke);
         const size_t total = (size_t)cout_pad * kpad;
         hipLaunchKernelGGL(pack_stem_weight_kernel<T>, dim3((unsigned)cn_cdiv((int)total, 256)),
                            dim3(256), 0, st, w_oihw, (T *)w_packed, Cout, taps, cout_pad, kpad);
@@ -761,7 +772,8 @@ static int conv_fill_args(const cn_conv_desc *d, IgemmArgs *a)
     if (d->dtype != CN_DTYPE_F32 && !f16) return CN_ERR_UNSUPPORTED;
     const int bke = f16 ? 64 : 32, epv = f16 ? 8 : 4;
     if (is_stem(d->Cin, d->in_layout)) {
-        a->cin_pad = round_up(d->KH * d->KW * 4, bke);
+        a->cin_pad = round_up(d->KH * d->KW * 3, bke);
+        if (a->cin_pad > STEM_KMAX) return CN_ERR_UNSUPPORTED;
         a->nchunk = a->cin_pad / bke;
         a->KT = a->nchunk;
     } else {

@@ -46,7 +46,7 @@ def test_shape_queries_without_gpu():
     lib = native.lib()
     assert lib.cn_packed_conv_weight_floats(64, 64, 3, 3) == 9 * 64 * 64
     assert lib.cn_packed_conv_weight_floats(27, 512, 3, 3) == 9 * 32 * 512
-    assert lib.cn_packed_conv_weight_floats(64, 3, 7, 7) == 64 * 224
+    assert lib.cn_packed_conv_weight_floats(64, 3, 7, 7) == 64 * 160
     n = lib.cn_ctdet_decode_workspace_bytes(32, 80, 128, 128, 100)
     assert n >= 2 * 4 * 32 * 80 * 100
     assert lib.cn_ctdet_decode_workspace_bytes(1, 80, 128, 128, 100) > 0

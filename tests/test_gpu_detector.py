@@ -82,3 +82,38 @@ def test_multi_scale_with_soft_nms(dev):
     assert 100 <= n <= 200          # top-100 threshold keeps ties, at most 2x100 candidates
     allb = np.concatenate([v for v in res.values() if len(v)], 0)
     assert np.isfinite(allb).all() and (allb[:, 4] > 0).all() and (allb[:, 4] <= 1).all()
+
+
+def test_multi_pose_detector_matches_oracle(dev):
+    """multi_pose task on DLA-34 (BASELINE configs[3]): run(img) -> {1: [[39 floats], ...]};
+    compared with the CPU restatement of network + multi_pose_decode + post-process."""
+    from centernet_amd.detectors import detector_factory
+    from centernet_amd.opts import opts
+    from oracle import cref
+    opt = opts().init(["multi_pose", "--arch", "dla_34"])
+    det = detector_factory[opt.task](opt)
+    synth.fill_state_dict_(det.model, 317)
+    image = np.random.RandomState(5).randint(0, 256, (512, 512, 3)).astype(np.uint8)
+    ret = det.run(image)
+    res = ret["results"]
+    assert list(res.keys()) == [1] and np.array(res[1]).shape == (100, 39)
+    got = np.array(res[1], np.float32)
+    images, meta = det.pre_process(image, 1.0)
+    out = net_oracle.forward("dla_34", det.model.state_dict(), images, list(opt.heads))
+    hm = out["hm"].sigmoid_().numpy()
+    hm_hp = out["hm_hp"].sigmoid_().numpy()
+    dets = cref.multi_pose_decode(hm, out["wh"].numpy(), out["hps"].numpy(), out["reg"].numpy(),
+                                  hm_hp, out["hp_offset"].numpy(), K=opt.K)
+    from centernet_amd.post_process import multi_pose_post_process
+    ref = np.array(multi_pose_post_process(dets.copy(), [meta["c"]], [meta["s"]], meta["out_height"],
+                                           meta["out_width"])[0][1], np.float32)
+    assert np.abs(got[:, 4] - ref[:, 4]).max() < 1e-4            # scores
+    same = np.abs(got[:, 4] - ref[:, 4]) < 1e-6
+    gap = np.minimum(np.abs(np.diff(ref[:, 4], prepend=np.inf)), np.abs(np.diff(ref[:, 4], append=-np.inf)))
+    safe = gap > 2e-6
+    assert safe.mean() > 0.8
+    assert np.abs(got[safe, :4] - ref[safe, :4]).max() < 5e-3    # boxes, image pixels
+    # keypoints: regression branch within 5e-3 px; the heat-map-snapped ones are discrete
+    # choices, so allow a few to differ where the reject rule sits on its threshold
+    kd = np.abs(got[safe, 5:] - ref[safe, 5:])
+    assert (kd < 5e-3).mean() > 0.97
