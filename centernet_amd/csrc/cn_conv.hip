@@ -61,6 +61,7 @@ struct IgemmArgs {
     int zparity;   // ConvTranspose 4x4/s2: blockIdx.z = output parity class (py*2+px)
     int w_zstride; // floats between the packed weights of two parity classes
     int vec_out;   // NHWC output base/pitch allow 16-byte stores
+    int xcd_swizzle; // remap blockIdx.x so that each XCD owns a contiguous range of M tiles
     int ksplit;    // split-K: blockIdx.z owns chunks [z*KT/ksplit, (z+1)*KT/ksplit)
     float *partial; // split-K: raw fp32 partial sums [ksplit][M][cout_pad]
 };
@@ -128,7 +129,17 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM;
+    // Optional XCD-aware tile order (cn_set_tuning key 7): workgroup b runs on XCD b % 8 and
+    // every XCD has its own 4 MB L2, so each XCD can be given a CONTIGUOUS range of pixel
+    // tiles.  Measured on MI355X (tools/bench_knob.py 7 1 0): 9.23 vs 9.20 ms per resdcn_18
+    // forward, 27.07 vs 26.81 ms for dla_34 -- no gain (the kernels are MFMA-bound and the
+    // Infinity Cache absorbs the re-reads), so it is off by default.
+    int bx = blockIdx.x;
+    if (a.xcd_swizzle) {
+        const int q8 = gridDim.x >> 3;
+        if (bx < (q8 << 3)) bx = (bx & 7) * q8 + (bx >> 3);
+    }
+    const int m0 = bx * BM;
     const int n0 = blockIdx.y * BN;
     const int lrow = tid >> 3;  // 0..31: row inside a 32-row pass
     const int q = tid & 7;      // float4 slot inside the 32-float chunk
@@ -550,11 +561,13 @@ constexpr size_t igemm_lds_bytes()
            (AMODE == A_STEM ? (size_t)STEM_KMAX * 8 : 0);
 }
 
+int g_tune_swz = 0;   // cn_set_tuning key 7: 1 = XCD-aware tile order (measured: no gain, off)
 int g_tune_nbuf = 0;  // 0 = per-shape default, 1 / 2 = force (cn_set_tuning key 1)
 int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-wide tiles
 int g_tune_dcn_tile = 0; // cn_set_tuning key 3: 0 = default, 64 / 128 = force the DCN pixel tile
 int g_tune_bm = 0;       // cn_set_tuning key 4: 0 = default, 64 / 128 = force the dense pixel tile
 int g_tune_nosplit = 0;  // cn_set_tuning key 5: 1 = never split K
+int g_tune_nostem = 0;   // cn_set_tuning key 6: 1 = generic implicit-GEMM stem instead of cn_stem.hip
 
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
 int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
@@ -568,8 +581,10 @@ int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
         attr_set = true;
     }
     dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : (a.ksplit > 1 ? a.ksplit : 1));
+    IgemmArgs b = a;
+    b.xcd_swizzle = (g_tune_swz && grid.x >= 16) ? 1 : 0;
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), grid, dim3(NT),
-                       lds, st, a);
+                       lds, st, b);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -632,6 +647,11 @@ __global__ void pack_stem_weight_kernel(const float *__restrict__ w, T *__restri
 }
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+}  // namespace
+int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
+                     float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
+                     int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st);
+namespace {
 
 // split-K second stage: sum the partial tiles, then the usual epilogue
 // y = relu?((sum + bias) * scale + shift + residual), NHWC (element type T)
@@ -865,6 +885,14 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
             if (d->Cout > 32) return launch_igemm_h<128, 64, 2, 2, A_STEM, false>(a, st);
             return launch_igemm_h<128, 32, 4, 1, A_STEM, false>(a, st);
         }
+        // LDS-window kernel (cn_stem.hip) when the tile's input window fits; else generic
+        if (!g_tune_nostem && d->pad_h == d->pad_w && d->dil == 1 && d->oy_mul == 1 &&
+            d->ox_mul == 1 && d->OH == d->Ho && d->OW == d->Wo) {
+            rc = cn_stem_conv_f32((const float *)x, (const float *)w_packed, scale, shift,
+                                  (float *)y, d->B, d->H, d->W, d->Ho, d->Wo, d->Cout, d->KH,
+                                  d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad, st);
+            if (rc != CN_ERR_UNSUPPORTED) return rc;
+        }
         if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_STEM, false>(a, st);
         if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
         return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
@@ -1044,6 +1072,14 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 5 && (value == 0 || value == 1)) {
         g_tune_nosplit = value;
+        return CN_OK;
+    }
+    if (key == 6 && (value == 0 || value == 1)) {
+        g_tune_nostem = value;
+        return CN_OK;
+    }
+    if (key == 7 && (value == 0 || value == 1)) {
+        g_tune_swz = value;
         return CN_OK;
     }
     return CN_ERR_UNSUPPORTED;

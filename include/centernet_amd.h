@@ -59,7 +59,10 @@ const char *cn_arch(void);
  *        avoid a half-empty 128-wide tile).
  * key 3: pixel tile of the deformable kernel, 0 = default, 64 or 128.
  * key 4: pixel tile of the dense kernels for Cout > 64, 0 = default, 64 or 128.
- * key 5: 1 = never split K. */
+ * key 5: 1 = never split K.
+ * key 6: 1 = run the 3-channel stem on the generic implicit-GEMM kernel instead of the
+ *        LDS-window kernel (cn_stem.hip).
+ * key 7: 1 = enable the XCD-aware tile order of the implicit-GEMM kernels (off: no gain). */
 int cn_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------
