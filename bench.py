@@ -27,6 +27,33 @@ F32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md)
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (tools/pmc_traffic.py,
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); summed per kernel class."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        raw = json.load(f)
+    cls = {"conv": 0.0, "dcn": 0.0, "decode": 0.0, "maxpool": 0.0}
+    n = {"conv": 0, "dcn": 0, "decode": 0, "maxpool": 0}
+    steps = max(1, raw.get("nms_topk_kernel", {}).get("launches", 1))
+    for k, v in raw.items():
+        if k.startswith("igemm_kernel"):
+            c = "dcn" if k.rstrip(">").split(",")[5].strip() == "2" else "conv"
+        elif k.startswith(("stem_conv", "splitk_reduce")):
+            c = "conv"
+        elif k.startswith(("nms_topk", "merge_topk")):
+            c = "decode"
+        elif k.startswith("maxpool"):
+            c = "maxpool"
+        else:
+            continue
+        cls[c] += v["hbm_bytes_per_launch"] * v["launches"] / steps   # bytes per forward step
+        n[c] += v["launches"] // steps
+    return {c: (cls[c], n[c]) for c in cls if n[c]}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -150,20 +177,29 @@ def main():
         kinds["decode"] = {"ms": dec_ms, "flops": 0, "bytes": dec_bytes * a.steps,
                            "launches": 2 * a.steps}
         dom = max(kinds, key=lambda k: kinds[k]["ms"])
+        pmc = pmc_traffic() if (a.arch == "resdcn_18" and B == 32 and a.res == 512 and not a.fp16) else {}
+
+        def traffic(k):
+            # measured HBM bytes per launch of this kernel class (committed PMC profile of the
+            # same command), or null when the profile does not cover this configuration
+            if k not in pmc:
+                return None
+            byts, launches = pmc[k]
+            return byts / max(launches, 1)
 
         def mfma_roof(k):
             s = kinds[k]
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
             peak = F16_MFMA_PEAK_TF if a.fp16 else F32_MFMA_PEAK_TF
             return {"kernel": k, "bound": "mfma", "achieved": ach, "peak": peak,
-                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic(k),
                     "avg_launch_ms": s["ms"] / max(s["launches"], 1), "launches_per_step": s["launches"] // a.steps}
 
         def hbm_roof(k):
             s = kinds[k]
             ach = s["bytes"] / (s["ms"] * 1e-3) / 1e9 if s["ms"] > 0 else 0.0
             return {"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic(k),
                     "avg_launch_ms": s["ms"] / max(s["launches"], 1), "launches_per_step": s["launches"] // a.steps}
 
         roofline = mfma_roof(dom) if kinds[dom]["flops"] > 0 else hbm_roof(dom)
