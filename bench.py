@@ -98,14 +98,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_DEVICE / BENCH_BACKEND exist only so the multi-rank control flow can be exercised on
+    # a single-GPU box (two ranks sharing cuda:0 over gloo); the driver never sets them.
+    dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
+    backend = os.environ.get("BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from centernet_amd import synth
     from centernet_amd.opts import opts

@@ -62,6 +62,8 @@ struct IgemmArgs {
     int w_zstride; // floats between the packed weights of two parity classes
     int vec_out;   // NHWC output base/pitch allow 16-byte stores
     int xcd_swizzle; // remap blockIdx.x so that each XCD owns a contiguous range of M tiles
+    int setprio;     // raise the wave priority around the MFMA clusters (cn_set_tuning key 8)
+    int dbgskip;     // ablation: skip A (bit 0) / B (bit 1) staging after the first chunk (WRONG results)
     int ksplit;    // split-K: blockIdx.z owns chunks [z*KT/ksplit, (z+1)*KT/ksplit)
     float *partial; // split-K: raw fp32 partial sums [ksplit][M][cout_pad]
 };
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         const int tap = kt / a.nchunk;
         const int c0 = (kt - tap * a.nchunk) * BKE;
         // ---- B: packed weight [tap][cout_pad][cin_pad]
+        if (!(a.dbgskip & 2))
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             // rows past cout_pad are clamped: their columns are never stored
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 wbase + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + c0 + EPV * q));
         }
         // ---- A
+        if (a.dbgskip & 1) return;
         if (AMODE == A_DENSE) {
             const int ky = tap / a.KW, kx = tap - ky * a.KW;
             const int c = c0 + EPV * q;
@@ -335,9 +339,11 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     auto store_tiles = [&](int buf, int kt) {
         float *Ad = As + buf * BM * LDT;
         float *Bd = Bs + buf * BN * LDT;
+        if (!(a.dbgskip & 2))
 #pragma unroll
         for (int p = 0; p < PB; ++p)
             *reinterpret_cast<cn_f32x4 *>(Bd + (p * 32 + lrow) * LDT + 4 * q) = rb[p];
+        if (a.dbgskip & 1) return;
         if (AMODE == A_DCN) {
             const int tap = kt / a.nchunk;
 #pragma unroll
@@ -363,6 +369,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     auto compute = [&](int buf) {
         const float *Ab = As + buf * BM * LDT + (wm * TM + l31) * LDT + 4 * lh;
         const float *Bb = Bs + buf * BN * LDT + (wn * TN + l31) * LDT + 4 * lh;
+        if (a.setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             cn_f32x4 af[MB], bf[NB];
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                         }
             }
         }
+        if (a.setprio) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- main loop: register prefetch of chunk k+1 during the MFMAs of chunk k.
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     store_tiles(0, kt0);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = (kt + 1) < kt1;
+        const bool more = (kt + 1) < kt1 && !(a.dbgskip == 3);
         if (more) load_tiles(kt + 1);
         // DCN: the records of tap t (t >= 2) are first read by load_tiles(t*nchunk) in
         // iteration t*nchunk-1; their buffer (parity of t) was last read in iteration
@@ -561,12 +569,15 @@ constexpr size_t igemm_lds_bytes()
            (AMODE == A_STEM ? (size_t)STEM_KMAX * 8 : 0);
 }
 
+int g_tune_setprio = 1; // cn_set_tuning key 8: s_setprio(1) around the MFMA clusters (+0.9 % measured)
+int g_tune_dbgskip = 0; // cn_set_tuning key 9 (ablation only): bit0 skip A staging, bit1 skip B staging
 int g_tune_swz = 0;   // cn_set_tuning key 7: 1 = XCD-aware tile order (measured: no gain, off)
 int g_tune_nbuf = 0;  // 0 = per-shape default, 1 / 2 = force (cn_set_tuning key 1)
 int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-wide tiles
 int g_tune_dcn_tile = 0; // cn_set_tuning key 3: 0 = default, 64 / 128 = force the DCN pixel tile
 int g_tune_bm = 0;       // cn_set_tuning key 4: 0 = default, 64 / 128 = force the dense pixel tile
 int g_tune_nosplit = 0;  // cn_set_tuning key 5: 1 = never split K
+int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip
 int g_tune_nostem = 0;   // cn_set_tuning key 6: 1 = generic implicit-GEMM stem instead of cn_stem.hip
 
 template <typename T, int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, int NBUF>
@@ -583,6 +594,8 @@ int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
     dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : (a.ksplit > 1 ? a.ksplit : 1));
     IgemmArgs b = a;
     b.xcd_swizzle = (g_tune_swz && grid.x >= 16) ? 1 : 0;
+    b.setprio = g_tune_setprio;
+    b.dbgskip = g_tune_dbgskip;
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), grid, dim3(NT),
                        lds, st, b);
     CN_CHECK_LAUNCH();
@@ -651,6 +664,10 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
                      int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st);
+int cn_conv3x3s1_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
+                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
+                     int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
+                     hipStream_t st);
 namespace {
 
 // split-K second stage: sum the partial tiles, then the usual epilogue
@@ -897,6 +914,14 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
         return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
     }
+    // 3x3 / stride 1 / pad 1 in fp32: the LDS-halo kernel (cn_conv3x3.hip) unless split-K applies
+    if (!f16 && !g_tune_nohalo && a.ksplit == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
+        d->pad_h == 1 && d->pad_w == 1 && d->dil == 1 && d->oy_mul == 1 && d->ox_mul == 1 &&
+        d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho && d->OW == d->Wo)
+        return cn_conv3x3s1_f32((const float *)x, (const float *)w_packed, scale, shift,
+                                (const float *)residual, (float *)y, d->B, d->H, d->W, d->Cin,
+                                d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
+                                g_tune_setprio, cls, st);
     if (f16) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_h<64, 128, 2, 2, A_DENSE, false>(a, st)
@@ -1076,6 +1101,18 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 6 && (value == 0 || value == 1)) {
         g_tune_nostem = value;
+        return CN_OK;
+    }
+    if (key == 8 && (value == 0 || value == 1)) {
+        g_tune_setprio = value;
+        return CN_OK;
+    }
+    if (key == 9 && value >= 0 && value <= 3) {
+        g_tune_dbgskip = value;
+        return CN_OK;
+    }
+    if (key == 10 && (value == 0 || value == 1)) {
+        g_tune_nohalo = value;
         return CN_OK;
     }
     if (key == 7 && (value == 0 || value == 1)) {

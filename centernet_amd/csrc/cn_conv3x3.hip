@@ -1,0 +1,298 @@
+// cn_conv3x3.hip -- 3x3 / stride-1 / pad-1 convolution, the bulk of every CenterNet backbone
+// (resnet_dcn.py:38-67 BasicBlock convs, the 3x3 of every head :155-177, conv_offset_mask of
+// DCN dcn_v2.py:52-57, DLA tree blocks pose_dla_dcn.py:31-62, hourglass residuals
+// large_hourglass.py:48-74), as an im2col-free LDS tiling on the fp32 matrix cores.
+//
+// Why a second kernel next to the generic implicit GEMM (cn_conv.hip): there the A tile of
+// every (tap, 32-channel chunk) is re-fetched from global memory and re-written to LDS, and
+// an ablation (tools/bench_kernels.py, cn_set_tuning key 9) showed that this staging costs
+// 25-35 % of the kernel (MFMA loop alone: 137-147 TFLOP/s; with staging: 88-110).  Here a
+// workgroup owns a TH x TW block of output pixels of one image and stages, per 32-channel
+// chunk, the (TH+2) x (TW+2) input HALO once; the nine taps read their A fragments from that
+// one LDS image at a constant address offset ((ky*(TW+2)+kx) rows).  A traffic and A staging
+// instructions drop ~6x; only the weight tile is re-staged per tap (double-buffered, one
+// barrier per tap).
+//
+// Same numerics as the generic kernel: v_mfma_f32_32x32x2_f32, fp32 accumulate, K consumed
+// chunk-major then tap, epilogue y = relu?(acc*scale + shift + residual).
+#include "cn_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int LDT = 36;  // floats per LDS row (32 + 4 pad = 144 bytes, conflict-free b128 reads)
+
+struct C3Args {
+    const float *x, *w, *scale, *shift, *residual;
+    float *y;
+    int B, H, W, Cin, Cout, in_pitch, out_pitch, relu;
+    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio;
+};
+
+template <int TW, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
+{
+    constexpr int BM = 128;
+    constexpr int TH = BM / TW;
+    constexpr int HW_ = TW + 2;              // halo width
+    constexpr int HR = (TH + 2) * HW_;       // halo rows (pixels)
+    constexpr int NPA = (HR + 31) / 32;      // halo load passes per thread
+    constexpr int PB = BN / 32;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MB = TM / 32, NB = TN / 32;
+    static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "wave tiling");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_FLOATS = HR * LDT;
+    constexpr int B_FLOATS = 2 * BN * LDT;
+    constexpr int CS_FLOATS = TM * (BN + 4);
+    constexpr int UNION = (A_FLOATS + B_FLOATS) > CS_FLOATS ? (A_FLOATS + B_FLOATS) : CS_FLOATS;
+    float *As = reinterpret_cast<float *>(smem);  // [HR][LDT]
+    float *Bs = As + A_FLOATS;                    // [2][BN][LDT]
+    int *rowoff = reinterpret_cast<int *>(As + UNION);  // [BM]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = tid >> 3, q = tid & 7;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int tr = blockIdx.x - b * tiles;
+    const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-thread halo rows: pixel offset in the input (or -1: outside image / halo)
+    int hoff[NPA];
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) {
+        const int hr = p * 32 + lrow;
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        hoff[p] = (hr < HR && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                      ? (b * a.H + iy) * a.W + ix : -1;
+    }
+    for (int m = tid; m < BM; m += NT) {
+        const int ty = m / TW, tx = m - ty * TW;
+        const int oy = ty0 + ty, ox = tx0 + tx;
+        rowoff[m] = (oy < a.H && ox < a.W) ? (b * a.H + oy) * a.W + ox : -1;
+    }
+
+    cn_f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    cn_f32x4 ra[NPA], rb[PB];
+    auto load_A = [&](int chunk) {
+        const int c = chunk * 32 + 4 * q;
+#pragma unroll
+        for (int p = 0; p < NPA; ++p) {
+            const bool ok = hoff[p] >= 0 && c < a.Cin;
+            const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
+                a.x + (ok ? ((size_t)hoff[p] * a.in_pitch + c) : 0));
+            ra[p] = ok ? v : zero4;
+        }
+    };
+    auto store_A = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPA; ++p) {
+            const int hr = p * 32 + lrow;
+            if (hr < HR) *reinterpret_cast<cn_f32x4 *>(As + hr * LDT + 4 * q) = ra[p];
+        }
+    };
+    auto load_B = [&](int chunk, int tap) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int n = min(n0 + p * 32 + lrow, a.cout_pad - 1);
+            rb[p] = *reinterpret_cast<const cn_f32x4 *>(
+                a.w + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + chunk * 32 + 4 * q));
+        }
+    };
+    auto store_B = [&](int buf) {
+        float *Bd = Bs + buf * BN * LDT;
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<cn_f32x4 *>(Bd + (p * 32 + lrow) * LDT + 4 * q) = rb[p];
+    };
+
+    // A-fragment base of this lane's pixel in every M block (halo row of tap (0,0))
+    int abase[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int m = wm * TM + i * 32 + l31;
+        const int ty = m / TW, tx = m - ty * TW;
+        abase[i] = (ty * HW_ + tx) * LDT + 4 * lh;
+    }
+    auto compute = [&](int tap, int buf) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int toff = (ky * HW_ + kx) * LDT;
+        const float *Bb = Bs + buf * BN * LDT + (wn * TN + l31) * LDT + 4 * lh;
+        if (a.setprio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            cn_f32x4 af[MB], bf[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                af[i] = *reinterpret_cast<const cn_f32x4 *>(As + abase[i] + toff + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                bf[j] = *reinterpret_cast<const cn_f32x4 *>(Bb + j * 32 * LDT + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s],
+                                                                         acc[i][j], 0, 0, 0);
+        }
+        if (a.setprio) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- main loop: chunk-major, taps inner; B double-buffered, A halo single-buffered
+    load_A(0);
+    load_B(0, 0);
+    store_A();
+    store_B(0);
+    __syncthreads();
+    const int total = a.nchunk * 9;
+    int it = 0;
+    for (int c = 0; c < a.nchunk; ++c) {
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t, ++it) {
+            const bool more = (it + 1) < total;
+            const bool newA = (t == 8) && (c + 1 < a.nchunk);
+            if (more) load_B(t == 8 ? c + 1 : c, t == 8 ? 0 : t + 1);
+            if (newA) load_A(c + 1);
+            compute(t, it & 1);
+            if (newA) {
+                __syncthreads();  // every wave is done with the old halo
+                store_A();
+            }
+            if (more) store_B((it + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (as in cn_conv.hip): stage one wave-row of the tile through LDS, then
+    // 16-byte residual loads / stores along Cout
+    constexpr int LDC = BN + 4;
+    float *Cs = reinterpret_cast<float *>(smem);
+    constexpr int C4 = BN / 4;
+    constexpr int RPI = NT / C4;
+    constexpr int ITERS = (TM + RPI - 1) / RPI;
+    const int c4 = tid % C4, r0 = tid / C4;
+    const int n = n0 + c4 * 4;
+    float sc[4], sf[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool ok = (n + e) < a.Cout;
+        sc[e] = (a.scale && ok) ? a.scale[n + e] : 1.f;
+        sf[e] = (a.shift && ok) ? a.shift[n + e] : 0.f;
+    }
+    const bool vec = a.vec_out && (n + 4 <= a.Cout);
+#pragma unroll 1
+    for (int pass = 0; pass < WM; ++pass) {
+        if (pass) __syncthreads();
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        Cs[row * LDC + wn * TN + j * 32 + l31] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        const int rbase = pass * TM;
+        if (vec) {
+            cn_f32x4 res[ITERS];
+            int offs[ITERS];
+#pragma unroll
+            for (int k = 0; k < ITERS; ++k) {
+                const int lr = k * RPI + r0;
+                offs[k] = (lr < TM) ? rowoff[rbase + lr] : -1;
+                if (a.residual)
+                    res[k] = *reinterpret_cast<const cn_f32x4 *>(
+                        a.residual + (size_t)(offs[k] >= 0 ? offs[k] : 0) * a.out_pitch + n);
+            }
+#pragma unroll
+            for (int k = 0; k < ITERS; ++k) {
+                if (offs[k] < 0) continue;
+                cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(Cs + (k * RPI + r0) * LDC + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[e] * sc[e] + sf[e];
+                    if (a.residual) t += res[k][e];
+                    v[e] = a.relu ? fmaxf(t, 0.f) : t;
+                }
+                *reinterpret_cast<cn_f32x4 *>(a.y + (size_t)offs[k] * a.out_pitch + n) = v;
+            }
+        } else if (n < a.Cout) {
+            for (int k = 0; k < ITERS; ++k) {
+                const int lr = k * RPI + r0;
+                if (lr >= TM) continue;
+                const int off = rowoff[rbase + lr];
+                if (off < 0) continue;
+                for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
+                    const size_t o = (size_t)off * a.out_pitch + n + e;
+                    float t = Cs[lr * LDC + c4 * 4 + e] * sc[e] + sf[e];
+                    if (a.residual) t += a.residual[o];
+                    a.y[o] = a.relu ? fmaxf(t, 0.f) : t;
+                }
+            }
+        }
+    }
+}
+
+template <int TW, int BN, int WM, int WN>
+int launch_c3(const C3Args &a, hipStream_t st)
+{
+    constexpr int TH = 128 / TW;
+    constexpr int HR = (TH + 2) * (TW + 2);
+    constexpr size_t tiles = (size_t)(HR * LDT + 2 * BN * LDT);
+    constexpr size_t cs = (size_t)(128 / WM) * (BN + 4);
+    constexpr size_t lds = (tiles > cs ? tiles : cs) * 4 + 128 * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)conv3x3s1_kernel<TW, BN, WM, WN>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    C3Args b = a;
+    b.tiles_x = cn_cdiv(a.W, TW);
+    b.tiles_y = cn_cdiv(a.H, TH);
+    dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, BN));
+    hipLaunchKernelGGL((conv3x3s1_kernel<TW, BN, WM, WN>), grid, dim3(NT), lds, st, b);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+}  // namespace
+
+// bn_class: 2 = 128-wide N tiles, 1 = 64, 0 = 32 (chosen by the caller, same rule as cn_conv.hip)
+int cn_conv3x3s1_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
+                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
+                     int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
+                     hipStream_t st)
+{
+    C3Args a = {};
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_pitch = in_pitch;
+    a.out_pitch = out_pitch; a.relu = relu; a.vec_out = vec_out; a.setprio = setprio;
+    a.cin_pad = (Cin + 31) / 32 * 32;
+    a.cout_pad = (Cout + 31) / 32 * 32;
+    a.nchunk = a.cin_pad / 32;
+    const bool wide = W >= 32;  // 4 x 32 tiles keep an MFMA block on one halo row
+    if (bn_class == 2)
+        return wide ? launch_c3<32, 128, 2, 2>(a, st) : launch_c3<16, 128, 2, 2>(a, st);
+    if (bn_class == 1)
+        return wide ? launch_c3<32, 64, 2, 2>(a, st) : launch_c3<16, 64, 2, 2>(a, st);
+    return wide ? launch_c3<32, 32, 4, 1>(a, st) : launch_c3<16, 32, 4, 1>(a, st);
+}

@@ -62,6 +62,9 @@ const char *cn_arch(void);
  * key 5: 1 = never split K.
  * key 6: 1 = run the 3-channel stem on the generic implicit-GEMM kernel instead of the
  *        LDS-window kernel (cn_stem.hip).
+ * key 8: s_setprio(1) around the MFMA clusters (default 1).  key 9: ablation only.
+ * key 10: 1 = run 3x3/stride-1 layers on the generic implicit GEMM instead of the LDS-halo
+ *         kernel (cn_conv3x3.hip).
  * key 7: 1 = enable the XCD-aware tile order of the implicit-GEMM kernels (off: no gain). */
 int cn_set_tuning(int key, int value);
 

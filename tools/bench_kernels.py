@@ -35,7 +35,7 @@ def time_ops(pb, iters=20):
     return s.elapsed_time(e) / iters
 
 
-knobs = [(4, 128), (4, 64)]
+knobs = [(10, 1), (10, 0)]
 if os.environ.get('ONLY'):
     SHAPES = [SHAPES[int(i)] for i in os.environ['ONLY'].split(',')]
 if os.environ.get('NBUF'):
@@ -52,4 +52,4 @@ for (ci, H, W, co, k, s) in SHAPES:
         ms = time_ops(pb)
         row.append("%6.3f ms %6.1f TF" % (ms, pb.flops / ms / 1e9))
     print("%-34s" % str((ci, H, W, co, k, s)), *row)
-lib.cn_set_tuning(1, 0); lib.cn_set_tuning(4, 0)
+lib.cn_set_tuning(1, 0); lib.cn_set_tuning(4, 0); lib.cn_set_tuning(9, 0); lib.cn_set_tuning(10, 0)
