@@ -664,10 +664,10 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
                      int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st);
-int cn_conv3x3s1_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
-                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
-                     int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
-                     hipStream_t st);
+int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
+                 const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
+                 int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
+                 int f16, hipStream_t st);
 namespace {
 
 // split-K second stage: sum the partial tiles, then the usual epilogue
@@ -914,14 +914,13 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
         return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
     }
-    // 3x3 / stride 1 / pad 1 in fp32: the LDS-halo kernel (cn_conv3x3.hip) unless split-K applies
-    if (!f16 && !g_tune_nohalo && a.ksplit == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
+    // 3x3 / stride 1 / pad 1: the LDS-halo kernel (cn_conv3x3.hip) unless split-K applies
+    if (!g_tune_nohalo && a.ksplit == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
         d->pad_h == 1 && d->pad_w == 1 && d->dil == 1 && d->oy_mul == 1 && d->ox_mul == 1 &&
         d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho && d->OW == d->Wo)
-        return cn_conv3x3s1_f32((const float *)x, (const float *)w_packed, scale, shift,
-                                (const float *)residual, (float *)y, d->B, d->H, d->W, d->Cin,
-                                d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
-                                g_tune_setprio, cls, st);
+        return cn_conv3x3s1(x, w_packed, scale, shift, residual, y, d->B, d->H, d->W, d->Cin,
+                            d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
+                            g_tune_setprio, cls, f16 ? 1 : 0, st);
     if (f16) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_h<64, 128, 2, 2, A_DENSE, false>(a, st)

@@ -22,16 +22,44 @@ namespace {
 constexpr int NT = 256;
 constexpr int LDT = 36;  // floats per LDS row (32 + 4 pad = 144 bytes, conflict-free b128 reads)
 
+typedef _Float16 c3_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 c3_f16x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct C3Elem;
+template <> struct C3Elem<float> { static constexpr int EPV = 4; };
+template <> struct C3Elem<_Float16> { static constexpr int EPV = 8; };
+__device__ __forceinline__ cn_f32x4 c3_load4(const float *p) { return *reinterpret_cast<const cn_f32x4 *>(p); }
+__device__ __forceinline__ cn_f32x4 c3_load4(const _Float16 *p)
+{
+    const c3_f16x4 h = *reinterpret_cast<const c3_f16x4 *>(p);
+    cn_f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return r;
+}
+__device__ __forceinline__ void c3_store4(float *p, cn_f32x4 v) { *reinterpret_cast<cn_f32x4 *>(p) = v; }
+__device__ __forceinline__ void c3_store4(_Float16 *p, cn_f32x4 v)
+{
+    c3_f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    *reinterpret_cast<c3_f16x4 *>(p) = h;
+}
+
 struct C3Args {
-    const float *x, *w, *scale, *shift, *residual;
-    float *y;
+    const void *x, *w;           // element type T (fp32 or fp16)
+    const float *scale, *shift;
+    const void *residual;        // element type T
+    void *y;                     // element type T
     int B, H, W, Cin, Cout, in_pitch, out_pitch, relu;
     int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio;
 };
 
-template <int TW, int BN, int WM, int WN>
+// T = float: v_mfma_f32_32x32x2_f32, 32 channels per chunk; T = fp16: v_mfma_f32_32x32x16_f16
+// (fp32 accumulate), 64 channels per chunk -- same 128-byte LDS rows and read addresses.
+template <typename T, int TW, int BN, int WM, int WN>
 __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
 {
+    constexpr int EPV = C3Elem<T>::EPV;
+    constexpr int BKE = 8 * EPV;
+    constexpr bool F16 = (EPV == 8);
+    const T *xT = reinterpret_cast<const T *>(a.x);
+    const T *wT = reinterpret_cast<const T *>(a.w);
     constexpr int BM = 128;
     constexpr int TH = BM / TW;
     constexpr int HW_ = TW + 2;              // halo width
@@ -88,12 +116,12 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
 
     cn_f32x4 ra[NPA], rb[PB];
     auto load_A = [&](int chunk) {
-        const int c = chunk * 32 + 4 * q;
+        const int c = chunk * BKE + EPV * q;
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {
             const bool ok = hoff[p] >= 0 && c < a.Cin;
             const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
-                a.x + (ok ? ((size_t)hoff[p] * a.in_pitch + c) : 0));
+                xT + (ok ? ((size_t)hoff[p] * a.in_pitch + c) : 0));
             ra[p] = ok ? v : zero4;
         }
     };
@@ -109,7 +137,7 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
         for (int p = 0; p < PB; ++p) {
             const int n = min(n0 + p * 32 + lrow, a.cout_pad - 1);
             rb[p] = *reinterpret_cast<const cn_f32x4 *>(
-                a.w + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + chunk * 32 + 4 * q));
+                wT + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + chunk * BKE + EPV * q));
         }
     };
     auto store_B = [&](int buf) {
@@ -141,14 +169,24 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
 #pragma unroll
             for (int j = 0; j < NB; ++j)
                 bf[j] = *reinterpret_cast<const cn_f32x4 *>(Bb + j * 32 * LDT + kk * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
+            if constexpr (F16) {
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s],
-                                                                         acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(c3_f16x8, af[i]), __builtin_bit_cast(c3_f16x8, bf[j]),
+                            acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            }
         }
         if (a.setprio) __builtin_amdgcn_s_setprio(0);
     };
@@ -219,8 +257,8 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
                 const int lr = k * RPI + r0;
                 offs[k] = (lr < TM) ? rowoff[rbase + lr] : -1;
                 if (a.residual)
-                    res[k] = *reinterpret_cast<const cn_f32x4 *>(
-                        a.residual + (size_t)(offs[k] >= 0 ? offs[k] : 0) * a.out_pitch + n);
+                    res[k] = c3_load4(reinterpret_cast<const T *>(a.residual) +
+                                      (size_t)(offs[k] >= 0 ? offs[k] : 0) * a.out_pitch + n);
             }
 #pragma unroll
             for (int k = 0; k < ITERS; ++k) {
@@ -232,7 +270,7 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
                     if (a.residual) t += res[k][e];
                     v[e] = a.relu ? fmaxf(t, 0.f) : t;
                 }
-                *reinterpret_cast<cn_f32x4 *>(a.y + (size_t)offs[k] * a.out_pitch + n) = v;
+                c3_store4(reinterpret_cast<T *>(a.y) + (size_t)offs[k] * a.out_pitch + n, v);
             }
         } else if (n < a.Cout) {
             for (int k = 0; k < ITERS; ++k) {
@@ -243,15 +281,15 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
                 for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
                     const size_t o = (size_t)off * a.out_pitch + n + e;
                     float t = Cs[lr * LDC + c4 * 4 + e] * sc[e] + sf[e];
-                    if (a.residual) t += a.residual[o];
-                    a.y[o] = a.relu ? fmaxf(t, 0.f) : t;
+                    if (a.residual) t += (float)reinterpret_cast<const T *>(a.residual)[o];
+                    reinterpret_cast<T *>(a.y)[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
                 }
             }
         }
     }
 }
 
-template <int TW, int BN, int WM, int WN>
+template <typename T, int TW, int BN, int WM, int WN>
 int launch_c3(const C3Args &a, hipStream_t st)
 {
     constexpr int TH = 128 / TW;
@@ -261,7 +299,7 @@ int launch_c3(const C3Args &a, hipStream_t st)
     constexpr size_t lds = (tiles > cs ? tiles : cs) * 4 + 128 * 4;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)conv3x3s1_kernel<TW, BN, WM, WN>,
+        (void)hipFuncSetAttribute((const void *)conv3x3s1_kernel<T, TW, BN, WM, WN>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
@@ -269,30 +307,38 @@ int launch_c3(const C3Args &a, hipStream_t st)
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
     dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, BN));
-    hipLaunchKernelGGL((conv3x3s1_kernel<TW, BN, WM, WN>), grid, dim3(NT), lds, st, b);
+    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN>), grid, dim3(NT), lds, st, b);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
 
 }  // namespace
 
+template <typename T>
+static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
+{
+    const bool wide = a.W >= 32;  // 4 x 32 tiles keep an MFMA block on one halo row
+    if (bn_class == 2)
+        return wide ? launch_c3<T, 32, 128, 2, 2>(a, st) : launch_c3<T, 16, 128, 2, 2>(a, st);
+    if (bn_class == 1)
+        return wide ? launch_c3<T, 32, 64, 2, 2>(a, st) : launch_c3<T, 16, 64, 2, 2>(a, st);
+    return wide ? launch_c3<T, 32, 32, 4, 1>(a, st) : launch_c3<T, 16, 32, 4, 1>(a, st);
+}
+
 // bn_class: 2 = 128-wide N tiles, 1 = 64, 0 = 32 (chosen by the caller, same rule as cn_conv.hip)
-int cn_conv3x3s1_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
-                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
-                     int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
-                     hipStream_t st)
+// f16: 0 = fp32 tensors, 1 = fp16 tensors (fp32 accumulate, scale/shift fp32)
+int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
+                 const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
+                 int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
+                 int f16, hipStream_t st)
 {
     C3Args a = {};
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_pitch = in_pitch;
     a.out_pitch = out_pitch; a.relu = relu; a.vec_out = vec_out; a.setprio = setprio;
-    a.cin_pad = (Cin + 31) / 32 * 32;
+    const int bke = f16 ? 64 : 32;
+    a.cin_pad = (Cin + bke - 1) / bke * bke;
     a.cout_pad = (Cout + 31) / 32 * 32;
-    a.nchunk = a.cin_pad / 32;
-    const bool wide = W >= 32;  // 4 x 32 tiles keep an MFMA block on one halo row
-    if (bn_class == 2)
-        return wide ? launch_c3<32, 128, 2, 2>(a, st) : launch_c3<16, 128, 2, 2>(a, st);
-    if (bn_class == 1)
-        return wide ? launch_c3<32, 64, 2, 2>(a, st) : launch_c3<16, 64, 2, 2>(a, st);
-    return wide ? launch_c3<32, 32, 4, 1>(a, st) : launch_c3<16, 32, 4, 1>(a, st);
+    a.nchunk = a.cin_pad / bke;
+    return f16 ? c3_dispatch<_Float16>(a, bn_class, st) : c3_dispatch<float>(a, bn_class, st);
 }
