@@ -577,6 +577,7 @@ int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-
 int g_tune_dcn_tile = 0; // cn_set_tuning key 3: 0 = default, 64 / 128 = force the DCN pixel tile
 int g_tune_bm = 0;       // cn_set_tuning key 4: 0 = default, 64 / 128 = force the dense pixel tile
 int g_tune_nosplit = 0;  // cn_set_tuning key 5: 1 = never split K
+int g_tune_dcn_window = 0; // cn_set_tuning key 11: 1 = LDS-window DCN (cn_dcn.hip); default global gather (faster, measured)
 int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip
 int g_tune_nostem = 0;   // cn_set_tuning key 6: 1 = generic implicit-GEMM stem instead of cn_stem.hip
 
@@ -664,6 +665,9 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
                      int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st);
+int cn_dcn_window_f32(const float *x, const float *w_packed, const float *bias, const float *om,
+                      int om_pitch, const float *scale, const float *shift, float *y, int B, int Cin,
+                      int H, int W, int Cout, int mask_sigmoid, int relu, int setprio, hipStream_t st);
 int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                  int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
@@ -970,6 +974,14 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
     if ((Cin & 3) != 0) return CN_ERR_UNSUPPORTED;
     if (!cn_aligned16(input_nhwc) || !cn_aligned16(weight_packed)) return CN_ERR_ALIGN;
     if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return CN_ERR_UNSUPPORTED;
+    // LDS-staged input window (cn_dcn.hip): measured 20-30 % SLOWER than the L1/L2-served
+    // gather below on every CenterNet shape (tools/bench_dcn.py), so it is opt-in only
+    if (g_tune_dcn_window && Cout > 32) {
+        const int rc = cn_dcn_window_f32(input_nhwc, weight_packed, bias, offset_mask_nhwc, om_pitch,
+                                         scale, shift, output_nhwc, B, Cin, H, W, Cout,
+                                         mask_sigmoid, relu, g_tune_setprio, (hipStream_t)stream);
+        if (rc != CN_ERR_UNSUPPORTED) return rc;
+    }
     IgemmArgs a = {};
     a.x = input_nhwc; a.w = weight_packed; a.bias = bias; a.scale = scale; a.shift = shift;
     a.residual = nullptr; a.y = output_nhwc; a.om = offset_mask_nhwc; a.om_pitch = om_pitch;
@@ -1112,6 +1124,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 10 && (value == 0 || value == 1)) {
         g_tune_nohalo = value;
+        return CN_OK;
+    }
+    if (key == 11 && (value == 0 || value == 1)) {
+        g_tune_dcn_window = value;
         return CN_OK;
     }
     if (key == 7 && (value == 0 || value == 1)) {

@@ -65,6 +65,8 @@ const char *cn_arch(void);
  * key 8: s_setprio(1) around the MFMA clusters (default 1).  key 9: ablation only.
  * key 10: 1 = run 3x3/stride-1 layers on the generic implicit GEMM instead of the LDS-halo
  *         kernel (cn_conv3x3.hip).
+ * key 11: 1 = LDS-window deformable kernel (cn_dcn.hip) instead of the default global-gather
+ *         form (cn_conv.hip); kept for A/B: it measured 20-30 % slower.
  * key 7: 1 = enable the XCD-aware tile order of the implicit-GEMM kernels (off: no gain). */
 int cn_set_tuning(int key, int value);
 

@@ -102,3 +102,21 @@ def test_full_size_linearity(dev):
     assert float((y12 - (y1 + y2)).abs().max()) < 1e-4
     ym = dcn_v2_forward(x1, off, 0.5 * mask, w, b0)
     assert float((ym - 0.5 * y1).abs().max()) < 1e-5
+
+
+def test_lds_window_variant_matches_oracle(dev):
+    """The opt-in LDS-window kernel (cn_dcn.hip, cn_set_tuning key 11) against the oracle,
+    including offsets far beyond its window (global fallback per corner)."""
+    from centernet_amd import native
+    from centernet_amd.dcn_v2 import dcn_v2_forward
+    lib = native.lib()
+    try:
+        assert lib.cn_set_tuning(11, 1) == 0
+        for (B, Cin, H, W, Cout, std) in [(2, 64, 16, 16, 64, 2.0), (1, 128, 20, 12, 128, 6.0),
+                                          (1, 36, 9, 11, 40, 1.0)]:
+            x, off, mask, w, b = _case(B, Cin, H, W, Cout, 50 + Cin, off_std=std)
+            ref = cref.dcn_v2_forward(x, off, mask, w, b)
+            y = dcn_v2_forward(*[torch.from_numpy(a).to(dev) for a in (x, off, mask, w, b)])
+            _check(y.cpu().numpy(), ref)
+    finally:
+        lib.cn_set_tuning(11, 0)

@@ -10,15 +10,15 @@ dev = torch.device("cuda:0")
 lib = native.lib()
 B = int(os.environ.get("B", 32))
 SHAPES = [(512, 16, 16, 256), (256, 32, 32, 128), (128, 64, 64, 64), (64, 128, 128, 64), (256, 32, 32, 64)]
-print("%-24s" % "Cin,H,W,Cout", "  ".join("tile%d/nbuf%d" % (t, n) for t in (64, 128) for n in (2, 1)))
+print("%-24s" % "Cin,H,W,Cout", "gather-kernel(tile64,nbuf1)   window-kernel")
 for ci, H, W, co in SHAPES:
     m = DCN(ci, co, (3, 3), 1, 1)
     synth.fill_state_dict_(m, 3)
     x = Act(torch.randn((B, H, W, ci), device=dev), B, H, W, ci)
     row = []
-    for tile in (64, 128):
-        for nbuf in (2, 1):
-            lib.cn_set_tuning(3, tile); lib.cn_set_tuning(1, nbuf)
+    for gather in (0, 1):
+        for nbuf in (1,):
+            lib.cn_set_tuning(11, gather); lib.cn_set_tuning(3, 64); lib.cn_set_tuning(1, nbuf)
             pb = PlanBuilder(dev, B, H, W)
             pb.dcn(x, m, relu=True)
             op = pb.ops[-1]          # the deformable launch (ops[0] is the offset conv)
@@ -31,4 +31,4 @@ for ci, H, W, co in SHAPES:
             ms = s.elapsed_time(e) / 20
             row.append("%.3fms %5.1fTF" % (ms, pb.meta[-1]["flops"] / ms / 1e9))
     print("%-24s" % str((ci, H, W, co)), "  ".join(row))
-lib.cn_set_tuning(3, 0); lib.cn_set_tuning(1, 0)
+lib.cn_set_tuning(3, 0); lib.cn_set_tuning(1, 0); lib.cn_set_tuning(11, 0)
