@@ -5,7 +5,18 @@
 #include <stddef.h>
 #include "../../include/centernet_amd.h"
 
+#include <mutex>
 #define CN_WAVE 64
+
+// Raise a kernel's dynamic-LDS limit exactly once per process (thread-safe).
+#define CN_SET_MAX_LDS_ONCE(kernel, bytes)                                                   \
+    do {                                                                                     \
+        static std::once_flag cn_once__;                                                     \
+        std::call_once(cn_once__, [] {                                                       \
+            (void)hipFuncSetAttribute((const void *)(kernel),                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+        });                                                                                  \
+    } while (0)
 
 #define CN_CHECK_LAUNCH()                                  \
     do {                                                   \

@@ -585,13 +585,7 @@ template <typename T, int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW, 
 int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
 {
     constexpr size_t lds = igemm_lds_bytes<BM, BN, WM, AMODE, OUT_NCHW, NBUF>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(
-            (const void *)igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>,
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    CN_SET_MAX_LDS_ONCE((igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), lds);
     dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : (a.ksplit > 1 ? a.ksplit : 1));
     IgemmArgs b = a;
     b.xcd_swizzle = (g_tune_swz && grid.x >= 16) ? 1 : 0;

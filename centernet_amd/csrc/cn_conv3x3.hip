@@ -297,12 +297,7 @@ int launch_c3(const C3Args &a, hipStream_t st)
     constexpr size_t tiles = (size_t)(HR * LDT + 2 * BN * LDT);
     constexpr size_t cs = (size_t)(128 / WM) * (BN + 4);
     constexpr size_t lds = (tiles > cs ? tiles : cs) * 4 + 128 * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)conv3x3s1_kernel<T, TW, BN, WM, WN>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);

@@ -313,12 +313,7 @@ int launch_dcn(const DcnArgs &a, hipStream_t st)
     constexpr size_t lds = (size_t)(WPIX * LDT + BM * LDT + BN * LDT) * 4 +
                            (size_t)3 * BM * (2 + 4 + 1) * 4 + BM * 4;
     static_assert((size_t)(BM / 2) * (BN + 4) <= (size_t)(BM + BN) * LDT, "epilogue staging fits");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)dcn_window_kernel<BN>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    CN_SET_MAX_LDS_ONCE(dcn_window_kernel<BN>, lds);
     dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), cn_cdiv(a.Cout, BN));
     hipLaunchKernelGGL(dcn_window_kernel<BN>, grid, dim3(NT), lds, st, a);
     CN_CHECK_LAUNCH();

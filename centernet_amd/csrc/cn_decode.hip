@@ -520,12 +520,7 @@ int launch_nms_topk(const float *heat, int B, int C, int H, int W, int K, int ap
                     const BandPlan &bp, float *cand_score, int32_t *cand_idx, hipStream_t st)
 {
     dim3 grid(bp.nbands, C, B), block(NT);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)nms_topk_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    CN_SET_MAX_LDS_ONCE(nms_topk_kernel, 160 * 1024);
     hipLaunchKernelGGL(nms_topk_kernel, grid, block, bp.lds, st, heat, C, H, W, K, bp.R,
                        apply_sigmoid, cand_score, cand_idx);
     CN_CHECK_LAUNCH();

@@ -212,20 +212,10 @@ int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, 
     const size_t lds = (size_t)WIN_MAX * 4 + (size_t)bn * (KP + 4) * 4 + (size_t)KP * 4 + BM * 4;
     dim3 grid(a.tiles_per_image, cn_cdiv(Cout, bn), B);
     if (bn == 64) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)stem_conv_f32_kernel<64>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
+        CN_SET_MAX_LDS_ONCE(stem_conv_f32_kernel<64>, 160 * 1024);
         hipLaunchKernelGGL(stem_conv_f32_kernel<64>, grid, dim3(NT), lds, st, a);
     } else {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)stem_conv_f32_kernel<32>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
-        }
+        CN_SET_MAX_LDS_ONCE(stem_conv_f32_kernel<32>, 160 * 1024);
         hipLaunchKernelGGL(stem_conv_f32_kernel<32>, grid, dim3(NT), lds, st, a);
     }
     CN_CHECK_LAUNCH();
