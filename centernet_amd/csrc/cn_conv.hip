@@ -241,9 +241,17 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
             smk[pb * BM + r] = mk;
         }
     };
+    // split-K: blockIdx.z owns chunks [kt0, kt1); for the deformable kernel the split is on tap
+    // boundaries (ksplit divides 9), so a workgroup owns taps [tap0, tap1)
+    int kt0 = 0, kt1 = a.KT;
+    if (a.ksplit > 1) {  // small-M / deep-K layers: several workgroups share one output tile
+        kt0 = (int)((long)blockIdx.z * a.KT / a.ksplit);
+        kt1 = (int)((long)(blockIdx.z + 1) * a.KT / a.ksplit);
+    }
+    const int tap0 = kt0 / a.nchunk, tap1 = kt1 / a.nchunk;
     if (AMODE == A_DCN) {
-        dcn_records(0);
-        dcn_records(1);
+        dcn_records(tap0);
+        if (tap0 + 1 < tap1) dcn_records(tap0 + 1);
     }
     if (AMODE == A_STEM) {
         const int taps = a.KH * a.KW;
@@ -413,11 +421,6 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     // ---- main loop: register prefetch of chunk k+1 during the MFMAs of chunk k.
     // NBUF=2: LDS double buffer, one barrier per chunk.  NBUF=1: half the LDS (more
     // workgroups per CU hide the second barrier), two barriers per chunk.
-    int kt0 = 0, kt1 = a.KT;
-    if (a.ksplit > 1) {  // small-M / deep-K layers: several workgroups share one output tile
-        kt0 = (int)((long)blockIdx.z * a.KT / a.ksplit);
-        kt1 = (int)((long)(blockIdx.z + 1) * a.KT / a.ksplit);
-    }
     load_tiles(kt0);
     store_tiles(0, kt0);
     __syncthreads();
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         // iteration t*nchunk-1; their buffer (parity of t) was last read in iteration
         // (t-1)*nchunk-2, so iteration t*nchunk-2 is the safe place to write them.
         const bool rec = (AMODE == A_DCN) && ((kt + 2) % a.nchunk == 0) &&
-                         ((kt + 2) / a.nchunk >= 2) && ((kt + 2) / a.nchunk < 9);
+                         ((kt + 2) / a.nchunk >= tap0 + 2) && ((kt + 2) / a.nchunk < tap1);
         if (NBUF == 2) {
             const int buf = (kt - kt0) & 1;
             compute(buf);
@@ -577,6 +580,8 @@ int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-
 int g_tune_dcn_tile = 0; // cn_set_tuning key 3: 0 = default, 64 / 128 = force the DCN pixel tile
 int g_tune_bm = 0;       // cn_set_tuning key 4: 0 = default, 64 / 128 = force the dense pixel tile
 int g_tune_nosplit = 0;  // cn_set_tuning key 5: 1 = never split K
+int g_tune_stem_persist = 1; // cn_set_tuning key 12: persistent, prefetching stem kernel (cn_stem.hip)
+int g_tune_dcn_split = 0;   // cn_set_tuning key 13: 0 = auto, 1 = never, 3 / 9 = force tap split of the deformable kernel
 int g_tune_dcn_window = 0; // cn_set_tuning key 11: 1 = LDS-window DCN (cn_dcn.hip); default global gather (faster, measured)
 int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip
 int g_tune_nostem = 0;   // cn_set_tuning key 6: 1 = generic implicit-GEMM stem instead of cn_stem.hip
@@ -658,7 +663,8 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 }  // namespace
 int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
-                     int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st);
+                     int stride, int pad, int relu, int out_pitch, int KP, int persistent,
+                     hipStream_t st);
 int cn_dcn_window_f32(const float *x, const float *w_packed, const float *bias, const float *om,
                       int om_pitch, const float *scale, const float *shift, float *y, int B, int Cin,
                       int H, int W, int Cout, int mask_sigmoid, int relu, int setprio, hipStream_t st);
@@ -905,7 +911,8 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
             d->ox_mul == 1 && d->OH == d->Ho && d->OW == d->Wo) {
             rc = cn_stem_conv_f32((const float *)x, (const float *)w_packed, scale, shift,
                                   (float *)y, d->B, d->H, d->W, d->Ho, d->Wo, d->Cout, d->KH,
-                                  d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad, st);
+                                  d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad,
+                                  g_tune_stem_persist, st);
             if (rc != CN_ERR_UNSUPPORTED) return rc;
         }
         if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_STEM, false>(a, st);
@@ -956,11 +963,31 @@ extern "C" int cn_conv2d_f32(const cn_conv_desc *d, const float *x, const float 
     return cn_conv2d(d, x, w_packed, scale, shift, residual, y, nullptr, 0, stream);
 }
 
+// Tap-split factor of the deformable kernel: the gather makes every K chunk latency-bound, so a
+// layer needs ~4 workgroups per CU to keep the matrix cores busy; small maps get them by
+// splitting the 9 taps over 3 or 9 workgroups per tile (fp32 partial sums + reduce kernel).
+static int dcn_ksplit(int B, int H, int W, int Cout)
+{
+    if (g_tune_nosplit || g_tune_dcn_split == 1) return 1;
+    if (g_tune_dcn_split == 3 || g_tune_dcn_split == 9) return g_tune_dcn_split;
+    const long wgs = (long)cn_cdiv(B * H * W, 64) * cn_cdiv(Cout, Cout > 64 ? 128 : 64);
+    if (wgs >= 1024) return 1;
+    return wgs * 3 >= 600 ? 3 : 9;  // measured (tools/bench_dcn.py): 3 wins from ~2 workgroups/CU
+}
+
+extern "C" size_t cn_dcn_v2_forward_nhwc_workspace_bytes(int B, int Cin, int H, int W, int Cout)
+{
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    const int s = dcn_ksplit(B, H, W, Cout);
+    return s > 1 ? (size_t)s * B * H * W * round_up(Cout, 32) * sizeof(float) : 0;
+}
+
 extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_packed,
                                           const float *bias, const float *offset_mask_nhwc,
                                           int om_pitch, const float *scale, const float *shift,
                                           float *output_nhwc, int B, int Cin, int H, int W,
-                                          int Cout, int mask_sigmoid, int relu, void *stream)
+                                          int Cout, int mask_sigmoid, int relu, void *workspace,
+                                          size_t workspace_bytes, void *stream)
 {
     if (!input_nhwc || !weight_packed || !offset_mask_nhwc || !output_nhwc) return CN_ERR_NULL;
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return CN_ERR_SHAPE;
@@ -997,13 +1024,31 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
     const long tiles128 = (long)cn_cdiv(a.M, 128) * cn_cdiv(Cout, Cout > 64 ? 128 : 64);
     (void)tiles128;  // measured (tools/bench_dcn.py): 64-pixel tiles win at every CenterNet shape
     const bool small = g_tune_dcn_tile ? (g_tune_dcn_tile == 64) : true;
+    // tap split (needs the caller's workspace; without one the layer runs unsplit)
+    a.ksplit = 1;
+    if (small && Cout > 32) {
+        const int want = dcn_ksplit(B, H, W, Cout);
+        const size_t need = (size_t)want * a.M * a.cout_pad * sizeof(float);
+        if (want > 1 && workspace && workspace_bytes >= need && cn_aligned16(workspace)) {
+            a.ksplit = want;
+            a.partial = (float *)workspace;
+        }
+    }
+    int rc;
     if (Cout > 64)
-        return small ? launch_igemm<64, 128, 2, 2, A_DCN, false>(a, st)
-                     : launch_igemm<128, 128, 2, 2, A_DCN, false>(a, st);
-    if (Cout > 32)
-        return small ? launch_igemm<64, 64, 2, 2, A_DCN, false>(a, st)
-                     : launch_igemm<128, 64, 2, 2, A_DCN, false>(a, st);
-    return launch_igemm<128, 32, 4, 1, A_DCN, false>(a, st);
+        rc = small ? launch_igemm<64, 128, 2, 2, A_DCN, false>(a, st)
+                   : launch_igemm<128, 128, 2, 2, A_DCN, false>(a, st);
+    else if (Cout > 32)
+        rc = small ? launch_igemm<64, 64, 2, 2, A_DCN, false>(a, st)
+                   : launch_igemm<128, 64, 2, 2, A_DCN, false>(a, st);
+    else
+        rc = launch_igemm<128, 32, 4, 1, A_DCN, false>(a, st);
+    if (rc != CN_OK || a.ksplit == 1) return rc;
+    const size_t total = (size_t)a.M * (a.cout_pad >> 2);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
 }
 
 // ---- ConvTranspose2d(kernel 4, stride 2, padding 1, no output padding) -----------------
@@ -1126,6 +1171,14 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 7 && (value == 0 || value == 1)) {
         g_tune_swz = value;
+        return CN_OK;
+    }
+    if (key == 13 && (value == 0 || value == 1 || value == 3 || value == 9)) {
+        g_tune_dcn_split = value;
+        return CN_OK;
+    }
+    if (key == 12 && (value == 0 || value == 1)) {
+        g_tune_stem_persist = value;
         return CN_OK;
     }
     return CN_ERR_UNSUPPORTED;

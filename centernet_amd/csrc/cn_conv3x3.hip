@@ -50,11 +50,36 @@ struct C3Args {
     int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio;
 };
 
+// Fused detection heads (HEADS = true): blockIdx.y selects the head; its 64 hidden channels
+// never leave the workgroup.
+constexpr int MAX_HEADS = 8;
+constexpr int HEAD_CONV = 64;          // hidden width this kernel is built for (= BN)
+constexpr int LDS2 = HEAD_CONV + 4;    // floats per LDS row of the second GEMM (272 bytes)
+constexpr int W2_ROWS = 96;            // 1x1 output channels staged per pass
+struct C3Heads {
+    const float *w[MAX_HEADS];     // (cout, 64) row-major
+    const float *bias[MAX_HEADS];  // (cout) or null
+    float *y[MAX_HEADS];           // (B, cout, H, W)
+    int cout[MAX_HEADS];
+};
+
+// LDS floats of the kernel: the main loop's tiles, unioned with the epilogue staging
+template <int TW, int BN, int WM, bool HEADS>
+constexpr size_t c3_union_floats()
+{
+    constexpr int TH = 128 / TW;
+    constexpr size_t tiles = (size_t)((TH + 2) * (TW + 2) * LDT + 2 * BN * LDT);
+    // fused heads: S[128][LDS2] shares the main loop's tile space; the 1x1 weights sit behind it
+    constexpr size_t cs = HEADS ? (size_t)128 * LDS2 : (size_t)(128 / WM) * (BN + 4);
+    return (tiles > cs ? tiles : cs) + (HEADS ? (size_t)W2_ROWS * LDS2 : 0);
+}
+
 // T = float: v_mfma_f32_32x32x2_f32, 32 channels per chunk; T = fp16: v_mfma_f32_32x32x16_f16
 // (fp32 accumulate), 64 channels per chunk -- same 128-byte LDS rows and read addresses.
-template <typename T, int TW, int BN, int WM, int WN>
-__global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
+template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false>
+__global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
 {
+    static_assert(!HEADS || (BN == HEAD_CONV && sizeof(T) == 4), "fused heads: fp32, 64 hidden channels");
     constexpr int EPV = C3Elem<T>::EPV;
     constexpr int BKE = 8 * EPV;
     constexpr bool F16 = (EPV == 8);
@@ -72,9 +97,7 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int A_FLOATS = HR * LDT;
-    constexpr int B_FLOATS = 2 * BN * LDT;
-    constexpr int CS_FLOATS = TM * (BN + 4);
-    constexpr int UNION = (A_FLOATS + B_FLOATS) > CS_FLOATS ? (A_FLOATS + B_FLOATS) : CS_FLOATS;
+    constexpr int UNION = (int)c3_union_floats<TW, BN, WM, HEADS>();
     float *As = reinterpret_cast<float *>(smem);  // [HR][LDT]
     float *Bs = As + A_FLOATS;                    // [2][BN][LDT]
     int *rowoff = reinterpret_cast<int *>(As + UNION);  // [BM]
@@ -191,6 +214,24 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
         if (a.setprio) __builtin_amdgcn_s_setprio(0);
     };
 
+    if constexpr (HEADS) {
+        // 1x1 weights of this head (first W2_ROWS output channels) + their bias in pad column
+        // 64, staged now so the epilogue GEMM starts without a global round trip
+        float *W2 = As + UNION - W2_ROWS * LDS2;
+        const int cout2 = hd.cout[blockIdx.y];
+        const float *w2 = hd.w[blockIdx.y];
+        const float *b2 = hd.bias[blockIdx.y];
+        const int rows = min(W2_ROWS, (cout2 + 31) / 32 * 32);
+        for (int idx = tid; idx < rows * (HEAD_CONV / 4); idx += NT) {
+            const int row = idx / (HEAD_CONV / 4), k4 = idx - row * (HEAD_CONV / 4);
+            const int src = min(row, cout2 - 1);  // padded rows: computed, never stored
+            *reinterpret_cast<cn_f32x4 *>(W2 + row * LDS2 + k4 * 4) =
+                *reinterpret_cast<const cn_f32x4 *>(w2 + (size_t)src * HEAD_CONV + k4 * 4);
+        }
+        for (int row = tid; row < rows; row += NT)
+            W2[row * LDS2 + HEAD_CONV] = (b2 && row < cout2) ? b2[row] : 0.f;
+    }
+
     // ---- main loop: chunk-major, taps inner; B double-buffered, A halo single-buffered
     load_A(0);
     load_B(0, 0);
@@ -214,6 +255,93 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
             if (more) store_B((it + 1) & 1);
             __syncthreads();
         }
+    }
+
+    if constexpr (HEADS) {
+        // ---- fused head epilogue (resnet_dcn.py:155-177): hidden = relu(acc + bias1) stays in
+        // LDS as S[128 pixels][64]; the head's 1x1 convolution is a second MFMA GEMM
+        // out[cout][pixel] = W2[cout][64] . S^T with D rows = cout, cols = pixel, so that a
+        // wave's stores run along x of the NCHW map the decode consumes.
+        const int head = blockIdx.y;
+        const int cout2 = hd.cout[head];
+        float *y2 = hd.y[head];
+        float *S = reinterpret_cast<float *>(smem);      // [BM][LDS2] (main-loop tiles are dead)
+        float *W2 = As + UNION - W2_ROWS * LDS2;         // [W2_ROWS][LDS2], column 64 = bias
+        {
+            const int n = wn * TN + l31;  // NB == 1 for the 64-wide tile
+            const float s1 = a.scale ? a.scale[n0 + n] : 1.f;
+            const float b1 = a.shift ? a.shift[n0 + n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float t = acc[i][j][r] * s1 + b1;
+                        S[row * LDS2 + n + j * 32] = a.relu ? fmaxf(t, 0.f) : t;
+                    }
+        }
+        const int HWp = a.H * a.W;
+        const int mpix = wave * 32 + l31;            // this lane's pixel (column of D)
+        const int off = rowoff[mpix];                // (b*H + oy)*W + ox, or -1
+        const int pix = off - b * HWp;
+        const float *Sa = S + mpix * LDS2 + 4 * lh;
+        for (int g0 = 0; g0 < cout2; g0 += W2_ROWS) {
+            const int rows = min(W2_ROWS, (cout2 - g0 + 31) / 32 * 32);
+            if (g0) {  // heads wider than W2_ROWS: restage the next group of 1x1 rows
+                const float *w2 = hd.w[head];
+                const float *b2 = hd.bias[head];
+                __syncthreads();  // previous group's W2 fully read
+                for (int idx = tid; idx < rows * (HEAD_CONV / 4); idx += NT) {
+                    const int row = idx / (HEAD_CONV / 4), k4 = idx - row * (HEAD_CONV / 4);
+                    const int src = min(g0 + row, cout2 - 1);
+                    *reinterpret_cast<cn_f32x4 *>(W2 + row * LDS2 + k4 * 4) =
+                        *reinterpret_cast<const cn_f32x4 *>(w2 + (size_t)src * HEAD_CONV + k4 * 4);
+                }
+                for (int row = tid; row < rows; row += NT)
+                    W2[row * LDS2 + HEAD_CONV] = (b2 && g0 + row < cout2) ? b2[g0 + row] : 0.f;
+            }
+            __syncthreads();  // S (and a restaged W2) visible
+            const int nblk = rows / 32;
+            cn_f32x16 acc2[W2_ROWS / 32];
+#pragma unroll
+            for (int jb = 0; jb < W2_ROWS / 32; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[jb][r] = 0.f;
+            const float *Wb = W2 + l31 * LDS2 + 4 * lh;
+#pragma unroll
+            for (int kk = 0; kk < HEAD_CONV / 8; ++kk) {
+                const cn_f32x4 af = *reinterpret_cast<const cn_f32x4 *>(Sa + kk * 8);
+#pragma unroll
+                for (int jb = 0; jb < W2_ROWS / 32; ++jb) {
+                    if (jb < nblk) {  // uniform
+                        const cn_f32x4 bf =
+                            *reinterpret_cast<const cn_f32x4 *>(Wb + jb * 32 * LDS2 + kk * 8);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc2[jb],
+                                                                            0, 0, 0);
+                    }
+                }
+            }
+            if (off >= 0) {
+#pragma unroll
+                for (int jb = 0; jb < W2_ROWS / 32; ++jb) {
+                    if (jb < nblk) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const int co = g0 + rr;
+                            if (co < cout2)
+                                y2[((size_t)b * cout2 + co) * HWp + pix] =
+                                    acc2[jb][r] + W2[rr * LDS2 + HEAD_CONV];
+                        }
+                    }
+                }
+            }
+        }
+        return;
     }
 
     // ---- epilogue (as in cn_conv.hip): stage one wave-row of the tile through LDS, then
@@ -289,20 +417,19 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a)
     }
 }
 
-template <typename T, int TW, int BN, int WM, int WN>
-int launch_c3(const C3Args &a, hipStream_t st)
+template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false>
+int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 {
     constexpr int TH = 128 / TW;
-    constexpr int HR = (TH + 2) * (TW + 2);
-    constexpr size_t tiles = (size_t)(HR * LDT + 2 * BN * LDT);
-    constexpr size_t cs = (size_t)(128 / WM) * (BN + 4);
-    constexpr size_t lds = (tiles > cs ? tiles : cs) * 4 + 128 * 4;
-    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN>), lds);
+    constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS>() * 4 + 128 * 4;
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
     dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, BN));
-    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN>), grid, dim3(NT), lds, st, b);
+    const C3Heads none = {};
+    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS>), grid, dim3(NT), lds, st, b,
+                       hd ? *hd : none);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -336,4 +463,35 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     a.cout_pad = (Cout + 31) / 32 * 32;
     a.nchunk = a.cin_pad / bke;
     return f16 ? c3_dispatch<_Float16>(a, bn_class, st) : c3_dispatch<float>(a, bn_class, st);
+}
+
+// Fused CenterNet heads: for every head h, y_h = conv1x1(relu(conv3x3(x) + bias1_h)) + bias2_h,
+// the 3x3 convolutions of all heads packed as one (n_heads*64, Cin, 3, 3) weight.
+// Replaces the per-head nn.Sequential of resnet_dcn.py:155-177 / msra_resnet.py (head_conv = 64).
+extern "C" int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin, int in_pitch,
+                                   const float *w1_packed, const float *bias1, int head_conv,
+                                   int n_heads, const cn_head_out *heads, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!x || !w1_packed || !heads) return CN_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || n_heads <= 0) return CN_ERR_SHAPE;
+    if (head_conv != HEAD_CONV || n_heads > MAX_HEADS) return CN_ERR_UNSUPPORTED;
+    if ((in_pitch & 3) || !cn_aligned16(x) || !cn_aligned16(w1_packed)) return CN_ERR_ALIGN;
+    C3Heads hd = {};
+    for (int h = 0; h < n_heads; ++h) {
+        if (!heads[h].w || !heads[h].y) return CN_ERR_NULL;
+        if (heads[h].cout <= 0) return CN_ERR_SHAPE;
+        if (!cn_aligned16(heads[h].w)) return CN_ERR_ALIGN;
+        hd.w[h] = heads[h].w; hd.bias[h] = heads[h].bias; hd.y[h] = heads[h].y;
+        hd.cout[h] = heads[h].cout;
+    }
+    C3Args a = {};
+    a.x = x; a.w = w1_packed; a.scale = nullptr; a.shift = bias1; a.residual = nullptr; a.y = nullptr;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = n_heads * HEAD_CONV; a.in_pitch = in_pitch;
+    a.out_pitch = 0; a.relu = 1; a.vec_out = 0; a.setprio = 1;
+    a.cin_pad = (Cin + 31) / 32 * 32;
+    a.cout_pad = a.Cout;
+    a.nchunk = a.cin_pad / 32;
+    return (W >= 32) ? launch_c3<float, 32, 64, 2, 2, true>(a, st, &hd)
+                     : launch_c3<float, 16, 64, 2, 2, true>(a, st, &hd);
 }

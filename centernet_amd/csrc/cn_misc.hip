@@ -257,7 +257,7 @@ extern "C" int cn_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, 
 // ---- reference-layout (NCHW) DCNv2 entry point --------------------------------
 namespace {
 struct DcnWs {
-    size_t x_off, om_off, w_off, y_off, total;
+    size_t x_off, om_off, w_off, y_off, split_off, split_bytes, total;
 };
 DcnWs dcn_ws_plan(int B, int Cin, int H, int W, int Cout, int kh, int kw)
 {
@@ -272,6 +272,9 @@ DcnWs dcn_ws_plan(int B, int Cin, int H, int W, int Cout, int kh, int kw)
     o += cn_align_up(cn_packed_conv_weight_floats(Cout, Cin, kh, kw) * 4, 256);
     p.y_off = o;
     o += cn_align_up(hw * Cout * 4, 256);
+    p.split_off = o;
+    p.split_bytes = cn_dcn_v2_forward_nhwc_workspace_bytes(B, Cin, H, W, Cout);
+    o += cn_align_up(p.split_bytes, 256);
     p.total = o;
     return p;
 }
@@ -317,7 +320,8 @@ extern "C" int cn_dcn_v2_forward_f32(const float *input, const float *weight, co
     rc = cn_pack_conv_weight_f32(weight, wp, Cout, Cin, 3, 3, stream);
     if (rc != CN_OK) return rc;
     rc = cn_dcn_v2_forward_nhwc_f32(x_nhwc, wp, bias, om, 32, nullptr, nullptr, y_nhwc, B, Cin, H, W,
-                                    Cout, apply_mask_sigmoid, 0, stream);
+                                    Cout, apply_mask_sigmoid, 0, ws + p.split_off, p.split_bytes,
+                                    stream);
     if (rc != CN_OK) return rc;
     return cn_nhwc_to_nchw_f32(y_nhwc, output, B, Cout, H, W, Cout, stream);
 }

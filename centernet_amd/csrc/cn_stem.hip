@@ -178,15 +178,204 @@ __global__ __launch_bounds__(NT) void stem_conv_f32_kernel(const StemArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Persistent variant for 7x7 stems whose output rows are a multiple of 128 pixels wide (every
+// network at 512x512).  gridDim.x workgroups (two per CU) walk the tile list:
+//   * weights are staged ONCE per workgroup;
+//   * the input window of the NEXT tile is fetched into registers while the current tile's
+//     MFMAs run (the zero-fill select is deferred to the LDS store, so nothing in between
+//     waits on the loads);
+//   * K is ordered as (c, ky-pair, kx): the two lane halves of v_mfma_f32_32x32x2_f32 take
+//     ky = 2p and ky = 2p+1 of the same (c, kx), i.e. LDS addresses exactly one window row
+//     apart.  With stride and window pitch compile-time, every A-fragment read is
+//     `ds_read_b32 base offset:imm` -- no offset table, no address arithmetic in the K loop.
+//     ky = 7 (the pad of the 4th pair) has zero weight and reads the next plane's first row
+//     (finite data) or, for the last plane, a zeroed spare row.
+// A tile = 128 consecutive output pixels of one output row: window = 7 rows x WX columns
+// x 3 planes, WX = 127*stride + 7.
+constexpr int PKH = 7, PKW = 7, PROWS = 3 * PKH;
+constexpr int PPE = 3 * 4 * PKW;   // 84 (c, ky-pair, kx) elements
+constexpr int PKP = 2 * PPE;       // 168 K values
+constexpr int PLDW = PKP + 4;      // LDS weight row pitch (floats)
+
+template <int BN, int S>
+__global__ __launch_bounds__(NT) void stem_persist_f32_kernel(const StemArgs a, int total_tiles)
+{
+    constexpr int WN = BN / 32;
+    constexpr int WM = 4 / WN;
+    constexpr int TM = BM / WM;
+    constexpr int MB = TM / 32;
+    constexpr int WX = (BM - 1) * S + PKW;
+    constexpr int WXP = WX | 1;
+    constexpr int WIN_FLOATS = ((PROWS + 1) * WXP + 3) & ~3;  // + one zero row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *win = reinterpret_cast<float *>(smem);   // [22][WXP]
+    float *dummy = win + WIN_FLOATS;                 // [NT] sink of masked-off window stores
+    float *Ws = dummy + NT;                          // [BN][PLDW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.y * BN;
+    const int tpr = a.Wo / BM;  // tiles per output row
+
+    // ---- once per workgroup: weights of this N tile, permuted from the packed
+    // [cout_pad][KP] (k = tap*3 + c) layout into the (group, half, element) K order
+    for (int i = tid; i < BN * PKP; i += NT) {
+        const int nrow = i / PKP, k = i - nrow * PKP;
+        const int g = k >> 3, half = (k >> 2) & 1, e = k & 3;
+        const int pe = g * 4 + e;
+        const int c = pe / (4 * PKW), rem = pe - c * (4 * PKW);
+        const int kyp = rem / PKW, kx = rem - kyp * PKW;
+        const int ky = 2 * kyp + half;
+        const int nn = min(n0 + nrow, a.cout_pad - 1);  // rows past the padded Cout: never stored
+        float w = 0.f;
+        if (ky < PKH) w = a.w[(size_t)nn * a.KP + (ky * PKW + kx) * 3 + c];
+        Ws[nrow * PLDW + k] = w;
+    }
+    for (int i = tid; i < WXP; i += NT) win[PROWS * WXP + i] = 0.f;  // spare zero row
+
+    // tail columns (>= 256) of all 21 window rows ride in one extra load per thread
+    const int trow = tid >> 3, tcol = NT + (tid & 7);
+    const bool tail_ok = trow < PROWS && tcol < WX;
+    const int tc = trow / PKH, twy = trow - tc * PKH;
+    const int tail_dst = tail_ok ? trow * WXP + tcol : WIN_FLOATS + tid;
+    const bool col_ok = tid < WX;
+
+    float v[PROWS], vt;
+    unsigned vmask = 0;
+    auto prefetch = [&](int tile) {
+        const int xt = tile % tpr;
+        const int rowid = tile / tpr;  // b*Ho + oy
+        const int b = rowid / a.Ho, oy = rowid - b * a.Ho;
+        const int iy_min = oy * S - a.pad, ix_min = xt * BM * S - a.pad;
+        const float *xb = a.x + (size_t)b * 3 * a.H * a.W;
+        const int ix = ix_min + tid;
+        const bool cok = col_ok && ix >= 0 && ix < a.W;
+        unsigned mk = 0;
+#pragma unroll
+        for (int u = 0; u < PROWS; ++u) {
+            const int c = u / PKH, wy = u % PKH;
+            const int iy = iy_min + wy;
+            const bool ok = cok && iy >= 0 && iy < a.H;
+            v[u] = xb[ok ? ((size_t)(c * a.H + iy) * a.W + ix) : 0];
+            mk |= ok ? (1u << u) : 0u;
+        }
+        {
+            const int iy = iy_min + twy, jx = ix_min + tcol;
+            const bool ok = tail_ok && iy >= 0 && iy < a.H && jx >= 0 && jx < a.W;
+            vt = xb[ok ? ((size_t)(tc * a.H + iy) * a.W + jx) : 0];
+            mk |= ok ? (1u << PROWS) : 0u;
+        }
+        vmask = mk;
+    };
+    auto store_window = [&]() {  // branch-free: masked-off lanes write to the sink
+#pragma unroll
+        for (int u = 0; u < PROWS; ++u)
+            win[col_ok ? u * WXP + tid : WIN_FLOATS + tid] = ((vmask >> u) & 1u) ? v[u] : 0.f;
+        win[tail_dst] = ((vmask >> PROWS) & 1u) ? vt : 0.f;
+    };
+
+    const float *abase[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) abase[i] = win + (wm * TM + i * 32 + l31) * S + lh * WXP;
+    const float *wrow = Ws + (wn * 32 + l31) * PLDW + 4 * lh;
+    const int n = n0 + wn * 32 + l31;
+    float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+    float sf = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+    asm volatile("" : "+v"(sc), "+v"(sf));  // settle these loads before the tile loop
+
+    int tile = blockIdx.x;
+    if (tile < total_tiles) prefetch(tile);
+    for (; tile < total_tiles; tile += gridDim.x) {
+        store_window();
+        __syncthreads();  // window (and, first time, weights) visible
+        const int next = tile + gridDim.x;
+        if (next < total_tiles) prefetch(next);  // in flight during the MFMAs below
+
+        cn_f32x16 acc[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < PKP / 8; ++g) {
+            const cn_f32x4 bf = *reinterpret_cast<const cn_f32x4 *>(wrow + g * 8);
+            float af[MB][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pe = g * 4 + e;
+                const int c = pe / (4 * PKW), rem = pe % (4 * PKW);
+                const int kyp = rem / PKW, kx = rem % PKW;
+                const int off = (c * PKH + 2 * kyp) * WXP + kx;  // compile-time immediate
+#pragma unroll
+                for (int i = 0; i < MB; ++i) af[i][e] = abase[i][off];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[e], acc[i], 0, 0, 0);
+        }
+
+        // epilogue: BN (scale/shift) + ReLU, NHWC; lanes run along Cout (128-byte rows)
+        if (n < a.Cout) {
+            const int xt = tile % tpr;
+            const int rowid = tile / tpr;
+            float *yb = a.y + ((size_t)rowid * a.Wo + (size_t)xt * BM) * a.out_pitch + n;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float t = acc[i][r] * sc + sf;
+                    if (a.relu) t = fmaxf(t, 0.f);
+                    yb[(size_t)m * a.out_pitch] = t;
+                }
+        }
+        __syncthreads();  // every wave is done reading the window
+    }
+}
+
+template <int BN, int S>
+int launch_stem_persist(const StemArgs &a, int B, hipStream_t st)
+{
+    constexpr int WXP = ((BM - 1) * S + PKW) | 1;
+    constexpr size_t lds = (size_t)((((PROWS + 1) * WXP + 3) & ~3) + NT + BN * PLDW) * 4;
+    const long total = (long)B * a.tiles_per_image;
+    const int wgs = (int)(total < 512 ? total : 512);  // two resident workgroups per CU
+    dim3 grid(wgs, cn_cdiv(a.Cout, BN));
+    CN_SET_MAX_LDS_ONCE((stem_persist_f32_kernel<BN, S>), lds);
+    hipLaunchKernelGGL((stem_persist_f32_kernel<BN, S>), grid, dim3(NT), lds, st, a, (int)total);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
 }  // namespace
 
 // Returns CN_ERR_UNSUPPORTED when the shape does not fit this kernel (the caller then uses
 // the generic implicit-GEMM stem).
 int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
-                     int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st)
+                     int stride, int pad, int relu, int out_pitch, int KP, int persistent,
+                     hipStream_t st)
 {
     if (KP & 7) return CN_ERR_UNSUPPORTED;
+    if (persistent && KH == PKH && KW == PKW && Wo % BM == 0 && (stride == 1 || stride == 2) &&
+        KP >= PKH * PKW * 3) {
+        StemArgs a;
+        a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y;
+        a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = KH; a.KW = KW;
+        a.stride = stride; a.pad = pad; a.relu = relu; a.out_pitch = out_pitch; a.KP = KP;
+        a.tiles_per_image = Ho * (Wo / BM);
+        a.cout_pad = (Cout + 31) / 32 * 32;
+        if (Cout > 32)
+            return stride == 2 ? launch_stem_persist<64, 2>(a, B, st)
+                               : launch_stem_persist<64, 1>(a, B, st);
+        return stride == 2 ? launch_stem_persist<32, 2>(a, B, st)
+                           : launch_stem_persist<32, 1>(a, B, st);
+    }
     // worst-case window of a 128-pixel tile
     int wy, wx;
     if (Wo >= BM) {

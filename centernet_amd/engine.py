@@ -14,6 +14,7 @@ Reference call sites being replaced: ``self.model(images)[-1]``
 (src/lib/models/networks/*.py ``forward``).
 """
 import ctypes
+import os
 
 import torch
 
@@ -78,6 +79,7 @@ class PlanBuilder:
         self.input = None
         self.trace = []        # (kind, Act) of every op output, in launch order (debugging)
         self.ws = None         # split-K scratch shared by all launches (stream-ordered)
+        self.fuse_heads = os.environ.get("CN_FUSE_HEADS", "1") != "0"
         self.ws_bytes = 0
 
     # ---- helpers -------------------------------------------------------------
@@ -97,6 +99,12 @@ class PlanBuilder:
         torch.cuda.current_stream().synchronize()
         self.keep.append(wp)
         return wp
+
+    def _grow_ws(self, need):
+        # split-K scratch shared by every launch (stream-ordered; ops read self.ws at run time)
+        if need > self.ws_bytes:
+            self.ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+            self.ws_bytes = need
 
     def set_input(self, C=3):
         """Network input: user NCHW image batch, bound at run time."""
@@ -141,10 +149,7 @@ class PlanBuilder:
         rp = residual.ptr() if residual is not None else None
         wpp, op = native.ptr(wp), out.ptr()
         dref = ctypes.byref(d)
-        need = lib.cn_conv2d_workspace_bytes(dref)
-        if need > self.ws_bytes:   # grow the shared scratch (ops read self.ws at run time)
-            self.ws = torch.empty(need, device=self.device, dtype=torch.uint8)
-            self.ws_bytes = need
+        self._grow_ws(lib.cn_conv2d_workspace_bytes(dref))
 
         def run():
             xp = ctypes.c_void_p(self.input.t.data_ptr()) if is_input else x.ptr()
@@ -295,10 +300,13 @@ class PlanBuilder:
         assert x.pitch == x.C and x.c_off == 0
         bp, sp, hp, wpp = native.ptr(bias), native.ptr(scale), native.ptr(shift), native.ptr(wp)
 
+        self._grow_ws(lib.cn_dcn_v2_forward_nhwc_workspace_bytes(x.B, ci, x.H, x.W, co))
+
         def run():
+            wsp = ctypes.c_void_p(self.ws.data_ptr()) if self.ws is not None else None
             rc = lib.cn_dcn_v2_forward_nhwc_f32(x.ptr(), wpp, bp, om.ptr(), om.pitch, sp, hp,
                                                 out.ptr(), x.B, ci, x.H, x.W, co, 1, int(relu),
-                                                native.stream_ptr())
+                                                wsp, self.ws_bytes, native.stream_ptr())
             if rc:
                 native.check(rc, "cn_dcn_v2_forward_nhwc_f32")
         self.ops.append(run)
@@ -332,6 +340,12 @@ class PlanBuilder:
         w = torch.cat([c.weight.detach() for c in firsts], 0)
         b = torch.cat([c.bias.detach() for c in firsts], 0)
         k = firsts[0].kernel_size[0]
+        if (self.fuse_heads and self.dtype == torch.float32 and k == 3 and len(names) <= 8 and
+                not x.nchw and x.c_off == 0 and
+                all(c.weight.shape[0] == 64 and c.padding[0] == 1 and c.stride[0] == 1
+                    for c in firsts) and
+                all(tuple(pairs[n][1].kernel_size) == (1, 1) for n in names)):
+            return self._heads_fused(x, names, pairs, w, b)
         mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2)
         outs = {}
         off = 0
@@ -342,6 +356,49 @@ class PlanBuilder:
             outs[n] = self.conv(sl, last.weight, bias=last.bias, stride=1,
                                 padding=last.kernel_size[0] // 2, out_nchw=True)
             off += hc
+        return outs
+
+
+    def _heads_fused(self, x, names, pairs, w1, b1):
+        """All heads as ONE launch (cn_heads3x3_1x1_f32): the 64 hidden channels of a head
+        stay in LDS between its 3x3 and its 1x1 convolution."""
+        lib = self.lib
+        nh = len(names)
+        wp = self._pack(w1)
+        b1 = b1.to(device=self.device, dtype=torch.float32).contiguous()
+        arr = (native.HeadOut * nh)()
+        outs = {}
+        fl = 2 * x.B * x.H * x.W * w1.shape[0] * x.C * 9
+        by = 4 * (x.B * x.H * x.W * x.C + w1.numel())
+        for i, n in enumerate(names):
+            last = pairs[n][1]
+            co = last.weight.shape[0]
+            w2 = last.weight.detach().to(device=self.device, dtype=torch.float32)
+            w2 = w2.reshape(co, 64).contiguous()
+            b2 = None if last.bias is None else \
+                last.bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            t = torch.empty((x.B, co, x.H, x.W), device=self.device, dtype=torch.float32)
+            outs[n] = Act(t, x.B, x.H, x.W, co, nchw=True)
+            self.keep += [w2, b2, t]
+            arr[i].w = w2.data_ptr()
+            arr[i].bias = b2.data_ptr() if b2 is not None else None
+            arr[i].y = t.data_ptr()
+            arr[i].cout = co
+            fl += 2 * x.B * x.H * x.W * co * 64
+            by += 4 * (x.B * x.H * x.W * co + co * 64)
+        self.keep += [b1, arr]
+        wpp, b1p = native.ptr(wp), native.ptr(b1)
+        ci = x.C
+
+        def run():
+            rc = lib.cn_heads3x3_1x1_f32(x.ptr(), x.B, x.H, x.W, ci, x.pitch, wpp, b1p, 64, nh,
+                                         arr, native.stream_ptr())
+            if rc:
+                native.check(rc, "cn_heads3x3_1x1_f32")
+        self.ops.append(run)
+        self.meta.append(dict(kind="conv", flops=fl, bytes=by))
+        self.trace.append(("heads", outs[names[0]]))
+        self.flops += fl
         return outs
 
 

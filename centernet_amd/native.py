@@ -36,6 +36,12 @@ class ConvDesc(ctypes.Structure):
         "oy_add", "ox_mul", "ox_add", "relu", "dtype")]
 
 
+class HeadOut(ctypes.Structure):
+    """Mirror of ``cn_head_out`` (include/centernet_amd.h)."""
+    _fields_ = [("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("cout", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
 def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     args = ["make", "-C", CSRC, "-j8"]
@@ -61,7 +67,9 @@ def _declare(lib):
     lib.cn_dcn_v2_forward_f32.restype = i
     lib.cn_dcn_v2_forward_f32.argtypes = [vp] * 6 + [i] * 15 + [vp, sz, vp]
     lib.cn_dcn_v2_forward_nhwc_f32.restype = i
-    lib.cn_dcn_v2_forward_nhwc_f32.argtypes = [vp, vp, vp, vp, i, vp, vp, vp] + [i] * 7 + [vp]
+    lib.cn_dcn_v2_forward_nhwc_f32.argtypes = [vp, vp, vp, vp, i, vp, vp, vp] + [i] * 7 + [vp, sz, vp]
+    lib.cn_dcn_v2_forward_nhwc_workspace_bytes.restype = sz
+    lib.cn_dcn_v2_forward_nhwc_workspace_bytes.argtypes = [i] * 5
     lib.cn_packed_conv_weight_floats.restype = sz
     lib.cn_packed_conv_weight_floats.argtypes = [i] * 4
     lib.cn_pack_conv_weight_f32.restype = i
@@ -94,6 +102,8 @@ def _declare(lib):
     lib.cn_copy_channels_f32.argtypes = [vp, i, vp, i, sz, i, vp]
     lib.cn_upsample2x_add_f32.restype = i
     lib.cn_upsample2x_add_f32.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    lib.cn_heads3x3_1x1_f32.restype = i
+    lib.cn_heads3x3_1x1_f32.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, ctypes.POINTER(HeadOut), vp]
     lib.cn_soft_nms_f32.restype = i
     lib.cn_soft_nms_f32.argtypes = [vp, i, i, ctypes.c_float, ctypes.c_float, ctypes.c_float, i]
     lib.cn_nchw_to_nhwc_f32.restype = i

@@ -67,7 +67,10 @@ const char *cn_arch(void);
  *         kernel (cn_conv3x3.hip).
  * key 11: 1 = LDS-window deformable kernel (cn_dcn.hip) instead of the default global-gather
  *         form (cn_conv.hip); kept for A/B: it measured 20-30 % slower.
- * key 7: 1 = enable the XCD-aware tile order of the implicit-GEMM kernels (off: no gain). */
+ * key 7: 1 = enable the XCD-aware tile order of the implicit-GEMM kernels (off: no gain).
+ * key 13: tap split of the deformable kernel, 0 = auto, 1 = never, 3 or 9 = force.
+ * key 12: 0 = one-tile-per-workgroup stem kernel instead of the persistent, prefetching one
+ *         (default 1; both in cn_stem.hip). */
 int cn_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------
@@ -120,12 +123,19 @@ int cn_dcn_v2_forward_f32(const float *input, const float *weight, const float *
  * epilogue  y = relu?( (acc + bias) * scale + shift )  that folds the
  * BatchNorm + ReLU following every DCN in resnet_dcn.py:237-239 /
  * pose_dla_dcn.py:345-357.  scale/shift may be NULL (identity).
+ * workspace: small maps split the nine taps over 3 or 9 workgroups per output tile (fp32
+ * partial sums, deterministic reduce + epilogue in a second launch) so that the
+ * latency-bound gather still fills the 256 CUs; that needs
+ * cn_dcn_v2_forward_nhwc_workspace_bytes() of 16-byte aligned scratch.  With a NULL or
+ * too small workspace the layer runs unsplit (same result up to fp32 summation order).
  */
+size_t cn_dcn_v2_forward_nhwc_workspace_bytes(int B, int Cin, int H, int W, int Cout);
 int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_packed,
                                const float *bias, const float *offset_mask_nhwc,
                                int om_pitch, const float *scale, const float *shift,
                                float *output_nhwc, int B, int Cin, int H, int W,
-                               int Cout, int mask_sigmoid, int relu, void *stream);
+                               int Cout, int mask_sigmoid, int relu, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * Dense convolution as an implicit GEMM on fp32 MFMA (no im2col buffer).
@@ -215,6 +225,27 @@ int cn_upsample2x_add_f32(const float *x, const float *add, float *y, int B, int
                           int C, void *stream);
 int cn_upsample2x_add_f16(const void *x, const void *add, void *y, int B, int H, int W, int C,
                           void *stream);
+
+/* Fused detection heads.  The reference builds every head as
+ *   nn.Sequential(Conv2d(F, head_conv, 3, padding=1, bias=True), ReLU, Conv2d(head_conv, C, 1))
+ * (resnet_dcn.py:155-177, msra_resnet.py) and runs them one after the other on the same
+ * feature map.  Here all heads are ONE launch: w1_packed is cn_pack_conv_weight_f32 of the
+ * first convolutions concatenated along Cout, (n_heads*head_conv, F, 3, 3); bias1 the
+ * concatenated biases; the hidden activations stay in LDS and each head's 1x1 convolution
+ * runs as a second matrix-core GEMM in the same workgroup, writing the NCHW maps
+ * (B, cout, H, W) that cn_ctdet_decode_f32 / cn_multi_pose_decode_f32 consume.
+ * x is NHWC with row pitch in_pitch.  Built for head_conv == 64 and n_heads <= 8; anything
+ * else returns CN_ERR_UNSUPPORTED (the caller then issues cn_conv2d per convolution). */
+typedef struct cn_head_out {
+    const float *w;    /* (cout, head_conv) row-major == Conv2d(head_conv, cout, 1).weight */
+    const float *bias; /* (cout) or NULL */
+    float *y;          /* (B, cout, H, W) */
+    int cout;
+    int reserved;
+} cn_head_out;
+int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin, int in_pitch,
+                        const float *w1_packed, const float *bias1, int head_conv, int n_heads,
+                        const cn_head_out *heads, void *stream);
 
 /* Soft-NMS on a HOST array, in place (rows of `stride` floats: x1,y1,x2,y2,score,...).
  * Replaces external.nms.soft_nms / soft_nms_39 (src/lib/external/nms.pyx:77-275), used by

@@ -179,3 +179,38 @@ def test_fp16_stem_and_nchw_head(dev):
     ref2 = F.conv2d(got.half().float(), w2.half().float(), b2)
     err2 = (z.t.cpu() - ref2).abs() / (1 + ref2.abs())
     assert float(err2.max()) < 2e-3, float(err2.max())
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, F, H, W, {head: classes}
+    (2, 64, 32, 32, {"hm": 80, "wh": 2, "reg": 2}),
+    (1, 64, 21, 45, {"hm": 80, "wh": 2, "reg": 2}),                 # ragged tiles, W >= 32
+    (2, 64, 12, 20, {"hm": 3, "dep": 1}),                            # W < 32: 8x16 tiles
+    (1, 256, 16, 16, {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}),
+    (1, 64, 8, 40, {"big": 130, "wh": 2}),                           # > 96 channels: two passes
+])
+def test_fused_heads(dev, cfg):
+    """cn_heads3x3_1x1_f32 (one launch for all heads, hidden channels kept in LDS) vs the
+    per-head Sequential(conv3x3, ReLU, conv1x1) of resnet_dcn.py:155-177 on torch CPU."""
+    from centernet_amd.engine import PlanBuilder
+    B, Fc, H, W, heads = cfg
+    x = torch.from_numpy(synth.normal((B, Fc, H, W), 1.0, 11))
+    pairs, ref = {}, {}
+    for i, (name, classes) in enumerate(heads.items()):
+        c1 = torch.nn.Conv2d(Fc, 64, 3, padding=1, bias=True)
+        c2 = torch.nn.Conv2d(64, classes, 1, bias=True)
+        with torch.no_grad():
+            c1.weight.copy_(torch.from_numpy(synth.normal(tuple(c1.weight.shape), (2.0 / (Fc * 9)) ** 0.5, 20 + i)))
+            c1.bias.copy_(torch.from_numpy(synth.normal((64,), 0.2, 30 + i)))
+            c2.weight.copy_(torch.from_numpy(synth.normal(tuple(c2.weight.shape), 0.15, 40 + i)))
+            c2.bias.copy_(torch.from_numpy(synth.normal((classes,), 0.5, 50 + i)))
+            ref[name] = c2(F.relu(c1(x)))
+        pairs[name] = (c1, c2)
+    pb = PlanBuilder(dev, B, H, W)
+    assert pb.fuse_heads
+    outs = pb.heads_from_convs(_nhwc_act(x, dev), pairs)
+    assert len(pb.ops) == 1, "heads with 64 hidden channels must be a single fused launch"
+    _run(pb)
+    for name in heads:
+        assert outs[name].nchw and tuple(outs[name].t.shape) == tuple(ref[name].shape)
+        _check(outs[name].t.cpu(), ref[name])

@@ -1,4 +1,5 @@
-"""DCN layer micro-benchmark under the tuning knobs (GPU box only)."""
+"""DCN layer micro-benchmark under the tuning knobs (GPU box only).
+Columns: tap split off / auto (key 13), LDS tile buffers 1 / 2 (key 1)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,17 +9,17 @@ from centernet_amd.engine import PlanBuilder, Act
 
 dev = torch.device("cuda:0")
 lib = native.lib()
-B = int(os.environ.get("B", 32))
 SHAPES = [(512, 16, 16, 256), (256, 32, 32, 128), (128, 64, 64, 64), (64, 128, 128, 64), (256, 32, 32, 64)]
-print("%-24s" % "Cin,H,W,Cout", "gather-kernel(tile64,nbuf1)   window-kernel")
-for ci, H, W, co in SHAPES:
-    m = DCN(ci, co, (3, 3), 1, 1)
-    synth.fill_state_dict_(m, 3)
-    x = Act(torch.randn((B, H, W, ci), device=dev), B, H, W, ci)
-    row = []
-    for gather in (0, 1):
-        for nbuf in (1,):
-            lib.cn_set_tuning(11, gather); lib.cn_set_tuning(3, 64); lib.cn_set_tuning(1, nbuf)
+CFGS = [("split1,nbuf1", 1, 1), ("auto,nbuf1", 0, 1), ("split3,nbuf1", 3, 1), ("auto,nbuf2", 0, 2)]
+for B in [int(b) for b in os.environ.get("B", "32,1").split(",")]:
+    print("B=%d  %-22s" % (B, "Cin,H,W,Cout"), "   ".join("%-16s" % c[0] for c in CFGS))
+    for ci, H, W, co in SHAPES:
+        m = DCN(ci, co, (3, 3), 1, 1)
+        synth.fill_state_dict_(m, 3)
+        x = Act(torch.randn((B, H, W, ci), device=dev), B, H, W, ci)
+        row = []
+        for _, split, nbuf in CFGS:
+            lib.cn_set_tuning(13, split); lib.cn_set_tuning(1, nbuf)
             pb = PlanBuilder(dev, B, H, W)
             pb.dcn(x, m, relu=True)
             op = pb.ops[-1]          # the deformable launch (ops[0] is the offset conv)
@@ -30,5 +31,5 @@ for ci, H, W, co in SHAPES:
             e.record(); torch.cuda.synchronize()
             ms = s.elapsed_time(e) / 20
             row.append("%.3fms %5.1fTF" % (ms, pb.meta[-1]["flops"] / ms / 1e9))
-    print("%-24s" % str((ci, H, W, co)), "  ".join(row))
-lib.cn_set_tuning(3, 0); lib.cn_set_tuning(1, 0); lib.cn_set_tuning(11, 0)
+        print("      %-22s" % str((ci, H, W, co)), "   ".join("%-16s" % r for r in row))
+lib.cn_set_tuning(13, 0); lib.cn_set_tuning(1, 0)
