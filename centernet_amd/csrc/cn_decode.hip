@@ -25,6 +25,15 @@
 // that a strict total order, so the result is deterministic.
 #include "cn_common.h"
 
+// Decode arithmetic must round exactly like the reference's torch ops (bit-exact parity):
+// no mul+add fusion anywhere in this file (hipcc's default is -ffp-contract=fast-honor-pragmas
+// and HIP's __fmul_rn/__fadd_rn are plain operators).
+#pragma clang fp contract(off)
+// Rounded-once helpers compiled under contract(off): unlike HIP's header-inline __fmul_rn /
+// __fadd_rn their results can never be fused into an FMA after inlining.
+static __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+static __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+
 namespace {
 
 constexpr int NT = 256;      // threads per workgroup (4 waves)
@@ -630,17 +639,17 @@ __global__ __launch_bounds__(KMAX) void pose_match_kernel(
         const int yi = ind / W, xi = ind - yi * W;
         float x = (float)xi, y = (float)yi;
         if (hp_offset) {  // decode.py:534-539
-            x = __fadd_rn(x, hp_offset[((size_t)b * 2 + 0) * HW + ind]);
-            y = __fadd_rn(y, hp_offset[((size_t)b * 2 + 1) * HW + ind]);
+            x = add_rn(x, hp_offset[((size_t)b * 2 + 0) * HW + ind]);
+            y = add_rn(y, hp_offset[((size_t)b * 2 + 1) * HW + ind]);
         } else {
-            x = __fadd_rn(x, 0.5f);
-            y = __fadd_rn(y, 0.5f);
+            x = add_rn(x, 0.5f);
+            y = add_rn(y, 0.5f);
         }
         const float m = (s > thresh) ? 1.0f : 0.0f;  // decode.py:544-547
         const float im = __fsub_rn(1.0f, m);
-        cs[q] = __fadd_rn(__fmul_rn(im, -1.0f), __fmul_rn(m, s));
-        cy[q] = __fadd_rn(__fmul_rn(im, -10000.0f), __fmul_rn(m, y));
-        cx[q] = __fadd_rn(__fmul_rn(im, -10000.0f), __fmul_rn(m, x));
+        cs[q] = add_rn(mul_rn(im, -1.0f), mul_rn(m, s));
+        cy[q] = add_rn(mul_rn(im, -10000.0f), mul_rn(m, y));
+        cx[q] = add_rn(mul_rn(im, -10000.0f), mul_rn(m, x));
     }
     __syncthreads();
     if (q < K) {
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(KMAX) void pose_match_kernel(
         for (int c = 0; c < K; ++c) {  // decode.py:550-551, first minimum
             const float dx = __fsub_rn(rx, cx[c]);
             const float dy = __fsub_rn(ry, cy[c]);
-            const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+            const float dist = __fsqrt_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)));
             if (bi < 0 || dist < best) {
                 best = dist;
                 bi = c;
@@ -660,13 +669,13 @@ __global__ __launch_bounds__(KMAX) void pose_match_kernel(
         const float sc = cs[bi], kx = cx[bi], ky = cy[bi];
         const float l = d[0], t = d[1], r = d[2], bt = d[3];
         const float bh = __fsub_rn(bt, t), bw = __fsub_rn(r, l);
-        const float mx = __fmul_rn(fmaxf(bh, bw), 0.3f);
+        const float mx = mul_rn(fmaxf(bh, bw), 0.3f);
         const bool reject = (kx < l) || (kx > r) || (ky < t) || (ky > bt) || (sc < thresh) ||
                             (best > mx);  // decode.py:562-565
         const float m = reject ? 1.0f : 0.0f;
         const float im = __fsub_rn(1.0f, m);
-        d[5 + 2 * j] = __fadd_rn(__fmul_rn(im, kx), __fmul_rn(m, rx));  // decode.py:566
-        d[5 + 2 * j + 1] = __fadd_rn(__fmul_rn(im, ky), __fmul_rn(m, ry));
+        d[5 + 2 * j] = add_rn(mul_rn(im, kx), mul_rn(m, rx));  // decode.py:566
+        d[5 + 2 * j + 1] = add_rn(mul_rn(im, ky), mul_rn(m, ry));
     }
 }
 

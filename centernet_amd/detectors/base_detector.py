@@ -62,6 +62,53 @@ class BaseDetector(object):
                 'out_width': inp_width // self.opt.down_ratio}
         return images, meta
 
+    def pre_process_device(self, image, scale, meta=None):
+        """pre_process with the resize / warp / normalise / CHW (/ flip) steps on the device
+        (cn_resize_bilinear_u8 + cn_warp_normalize_u8_f32): the uint8 frame is uploaded and the
+        fp32 (1|2,3,H,W) batch is produced in HBM.  Same arithmetic as ``pre_process``
+        (bit-identical output); used by ``run`` for ndarray / path inputs on a HIP device."""
+        import ctypes
+        from .. import native
+        from ..image import invert_affine
+        lib = native.lib()
+        height, width = image.shape[0:2]
+        new_height = int(height * scale)
+        new_width = int(width * scale)
+        if self.opt.fix_res:
+            inp_height, inp_width = self.opt.input_h, self.opt.input_w
+            c = np.array([new_width / 2., new_height / 2.], dtype=np.float32)
+            s = max(height, width) * 1.0
+        else:
+            inp_height = (new_height | self.opt.pad) + 1
+            inp_width = (new_width | self.opt.pad) + 1
+            c = np.array([new_width // 2, new_height // 2], dtype=np.float32)
+            s = np.array([inp_width, inp_height], dtype=np.float32)
+        trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
+        dev = self.opt.device
+        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+            raise ValueError("pre_process_device needs an (H, W, 3) uint8 BGR image")
+        src = torch.from_numpy(np.ascontiguousarray(image)).to(dev)
+        st = native.stream_ptr()
+        if (new_height, new_width) != (height, width):
+            resized = torch.empty((new_height, new_width, 3), device=dev, dtype=torch.uint8)
+            native.check(lib.cn_resize_bilinear_u8(native.ptr(src), height, width, width * 3,
+                                                   new_height, new_width, native.ptr(resized), st),
+                         "cn_resize_bilinear_u8")
+            src = resized
+        nb = 2 if self.opt.flip_test else 1
+        images = torch.empty((nb, 3, inp_height, inp_width), device=dev, dtype=torch.float32)
+        mi = (ctypes.c_double * 6)(*invert_affine(trans_input).reshape(-1))
+        mean = (ctypes.c_float * 3)(*[float(v) for v in self.mean.reshape(-1)])
+        std = (ctypes.c_float * 3)(*[float(v) for v in self.std.reshape(-1)])
+        native.check(lib.cn_warp_normalize_u8_f32(native.ptr(src), new_height, new_width,
+                                                  new_width * 3, mi, inp_height, inp_width, mean,
+                                                  std, int(self.opt.flip_test), native.ptr(images),
+                                                  st),
+                     "cn_warp_normalize_u8_f32")
+        meta = {'c': c, 's': s, 'out_height': inp_height // self.opt.down_ratio,
+                'out_width': inp_width // self.opt.down_ratio}
+        return images, meta
+
     def process(self, images, return_time=False):
         raise NotImplementedError
 
@@ -102,7 +149,12 @@ class BaseDetector(object):
         for scale in self.scales:
             scale_start_time = time.time()
             if not pre_processed:
-                images, meta = self.pre_process(image, scale, meta)
+                on_device = getattr(self.opt.device, 'type', str(self.opt.device)) == 'cuda'
+                if on_device and not getattr(self.opt, 'host_pre_process', False) and \
+                        image.dtype == np.uint8:
+                    images, meta = self.pre_process_device(image, scale, meta)
+                else:
+                    images, meta = self.pre_process(image, scale, meta)
             else:
                 images = pre_processed_images['images'][scale][0]
                 meta = pre_processed_images['meta'][scale]

@@ -1,9 +1,10 @@
 """Host-side geometry helpers (mirror of src/lib/utils/image.py:19-66).
 
-OpenCV is not available in this image, so the two cv2 calls the reference makes are
-restated: ``cv2.getAffineTransform`` (exact 3-point solve, float64) and
-``cv2.warpAffine(..., INTER_LINEAR)`` (float bilinear, zero border).  For the benchmark
-configuration (512x512 input, fix_res) the warp is the identity.
+OpenCV is not available in this image, so the cv2 calls the reference makes are restated:
+``cv2.getAffineTransform`` (exact 3-point solve, float64), ``cv2.warpAffine(..., INTER_LINEAR)``
+and ``cv2.resize`` (float64 bilinear, round-half-even to uint8; the same arithmetic, operation for
+operation, as the device kernels in csrc/cn_pre.hip).  For the benchmark configuration
+(512x512 input, fix_res) the warp is the identity.
 """
 import numpy as np
 
@@ -68,54 +69,81 @@ def transform_preds(coords, center, scale, output_size):
     return target
 
 
-def warp_affine(img, trans, dsize):
-    """Bilinear warp, zero border: dst(x,y) = src(M^-1 [x,y,1]); img HxWxC, dsize (w,h)."""
+def invert_affine(trans):
+    """dst -> src 2x3 float64 matrix of a src -> dst 2x3 affine (what cv2.warpAffine does
+    with its M unless WARP_INVERSE_MAP is set)."""
+    M = np.vstack([np.asarray(trans, np.float64), [0, 0, 1]])
+    return np.linalg.inv(M)[:2].copy()
+
+
+def resize_matrix(in_size, out_size):
+    """dst -> src matrix of cv2.resize(INTER_LINEAR): src = (dst + 0.5) * (in/out) - 0.5."""
+    (w_in, h_in), (w_out, h_out) = in_size, out_size
+    sx, sy = float(w_in) / float(w_out), float(h_in) / float(h_out)
+    return np.array([[sx, 0.0, 0.5 * sx - 0.5], [0.0, sy, 0.5 * sy - 0.5]], np.float64)
+
+
+def warp_bilinear_u8(img, Mi, dsize, replicate=False):
+    """The arithmetic contract shared with the device kernel (csrc/cn_pre.hip) and
+    oracle/pre_oracle.py: float64 bilinear in a fixed operation order, taps outside the image
+    zero (or clamped when ``replicate``), round-half-even to uint8."""
     w_out, h_out = int(dsize[0]), int(dsize[1])
     h_in, w_in = img.shape[:2]
-    M = np.vstack([np.asarray(trans, np.float64), [0, 0, 1]])
-    Mi = np.linalg.inv(M)
-    if (abs(Mi[0, 0] - 1) < 1e-12 and abs(Mi[1, 1] - 1) < 1e-12 and abs(Mi[0, 1]) < 1e-12 and
-            abs(Mi[1, 0]) < 1e-12 and abs(Mi[0, 2]) < 1e-9 and abs(Mi[1, 2]) < 1e-9 and
-            (h_in, w_in) == (h_out, w_out)):
-        return img.copy()
+    Mi = np.asarray(Mi, np.float64)
     xs, ys = np.meshgrid(np.arange(w_out, dtype=np.float64), np.arange(h_out, dtype=np.float64))
-    sx = Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]
-    sy = Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]
-    x0 = np.floor(sx).astype(np.int64)
-    y0 = np.floor(sy).astype(np.int64)
-    fx = (sx - x0)[..., None]
-    fy = (sy - y0)[..., None]
+    sx = (Mi[0, 0] * xs + Mi[0, 1] * ys) + Mi[0, 2]
+    sy = (Mi[1, 0] * xs + Mi[1, 1] * ys) + Mi[1, 2]
+    fx0, fy0 = np.floor(sx), np.floor(sy)
+    far = ~((fx0 > -4.0) & (fx0 < w_in + 4.0) & (fy0 > -4.0) & (fy0 < h_in + 4.0))
+    x0 = np.where(far, -4, fx0).astype(np.int64)
+    y0 = np.where(far, -4, fy0).astype(np.int64)
+    fx = np.where(far, 0.0, sx - fx0)[..., None]
+    fy = np.where(far, 0.0, sy - fy0)[..., None]
+    gx, gy = 1.0 - fx, 1.0 - fy
     src = img.astype(np.float64)
     if src.ndim == 2:
         src = src[..., None]
 
     def tap(yy, xx):
-        ok = (yy >= 0) & (yy < h_in) & (xx >= 0) & (xx < w_in)
+        if replicate:
+            ok = ~far
+        else:
+            ok = (yy >= 0) & (yy < h_in) & (xx >= 0) & (xx < w_in)
         v = src[np.clip(yy, 0, h_in - 1), np.clip(xx, 0, w_in - 1)]
         return v * ok[..., None]
 
-    out = (tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy) +
-           tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy)
-    if np.issubdtype(img.dtype, np.integer):
-        out = np.clip(np.rint(out), np.iinfo(img.dtype).min, np.iinfo(img.dtype).max)
-    out = out.astype(img.dtype)
+    out = (tap(y0, x0) * gx) * gy
+    out = out + (tap(y0, x0 + 1) * fx) * gy
+    out = out + (tap(y0 + 1, x0) * gx) * fy
+    out = out + (tap(y0 + 1, x0 + 1) * fx) * fy
+    out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
     return out if img.ndim == 3 else out[..., 0]
 
 
+def warp_affine(img, trans, dsize):
+    """cv2.warpAffine(img, trans, dsize, flags=INTER_LINEAR), zero border (float bilinear; see
+    warp_bilinear_u8 for the exact arithmetic).  uint8 images only."""
+    assert img.dtype == np.uint8, "warp_affine restates the uint8 path the detectors use"
+    return warp_bilinear_u8(img, invert_affine(trans), dsize, replicate=False)
+
+
 def resize_bilinear(img, dsize):
-    """cv2.resize(img, (w, h)) with INTER_LINEAR (half-pixel centres)."""
+    """cv2.resize(img, (w, h)) with INTER_LINEAR (half-pixel centres, replicated border)."""
     w_out, h_out = int(dsize[0]), int(dsize[1])
     h_in, w_in = img.shape[:2]
     if (h_in, w_in) == (h_out, w_out):
         return img.copy()
-    sx, sy = w_in / float(w_out), h_in / float(h_out)
-    trans = np.array([[1.0 / sx, 0, 0.5 / sx - 0.5], [0, 1.0 / sy, 0.5 / sy - 0.5]])
-    # border handling: replicate (cv2.resize clamps), so pad by edge first
-    pad = np.pad(img, ((1, 1), (1, 1)) + ((0, 0),) * (img.ndim - 2), mode="edge")
-    t2 = trans.copy()
-    t2[0, 2] -= 1.0 / sx
-    t2[1, 2] -= 1.0 / sy
-    return warp_affine(pad, t2, (w_out, h_out))
+    assert img.dtype == np.uint8
+    return warp_bilinear_u8(img, resize_matrix((w_in, h_in), (w_out, h_out)), (w_out, h_out),
+                            replicate=True)
+
+
+def normalize_chw(inp_u8, mean, std):
+    """((inp / 255. - mean) / std).astype(float32) then HWC -> CHW (base_detector.py:56-58)."""
+    mean = np.asarray(mean, np.float32).reshape(1, 1, 3)
+    std = np.asarray(std, np.float32).reshape(1, 1, 3)
+    inp = ((inp_u8 / 255. - mean) / std).astype(np.float32)
+    return inp.transpose(2, 0, 1)
 
 
 def flip(img):

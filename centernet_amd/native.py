@@ -104,6 +104,12 @@ def _declare(lib):
     lib.cn_upsample2x_add_f32.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.cn_heads3x3_1x1_f32.restype = i
     lib.cn_heads3x3_1x1_f32.argtypes = [vp, i, i, i, i, i, vp, vp, i, i, ctypes.POINTER(HeadOut), vp]
+    lib.cn_warp_normalize_u8_f32.restype = i
+    lib.cn_warp_normalize_u8_f32.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_double), i, i,
+                                             ctypes.POINTER(ctypes.c_float),
+                                             ctypes.POINTER(ctypes.c_float), i, vp, vp]
+    lib.cn_resize_bilinear_u8.restype = i
+    lib.cn_resize_bilinear_u8.argtypes = [vp, i, i, i, i, i, vp, vp]
     lib.cn_soft_nms_f32.restype = i
     lib.cn_soft_nms_f32.argtypes = [vp, i, i, ctypes.c_float, ctypes.c_float, ctypes.c_float, i]
     lib.cn_nchw_to_nhwc_f32.restype = i

@@ -34,6 +34,8 @@ _FLAGS = [
     ("--nms", dict(action="store_true")), ("--K", dict(type=int, default=100)),
     ("--not_prefetch_test", dict(action="store_true")), ("--fix_res", dict(action="store_true")),
     ("--keep_res", dict(action="store_true")), ("--not_rand_crop", dict(action="store_true")),
+    # new (not in the reference): keep pre_process on the host instead of the device kernels
+    ("--host_pre_process", dict(action="store_true")),
     ("--shift", dict(type=float, default=0.1)), ("--scale", dict(type=float, default=0.4)),
     ("--rotate", dict(type=float, default=0)), ("--flip", dict(type=float, default=0.5)),
     ("--no_color_aug", dict(action="store_true")), ("--aug_rot", dict(type=float, default=0)),

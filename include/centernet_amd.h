@@ -247,6 +247,29 @@ int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin, int in_pit
                         const float *w1_packed, const float *bias1, int head_conv, int n_heads,
                         const cn_head_out *heads, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Pre-process on the device: BaseDetector.pre_process
+ * (src/lib/detectors/base_detector.py:37-65) = cv2.resize (scale != 1) +
+ * cv2.warpAffine(INTER_LINEAR, zero border) + (x/255 - mean)/std + HWC->CHW (+ flip concat).
+ *
+ * cn_warp_normalize_u8_f32: image (H, W, 3) uint8 on the device (row pitch in bytes),
+ *   dst_to_src_2x3 = six HOST doubles mapping output pixel (x, y) to the source position
+ *   (the inverse of trans_input), out = (1 + flip_concat, 3, out_h, out_w) fp32 NCHW with
+ *   out[1] = out[0] flipped along x (base_detector.py:59-60).  mean3 / std3: HOST floats.
+ * cn_resize_bilinear_u8: cv2.resize(image, (out_w, out_h)) with half-pixel centres and a
+ *   replicated border, uint8 HWC -> dense uint8 HWC.
+ * Arithmetic: float64 bilinear, round-half-even to uint8, float64 normalise rounded once to
+ * fp32 -- bit-identical to centernet_amd/image.py and oracle/pre_oracle.py.  OpenCV's
+ * fixed-point bilinear may differ by one uint8 level on non-identity warps (unpinned: OpenCV
+ * is not available to this build).
+ * ------------------------------------------------------------------------ */
+int cn_warp_normalize_u8_f32(const uint8_t *image_hwc, int H, int W, int pitch_bytes,
+                             const double *dst_to_src_2x3, int out_h, int out_w,
+                             const float *mean3, const float *std3, int flip_concat,
+                             float *out_nchw, void *stream);
+int cn_resize_bilinear_u8(const uint8_t *image_hwc, int H, int W, int pitch_bytes, int out_h,
+                          int out_w, uint8_t *out_hwc, void *stream);
+
 /* Soft-NMS on a HOST array, in place (rows of `stride` floats: x1,y1,x2,y2,score,...).
  * Replaces external.nms.soft_nms / soft_nms_39 (src/lib/external/nms.pyx:77-275), used by
  * merge_outputs when --nms or multi-scale testing is on (detectors/ctdet.py:63-64).
