@@ -423,7 +423,7 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
 //           output = gathered boxes (decode.py:472-493)
 //   !CTDET: group = (image, channel); output = (scores, inds)  (_topk_channel)
 // ---------------------------------------------------------------------------
-enum { MODE_CTDET = 0, MODE_CHANNEL = 1, MODE_POSE = 2 };
+enum { MODE_CTDET = 0, MODE_CHANNEL = 1, MODE_POSE = 2, MODE_TOPK = 3 };
 
 constexpr int NTM = 1024;  // the merge runs one workgroup per image: make it a big one
 
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(NTM) void merge_topk_kernel(
     int per_class, int H, int W, int K, int C, const float *__restrict__ wh,
     const float *__restrict__ reg, int cat_spec_wh, float *__restrict__ dets, int det_dim,
     int32_t *__restrict__ inds_out, float *__restrict__ out_scores,
-    const float *__restrict__ kps_map, int J)
+    const float *__restrict__ kps_map, int J, int32_t *__restrict__ cls_out)
 {
     constexpr bool CTDET = (MODE != MODE_CHANNEL);  // group = image, class from position
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -467,6 +467,12 @@ __global__ __launch_bounds__(NTM) void merge_topk_kernel(
             const int yi = ind / W, xi = ind - yi * W;
             float xs = (float)xi, ys = (float)yi;
             const int b = g;
+            if (MODE == MODE_TOPK) {  // _topk (decode.py:103-119): scores, inds, clses only
+                out_scores[(size_t)b * K + tid] = score;
+                inds_out[(size_t)b * K + tid] = ind;
+                cls_out[(size_t)b * K + tid] = cls;
+                return;
+            }
             if (reg) {  // decode.py:472-476
                 xs = xs + reg[((size_t)b * 2 + 0) * HW + ind];
                 ys = ys + reg[((size_t)b * 2 + 1) * HW + ind];
@@ -577,7 +583,8 @@ extern "C" int cn_ctdet_decode_f32(const float *heat, const float *wh, const flo
     if (rc != CN_OK) return rc;
     hipLaunchKernelGGL(merge_topk_kernel<MODE_CTDET>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg,
-                       cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr, 0);
+                       cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr, 0,
+                       (int32_t *)nullptr);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -606,7 +613,7 @@ extern "C" int cn_nms_topk_channel_f32(const float *heat, int B, int C, int H, i
     hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * C), dim3(NTM), sizeof(SelShared),
                        st, cand_score, cand_idx, bp.nbands * K, bp.nbands * K, H, W, K, C,
                        (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0, inds,
-                       scores, (const float *)nullptr, 0);
+                       scores, (const float *)nullptr, 0, (int32_t *)nullptr);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -736,7 +743,7 @@ extern "C" int cn_multi_pose_decode_f32(const float *heat, const float *wh, cons
     if (rc != CN_OK) return rc;
     hipLaunchKernelGGL(merge_topk_kernel<MODE_POSE>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_s, cand_i, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg, 0,
-                       dets, D, (int32_t *)nullptr, (float *)nullptr, kps, J);
+                       dets, D, (int32_t *)nullptr, (float *)nullptr, kps, J, (int32_t *)nullptr);
     CN_CHECK_LAUNCH();
     if (!hm_hp) return CN_OK;
     // stage B: per-joint top-K of the keypoint heat-map
@@ -749,12 +756,134 @@ extern "C" int cn_multi_pose_decode_f32(const float *heat, const float *wh, cons
         hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * J), dim3(NTM),
                            sizeof(SelShared), st, cand_s, cand_i, bph.nbands * K, bph.nbands * K, H,
                            W, K, J, (const float *)nullptr, (const float *)nullptr, 0,
-                           (float *)nullptr, 0, hp_i, hp_s, (const float *)nullptr, 0);
+                           (float *)nullptr, 0, hp_i, hp_s, (const float *)nullptr, 0,
+                           (int32_t *)nullptr);
         CN_CHECK_LAUNCH();
     }
     // stage C
     hipLaunchKernelGGL(pose_match_kernel, dim3(J, B), dim3(KMAX), 0, st, hp_s, hp_i, hp_offset,
                        dets, J, K, H, W, D);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// _topk / _transpose_and_gather_feat / ddd_decode (models/decode.py:103-119,
+// models/utils.py:12-26, models/decode.py:426-462)
+// ---------------------------------------------------------------------------
+namespace {
+
+// out[b,k,c] = feat[b,c,ind[b,k]]  (NCHW map -> (B,K,C); replaces permute+contiguous+gather)
+__global__ void gather_feat_kernel(const float *__restrict__ feat, const int32_t *__restrict__ inds,
+                                   float *__restrict__ out, int C, int HW, int K, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const size_t bk = i / C;
+    const size_t b = bk / K;
+    out[i] = feat[(b * C + c) * HW + inds[bk]];
+}
+
+// one thread per (b,k): [xs, ys, score, rot(8), depth, dim(3), (wh(2),) cls]  (decode.py:433-460)
+__global__ void ddd_assemble_kernel(const float *__restrict__ scores, const int32_t *__restrict__ inds,
+                                    const int32_t *__restrict__ clses, const float *__restrict__ rot,
+                                    const float *__restrict__ depth, const float *__restrict__ dim,
+                                    const float *__restrict__ wh, const float *__restrict__ reg,
+                                    float *__restrict__ dets, int B, int K, int H, int W)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K;
+    const int HW = H * W;
+    const int ind = inds[i];
+    const int yi = ind / W, xi = ind - yi * W;
+    float xs = (float)xi, ys = (float)yi;
+    if (reg) {
+        xs = xs + reg[((size_t)b * 2 + 0) * HW + ind];
+        ys = ys + reg[((size_t)b * 2 + 1) * HW + ind];
+    } else {
+        xs = xs + 0.5f;
+        ys = ys + 0.5f;
+    }
+    const int D = wh ? 18 : 16;
+    float *d = dets + (size_t)i * D;
+    d[0] = xs; d[1] = ys; d[2] = scores[i];
+    for (int c = 0; c < 8; ++c) d[3 + c] = rot[((size_t)b * 8 + c) * HW + ind];
+    d[11] = depth[(size_t)b * HW + ind];
+    for (int c = 0; c < 3; ++c) d[12 + c] = dim[((size_t)b * 3 + c) * HW + ind];
+    if (wh) {
+        d[15] = wh[((size_t)b * 2 + 0) * HW + ind];
+        d[16] = wh[((size_t)b * 2 + 1) * HW + ind];
+    }
+    d[D - 1] = (float)clses[i];
+}
+
+}  // namespace
+
+extern "C" int cn_topk_f32(const float *heat, int B, int C, int H, int W, int K, int apply_sigmoid,
+                           float *scores, int32_t *inds, int32_t *clses, void *workspace,
+                           size_t workspace_bytes, void *stream)
+{
+    BandPlan bp;
+    int rc = decode_checks(heat, B, C, H, W, K, &bp);
+    if (rc != CN_OK) return rc;
+    if (!scores || !inds || !clses || !workspace) return CN_ERR_NULL;
+    const size_t need = cn_ctdet_decode_workspace_bytes(B, C, H, W, K);
+    if (workspace_bytes < need) return CN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)B * C * bp.nbands * K;
+    float *cand_score = (float *)workspace;
+    int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
+    rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
+    if (rc != CN_OK) return rc;
+    hipLaunchKernelGGL(merge_topk_kernel<MODE_TOPK>, dim3(B), dim3(NTM), sizeof(SelShared), st,
+                       cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C,
+                       (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0, inds,
+                       scores, (const float *)nullptr, 0, clses);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_gather_feat_f32(const float *feat, const int32_t *inds, float *out, int B, int C,
+                                  int H, int W, int K, void *stream)
+{
+    if (!feat || !inds || !out) return CN_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return CN_ERR_SHAPE;
+    const size_t total = (size_t)B * K * C;
+    hipLaunchKernelGGL(gather_feat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, inds, out, C, H * W, K, total);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" size_t cn_ddd_decode_workspace_bytes(int B, int C, int H, int W, int K)
+{
+    const size_t base = cn_ctdet_decode_workspace_bytes(B, C, H, W, K);
+    if (!base) return 0;
+    return base + 3 * cn_align_up((size_t)B * K * 4, 256);
+}
+
+extern "C" int cn_ddd_decode_f32(const float *heat, const float *rot, const float *depth,
+                                 const float *dim, const float *wh, const float *reg, int B, int C,
+                                 int H, int W, int K, int apply_sigmoid, float *dets,
+                                 void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!rot || !depth || !dim || !dets || !workspace) return CN_ERR_NULL;
+    const size_t base = cn_ctdet_decode_workspace_bytes(B, C, H, W, K);
+    if (!base) return CN_ERR_UNSUPPORTED;
+    if (workspace_bytes < cn_ddd_decode_workspace_bytes(B, C, H, W, K)) return CN_ERR_WORKSPACE;
+    const size_t slot = cn_align_up((size_t)B * K * 4, 256);
+    float *scores = (float *)((char *)workspace + base);
+    int32_t *inds = (int32_t *)((char *)workspace + base + slot);
+    int32_t *clses = (int32_t *)((char *)workspace + base + 2 * slot);
+    int rc = cn_topk_f32(heat, B, C, H, W, K, apply_sigmoid, scores, inds, clses, workspace, base,
+                         stream);
+    if (rc != CN_OK) return rc;
+    hipLaunchKernelGGL(ddd_assemble_kernel, dim3(cn_cdiv(B * K, 128)), dim3(128), 0,
+                       (hipStream_t)stream, scores, inds, clses, rot, depth, dim, wh, reg, dets, B, K,
+                       H, W);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -97,3 +97,57 @@ def multi_pose_decode(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100
                                       native.ptr(ws), ws.numel(), native.stream_ptr())
     native.check(rc, "cn_multi_pose_decode_f32")
     return dets
+
+
+def _topk(scores, K=40, apply_sigmoid=False, nms=False):
+    """decode.py:103-119 with the 3x3 peak test fused in front (``nms=True``: the only way
+    the reference calls it): (scores, inds, clses, ys, xs), each (B, K)."""
+    (scores,) = _prep(scores)
+    lib = native.lib()
+    B, C, H, W = scores.shape
+    if K > H * W:
+        raise RuntimeError("selected index k out of range")
+    if not nms:
+        raise native.NativeError("the HIP kernel fuses _nms with _topk; call with nms=True")
+    s = torch.empty((B, K), device=scores.device, dtype=torch.float32)
+    i = torch.empty((B, K), device=scores.device, dtype=torch.int32)
+    c = torch.empty((B, K), device=scores.device, dtype=torch.int32)
+    ws = _workspace(lib.cn_ctdet_decode_workspace_bytes(B, C, H, W, K), scores.device)
+    rc = lib.cn_topk_f32(native.ptr(scores), B, C, H, W, K, int(bool(apply_sigmoid)), native.ptr(s),
+                         native.ptr(i), native.ptr(c), native.ptr(ws), ws.numel(),
+                         native.stream_ptr())
+    native.check(rc, "cn_topk_f32")
+    i = i.long()
+    return s, i, c.int(), (i // W).float(), (i % W).float()
+
+
+def _transpose_and_gather_feat(feat, ind):
+    """models/utils.py:21-26: (B,C,H,W), (B,K) -> (B,K,C), without the full-tensor transpose."""
+    (feat,) = _prep(feat)
+    lib = native.lib()
+    B, C, H, W = feat.shape
+    K = ind.shape[1]
+    ind32 = ind.to(torch.int32).contiguous()
+    out = torch.empty((B, K, C), device=feat.device, dtype=torch.float32)
+    rc = lib.cn_gather_feat_f32(native.ptr(feat), native.ptr(ind32), native.ptr(out), B, C, H, W, K,
+                                native.stream_ptr())
+    native.check(rc, "cn_gather_feat_f32")
+    return out
+
+
+def ddd_decode(heat, rot, depth, dim, wh=None, reg=None, K=40, apply_sigmoid=False):
+    """decode.py:426-462 -> (B, K, 16) or (B, K, 18) with wh."""
+    heat, rot, depth, dim, wh, reg = _prep(heat, rot, depth, dim, wh, reg)
+    lib = native.lib()
+    B, C, H, W = heat.shape
+    if K > H * W:
+        raise RuntimeError("selected index k out of range")
+    assert rot.shape[1] == 8 and depth.shape[1] == 1 and dim.shape[1] == 3
+    dets = torch.empty((B, K, 18 if wh is not None else 16), device=heat.device, dtype=torch.float32)
+    ws = _workspace(lib.cn_ddd_decode_workspace_bytes(B, C, H, W, K), heat.device)
+    rc = lib.cn_ddd_decode_f32(native.ptr(heat), native.ptr(rot), native.ptr(depth), native.ptr(dim),
+                               native.ptr(wh), native.ptr(reg), B, C, H, W, K,
+                               int(bool(apply_sigmoid)), native.ptr(dets), native.ptr(ws),
+                               ws.numel(), native.stream_ptr())
+    native.check(rc, "cn_ddd_decode_f32")
+    return dets

@@ -122,6 +122,14 @@ def _declare(lib):
     lib.cn_ctdet_decode_f32.argtypes = [vp, vp, vp] + [i] * 7 + [vp, vp, vp, sz, vp]
     lib.cn_nms_topk_channel_f32.restype = i
     lib.cn_nms_topk_channel_f32.argtypes = [vp] + [i] * 6 + [vp, vp, vp, sz, vp]
+    lib.cn_topk_f32.restype = i
+    lib.cn_topk_f32.argtypes = [vp] + [i] * 6 + [vp, vp, vp, vp, sz, vp]
+    lib.cn_gather_feat_f32.restype = i
+    lib.cn_gather_feat_f32.argtypes = [vp, vp, vp] + [i] * 5 + [vp]
+    lib.cn_ddd_decode_workspace_bytes.restype = sz
+    lib.cn_ddd_decode_workspace_bytes.argtypes = [i] * 5
+    lib.cn_ddd_decode_f32.restype = i
+    lib.cn_ddd_decode_f32.argtypes = [vp] * 6 + [i] * 6 + [vp, vp, sz, vp]
     lib.cn_multi_pose_decode_workspace_bytes.restype = sz
     lib.cn_multi_pose_decode_workspace_bytes.argtypes = [i] * 6
     lib.cn_multi_pose_decode_f32.restype = i

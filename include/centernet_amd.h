@@ -313,6 +313,28 @@ int cn_nms_topk_channel_f32(const float *heat, int B, int C, int H, int W, int K
                             int apply_sigmoid, float *scores, int32_t *inds,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* _nms + _topk (models/decode.py:9-15, 103-119): global top-K over all classes of an image.
+ * scores (B,K) desc, inds (B,K) = y*W+x, clses (B,K); ys = inds / W, xs = inds % W.
+ * Workspace: cn_ctdet_decode_workspace_bytes. */
+int cn_topk_f32(const float *heat, int B, int C, int H, int W, int K, int apply_sigmoid,
+                float *scores, int32_t *inds, int32_t *clses, void *workspace,
+                size_t workspace_bytes, void *stream);
+
+/* _transpose_and_gather_feat (models/utils.py:12-26): out[b,k,c] = feat[b,c,inds[b,k]] for an
+ * NCHW map, without the reference's full-tensor permute().contiguous(). */
+int cn_gather_feat_f32(const float *feat, const int32_t *inds, float *out, int B, int C, int H,
+                       int W, int K, void *stream);
+
+/* ddd_decode(heat, rot, depth, dim, wh=None, reg=None, K=40) (models/decode.py:426-462):
+ * dets (B,K,16) = [xs, ys, score, rot x8, depth, dim x3, cls], or (B,K,18) with wh x2 before
+ * cls when wh != NULL.  heat is post-sigmoid unless apply_sigmoid; depth is passed as the
+ * caller prepared it (the detector applies 1/(sigmoid(dep)+1e-6)-1 first, detectors/ddd.py:55). */
+size_t cn_ddd_decode_workspace_bytes(int B, int C, int H, int W, int K);
+int cn_ddd_decode_f32(const float *heat, const float *rot, const float *depth, const float *dim,
+                      const float *wh, const float *reg, int B, int C, int H, int W, int K,
+                      int apply_sigmoid, float *dets, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
 /* ------------------------------------------------------------------------
  * multi_pose decode.
  * Replaces: multi_pose_decode(heat, wh, kps, reg, hm_hp, hp_offset, K)

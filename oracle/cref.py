@@ -175,3 +175,34 @@ def multi_pose_decode(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100
     if rc != 0:
         raise RuntimeError("selected index k out of range")
     return dets
+
+
+def transpose_and_gather_feat(feat, ind):
+    """models/utils.py:21-26: (B,C,H,W), (B,K) int64 -> (B,K,C)."""
+    feat = np.ascontiguousarray(feat, np.float32)
+    B, C, H, W = feat.shape
+    flat = feat.reshape(B, C, H * W)
+    out = np.empty((B, ind.shape[1], C), np.float32)
+    for b in range(B):
+        out[b] = flat[b][:, ind[b]].T
+    return out
+
+
+def ddd_decode(heat, rot, depth, dim, wh=None, reg=None, K=40):
+    """models/decode.py:426-462 (heat is post-sigmoid): _nms, _topk, centre + reg (or + 0.5),
+    gather rot / depth / dim (/ wh), concatenate [xs, ys, score, rot, depth, dim, (wh,) cls]."""
+    s, i, c, y, x = topk(nms(heat), K)
+    B = heat.shape[0]
+    if reg is not None:
+        r = transpose_and_gather_feat(reg, i)
+        xs = x.reshape(B, K, 1) + r[:, :, 0:1]
+        ys = y.reshape(B, K, 1) + r[:, :, 1:2]
+    else:
+        xs = x.reshape(B, K, 1) + np.float32(0.5)
+        ys = y.reshape(B, K, 1) + np.float32(0.5)
+    parts = [xs, ys, s.reshape(B, K, 1), transpose_and_gather_feat(rot, i),
+             transpose_and_gather_feat(depth, i), transpose_and_gather_feat(dim, i)]
+    if wh is not None:
+        parts.append(transpose_and_gather_feat(wh, i))
+    parts.append(c.reshape(B, K, 1).astype(np.float32))
+    return np.concatenate(parts, axis=2).astype(np.float32)
