@@ -62,7 +62,7 @@ class BaseDetector(object):
                 'out_width': inp_width // self.opt.down_ratio}
         return images, meta
 
-    def pre_process_device(self, image, scale, meta=None):
+    def pre_process_device(self, image, scale, meta=None, out=None):
         """pre_process with the resize / warp / normalise / CHW (/ flip) steps on the device
         (cn_resize_bilinear_u8 + cn_warp_normalize_u8_f32): the uint8 frame is uploaded and the
         fp32 (1|2,3,H,W) batch is produced in HBM.  Same arithmetic as ``pre_process``
@@ -85,9 +85,15 @@ class BaseDetector(object):
             s = np.array([inp_width, inp_height], dtype=np.float32)
         trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
         dev = self.opt.device
-        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
-            raise ValueError("pre_process_device needs an (H, W, 3) uint8 BGR image")
-        src = torch.from_numpy(np.ascontiguousarray(image)).to(dev)
+        if torch.is_tensor(image):   # already uploaded (run_frames: one H2D copy per batch)
+            if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3 or \
+                    not image.is_cuda or not image.is_contiguous():
+                raise ValueError("pre_process_device needs a contiguous (H, W, 3) uint8 HIP tensor")
+            src = image
+        else:
+            if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+                raise ValueError("pre_process_device needs an (H, W, 3) uint8 BGR image")
+            src = torch.from_numpy(np.ascontiguousarray(image)).to(dev)
         st = native.stream_ptr()
         if (new_height, new_width) != (height, width):
             resized = torch.empty((new_height, new_width, 3), device=dev, dtype=torch.uint8)
@@ -96,7 +102,11 @@ class BaseDetector(object):
                          "cn_resize_bilinear_u8")
             src = resized
         nb = 2 if self.opt.flip_test else 1
-        images = torch.empty((nb, 3, inp_height, inp_width), device=dev, dtype=torch.float32)
+        if out is not None:   # caller-provided slice of a batch tensor (run_frames)
+            assert tuple(out.shape) == (nb, 3, inp_height, inp_width) and out.is_contiguous()
+            images = out
+        else:
+            images = torch.empty((nb, 3, inp_height, inp_width), device=dev, dtype=torch.float32)
         mi = (ctypes.c_double * 6)(*invert_affine(trans_input).reshape(-1))
         mean = (ctypes.c_float * 3)(*[float(v) for v in self.mean.reshape(-1)])
         std = (ctypes.c_float * 3)(*[float(v) for v in self.std.reshape(-1)])

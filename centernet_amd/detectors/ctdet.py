@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from ..decode import ctdet_decode
-from ..post_process import ctdet_post_process
+from ..post_process import ctdet_post_process, ctdet_results_batch
 from ..utils import flip_tensor
 from .base_detector import BaseDetector
 
@@ -72,3 +72,27 @@ class CtdetDetector(BaseDetector):
             return ctdet_decode(output['hm'], output['wh'],
                                 reg=output['reg'] if self.opt.reg_offset else None,
                                 cat_spec_wh=self.opt.cat_spec_wh, K=self.opt.K, apply_sigmoid=True)
+
+    def run_frames(self, frames):
+        """NEW surface (the reference's test loop is batch_size=1, test.py:60-62): a list of
+        (H, W, 3) uint8 BGR frames of one size -> list of per-image result dicts, exactly what
+        ``run(frame)['results']`` returns for each (single scale, no flip).  The frames are
+        uploaded as uint8, pre-processed on the device straight into one batch tensor, and the
+        whole batch goes through the network + decode once."""
+        assert len(self.scales) == 1 and not self.opt.flip_test, "run_frames is single-scale, no flip"
+        scale = self.scales[0]
+        batch, metas = None, []
+        if len({tuple(f.shape) for f in frames}) != 1:
+            raise ValueError("run_frames needs frames of one size")
+        stacked = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).to(self.opt.device)
+        for i, f in enumerate(stacked):
+            if batch is None:
+                probe, meta = self.pre_process_device(f, scale)
+                batch = torch.empty((len(frames),) + tuple(probe.shape[1:]), device=probe.device,
+                                    dtype=torch.float32)
+                batch[0:1].copy_(probe)
+            else:
+                _, meta = self.pre_process_device(f, scale, out=batch[i:i + 1])
+            metas.append(meta)
+        dets = self.run_batch(batch).detach().cpu().numpy()
+        return ctdet_results_batch(dets, metas, self.opt.num_classes, scale, self.max_per_image)

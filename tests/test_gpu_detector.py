@@ -117,3 +117,25 @@ def test_multi_pose_detector_matches_oracle(dev):
     # choices, so allow a few to differ where the reject rule sits on its threshold
     kd = np.abs(got[safe, 5:] - ref[safe, 5:])
     assert (kd < 5e-3).mean() > 0.97
+
+
+def test_run_frames_equals_run(dev):
+    """run_frames (batched, device pre-process) == run() per frame (same kernels per image up to
+    the batch-size dependent split-K summation order)."""
+    import contextlib, sys
+    from centernet_amd.opts import opts
+    from centernet_amd.detectors.detector_factory import detector_factory
+    with contextlib.redirect_stdout(sys.stderr):
+        opt = opts().init(["ctdet", "--arch", "resdcn_18", "--input_h", "128", "--input_w", "128"])
+        det = detector_factory[opt.task](opt)
+    synth.fill_state_dict_(det.model, 317)
+    det.model.invalidate_plans()
+    rng = np.random.RandomState(5)
+    frames = [rng.randint(0, 256, (100, 140, 3)).astype(np.uint8) for _ in range(3)]
+    batched = det.run_frames(frames)
+    for f, rb in zip(frames, batched):
+        rs = det.run(f)['results']
+        for j in range(1, 81):
+            assert rb[j].shape == rs[j].shape
+            if len(rb[j]):
+                assert np.abs(rb[j] - rs[j]).max() < 2e-3

@@ -114,3 +114,25 @@ def test_soft_nms_known_answer():
     g = b.copy()
     assert soft_nms(g, Nt=0.5, method=2) == [0, 1, 2]
     assert abs(g[np.argmin(np.abs(g[:, 4] - 0.8 * np.exp(-2.0))), 4] - 0.8 * np.exp(-2.0)) < 1e-6
+
+
+def test_ctdet_results_batch_equals_per_image_loop():
+    """Vectorised batch tail == post_process + merge_outputs per image (bit-identical rows)."""
+    from centernet_amd.post_process import ctdet_results_batch
+    from oracle import post_oracle
+    rng = np.random.RandomState(3)
+    for K, max_per in ((100, 100), (120, 100)):
+        B = 3
+        dets = np.zeros((B, K, 6), np.float32)
+        dets[:, :, :4] = rng.uniform(0, 128, (B, K, 4))
+        dets[:, :, 4] = np.sort(rng.uniform(0, 1, (B, K)), axis=1)[:, ::-1]
+        dets[:, :, 5] = rng.randint(0, 80, (B, K))
+        metas = [{'c': np.array([250., 187.5], np.float32), 's': 500.0, 'out_height': 128,
+                  'out_width': 128} for _ in range(B)]
+        got = ctdet_results_batch(dets.copy(), metas, 80, scale=1, max_per_image=max_per)
+        for i in range(B):
+            ref = post_oracle.ctdet_results(dets[i:i + 1].copy(), metas[i], 80, scale=1,
+                                            max_per_image=max_per)
+            for j in range(1, 81):
+                assert got[i][j].dtype == np.float32 and got[i][j].shape == ref[j].shape
+                assert np.array_equal(got[i][j], ref[j])
