@@ -19,7 +19,6 @@
 
 namespace {
 
-constexpr int NT = 256;
 constexpr int LDT = 36;  // floats per LDS row (32 + 4 pad = 144 bytes, conflict-free b128 reads)
 
 typedef _Float16 c3_f16x8 __attribute__((ext_vector_type(8)));
@@ -47,7 +46,7 @@ struct C3Args {
     const void *residual;        // element type T
     void *y;                     // element type T
     int B, H, W, Cin, Cout, in_pitch, out_pitch, relu;
-    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio;
+    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio, bm256, waves8;
 };
 
 // Fused detection heads (HEADS = true): blockIdx.y selects the head; its 64 hidden channels
@@ -64,40 +63,44 @@ struct C3Heads {
 };
 
 // LDS floats of the kernel: the main loop's tiles, unioned with the epilogue staging
-template <int TW, int BN, int WM, bool HEADS>
+template <int TW, int BN, int WM, bool HEADS, int BM>
 constexpr size_t c3_union_floats()
 {
-    constexpr int TH = 128 / TW;
+    constexpr int TH = BM / TW;
     constexpr size_t tiles = (size_t)((TH + 2) * (TW + 2) * LDT + 2 * BN * LDT);
     // fused heads: S[128][LDS2] shares the main loop's tile space; the 1x1 weights sit behind it
-    constexpr size_t cs = HEADS ? (size_t)128 * LDS2 : (size_t)(128 / WM) * (BN + 4);
+    constexpr size_t cs = HEADS ? (size_t)128 * LDS2 : (size_t)(BM / WM) * (BN + 4);
     return (tiles > cs ? tiles : cs) + (HEADS ? (size_t)W2_ROWS * LDS2 : 0);
 }
 
 // T = float: v_mfma_f32_32x32x2_f32, 32 channels per chunk; T = fp16: v_mfma_f32_32x32x16_f16
 // (fp32 accumulate), 64 channels per chunk -- same 128-byte LDS rows and read addresses.
-template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false>
-__global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
+template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128>
+__global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
 {
+    constexpr int NT = WM * WN * 64;  // 4 waves (256 threads) or 8 waves (512 threads)
+    constexpr int RPP = NT / 8;       // LDS rows staged per pass of the block
+    static_assert(!HEADS || NT == 256, "fused heads are built for 4 waves");
+    static_assert(!HEADS || BM == 128, "fused heads are built for 128-pixel tiles");
     static_assert(!HEADS || (BN == HEAD_CONV && sizeof(T) == 4), "fused heads: fp32, 64 hidden channels");
     constexpr int EPV = C3Elem<T>::EPV;
     constexpr int BKE = 8 * EPV;
     constexpr bool F16 = (EPV == 8);
     const T *xT = reinterpret_cast<const T *>(a.x);
     const T *wT = reinterpret_cast<const T *>(a.w);
-    constexpr int BM = 128;
     constexpr int TH = BM / TW;
     constexpr int HW_ = TW + 2;              // halo width
     constexpr int HR = (TH + 2) * HW_;       // halo rows (pixels)
-    constexpr int NPA = (HR + 31) / 32;      // halo load passes per thread
-    constexpr int PB = BN / 32;
+    constexpr int NPA = (HR + RPP - 1) / RPP;  // halo load passes per thread
+    constexpr int PB = BN / RPP;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MB = TM / 32, NB = TN / 32;
-    static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "wave tiling");
+    static_assert((NT == 256 || NT == 512) && BN % RPP == 0 && TM % 32 == 0 && TN % 32 == 0,
+                  "wave tiling");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int A_FLOATS = HR * LDT;
-    constexpr int UNION = (int)c3_union_floats<TW, BN, WM, HEADS>();
+    constexpr int UNION = (int)c3_union_floats<TW, BN, WM, HEADS, BM>();
     float *As = reinterpret_cast<float *>(smem);  // [HR][LDT]
     float *Bs = As + A_FLOATS;                    // [2][BN][LDT]
     int *rowoff = reinterpret_cast<int *>(As + UNION);  // [BM]
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a, const C3H
     int hoff[NPA];
 #pragma unroll
     for (int p = 0; p < NPA; ++p) {
-        const int hr = p * 32 + lrow;
+        const int hr = p * RPP + lrow;
         const int hy = hr / HW_, hx = hr - hy * HW_;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
         hoff[p] = (hr < HR && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
@@ -151,14 +154,14 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a, const C3H
     auto store_A = [&]() {
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {
-            const int hr = p * 32 + lrow;
+            const int hr = p * RPP + lrow;
             if (hr < HR) *reinterpret_cast<cn_f32x4 *>(As + hr * LDT + 4 * q) = ra[p];
         }
     };
     auto load_B = [&](int chunk, int tap) {
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int n = min(n0 + p * 32 + lrow, a.cout_pad - 1);
+            const int n = min(n0 + p * RPP + lrow, a.cout_pad - 1);
             rb[p] = *reinterpret_cast<const cn_f32x4 *>(
                 wT + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + chunk * BKE + EPV * q));
         }
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a, const C3H
         float *Bd = Bs + buf * BN * LDT;
 #pragma unroll
         for (int p = 0; p < PB; ++p)
-            *reinterpret_cast<cn_f32x4 *>(Bd + (p * 32 + lrow) * LDT + 4 * q) = rb[p];
+            *reinterpret_cast<cn_f32x4 *>(Bd + (p * RPP + lrow) * LDT + 4 * q) = rb[p];
     };
 
     // A-fragment base of this lane's pixel in every M block (halo row of tap (0,0))
@@ -417,18 +420,19 @@ __global__ __launch_bounds__(NT) void conv3x3s1_kernel(const C3Args a, const C3H
     }
 }
 
-template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false>
+template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128>
 int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 {
-    constexpr int TH = 128 / TW;
-    constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS>() * 4 + 128 * 4;
-    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS>), lds);
+    constexpr int TH = BM / TW;
+    constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS, BM>() * 4 + BM * 4;
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
     dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, BN));
     const C3Heads none = {};
-    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS>), grid, dim3(NT), lds, st, b,
+    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM>), grid, dim3(WM * WN * 64), lds,
+                       st, b,
                        hd ? *hd : none);
     CN_CHECK_LAUNCH();
     return CN_OK;
@@ -440,10 +444,23 @@ template <typename T>
 static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
 {
     const bool wide = a.W >= 32;  // 4 x 32 tiles keep an MFMA block on one halo row
-    if (bn_class == 2)
+    if (bn_class == 2) {
+        // 8 waves per 128 x 128 tile (wave tile 32 x 64): 4 waves/SIMD at 2 workgroups per CU
+        // hide the barrier / LDS latency better than 4-wave workgroups: +1 % on resdcn_18 and
+        // dla_34 (tools/bench_knob.py 15).  The same change on 64-wide tiles measured no gain.
+        if (a.waves8 & 1)
+            return wide ? launch_c3<T, 32, 128, 4, 2>(a, st) : launch_c3<T, 16, 128, 4, 2>(a, st);
         return wide ? launch_c3<T, 32, 128, 2, 2>(a, st) : launch_c3<T, 16, 128, 2, 2>(a, st);
-    if (bn_class == 1)
+    }
+    if (bn_class == 1) {
+        // 64-wide N tiles: 256-pixel (8 x 32) tiles double the MFMA work per weight tile and
+        // per barrier.  Measured on MI355X (tools/bench_knob.py 14): no gain (resdcn_18 8.21 vs
+        // 8.23 ms, dla_34 24.36 vs 24.39 ms per 32 images), so opt-in only (cn_set_tuning 14).
+        const long wgs256 = (long)a.B * cn_cdiv(a.H, 8) * cn_cdiv(a.W, 32) * cn_cdiv(a.Cout, 64);
+        if (wide && a.H >= 8 && a.bm256 && wgs256 >= 1024)
+            return launch_c3<T, 32, 64, 4, 1, false, 256>(a, st);
         return wide ? launch_c3<T, 32, 64, 2, 2>(a, st) : launch_c3<T, 16, 64, 2, 2>(a, st);
+    }
     return wide ? launch_c3<T, 32, 32, 4, 1>(a, st) : launch_c3<T, 16, 32, 4, 1>(a, st);
 }
 
@@ -455,6 +472,9 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
                  int f16, hipStream_t st)
 {
     C3Args a = {};
+    a.bm256 = (setprio >> 1) & 1;  // bit 1 of the knob word: cn_set_tuning key 14
+    a.waves8 = (setprio >> 2) & 1; // bit 2: cn_set_tuning key 15
+    setprio &= 1;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_pitch = in_pitch;
     a.out_pitch = out_pitch; a.relu = relu; a.vec_out = vec_out; a.setprio = setprio;

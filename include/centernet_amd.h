@@ -68,6 +68,10 @@ const char *cn_arch(void);
  * key 11: 1 = LDS-window deformable kernel (cn_dcn.hip) instead of the default global-gather
  *         form (cn_conv.hip); kept for A/B: it measured 20-30 % slower.
  * key 7: 1 = enable the XCD-aware tile order of the implicit-GEMM kernels (off: no gain).
+ * key 15: 0 = 4-wave instead of 8-wave workgroups for the 128-wide tiles of the LDS-halo kernel
+ *         (default 1: +1 %, measured).
+ * key 14: 1 = 256-pixel tiles for 64-wide layers in the LDS-halo kernel (default 0: measured,
+ *         no gain).
  * key 13: tap split of the deformable kernel, 0 = auto, 1 = never, 3 or 9 = force.
  * key 12: 0 = one-tile-per-workgroup stem kernel instead of the persistent, prefetching one
  *         (default 1; both in cn_stem.hip). */

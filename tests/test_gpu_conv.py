@@ -50,8 +50,38 @@ def _bn(C, seed):
     (2, 512, 8, 8, 27, 3, 1, 1, True, False, False, False),
     (1, 384, 4, 4, 384, 3, 1, 1, False, True, True, False),
     (2, 256, 16, 16, 128, 3, 2, 1, False, True, True, False),
+    (5, 48, 100, 132, 64, 3, 1, 1, True, False, True, False),
 ])
 def test_conv_bn_relu_residual(dev, cfg):
+    _conv_case(dev, cfg)
+
+
+def test_conv_256_pixel_tiles(dev):
+    """Opt-in 8 x 32 tiles of the LDS-halo kernel (cn_set_tuning key 14)."""
+    from centernet_amd import native
+    lib = native.lib()
+    lib.cn_set_tuning(14, 1)
+    try:
+        _conv_case(dev, (16, 64, 128, 128, 64, 3, 1, 1, False, True, True, True))
+        _conv_case(dev, (17, 48, 100, 132, 64, 3, 1, 1, True, False, True, False))
+    finally:
+        lib.cn_set_tuning(14, 0)
+
+
+def test_conv_8_wave_tiles(dev):
+    """Both workgroup shapes of the 128-wide LDS-halo tiles (key 15: 8 waves default, 4 waves)."""
+    from centernet_amd import native
+    lib = native.lib()
+    try:
+        for v in (1, 0):
+            lib.cn_set_tuning(15, v)
+            _conv_case(dev, (2, 256, 32, 32, 256, 3, 1, 1, False, True, True, True))
+            _conv_case(dev, (3, 160, 19, 27, 130, 3, 1, 1, True, False, True, False))
+    finally:
+        lib.cn_set_tuning(15, 1)
+
+
+def _conv_case(dev, cfg):
     from centernet_amd.engine import PlanBuilder
     B, Cin, H, W, Cout, k, s, p, use_bias, use_bn, relu, use_res = cfg
     x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1))
