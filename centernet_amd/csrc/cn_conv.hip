@@ -131,11 +131,10 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // Optional XCD-aware tile order (cn_set_tuning key 7): workgroup b runs on XCD b % 8 and
-    // every XCD has its own 4 MB L2, so each XCD can be given a CONTIGUOUS range of pixel
-    // tiles.  Measured on MI355X (tools/bench_knob.py 7 1 0): 9.23 vs 9.20 ms per resdcn_18
-    // forward, 27.07 vs 26.81 ms for dla_34 -- no gain (the kernels are MFMA-bound and the
-    // Infinity Cache absorbs the re-reads), so it is off by default.
+    // XCD-aware tile order (cn_set_tuning key 7): workgroup b runs on XCD b % 8 and every XCD
+    // has its own 4 MB L2, so each XCD is given a CONTIGUOUS range of pixel tiles.  Pays for
+    // the deformable gather (+5-10 %); the dense kernels are MFMA-bound and the Infinity Cache
+    // absorbs their re-reads (no gain measured), so there it stays off.
     int bx = blockIdx.x;
     if (a.xcd_swizzle) {
         const int q8 = gridDim.x >> 3;
@@ -574,7 +573,7 @@ constexpr size_t igemm_lds_bytes()
 
 int g_tune_setprio = 1; // cn_set_tuning key 8: s_setprio(1) around the MFMA clusters (+0.9 % measured)
 int g_tune_dbgskip = 0; // cn_set_tuning key 9 (ablation only): bit0 skip A staging, bit1 skip B staging
-int g_tune_swz = 0;   // cn_set_tuning key 7: 1 = XCD-aware tile order (measured: no gain, off)
+int g_tune_swz = 0;   // cn_set_tuning key 7: XCD-aware tile order, 0 = deformable kernel only (default), 1 = all, 2 = none
 int g_tune_nbuf = 0;  // 0 = per-shape default, 1 / 2 = force (cn_set_tuning key 1)
 int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-wide tiles
 int g_tune_dcn_tile = 0; // cn_set_tuning key 3: 0 = default, 64 / 128 = force the DCN pixel tile
@@ -595,7 +594,11 @@ int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
     CN_SET_MAX_LDS_ONCE((igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), lds);
     dim3 grid(cn_cdiv(a.M, BM), cn_cdiv(a.Cout, BN), a.zparity ? 4 : (a.ksplit > 1 ? a.ksplit : 1));
     IgemmArgs b = a;
-    b.xcd_swizzle = (g_tune_swz && grid.x >= 16) ? 1 : 0;
+    // XCD-aware tile order: on for the deformable kernel (its gather re-reads every input line
+    // ~36x; with round-robin tile -> XCD placement only 31 % of those hit the 4 MB L2, measured
+    // TCC_HIT/TCC_MISS; contiguous tile ranges per XCD: +5-10 %, tools/bench_dcn.py SWZ=1);
+    // cn_set_tuning key 7: 0 = default, 1 = also the dense kernels, 2 = nowhere
+    b.xcd_swizzle = (grid.x >= 16 && g_tune_swz != 2 && (AMODE == A_DCN || g_tune_swz == 1)) ? 1 : 0;
     b.setprio = g_tune_setprio;
     b.dbgskip = g_tune_dbgskip;
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), grid, dim3(NT),
@@ -1171,7 +1174,7 @@ extern "C" int cn_set_tuning(int key, int value)
         g_tune_dcn_window = value;
         return CN_OK;
     }
-    if (key == 7 && (value == 0 || value == 1)) {
+    if (key == 7 && (value == 0 || value == 1 || value == 2)) {
         g_tune_swz = value;
         return CN_OK;
     }

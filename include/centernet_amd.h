@@ -67,7 +67,8 @@ const char *cn_arch(void);
  *         kernel (cn_conv3x3.hip).
  * key 11: 1 = LDS-window deformable kernel (cn_dcn.hip) instead of the default global-gather
  *         form (cn_conv.hip); kept for A/B: it measured 20-30 % slower.
- * key 7: 1 = enable the XCD-aware tile order of the implicit-GEMM kernels (off: no gain).
+ * key 7: XCD-aware tile order: 0 = deformable kernel only (default, +5-10 % there), 1 = also
+ *        the dense implicit-GEMM kernels (no gain measured), 2 = nowhere.
  * key 15: 0 = 4-wave instead of 8-wave workgroups for the 128-wide tiles of the LDS-halo kernel
  *         (default 1: +1 %, measured).
  * key 14: 1 = 256-pixel tiles for 64-wide layers in the LDS-halo kernel (default 0: measured,
