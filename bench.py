@@ -140,13 +140,24 @@ def main():
     torch.cuda.synchronize()
 
     plan = det.model.plan_for(B, a.res, a.res, dev)
+    # HIP events on the launch stream, inside the timed region.  A marker after every launch
+    # costs ~7 us of bubble each (35 per step), so by default events sit only where the kernel
+    # class changes (the per-class sums stay exact); --per-op records one after every launch.
+    metas = plan.b.meta
+    nops = len(metas)
+    if a.per_op:
+        bounds = list(range(nops))
+    else:
+        bounds = [i for i in range(nops) if i == nops - 1 or metas[i]["kind"] != metas[i + 1]["kind"]]
+    bset = set(bounds)
+    seg_first = [0] + [b + 1 for b in bounds[:-1]]   # first op of every segment
     ev_all = []
     e_dec0, e_dec1 = [], []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         evs = []
         with torch.no_grad():
-            out = plan.run(images, events=evs)
+            out = plan.run(images, events=evs, event_after=bset)
             e0 = torch.cuda.Event(enable_timing=True); e0.record()
             from centernet_amd.decode import ctdet_decode
             dets = ctdet_decode(out["hm"], out["wh"], reg=out["reg"], K=opt.K, apply_sigmoid=True)
@@ -166,10 +177,12 @@ def main():
         # ---- per-kernel-class time from the HIP events recorded inside the timed region
         kinds = {}
         for evs in ev_all:
-            for i, m in enumerate(plan.b.meta):
-                ms = evs[i].elapsed_time(evs[i + 1])
-                k = kinds.setdefault(m["kind"], {"ms": 0.0, "flops": 0, "bytes": 0, "launches": 0})
-                k["ms"] += ms; k["flops"] += m["flops"]; k["bytes"] += m["bytes"]; k["launches"] += 1
+            for si, (first, last) in enumerate(zip(seg_first, bounds)):
+                ms = evs[si].elapsed_time(evs[si + 1])
+                k = kinds.setdefault(metas[first]["kind"], {"ms": 0.0, "flops": 0, "bytes": 0, "launches": 0})
+                k["ms"] += ms
+                for m in metas[first:last + 1]:
+                    k["flops"] += m["flops"]; k["bytes"] += m["bytes"]; k["launches"] += 1
         if a.per_op:
             for i, m in enumerate(plan.b.meta):
                 ms = sum(evs[i].elapsed_time(evs[i + 1]) for evs in ev_all) / a.steps

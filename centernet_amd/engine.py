@@ -190,7 +190,7 @@ class PlanBuilder:
         self.ops.append(run)
         fl = 2 * x.B * (2 * x.H) * (2 * x.W) * co * ci * 4
         by = 4 * (x.B * x.H * x.W * (ci + 4 * co) + co * ci * 16)
-        self.meta.append(dict(kind="deconv", flops=fl, bytes=by))
+        self.meta.append(dict(kind="conv", flops=fl, bytes=by))
         self.trace.append(("deconv", out))
         self.flops += fl
         return out
@@ -415,9 +415,11 @@ class Plan:
     def flops(self):
         return self.b.flops
 
-    def run(self, images, events=None):
+    def run(self, images, events=None, event_after=None):
         """Replay the launch list.  ``events``: optional list that receives one
-        torch.cuda.Event per op boundary (len(ops)+1), recorded on the launch stream."""
+        torch.cuda.Event per op boundary (len(ops)+1), recorded on the launch stream; with
+        ``event_after`` (a set of op indices) events are recorded only at the start and after
+        those ops (segment timing with fewer stream markers)."""
         if not images.is_cuda:
             raise native.NativeError("input batch must be on a HIP device; there is no CPU path")
         native.require_f32(images)
@@ -435,11 +437,12 @@ class Plan:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 events.append(e)
-                for op in self.b.ops:
+                for i, op in enumerate(self.b.ops):
                     op()
-                    e = torch.cuda.Event(enable_timing=True)
-                    e.record()
-                    events.append(e)
+                    if event_after is None or i in event_after:
+                        e = torch.cuda.Event(enable_timing=True)
+                        e.record()
+                        events.append(e)
         return {k: v.t for k, v in self.outputs.items()}
 
     def capture(self):
