@@ -718,13 +718,15 @@ __global__ void splitk_reduce_kernel(const IgemmArgs a)
 
 // How many K-splits a dense NHWC layer gets: enough workgroups to put ~2 on every CU,
 // at least 8 chunks of K per split, only when the plain grid is badly under-filled.
+int g_tune_split_min_chunks = 8;  // cn_set_tuning key 16: K chunks per split-K slice, at least
+int g_tune_split_max = 16;        // cn_set_tuning key 17: split-K slices, at most
 inline int plan_ksplit(int M, int Cout, int KT, int bm, int bn)
 {
     const long wgs = (long)cn_cdiv(M, bm) * cn_cdiv(Cout, bn);
     if (wgs >= 256 || KT < 16) return 1;
     int s = (int)((512 + wgs - 1) / wgs);
-    if (s > KT / 8) s = KT / 8;
-    if (s > 16) s = 16;
+    if (s > KT / g_tune_split_min_chunks) s = KT / g_tune_split_min_chunks;
+    if (s > g_tune_split_max) s = g_tune_split_max;
     return s < 2 ? 1 : s;
 }
 inline bool is_stem(int Cin, int in_layout) { return in_layout == CN_LAYOUT_NCHW && Cin == 3; }
@@ -1184,6 +1186,14 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 14 && (value == 0 || value == 1)) {
         g_tune_bm256 = value;
+        return CN_OK;
+    }
+    if (key == 16 && value >= 1 && value <= 64) {
+        g_tune_split_min_chunks = value;
+        return CN_OK;
+    }
+    if (key == 17 && value >= 1 && value <= 64) {
+        g_tune_split_max = value;
         return CN_OK;
     }
     if (key == 15 && (value == 0 || value == 1)) {

@@ -46,7 +46,7 @@ struct C3Args {
     const void *residual;        // element type T
     void *y;                     // element type T
     int B, H, W, Cin, Cout, in_pitch, out_pitch, relu;
-    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio, bm256, waves8;
+    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio, bm256, waves8, nkk_last;
 };
 
 // Fused detection heads (HEADS = true): blockIdx.y selects the head; its 64 hidden channels
@@ -75,7 +75,8 @@ constexpr size_t c3_union_floats()
 
 // T = float: v_mfma_f32_32x32x2_f32, 32 channels per chunk; T = fp16: v_mfma_f32_32x32x16_f16
 // (fp32 accumulate), 64 channels per chunk -- same 128-byte LDS rows and read addresses.
-template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128>
+template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
+          bool KSKIP = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
 {
     constexpr int NT = WM * WN * 64;  // 4 waves (256 threads) or 8 waves (512 threads)
@@ -181,13 +182,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
         const int ty = m / TW, tx = m - ty * TW;
         abase[i] = (ty * HW_ + tx) * LDT + 4 * lh;
     }
-    auto compute = [&](int tap, int buf) {
+    // KSKIP (Cin % 32 != 0, e.g. DLA level0's 16 channels): the last chunk's all-zero 8-channel
+    // K groups are not multiplied at all
+    auto compute = [&](int tap, int buf, int nkk) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const int toff = (ky * HW_ + kx) * LDT;
         const float *Bb = Bs + buf * BN * LDT + (wn * TN + l31) * LDT + 4 * lh;
         if (a.setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
+            if (KSKIP && kk >= nkk) break;
             cn_f32x4 af[MB], bf[NB];
 #pragma unroll
             for (int i = 0; i < MB; ++i)
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
             const bool newA = (t == 8) && (c + 1 < a.nchunk);
             if (more) load_B(t == 8 ? c + 1 : c, t == 8 ? 0 : t + 1);
             if (newA) load_A(c + 1);
-            compute(t, it & 1);
+            compute(t, it & 1, (KSKIP && c == a.nchunk - 1) ? a.nkk_last : 4);
             if (newA) {
                 __syncthreads();  // every wave is done with the old halo
                 store_A();
@@ -420,18 +424,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
     }
 }
 
-template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128>
+template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
+          bool KSKIP = false>
 int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 {
     constexpr int TH = BM / TW;
     constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS, BM>() * 4 + BM * 4;
-    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM>), lds);
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
     dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, BN));
     const C3Heads none = {};
-    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM>), grid, dim3(WM * WN * 64), lds,
+    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP>), grid,
+                       dim3(WM * WN * 64), lds,
                        st, b,
                        hd ? *hd : none);
     CN_CHECK_LAUNCH();
@@ -444,6 +450,8 @@ template <typename T>
 static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
 {
     const bool wide = a.W >= 32;  // 4 x 32 tiles keep an MFMA block on one halo row
+    // fp32 layers whose last 32-channel chunk is less than 3/4 full skip its empty K groups
+    const bool kskip = sizeof(T) == 4 && a.nkk_last < 4;
     if (bn_class == 2) {
         // 8 waves per 128 x 128 tile (wave tile 32 x 64): 4 waves/SIMD at 2 workgroups per CU
         // hide the barrier / LDS latency better than 4-wave workgroups: +1 % on resdcn_18 and
@@ -459,8 +467,14 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
         const long wgs256 = (long)a.B * cn_cdiv(a.H, 8) * cn_cdiv(a.W, 32) * cn_cdiv(a.Cout, 64);
         if (wide && a.H >= 8 && a.bm256 && wgs256 >= 1024)
             return launch_c3<T, 32, 64, 4, 1, false, 256>(a, st);
+        if (kskip)
+            return wide ? launch_c3<float, 32, 64, 2, 2, false, 128, true>(a, st)
+                        : launch_c3<float, 16, 64, 2, 2, false, 128, true>(a, st);
         return wide ? launch_c3<T, 32, 64, 2, 2>(a, st) : launch_c3<T, 16, 64, 2, 2>(a, st);
     }
+    if (kskip)
+        return wide ? launch_c3<float, 32, 32, 4, 1, false, 128, true>(a, st)
+                    : launch_c3<float, 16, 32, 4, 1, false, 128, true>(a, st);
     return wide ? launch_c3<T, 32, 32, 4, 1>(a, st) : launch_c3<T, 16, 32, 4, 1>(a, st);
 }
 
@@ -482,6 +496,7 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     a.cin_pad = (Cin + bke - 1) / bke * bke;
     a.cout_pad = (Cout + 31) / 32 * 32;
     a.nchunk = a.cin_pad / bke;
+    a.nkk_last = f16 ? 4 : ((Cin - (a.nchunk - 1) * 32) + 7) / 8;
     return f16 ? c3_dispatch<_Float16>(a, bn_class, st) : c3_dispatch<float>(a, bn_class, st);
 }
 

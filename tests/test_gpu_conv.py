@@ -51,6 +51,9 @@ def _bn(C, seed):
     (1, 384, 4, 4, 384, 3, 1, 1, False, True, True, False),
     (2, 256, 16, 16, 128, 3, 2, 1, False, True, True, False),
     (5, 48, 100, 132, 64, 3, 1, 1, True, False, True, False),
+    # partially filled last K chunk (DLA level0: 16 -> 16): empty 8-channel groups are skipped
+    (2, 16, 64, 64, 16, 3, 1, 1, False, True, True, False),
+    (1, 40, 20, 24, 24, 3, 1, 1, True, False, False, True),
 ])
 def test_conv_bn_relu_residual(dev, cfg):
     _conv_case(dev, cfg)

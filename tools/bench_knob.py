@@ -12,6 +12,8 @@ dev = torch.device("cuda:0")
 m = create_model(arch, {"hm": 80, "wh": 2, "reg": 2}, 256 if arch.startswith("dla") else 64)
 synth.fill_state_dict_(m, 317)
 m = m.to(dev).eval()
+if os.environ.get('FP16'):
+    m.half_compute()
 x = synth.images(B, 512, 512, 0).to(dev)
 res = {}
 for rnd in range(3):
@@ -27,4 +29,4 @@ for rnd in range(3):
         res.setdefault(v, []).append((time.perf_counter() - t) / 10 * 1e3)
 for v, ts in res.items():
     print("key %d = %d : %s ms/forward (min %.3f)" % (key, v, " ".join("%.3f" % t for t in ts), min(ts)))
-lib.cn_set_tuning(key, 0)
+
