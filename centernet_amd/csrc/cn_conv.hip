@@ -677,6 +677,9 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                  int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
                  int f16, hipStream_t st);
+int cn_deconv4x4s2_halo(const float *x, const float *w_packed, const float *scale, const float *shift,
+                        float *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
+                        int relu, int vec_out, int setprio, hipStream_t st);
 namespace {
 
 // split-K second stage: sum the partial tiles, then the usual epilogue
@@ -1129,6 +1132,11 @@ extern "C" int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_pa
     a.w_zstride = 4 * a.cout_pad * a.cin_pad;
     a.vec_out = ((out_pitch & 3) == 0 && cn_aligned16(y_nhwc)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
+    // LDS-halo form (cn_conv3x3.hip) unless disabled (cn_set_tuning key 10) or the tile would be
+    // mostly padding (Cout <= 32)
+    if (!g_tune_nohalo && Cout > 32 && a.vec_out && (in_pitch & 3) == 0)
+        return cn_deconv4x4s2_halo(x_nhwc, w_packed, scale, shift, y_nhwc, B, H, W, Cin, Cout,
+                                   in_pitch, out_pitch, relu, a.vec_out, g_tune_setprio, st);
     if (Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
     if (Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
     return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);

@@ -76,9 +76,16 @@ constexpr size_t c3_union_floats()
 // T = float: v_mfma_f32_32x32x2_f32, 32 channels per chunk; T = fp16: v_mfma_f32_32x32x16_f16
 // (fp32 accumulate), 64 channels per chunk -- same 128-byte LDS rows and read addresses.
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false>
+          bool KSKIP = false, bool DECONV = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
 {
+    // DECONV: ConvTranspose2d(4, stride 2, pad 1) -- blockIdx.z = output parity (py, px); each
+    // parity is a 2x2 convolution over the same input halo (taps (ty+py, tx+px) of the 3x3
+    // neighbourhood) with its own weights, writing out[2y+py][2x+px] (resnet_dcn.py:228-235)
+    constexpr int NTAPS = DECONV ? 4 : 9;
+    constexpr int TAPW = DECONV ? 2 : 3;
+    static_assert(!DECONV || (!HEADS && !KSKIP && sizeof(T) == 4), "deconv variant: plain fp32");
+    const int par_y = DECONV ? (int)(blockIdx.z >> 1) : 0, par_x = DECONV ? (int)(blockIdx.z & 1) : 0;
     constexpr int NT = WM * WN * 64;  // 4 waves (256 threads) or 8 waves (512 threads)
     constexpr int RPP = NT / 8;       // LDS rows staged per pass of the block
     static_assert(!HEADS || NT == 256, "fused heads are built for 4 waves");
@@ -88,7 +95,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
     constexpr int BKE = 8 * EPV;
     constexpr bool F16 = (EPV == 8);
     const T *xT = reinterpret_cast<const T *>(a.x);
-    const T *wT = reinterpret_cast<const T *>(a.w);
+    const T *wT = reinterpret_cast<const T *>(a.w) +
+                  (DECONV ? (size_t)blockIdx.z * NTAPS * a.cout_pad * a.cin_pad : (size_t)0);
     constexpr int TH = BM / TW;
     constexpr int HW_ = TW + 2;              // halo width
     constexpr int HR = (TH + 2) * HW_;       // halo rows (pixels)
@@ -130,7 +138,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
     for (int m = tid; m < BM; m += NT) {
         const int ty = m / TW, tx = m - ty * TW;
         const int oy = ty0 + ty, ox = tx0 + tx;
-        rowoff[m] = (oy < a.H && ox < a.W) ? (b * a.H + oy) * a.W + ox : -1;
+        if (DECONV)
+            rowoff[m] = (oy < a.H && ox < a.W)
+                            ? (b * 2 * a.H + 2 * oy + par_y) * 2 * a.W + 2 * ox + par_x : -1;
+        else
+            rowoff[m] = (oy < a.H && ox < a.W) ? (b * a.H + oy) * a.W + ox : -1;
     }
 
     cn_f32x16 acc[MB][NB];
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
     // KSKIP (Cin % 32 != 0, e.g. DLA level0's 16 channels): the last chunk's all-zero 8-channel
     // K groups are not multiplied at all
     auto compute = [&](int tap, int buf, int nkk) {
-        const int ky = tap / 3, kx = tap - ky * 3;
+        const int ky = tap / TAPW + par_y, kx = tap % TAPW + par_x;
         const int toff = (ky * HW_ + kx) * LDT;
         const float *Bb = Bs + buf * BN * LDT + (wn * TN + l31) * LDT + 4 * lh;
         if (a.setprio) __builtin_amdgcn_s_setprio(1);
@@ -245,14 +257,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
     store_A();
     store_B(0);
     __syncthreads();
-    const int total = a.nchunk * 9;
+    const int total = a.nchunk * NTAPS;
     int it = 0;
     for (int c = 0; c < a.nchunk; ++c) {
 #pragma unroll 1
-        for (int t = 0; t < 9; ++t, ++it) {
+        for (int t = 0; t < NTAPS; ++t, ++it) {
             const bool more = (it + 1) < total;
-            const bool newA = (t == 8) && (c + 1 < a.nchunk);
-            if (more) load_B(t == 8 ? c + 1 : c, t == 8 ? 0 : t + 1);
+            const bool newA = (t == NTAPS - 1) && (c + 1 < a.nchunk);
+            if (more) load_B(t == NTAPS - 1 ? c + 1 : c, t == NTAPS - 1 ? 0 : t + 1);
             if (newA) load_A(c + 1);
             compute(t, it & 1, (KSKIP && c == a.nchunk - 1) ? a.nkk_last : 4);
             if (newA) {
@@ -425,18 +437,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
 }
 
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false>
+          bool KSKIP = false, bool DECONV = false>
 int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 {
     constexpr int TH = BM / TW;
     constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS, BM>() * 4 + BM * 4;
-    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP>), lds);
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
-    dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, BN));
+    dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, BN), DECONV ? 4 : 1);
     const C3Heads none = {};
-    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP>), grid,
+    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV>), grid,
                        dim3(WM * WN * 64), lds,
                        st, b,
                        hd ? *hd : none);
@@ -529,4 +541,27 @@ extern "C" int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin,
     a.nchunk = a.cin_pad / 32;
     return (W >= 32) ? launch_c3<float, 32, 64, 2, 2, true>(a, st, &hd)
                      : launch_c3<float, 16, 64, 2, 2, true>(a, st, &hd);
+}
+
+// ConvTranspose2d(kernel 4, stride 2, padding 1) through the LDS-halo kernel: the four output
+// parities are 2x2 convolutions over the 3x3 neighbourhood the halo already holds.
+// w_packed: cn_pack_deconv4x4s2_weight_f32 layout [parity 4][tap 4][cout_pad][cin_pad].
+int cn_deconv4x4s2_halo(const float *x, const float *w_packed, const float *scale, const float *shift,
+                        float *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
+                        int relu, int vec_out, int setprio, hipStream_t st)
+{
+    C3Args a = {};
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = nullptr; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_pitch = in_pitch;
+    a.out_pitch = out_pitch; a.relu = relu; a.vec_out = vec_out; a.setprio = setprio & 1;
+    a.cin_pad = (Cin + 31) / 32 * 32;
+    a.cout_pad = (Cout + 31) / 32 * 32;
+    a.nchunk = a.cin_pad / 32;
+    a.nkk_last = 4;
+    const bool wide = W >= 32;
+    if (Cout > 64)
+        return wide ? launch_c3<float, 32, 128, 4, 2, false, 128, false, true>(a, st)
+                    : launch_c3<float, 16, 128, 4, 2, false, 128, false, true>(a, st);
+    return wide ? launch_c3<float, 32, 64, 2, 2, false, 128, false, true>(a, st)
+                : launch_c3<float, 16, 64, 2, 2, false, 128, false, true>(a, st);
 }

@@ -127,8 +127,20 @@ def test_stem_conv_nchw_input(dev):
     assert torch.equal(z.t.permute(0, 3, 1, 2).cpu(), pooled)
 
 
-@pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 64), (1, 256, 16, 16, 256), (1, 128, 9, 7, 64)])
-def test_conv_transpose_4x4_s2(dev, cfg):
+@pytest.mark.parametrize("halo", [True, False])
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 64), (1, 256, 16, 16, 256), (1, 128, 9, 7, 64),
+                                 (2, 128, 37, 45, 96), (1, 64, 8, 40, 24)])
+def test_conv_transpose_4x4_s2(dev, cfg, halo):
+    """Both forms: LDS-halo parity kernel (default) and the generic implicit GEMM (key 10)."""
+    from centernet_amd import native
+    native.lib().cn_set_tuning(10, 0 if halo else 1)
+    try:
+        _deconv_case(dev, cfg)
+    finally:
+        native.lib().cn_set_tuning(10, 0)
+
+
+def _deconv_case(dev, cfg):
     from centernet_amd.engine import PlanBuilder
     B, Cin, H, W, Cout = cfg
     x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1))
