@@ -887,3 +887,215 @@ extern "C" int cn_ddd_decode_f32(const float *heat, const float *rot, const floa
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
+
+// ---------------------------------------------------------------------------
+// exct_decode (models/decode.py:273-424), aggr_weight == 0: ExtremeNet-style grouping of the
+// K best top / left / bottom / right extreme points into boxes.
+//   stage A  cn_topk_f32 x4 (_nms + _topk of the four extreme-point heat-maps)
+//   stage B  exct_score_kernel: the K^4 candidate scores (decode.py:316-366), written once
+//   stage C  exct_select_kernel: exact top-num_dets (radix select + 1024-key bitonic sort in
+//            LDS) and the box / extreme-point assembly (decode.py:372-420)
+// Candidate index = ((t*K + l)*K + b)*K + r, as the reference's view(batch, -1).
+// Tie order (unspecified by torch.topk): score desc, candidate index asc.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int EXCT_MAX_DETS = 1024;
+
+struct ExctLists {  // (B, K) arrays of the four _topk calls, order t, l, b, r
+    const float *score[4];
+    const int32_t *ind[4];
+    const int32_t *cls[4];
+};
+
+__device__ __forceinline__ float exct_score(const ExctLists &L, const float *__restrict__ ct_heat,
+                                            int b, int K, int H, int W, int C, int it, int il,
+                                            int ib, int ir, float scores_thresh, float center_thresh)
+{
+    const int o = b * K;
+    const float ts = L.score[0][o + it], ls = L.score[1][o + il], bs = L.score[2][o + ib],
+                rs = L.score[3][o + ir];
+    const int ti = L.ind[0][o + it], li = L.ind[1][o + il], bi = L.ind[2][o + ib],
+              ri = L.ind[3][o + ir];
+    const int tc = L.cls[0][o + it], lc = L.cls[1][o + il], bc = L.cls[2][o + ib],
+              rc = L.cls[3][o + ir];
+    const float t_y = (float)(ti / W), t_x = (float)(ti % W);
+    const float l_y = (float)(li / W), l_x = (float)(li % W);
+    const float b_y = (float)(bi / W), b_x = (float)(bi % W);
+    const float r_y = (float)(ri / W), r_x = (float)(ri % W);
+    // decode.py:331-336: centre of the box -> centre heat-map of the TOP point's class
+    const int cx = (int)((l_x + r_x + 0.5f) / 2.0f);
+    const int cy = (int)((t_y + b_y + 0.5f) / 2.0f);
+    const float cs = ct_heat[((size_t)b * C + tc) * H * W + (size_t)cy * W + cx];
+    // decode.py:343: (t + l + b + r + 2*ct) / 6, left to right
+    float s = ((((ts + ls) + bs) + rs) + 2.0f * cs) / 6.0f;
+    // decode.py:346-366: one unit off per violated rule, in the reference's order
+    const bool sc_bad = (ts < scores_thresh) || (ls < scores_thresh) || (bs < scores_thresh) ||
+                        (rs < scores_thresh) || (cs < center_thresh);
+    const bool cls_bad = (tc != lc) || (tc != bc) || (tc != rc);
+    const bool top_bad = (t_y > l_y) || (t_y > b_y) || (t_y > r_y);
+    const bool left_bad = (l_x > t_x) || (l_x > b_x) || (l_x > r_x);
+    const bool bottom_bad = (b_y < t_y) || (b_y < l_y) || (b_y < r_y);
+    const bool right_bad = (r_x < t_x) || (r_x < l_x) || (r_x < b_x);
+    s = s - (sc_bad ? 1.0f : 0.0f);
+    s = s - (cls_bad ? 1.0f : 0.0f);
+    s = s - (top_bad ? 1.0f : 0.0f);
+    s = s - (left_bad ? 1.0f : 0.0f);
+    s = s - (bottom_bad ? 1.0f : 0.0f);
+    s = s - (right_bad ? 1.0f : 0.0f);
+    return s;
+}
+
+__global__ void exct_score_kernel(const ExctLists L, const float *__restrict__ ct_heat,
+                                  float *__restrict__ cand, int K, int H, int W, int C,
+                                  float scores_thresh, float center_thresh)
+{
+    const int b = blockIdx.y;
+    const size_t n = (size_t)K * K * K * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ir = (int)(i % K), ib = (int)((i / K) % K), il = (int)((i / ((size_t)K * K)) % K),
+                  it = (int)(i / ((size_t)K * K * K));
+        cand[(size_t)b * n + i] =
+            exct_score(L, ct_heat, b, K, H, W, C, it, il, ib, ir, scores_thresh, center_thresh);
+    }
+}
+
+struct ExctRegr {
+    const float *r[4];  // t, l, b, r regression maps (B,2,H,W) or all null
+};
+
+// one 1024-thread workgroup per image
+__global__ __launch_bounds__(NTM) void exct_select_kernel(
+    const float *__restrict__ cand, const ExctLists L, const ExctRegr R, float *__restrict__ dets,
+    int K, int H, int W, int num_dets)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SelShared &sh = *reinterpret_cast<SelShared *>(smem);
+    u64 *big = reinterpret_cast<u64 *>(smem + sizeof(SelShared));  // [EXCT_MAX_DETS]
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const uint32_t n = (uint32_t)K * K * K * K;
+    const float *cs = cand + (size_t)b * n;
+
+    auto for_each = [&](auto &&f) {
+        for (uint32_t j = tid; j < n; j += NTM) {
+            const uint32_t kk = f2key(cs[j] + 0.0f);
+            f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - j), false);
+        }
+    };
+    u64 prefix, mask;
+    radix_select<NTM>(for_each, (uint32_t)num_dets, sh, prefix, mask);
+    // collect the selected keys (exactly num_dets of them) and sort all 1024 slots descending
+    __syncthreads();
+    if (tid == 0) sh.cnt = 0;
+    big[tid] = 0;  // pad keys sort last (NTM == EXCT_MAX_DETS)
+    __syncthreads();
+    for_each([&](u64 k, bool) {
+        if ((k & mask) >= prefix) {
+            const uint32_t pos = atomicAdd(&sh.cnt, 1u);
+            if (pos < (uint32_t)EXCT_MAX_DETS) big[pos] = k;
+        }
+    });
+    __syncthreads();
+    for (int k = 2; k <= EXCT_MAX_DETS; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int partner = tid ^ j;
+            if (partner > tid) {
+                const u64 x = big[tid], y = big[partner];
+                const bool desc = (tid & k) == 0;
+                if (desc ? (x < y) : (x > y)) {
+                    big[tid] = y;
+                    big[partner] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid >= num_dets) return;
+    const u64 key = big[tid];
+    const float score = key2f((uint32_t)(key >> 32));
+    const uint32_t idx = 0xFFFFFFFFu - (uint32_t)key;
+    const int ir = (int)(idx % K), ib = (int)((idx / K) % K), il = (int)((idx / (K * K)) % K),
+              it = (int)(idx / (K * K * K));
+    const int o = b * K;
+    const int HW = H * W;
+    const int sel[4] = {it, il, ib, ir};
+    float xs[4], ys[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ind = L.ind[e][o + sel[e]];
+        float x = (float)(ind % W), y = (float)(ind / W);
+        if (R.r[0]) {  // decode.py:372-390 (all four regression maps given)
+            x = x + R.r[e][((size_t)b * 2 + 0) * HW + ind];
+            y = y + R.r[e][((size_t)b * 2 + 1) * HW + ind];
+        } else {      // decode.py:391-399
+            x = x + 0.5f;
+            y = y + 0.5f;
+        }
+        xs[e] = x;
+        ys[e] = y;
+    }
+    float *d = dets + ((size_t)b * num_dets + tid) * 14;
+    d[0] = xs[1]; d[1] = ys[0]; d[2] = xs[3]; d[3] = ys[2];  // bboxes = (l_x, t_y, r_x, b_y)
+    d[4] = score;
+    d[5] = xs[0]; d[6] = ys[0]; d[7] = xs[1]; d[8] = ys[1];
+    d[9] = xs[2]; d[10] = ys[2]; d[11] = xs[3]; d[12] = ys[3];
+    d[13] = (float)L.cls[0][o + it];                          // clses = t_clses
+}
+
+}  // namespace
+
+extern "C" size_t cn_exct_decode_workspace_bytes(int B, int C, int H, int W, int K)
+{
+    const size_t base = cn_ctdet_decode_workspace_bytes(B, C, H, W, K);
+    if (!base) return 0;
+    const size_t lists = 4 * 3 * cn_align_up((size_t)B * K * 4, 256);
+    const size_t cand = cn_align_up((size_t)B * K * K * K * K * sizeof(float), 256);
+    return base + lists + cand;
+}
+
+extern "C" int cn_exct_decode_f32(const float *t_heat, const float *l_heat, const float *b_heat,
+                                  const float *r_heat, const float *ct_heat, const float *t_regr,
+                                  const float *l_regr, const float *b_regr, const float *r_regr,
+                                  int B, int C, int H, int W, int K, float scores_thresh,
+                                  float center_thresh, int num_dets, int apply_sigmoid,
+                                  float *dets, void *workspace, size_t workspace_bytes,
+                                  void *stream)
+{
+    if (!t_heat || !l_heat || !b_heat || !r_heat || !ct_heat || !dets || !workspace) return CN_ERR_NULL;
+    if (num_dets <= 0 || K <= 0) return CN_ERR_SHAPE;
+    if (K > 64 || num_dets > EXCT_MAX_DETS) return CN_ERR_UNSUPPORTED;  // K^4 must fit 32 bits / LDS sort
+    if ((long)num_dets > (long)K * K * K * K) return CN_ERR_SHAPE;      // torch.topk: k out of range
+    if (apply_sigmoid) return CN_ERR_UNSUPPORTED;  // the centre map is gathered, not scanned
+    const size_t base = cn_ctdet_decode_workspace_bytes(B, C, H, W, K);
+    if (!base) return CN_ERR_UNSUPPORTED;
+    if (workspace_bytes < cn_exct_decode_workspace_bytes(B, C, H, W, K)) return CN_ERR_WORKSPACE;
+    const bool all_regr = t_regr && l_regr && b_regr && r_regr;  // decode.py:372-373
+    const size_t slot = cn_align_up((size_t)B * K * 4, 256);
+    char *p = (char *)workspace + base;
+    ExctLists L;
+    const float *heats[4] = {t_heat, l_heat, b_heat, r_heat};
+    for (int e = 0; e < 4; ++e) {
+        float *s = (float *)p; p += slot;
+        int32_t *i = (int32_t *)p; p += slot;
+        int32_t *c = (int32_t *)p; p += slot;
+        const int rc = cn_topk_f32(heats[e], B, C, H, W, K, 0, s, i, c, workspace, base, stream);
+        if (rc != CN_OK) return rc;
+        L.score[e] = s; L.ind[e] = i; L.cls[e] = c;
+    }
+    float *cand = (float *)p;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)K * K * K * K;
+    dim3 grid((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096), B);
+    hipLaunchKernelGGL(exct_score_kernel, grid, dim3(256), 0, st, L, ct_heat, cand, K, H, W, C,
+                       scores_thresh, center_thresh);
+    CN_CHECK_LAUNCH();
+    ExctRegr R;
+    R.r[0] = all_regr ? t_regr : nullptr; R.r[1] = all_regr ? l_regr : nullptr;
+    R.r[2] = all_regr ? b_regr : nullptr; R.r[3] = all_regr ? r_regr : nullptr;
+    const size_t lds = sizeof(SelShared) + EXCT_MAX_DETS * sizeof(u64);
+    hipLaunchKernelGGL(exct_select_kernel, dim3(B), dim3(NTM), lds, st, cand, L, R, dets, K, H, W,
+                       num_dets);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}

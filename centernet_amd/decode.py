@@ -151,3 +151,27 @@ def ddd_decode(heat, rot, depth, dim, wh=None, reg=None, K=40, apply_sigmoid=Fal
                                ws.numel(), native.stream_ptr())
     native.check(rc, "cn_ddd_decode_f32")
     return dets
+
+
+def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=None, b_regr=None,
+                r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, aggr_weight=0.0,
+                num_dets=1000):
+    """decode.py:273-424 -> (B, num_dets, 14).  Heat-maps post-sigmoid (values <= 1).
+    ``aggr_weight > 0`` (edge aggregation, decode.py:17-90) is not built."""
+    if aggr_weight > 0:
+        raise native.NativeError("exct_decode: aggr_weight > 0 (edge aggregation) is not built")
+    t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr, l_regr, b_regr, r_regr = _prep(
+        t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr, l_regr, b_regr, r_regr)
+    lib = native.lib()
+    B, C, H, W = t_heat.shape
+    if K > H * W or num_dets > K ** 4:
+        raise RuntimeError("selected index k out of range")
+    dets = torch.empty((B, num_dets, 14), device=t_heat.device, dtype=torch.float32)
+    ws = _workspace(lib.cn_exct_decode_workspace_bytes(B, C, H, W, K), t_heat.device)
+    rc = lib.cn_exct_decode_f32(native.ptr(t_heat), native.ptr(l_heat), native.ptr(b_heat),
+                                native.ptr(r_heat), native.ptr(ct_heat), native.ptr(t_regr),
+                                native.ptr(l_regr), native.ptr(b_regr), native.ptr(r_regr), B, C, H,
+                                W, K, scores_thresh, center_thresh, num_dets, 0, native.ptr(dets),
+                                native.ptr(ws), ws.numel(), native.stream_ptr())
+    native.check(rc, "cn_exct_decode_f32")
+    return dets

@@ -340,6 +340,20 @@ int cn_ddd_decode_f32(const float *heat, const float *rot, const float *depth, c
                       int apply_sigmoid, float *dets, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr.., K=40, scores_thresh=0.1,
+ *             center_thresh=0.1, aggr_weight=0.0, num_dets=1000)   (models/decode.py:273-424)
+ * for aggr_weight == 0: dets (B, num_dets, 14) = [l_x, t_y, r_x, b_y, score, t_x, t_y, l_x, l_y,
+ * b_x, b_y, r_x, r_y, cls].  The four regression maps are used only when all are given
+ * (decode.py:372-373).  Heat-maps are post-sigmoid.  K <= 64, num_dets <= 1024.
+ * Tie order of equal scores (unspecified by torch.topk): candidate index ascending. */
+size_t cn_exct_decode_workspace_bytes(int B, int C, int H, int W, int K);
+int cn_exct_decode_f32(const float *t_heat, const float *l_heat, const float *b_heat,
+                       const float *r_heat, const float *ct_heat, const float *t_regr,
+                       const float *l_regr, const float *b_regr, const float *r_regr, int B, int C,
+                       int H, int W, int K, float scores_thresh, float center_thresh, int num_dets,
+                       int apply_sigmoid, float *dets, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
 /* ------------------------------------------------------------------------
  * multi_pose decode.
  * Replaces: multi_pose_decode(heat, wh, kps, reg, hm_hp, hp_offset, K)

@@ -206,3 +206,63 @@ def ddd_decode(heat, rot, depth, dim, wh=None, reg=None, K=40):
         parts.append(transpose_and_gather_feat(wh, i))
     parts.append(c.reshape(B, K, 1).astype(np.float32))
     return np.concatenate(parts, axis=2).astype(np.float32)
+
+
+def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=None, b_regr=None,
+                r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, num_dets=1000):
+    """models/decode.py:273-424 with aggr_weight = 0, statement by statement in float32 numpy.
+    Ties of the final top-k are ordered by candidate index (torch leaves that unspecified)."""
+    f32 = np.float32
+    B, C, H, W = t_heat.shape
+    tops = [topk(np.minimum(nms(h), f32(1.0)), K) for h in (t_heat, l_heat, b_heat, r_heat)]  # :297-310
+
+    def ax(v, e):  # (B,K) -> broadcast along axis e of (B,K,K,K,K)
+        shape = [B, 1, 1, 1, 1]
+        shape[1 + e] = K
+        return v.reshape(shape)
+    S = [ax(tops[e][0], e) for e in range(4)]
+    CL = [ax(tops[e][2], e) for e in range(4)]
+    Y = [ax(tops[e][3], e) for e in range(4)]
+    X = [ax(tops[e][4], e) for e in range(4)]
+    t_ys, l_ys, b_ys, r_ys = Y
+    t_xs, l_xs, b_xs, r_xs = X
+    full = (B, K, K, K, K)
+    box_ct_xs = (((l_xs + r_xs) + f32(0.5)) / f32(2)).astype(np.int64)          # :331
+    box_ct_ys = (((t_ys + b_ys) + f32(0.5)) / f32(2)).astype(np.int64)          # :332
+    ct_inds = CL[0].astype(np.int64) * (H * W) + box_ct_ys * W + box_ct_xs      # :333
+    ct_inds = np.broadcast_to(ct_inds, full).reshape(B, -1)
+    ct_flat = np.ascontiguousarray(ct_heat, f32).reshape(B, -1)
+    ct_scores = np.take_along_axis(ct_flat, ct_inds, axis=1).reshape(full)      # :334-336
+    scores = ((((S[0] + S[1]) + S[2]) + S[3]) + f32(2) * ct_scores) / f32(6)    # :343
+    cls_inds = (CL[0] != CL[1]) | (CL[0] != CL[2]) | (CL[0] != CL[3])           # :346-348
+    top_inds = (t_ys > l_ys) | (t_ys > b_ys) | (t_ys > r_ys)                     # :350-357
+    left_inds = (l_xs > t_xs) | (l_xs > b_xs) | (l_xs > r_xs)
+    bottom_inds = (b_ys < t_ys) | (b_ys < l_ys) | (b_ys < r_ys)
+    right_inds = (r_xs < t_xs) | (r_xs < l_xs) | (r_xs < b_xs)
+    th, cth = f32(scores_thresh), f32(center_thresh)
+    sc_inds = (S[0] < th) | (S[1] < th) | (S[2] < th) | (S[3] < th) | (ct_scores < cth)  # :359-362
+    scores = scores.astype(f32)
+    for flag in (sc_inds, cls_inds, top_inds, left_inds, bottom_inds, right_inds):        # :364-369
+        scores = scores - np.broadcast_to(flag, full).astype(f32)
+    scores = scores.reshape(B, -1)
+    order = np.lexsort((np.broadcast_to(np.arange(scores.shape[1]), scores.shape), -scores), axis=1)
+    inds = order[:, :num_dets]                                                   # :372
+    top_scores = np.take_along_axis(scores, inds, axis=1)[..., None]
+    regs = (t_regr, l_regr, b_regr, r_regr)
+    XS, YS = [], []
+    for e in range(4):
+        if all(r is not None for r in regs):                                     # :375-392
+            g = transpose_and_gather_feat(regs[e], tops[e][1])
+            XS.append(X[e] + ax(g[..., 0], e))
+            YS.append(Y[e] + ax(g[..., 1], e))
+        else:                                                                    # :393-401
+            XS.append(X[e] + f32(0.5))
+            YS.append(Y[e] + f32(0.5))
+
+    def pick(v):
+        return np.take_along_axis(np.broadcast_to(v, full).reshape(B, -1), inds, axis=1)[..., None]
+    cols = [pick(XS[1]), pick(YS[0]), pick(XS[3]), pick(YS[2]), top_scores]       # bboxes :403
+    for e in range(4):
+        cols += [pick(XS[e]), pick(YS[e])]
+    cols.append(pick(CL[0]).astype(f32))
+    return np.concatenate(cols, axis=2).astype(f32)
