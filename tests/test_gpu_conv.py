@@ -127,6 +127,38 @@ def test_stem_conv_nchw_input(dev):
     assert torch.equal(z.t.permute(0, 3, 1, 2).cpu(), pooled)
 
 
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cout, stride, persistent-eligible (output rows a multiple of 128 px)
+    (2, 20, 256, 64, 2, True),     # resnet / hourglass stem shape class (Wo = 128)
+    (3, 9, 512, 128, 2, True),     # Wo = 256: two tiles per row, two N tiles (hourglass: 128 ch)
+    (2, 11, 128, 16, 1, True),     # DLA base_layer: stride 1, 16 channels (32-wide N tile)
+    (4, 300, 256, 64, 2, True),    # 600 tiles > 512 persistent workgroups: the tile loop runs > 1x
+    (2, 33, 200, 64, 2, False),    # not a multiple of 128: one-tile-per-workgroup kernel
+])
+def test_stem_kernels_vs_torch(dev, cfg):
+    """7x7 stem on the NCHW image: persistent prefetching kernel and the per-tile kernel
+    (cn_set_tuning key 12) against torch CPU conv + BN + ReLU."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder
+    B, H, W, Cout, stride, _ = cfg
+    x = synth.images(B, H, W, 7)
+    w = torch.from_numpy(synth.normal((Cout, 3, 7, 7), (2.0 / 147) ** 0.5, 2))
+    bn = _bn(Cout, 4)
+    ref = F.relu(bn(F.conv2d(x, w, None, stride, 3))).detach()
+    lib = native.lib()
+    try:
+        for variant in (1, 0):
+            lib.cn_set_tuning(12, variant)
+            pb = PlanBuilder(dev, B, H, W)
+            xin = pb.set_input(3)
+            y = pb.conv(xin, w, bn=bn, relu=True, stride=stride, padding=3)
+            pb.input.t = x.to(dev)
+            _run(pb)
+            _check(y.t.permute(0, 3, 1, 2).cpu(), ref)
+    finally:
+        lib.cn_set_tuning(12, 1)
+
+
 @pytest.mark.parametrize("halo", [True, False])
 @pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 64), (1, 256, 16, 16, 256), (1, 128, 9, 7, 64),
                                  (2, 128, 37, 45, 96), (1, 64, 8, 40, 24)])
