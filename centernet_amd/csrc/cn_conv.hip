@@ -935,7 +935,7 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho && d->OW == d->Wo)
         return cn_conv3x3s1(x, w_packed, scale, shift, residual, y, d->B, d->H, d->W, d->Cin,
                             d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
-                            g_tune_setprio | (g_tune_bm256 << 1) | (g_tune_waves8 << 2), cls, f16 ? 1 : 0, st);
+                            g_tune_setprio | (g_tune_bm256 << 1) | (g_tune_waves8 << 2) | (g_tune_dbgskip << 4), cls, f16 ? 1 : 0, st);
     if (f16) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_h<64, 128, 2, 2, A_DENSE, false>(a, st)
@@ -1172,7 +1172,7 @@ extern "C" int cn_set_tuning(int key, int value)
         g_tune_setprio = value;
         return CN_OK;
     }
-    if (key == 9 && value >= 0 && value <= 3) {
+    if (key == 9 && value >= 0 && value <= 7) {
         g_tune_dbgskip = value;
         return CN_OK;
     }

@@ -46,7 +46,7 @@ struct C3Args {
     const void *residual;        // element type T
     void *y;                     // element type T
     int B, H, W, Cin, Cout, in_pitch, out_pitch, relu;
-    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio, bm256, waves8, nkk_last;
+    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio, bm256, waves8, nkk_last, dbg;
 };
 
 // Fused detection heads (HEADS = true): blockIdx.y selects the head; its 64 hidden channels
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
         for (int t = 0; t < NTAPS; ++t, ++it) {
             const bool more = (it + 1) < total;
             const bool newA = (t == NTAPS - 1) && (c + 1 < a.nchunk);
-            if (more) load_B(t == NTAPS - 1 ? c + 1 : c, t == NTAPS - 1 ? 0 : t + 1);
-            if (newA) load_A(c + 1);
+            if (more && !(a.dbg & 2)) load_B(t == NTAPS - 1 ? c + 1 : c, t == NTAPS - 1 ? 0 : t + 1);
+            if (newA && !(a.dbg & 4)) load_A(c + 1);
             compute(t, it & 1, (KSKIP && c == a.nchunk - 1) ? a.nkk_last : 4);
             if (newA) {
                 __syncthreads();  // every wave is done with the old halo
@@ -363,6 +363,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
         return;
     }
 
+    if (a.dbg & 1) {  // ablation (cn_set_tuning key 9): no epilogue, one store keeps acc live
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) t += acc[i][j][0] + acc[i][j][7] + acc[i][j][15];
+        if (t == 12345.678f) reinterpret_cast<float *>(a.y)[0] = t;
+        return;
+    }
     // ---- epilogue (as in cn_conv.hip): stage one wave-row of the tile through LDS, then
     // 16-byte residual loads / stores along Cout
     constexpr int LDC = BN + 4;
@@ -465,6 +474,15 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
     // fp32 layers whose last 32-channel chunk is less than 3/4 full skip its empty K groups
     const bool kskip = sizeof(T) == 4 && a.nkk_last < 4;
     if (bn_class == 2) {
+        // fewer than two 128-wide workgroups per CU: nothing overlaps a workgroup's halo / weight
+        // staging and epilogue (ablation: 113 -> 133 TFLOP/s without them at 512->512@16^2), so
+        // take 64-wide tiles and get twice the workgroups
+        const long wgs = (long)a.B * cn_cdiv(a.H, wide ? 4 : 8) * cn_cdiv(a.W, wide ? 32 : 16) *
+                         cn_cdiv(a.Cout, 128);
+        // (threshold measured: 512 -> resdcn_18 B=8 2.77 -> 2.57 ms, B=32 7.96 -> 7.92; 768 / 1024 lose)
+        if (wgs < 512 && (a.Cout % 64) == 0) bn_class = 1;
+    }
+    if (bn_class == 2) {
         // 8 waves per 128 x 128 tile (wave tile 32 x 64): 4 waves/SIMD at 2 workgroups per CU
         // hide the barrier / LDS latency better than 4-wave workgroups: +1 % on resdcn_18 and
         // dla_34 (tools/bench_knob.py 15).  The same change on 64-wide tiles measured no gain.
@@ -500,6 +518,7 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     C3Args a = {};
     a.bm256 = (setprio >> 1) & 1;  // bit 1 of the knob word: cn_set_tuning key 14
     a.waves8 = (setprio >> 2) & 1; // bit 2: cn_set_tuning key 15
+    a.dbg = (setprio >> 4) & 7;    // bits 4-6: ablation switches (cn_set_tuning key 9)
     setprio &= 1;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_pitch = in_pitch;
