@@ -63,13 +63,21 @@ struct C3Heads {
 };
 
 // LDS floats of the kernel: the main loop's tiles, unioned with the epilogue staging
+// rows of the output tile staged through LDS per epilogue pass: the whole tile when it fits
+// in ~68 KB (keeps two 128 x 128 workgroups per CU), else one wave row
+template <int BN, int WM, int BM>
+constexpr int c3_epi_rows()
+{
+    return ((size_t)BM * (BN + 4) <= 17408) ? BM : BM / WM;
+}
+
 template <int TW, int BN, int WM, bool HEADS, int BM>
 constexpr size_t c3_union_floats()
 {
     constexpr int TH = BM / TW;
     constexpr size_t tiles = (size_t)((TH + 2) * (TW + 2) * LDT + 2 * BN * LDT);
     // fused heads: S[128][LDS2] shares the main loop's tile space; the 1x1 weights sit behind it
-    constexpr size_t cs = HEADS ? (size_t)128 * LDS2 : (size_t)(BM / WM) * (BN + 4);
+    constexpr size_t cs = HEADS ? (size_t)128 * LDS2 : (size_t)c3_epi_rows<BN, WM, BM>() * (BN + 4);
     return (tiles > cs ? tiles : cs) + (HEADS ? (size_t)W2_ROWS * LDS2 : 0);
 }
 
@@ -372,13 +380,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
         if (t == 12345.678f) reinterpret_cast<float *>(a.y)[0] = t;
         return;
     }
-    // ---- epilogue (as in cn_conv.hip): stage one wave-row of the tile through LDS, then
-    // 16-byte residual loads / stores along Cout
+    // ---- epilogue: the accumulator tile goes through LDS so that residual loads and output
+    // stores are 16-byte accesses along Cout.  The whole tile is staged at once when it fits
+    // the kernel's LDS (every shape but the 256-pixel tiles): one barrier, and the residual
+    // loads are issued BEFORE the staging so their latency hides behind it (ablation: the
+    // per-wave-row form cost 8-14 % of the 64- and 512-channel layers).
     constexpr int LDC = BN + 4;
+    constexpr int EP = c3_epi_rows<BN, WM, BM>();  // rows staged per pass: BM or one wave row
+    constexpr int NPASS = BM / EP;
     float *Cs = reinterpret_cast<float *>(smem);
     constexpr int C4 = BN / 4;
     constexpr int RPI = NT / C4;
-    constexpr int ITERS = (TM + RPI - 1) / RPI;
+    constexpr int ITERS = (EP + RPI - 1) / RPI;
     const int c4 = tid % C4, r0 = tid / C4;
     const int n = n0 + c4 * 4;
     float sc[4], sf[4];
@@ -390,32 +403,34 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
     }
     const bool vec = a.vec_out && (n + 4 <= a.Cout);
 #pragma unroll 1
-    for (int pass = 0; pass < WM; ++pass) {
-        if (pass) __syncthreads();
-        if (wm == pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int rbase = pass * EP;
+        cn_f32x4 res[ITERS];
+        int offs[ITERS];
+        if (vec) {
+#pragma unroll
+            for (int k = 0; k < ITERS; ++k) {
+                const int lr = k * RPI + r0;
+                offs[k] = (lr < EP) ? rowoff[rbase + lr] : -1;
+                if (a.residual)
+                    res[k] = c3_load4(reinterpret_cast<const T *>(a.residual) +
+                                      (size_t)(offs[k] >= 0 ? offs[k] : 0) * a.out_pitch + n);
+            }
+        }
+        if (pass) __syncthreads();  // previous pass fully read
+        if (wm * TM >= rbase && wm * TM < rbase + EP) {
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int row = wm * TM - rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         Cs[row * LDC + wn * TN + j * 32 + l31] = acc[i][j][r];
                     }
         }
         __syncthreads();
-        const int rbase = pass * TM;
         if (vec) {
-            cn_f32x4 res[ITERS];
-            int offs[ITERS];
-#pragma unroll
-            for (int k = 0; k < ITERS; ++k) {
-                const int lr = k * RPI + r0;
-                offs[k] = (lr < TM) ? rowoff[rbase + lr] : -1;
-                if (a.residual)
-                    res[k] = c3_load4(reinterpret_cast<const T *>(a.residual) +
-                                      (size_t)(offs[k] >= 0 ? offs[k] : 0) * a.out_pitch + n);
-            }
 #pragma unroll
             for (int k = 0; k < ITERS; ++k) {
                 if (offs[k] < 0) continue;
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
         } else if (n < a.Cout) {
             for (int k = 0; k < ITERS; ++k) {
                 const int lr = k * RPI + r0;
-                if (lr >= TM) continue;
+                if (lr >= EP) continue;
                 const int off = rowoff[rbase + lr];
                 if (off < 0) continue;
                 for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
