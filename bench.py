@@ -58,6 +58,8 @@ def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--tune", action="append", default=[],
+                   help="KEY=VALUE for cn_set_tuning (A/B experiments; not used by the driver)")
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     p.add_argument("--arch", default="resdcn_18")
@@ -113,7 +115,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from centernet_amd import synth
+    from centernet_amd import synth, native
+    for kv in a.tune:
+        k, v = kv.split("=")
+        assert native.lib().cn_set_tuning(int(k), int(v)) == 0, kv
     from centernet_amd.opts import opts
     from centernet_amd.detectors import detector_factory
     from centernet_amd.sharding import broadcast_weights

@@ -677,6 +677,7 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                  int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
                  int f16, hipStream_t st);
+extern int cn_tune_stagger_pct;  // cn_conv3x3.hip
 int cn_deconv4x4s2_halo(const float *x, const float *w_packed, const float *scale, const float *shift,
                         float *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
                         int relu, int vec_out, int setprio, hipStream_t st);
@@ -1202,6 +1203,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 17 && value >= 1 && value <= 64) {
         g_tune_split_max = value;
+        return CN_OK;
+    }
+    if (key == 18 && value >= 0 && value <= 255) {
+        cn_tune_stagger_pct = value;
         return CN_OK;
     }
     if (key == 15 && (value == 0 || value == 1)) {

@@ -17,6 +17,10 @@
 // chunk-major then tap, epilogue y = relu?(acc*scale + shift + residual).
 #include "cn_common.h"
 
+// cn_set_tuning key 18: phase shift of co-resident workgroups, percent of one tile's MFMA time
+// (0 = off); see the kernel prologue
+int cn_tune_stagger_pct = 100;
+
 namespace {
 
 constexpr int LDT = 36;  // floats per LDS row (32 + 4 pad = 144 bytes, conflict-free b128 reads)
@@ -46,7 +50,7 @@ struct C3Args {
     const void *residual;        // element type T
     void *y;                     // element type T
     int B, H, W, Cin, Cout, in_pitch, out_pitch, relu;
-    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio, bm256, waves8, nkk_last, dbg;
+    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio, bm256, waves8, nkk_last, dbg, stagger, stagger_slots;
 };
 
 // Fused detection heads (HEADS = true): blockIdx.y selects the head; its 64 hidden channels
@@ -133,6 +137,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
     const int n0 = blockIdx.y * BN;
     const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    if (a.stagger) {
+        // Phase shift of the workgroups that share a CU.  Workgroups of one launch all take the
+        // same time, so the 2-3 residents of a CU start, reach their epilogue and get replaced
+        // TOGETHER, round after round, and the matrix pipe idles during every such
+        // prologue/epilogue window (ablation: 14 % of a 64->64 layer).  Delaying the first
+        // occupant of slot s (dispatch is breadth-first: linear id / 256) by s * stagger cycles
+        // once makes the residents take turns for the rest of the launch: 64->64@128^2 in a
+        // back-to-back micro-benchmark 101.6 -> 118.4 TFLOP/s (tools/ablate_halo.py STAG=...),
+        // inside the network 113 -> 115 (the layers are less lock-stepped there).  Only used
+        // when the launch runs enough rounds to amortise the initial delay.
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned slot = lin / 256;
+        if (slot >= 1 && slot < (unsigned)a.stagger_slots) {
+            const long long t0 = __builtin_readcyclecounter();
+            const long long wait = (long long)slot * a.stagger;
+            while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     // ---- per-thread halo rows: pixel offset in the input (or -1: outside image / halo)
     int hoff[NPA];
 #pragma unroll
@@ -471,6 +493,21 @@ int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
     dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, BN), DECONV ? 4 : 1);
+    {
+        // resident workgroups per CU of this variant (registers / LDS), MFMA cycles one tile
+        // needs per SIMD, and the number of dispatch rounds of this launch
+        constexpr int slots = (BN >= 128 || HEADS || BM > 128) ? 2 : (BN == 64 ? 3 : 4);
+        constexpr long cyc_iter = sizeof(T) == 4 ? (long)BM * BN / 4 : (long)BM * BN / 32;
+        const long total = (long)grid.x * grid.y * grid.z;
+        const long rounds = total / (256L * slots);
+        const long tile_cycles = (long)b.nchunk * (DECONV ? 4 : 9) * cyc_iter;
+        if (cn_tune_stagger_pct > 0 && rounds >= 4) {
+            b.stagger_slots = slots;
+            b.stagger = (int)(tile_cycles * cn_tune_stagger_pct / 100);
+        } else {
+            b.stagger = 0;
+        }
+    }
     const C3Heads none = {};
     hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV>), grid,
                        dim3(WM * WN * 64), lds,

@@ -69,6 +69,9 @@ const char *cn_arch(void);
  *         form (cn_conv.hip); kept for A/B: it measured 20-30 % slower.
  * key 7: XCD-aware tile order: 0 = deformable kernel only (default, +5-10 % there), 1 = also
  *        the dense implicit-GEMM kernels (no gain measured), 2 = nowhere.
+ * key 18: phase shift of the workgroups that share a CU in the LDS-halo kernel, in percent of
+ *         one tile's MFMA time (default 100, 0 = off); applied to launches of >= 4 dispatch rounds.
+ * key 16 / 17: split-K: least K chunks per slice (default 8) / most slices (default 16).
  * key 15: 0 = 4-wave instead of 8-wave workgroups for the 128-wide tiles of the LDS-halo kernel
  *         (default 1: +1 %, measured).
  * key 14: 1 = 256-pixel tiles for 64-wide layers in the LDS-halo kernel (default 0: measured,

@@ -8,13 +8,14 @@ from centernet_amd import native
 from centernet_amd.engine import PlanBuilder, Act
 dev = torch.device("cuda:0"); lib = native.lib(); B = 32
 SHAPES = [(64, 128, 128, 64), (128, 64, 64, 128), (256, 32, 32, 256), (512, 16, 16, 512)]
-print("%-22s" % "Cin,H,W,Cout", "  ".join("%-12s" % n for n in ("full", "-epilogue", "-B stage", "-A stage", "-all three")))
+STAG = [int(v) for v in os.environ.get("STAG", "").split(",") if v]
+print("%-22s" % "Cin,H,W,Cout", "  ".join("%-12s" % n for n in (["stag%d" % v for v in STAG] if STAG else ("full", "-epilogue", "-B stage", "-A stage", "-all three"))))
 for ci, H, W, co in SHAPES:
     x = Act(torch.randn((B, H, W, ci), device=dev), B, H, W, ci)
     w = torch.randn((co, ci, 3, 3)) * 0.05
     row = []
-    for dbg in (0, 1, 2, 4, 7):
-        lib.cn_set_tuning(9, dbg)
+    for dbg in (STAG if STAG else (0, 1, 2, 4, 7)):
+        lib.cn_set_tuning(18 if STAG else 9, dbg)
         pb = PlanBuilder(dev, B, H, W)
         pb.conv(x, w, relu=True, stride=1, padding=1)
         for _ in range(3): pb.ops[0]()
@@ -26,4 +27,4 @@ for ci, H, W, co in SHAPES:
         ms = s.elapsed_time(e) / 20
         row.append("%.3f %5.1fTF" % (ms, pb.flops / ms / 1e9))
     print("%-22s" % str((ci, H, W, co)), "  ".join(row))
-lib.cn_set_tuning(9, 0)
+lib.cn_set_tuning(9, 0); lib.cn_set_tuning(18, 0)
