@@ -29,4 +29,5 @@ static inline int cn_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t cn_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 typedef float cn_f32x4 __attribute__((ext_vector_type(4)));
+typedef int cn_i32x4 __attribute__((ext_vector_type(4)));
 typedef float cn_f32x16 __attribute__((ext_vector_type(16)));

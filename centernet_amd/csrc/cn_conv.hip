@@ -119,13 +119,13 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     float *As = reinterpret_cast<float *>(smem);  // [NBUF][BM][LDT]
     float *Bs = As + NBUF * BM * LDT;             // [NBUF][BN][LDT]
     int *rowoff = reinterpret_cast<int *>(As + UNION_FLOATS);  // [BM]
-    // DCN sampling records of ONE tap per row (4 corner pixel indices, 4 weights, mask),
-    // double-buffered by tap parity: the records of tap t+1 are written while tap t runs
+    // DCN sampling records (4 corner byte offsets, 4 bilinear weights, mask) of every
+    // (tap, tile pixel), built ONCE in the prologue by all threads: 9 * BM * 36 bytes
     // stem: k -> (plane offset, ky, kx) table, k = tap*3 + rgb  [STEM_KMAX] x 2 ints
     int *ktab = rowoff + BM;
-    int *sidx = rowoff + BM;                                  // [2][BM][4]
-    float *swt = reinterpret_cast<float *>(sidx + 2 * BM * 4);  // [2][BM][4]
-    float *smk = swt + 2 * BM * 4;                            // [2][BM]
+    int *sidx = rowoff + BM;                                  // [9][BM][4] corner byte offsets
+    float *swt = reinterpret_cast<float *>(sidx + 9 * BM * 4);  // [9][BM][4] corner weights
+    float *smk = swt + 9 * BM * 4;                            // [9][BM]    modulation mask
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -192,9 +192,10 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         rowoff[r] = off;
     }
     // dcn_v2_im2col_cuda.cu:151-176 and :18-47, evaluated once per (pixel, tap)
-    auto dcn_records = [&](int tap) {
-        const int pb = tap & 1;
-        for (int r = tid; r < BM; r += NT) {
+    auto dcn_records = [&](int tap_lo, int tap_hi) {
+        for (int i = tid; i < (tap_hi - tap_lo) * BM; i += NT) {
+            const int tap = tap_lo + i / BM, r = i % BM;
+            const int pb = tap;
             const int m = m0 + r;
             int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
             float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
@@ -226,11 +227,14 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                     w4 = (hh_ok && wh_ok) ? lh * lw : 0.f;
                     const int yl = max(h_low, 0), yh = min(h_high, H - 1);
                     const int xl = max(w_low, 0), xh = min(w_high, W - 1);
+                    // byte offsets of the four corner pixels (fit 32 bits: checked by the host),
+                    // so the gather below is `global_load base(SGPR) + offset(VGPR)`
                     const int base = b * H * W;
-                    i0 = base + yl * W + xl;
-                    i1 = base + yl * W + xh;
-                    i2 = base + yh * W + xl;
-                    i3 = base + yh * W + xh;
+                    const int pb4 = a.in_pitch * (int)sizeof(float);
+                    i0 = (base + yl * W + xl) * pb4;
+                    i1 = (base + yl * W + xh) * pb4;
+                    i2 = (base + yh * W + xl) * pb4;
+                    i3 = (base + yh * W + xh) * pb4;
                 }
             }
             int *si = sidx + (pb * BM + r) * 4;
@@ -248,10 +252,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         kt1 = (int)((long)(blockIdx.z + 1) * a.KT / a.ksplit);
     }
     const int tap0 = kt0 / a.nchunk, tap1 = kt1 / a.nchunk;
-    if (AMODE == A_DCN) {
-        dcn_records(tap0);
-        if (tap0 + 1 < tap1) dcn_records(tap0 + 1);
-    }
+    if (AMODE == A_DCN) dcn_records(tap0, tap1);
     if (AMODE == A_STEM) {
         const int taps = a.KH * a.KW;
         for (int k = tid; k < a.cin_pad; k += NT) {
@@ -329,16 +330,22 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
             }
         } else {  // A_DCN: four bilinear corners, each a 16-byte channel vector
             const int c = c0 + EPV * q;
+            const char *xb = reinterpret_cast<const char *>(a.x);
+            const bool cok = c < a.Cin;  // false only in the padded tail of a Cin % 32 != 0 layer
+            const unsigned cbyte = (unsigned)(cok ? c : 0) * (unsigned)sizeof(float);
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int r = p * 32 + lrow;
-                const int *si = sidx + ((tap & 1) * BM + r) * 4;
+                const cn_i32x4 si = *reinterpret_cast<const cn_i32x4 *>(sidx + (tap * BM + r) * 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
-                        xT + ((size_t)si[j] * a.in_pitch + (c < a.Cin ? c : 0)));
-                    ra[p][j] = (c < a.Cin) ? v : zero4;
-                }
+                for (int j = 0; j < 4; ++j)
+                    ra[p][j] = *reinterpret_cast<const cn_f32x4 *>(xb + ((unsigned)si[j] + cbyte));
+            }
+            if (a.Cin & 31) {  // uniform: CenterNet's DCN layers have Cin % 32 == 0
+#pragma unroll
+                for (int p = 0; p < PA; ++p)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ra[p][j] = cok ? ra[p][j] : zero4;
             }
         }
     };
@@ -356,8 +363,8 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int r = p * 32 + lrow;
-                const float *wt = swt + ((tap & 1) * BM + r) * 4;
-                const float mk = smk[(tap & 1) * BM + r];
+                const float *wt = swt + (tap * BM + r) * 4;
+                const float mk = smk[tap * BM + r];
                 const float w1 = wt[0], w2 = wt[1], w3 = wt[2], w4 = wt[3];
                 cn_f32x4 v;
                 // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (dcn_v2_im2col_cuda.cu:43-45,174)
@@ -426,22 +433,15 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     for (int kt = kt0; kt < kt1; ++kt) {
         const bool more = (kt + 1) < kt1 && !(a.dbgskip == 3);
         if (more) load_tiles(kt + 1);
-        // DCN: the records of tap t (t >= 2) are first read by load_tiles(t*nchunk) in
-        // iteration t*nchunk-1; their buffer (parity of t) was last read in iteration
-        // (t-1)*nchunk-2, so iteration t*nchunk-2 is the safe place to write them.
-        const bool rec = (AMODE == A_DCN) && ((kt + 2) % a.nchunk == 0) &&
-                         ((kt + 2) / a.nchunk >= tap0 + 2) && ((kt + 2) / a.nchunk < tap1);
         if (NBUF == 2) {
             const int buf = (kt - kt0) & 1;
             compute(buf);
             if (more) store_tiles(buf ^ 1, kt + 1);
-            if (rec) dcn_records((kt + 2) / a.nchunk);
             __syncthreads();
         } else {
             compute(0);
             __syncthreads();
             if (more) store_tiles(0, kt + 1);
-            if (rec) dcn_records((kt + 2) / a.nchunk);
             __syncthreads();
         }
     }
@@ -567,7 +567,7 @@ constexpr size_t igemm_lds_bytes()
     constexpr size_t tiles = (size_t)NBUF * (BM + BN) * LDT;
     constexpr size_t cs = OUT_NCHW ? 0 : (size_t)(BM / WM) * (BN + 4);
     return (tiles > cs ? tiles : cs) * 4 + BM * 4 +
-           (AMODE == A_DCN ? (size_t)2 * BM * (4 * 4 + 4 * 4 + 4) : 0) +
+           (AMODE == A_DCN ? (size_t)9 * BM * (4 * 4 + 4 * 4 + 4) : 0) +
            (AMODE == A_STEM ? (size_t)STEM_KMAX * 8 : 0);
 }
 
@@ -1005,7 +1005,7 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
     if (om_pitch < 27) return CN_ERR_SHAPE;
     if ((Cin & 3) != 0) return CN_ERR_UNSUPPORTED;
     if (!cn_aligned16(input_nhwc) || !cn_aligned16(weight_packed)) return CN_ERR_ALIGN;
-    if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1L << 31)) return CN_ERR_UNSUPPORTED;
+    if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1L << 30)) return CN_ERR_UNSUPPORTED;  // 32-bit byte offsets
     // LDS-staged input window (cn_dcn.hip): measured 20-30 % SLOWER than the L1/L2-served
     // gather below on every CenterNet shape (tools/bench_dcn.py), so it is opt-in only
     if (g_tune_dcn_window && Cout > 32) {
