@@ -34,7 +34,9 @@ constexpr int NT = 256;
 constexpr int BK = 32;
 constexpr int LDT = BK + 4;  // LDS row pitch in floats
 
-enum { A_DENSE = 0, A_STEM = 1, A_DCN = 2 };
+// A_DCN_PAD: the deformable form for Cin % 32 != 0 (zero-fills the padded channels of the last
+// chunk); CenterNet's own layers (Cin = 64..512) take A_DCN, whose gather has no select at all
+enum { A_DENSE = 0, A_STEM = 1, A_DCN = 2, A_DCN_PAD = 3 };
 constexpr int STEM_KMAX = 512;  // largest padded K of a 3-channel stem (11x11 -> 363 -> 384)
 
 struct IgemmArgs {
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     constexpr int EPV = ElemTraits<T>::EPV;  // elements per 16-byte vector
     constexpr int BKE = 8 * EPV;             // channels per chunk (one 128-byte LDS row)
     constexpr bool F16 = (EPV == 8);
-    static_assert(!(F16 && AMODE == A_DCN), "the deformable kernel is fp32 only");
+    constexpr bool DCN = (AMODE == A_DCN || AMODE == A_DCN_PAD);
+    static_assert(!(F16 && DCN), "the deformable kernel is fp32 only");
     static_assert(NBUF == 1 || NBUF == 2, "LDS tile buffers");
     static_assert(WM * WN == NT / CN_WAVE, "4 waves");
     constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         kt1 = (int)((long)(blockIdx.z + 1) * a.KT / a.ksplit);
     }
     const int tap0 = kt0 / a.nchunk, tap1 = kt1 / a.nchunk;
-    if (AMODE == A_DCN) dcn_records(tap0, tap1);
+    if (DCN) dcn_records(tap0, tap1);
     if (AMODE == A_STEM) {
         const int taps = a.KH * a.KW;
         for (int k = tid; k < a.cin_pad; k += NT) {
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int NCORN = (AMODE == A_DCN) ? 4 : 1;
+    constexpr int NCORN = DCN ? 4 : 1;
     cn_f32x4 ra[PA][NCORN];
     cn_f32x4 rb[PB];
     const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 for (int j = 0; j < 4; ++j)
                     ra[p][j] = *reinterpret_cast<const cn_f32x4 *>(xb + ((unsigned)si[j] + cbyte));
             }
-            if (a.Cin & 31) {  // uniform: CenterNet's DCN layers have Cin % 32 == 0
+            if (AMODE == A_DCN_PAD) {
 #pragma unroll
                 for (int p = 0; p < PA; ++p)
 #pragma unroll
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         for (int p = 0; p < PB; ++p)
             *reinterpret_cast<cn_f32x4 *>(Bd + (p * 32 + lrow) * LDT + 4 * q) = rb[p];
         if (a.dbgskip & 1) return;
-        if (AMODE == A_DCN) {
+        if (DCN) {
             const int tap = kt / a.nchunk;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
@@ -567,7 +570,7 @@ constexpr size_t igemm_lds_bytes()
     constexpr size_t tiles = (size_t)NBUF * (BM + BN) * LDT;
     constexpr size_t cs = OUT_NCHW ? 0 : (size_t)(BM / WM) * (BN + 4);
     return (tiles > cs ? tiles : cs) * 4 + BM * 4 +
-           (AMODE == A_DCN ? (size_t)9 * BM * (4 * 4 + 4 * 4 + 4) : 0) +
+           ((AMODE == A_DCN || AMODE == A_DCN_PAD) ? (size_t)9 * BM * (4 * 4 + 4 * 4 + 4) : 0) +
            (AMODE == A_STEM ? (size_t)STEM_KMAX * 8 : 0);
 }
 
@@ -576,7 +579,6 @@ int g_tune_dbgskip = 0; // cn_set_tuning key 9 (ablation only): bit0 skip A stag
 int g_tune_swz = 0;   // cn_set_tuning key 7: XCD-aware tile order, 0 = deformable kernel only (default), 1 = all, 2 = none
 int g_tune_nbuf = 0;  // 0 = per-shape default, 1 / 2 = force (cn_set_tuning key 1)
 int g_tune_narrow = 0; // cn_set_tuning key 2: 0 = default, 1 = never prefer 64-wide tiles
-int g_tune_dcn_tile = 0; // cn_set_tuning key 3: 0 = default, 64 / 128 = force the DCN pixel tile
 int g_tune_bm = 0;       // cn_set_tuning key 4: 0 = default, 64 / 128 = force the dense pixel tile
 int g_tune_nosplit = 0;  // cn_set_tuning key 5: 1 = never split K
 int g_tune_stem_persist = 1; // cn_set_tuning key 12: persistent, prefetching stem kernel (cn_stem.hip)
@@ -598,7 +600,7 @@ int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
     // ~36x; with round-robin tile -> XCD placement only 31 % of those hit the 4 MB L2, measured
     // TCC_HIT/TCC_MISS; contiguous tile ranges per XCD: +5-10 %, tools/bench_dcn.py SWZ=1);
     // cn_set_tuning key 7: 0 = default, 1 = also the dense kernels, 2 = nowhere
-    b.xcd_swizzle = (grid.x >= 16 && g_tune_swz != 2 && (AMODE == A_DCN || g_tune_swz == 1)) ? 1 : 0;
+    b.xcd_swizzle = (grid.x >= 16 && g_tune_swz != 2 && (AMODE == A_DCN || AMODE == A_DCN_PAD || g_tune_swz == 1)) ? 1 : 0;
     b.setprio = g_tune_setprio;
     b.dbgskip = g_tune_dbgskip;
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, AMODE, OUT_NCHW, NBUF>), grid, dim3(NT),
@@ -611,7 +613,7 @@ int launch_igemm_n(const IgemmArgs &a, hipStream_t st)
 template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW>
 int launch_igemm_h(const IgemmArgs &a, hipStream_t st)
 {
-    static_assert(AMODE != A_DCN, "fp16 DCN is not built");
+    static_assert(AMODE != A_DCN && AMODE != A_DCN_PAD, "fp16 DCN is not built");
     if (!OUT_NCHW && AMODE == A_DENSE && a.stride == 1)
         return launch_igemm_n<_Float16, BM, BN, WM, WN, AMODE, OUT_NCHW, 1>(a, st);
     return launch_igemm_n<_Float16, BM, BN, WM, WN, AMODE, OUT_NCHW, 2>(a, st);
@@ -1030,14 +1032,11 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
     a.KT = 9 * a.nchunk;
     a.vec_out = ((Cout & 3) == 0 && cn_aligned16(output_nhwc)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    // 128-pixel tiles amortise the gather over more MFMAs; 64-pixel tiles when the layer
-    // would otherwise not fill the 256 CUs (cn_set_tuning key 3 forces one or the other)
-    const long tiles128 = (long)cn_cdiv(a.M, 128) * cn_cdiv(Cout, Cout > 64 ? 128 : 64);
-    (void)tiles128;  // measured (tools/bench_dcn.py): 64-pixel tiles win at every CenterNet shape
-    const bool small = g_tune_dcn_tile ? (g_tune_dcn_tile == 64) : true;
+    // 64-pixel tiles: 128-pixel tiles were measured slower at every CenterNet shape
+    // (tools/bench_dcn.py) and are no longer built
     // tap split (needs the caller's workspace; without one the layer runs unsplit)
     a.ksplit = 1;
-    if (small && Cout > 32) {
+    if (Cout > 32) {
         const int want = dcn_ksplit(B, H, W, Cout);
         const size_t need = (size_t)want * a.M * a.cout_pad * sizeof(float);
         if (want > 1 && workspace && workspace_bytes >= need && cn_aligned16(workspace)) {
@@ -1046,14 +1045,16 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
         }
     }
     int rc;
+    const bool padk = (Cin & 31) != 0;
     if (Cout > 64)
-        rc = small ? launch_igemm<64, 128, 2, 2, A_DCN, false>(a, st)
-                   : launch_igemm<128, 128, 2, 2, A_DCN, false>(a, st);
+        rc = padk ? launch_igemm<64, 128, 2, 2, A_DCN_PAD, false>(a, st)
+                  : launch_igemm<64, 128, 2, 2, A_DCN, false>(a, st);
     else if (Cout > 32)
-        rc = small ? launch_igemm<64, 64, 2, 2, A_DCN, false>(a, st)
-                   : launch_igemm<128, 64, 2, 2, A_DCN, false>(a, st);
+        rc = padk ? launch_igemm<64, 64, 2, 2, A_DCN_PAD, false>(a, st)
+                  : launch_igemm<64, 64, 2, 2, A_DCN, false>(a, st);
     else
-        rc = launch_igemm<128, 32, 4, 1, A_DCN, false>(a, st);
+        rc = padk ? launch_igemm<128, 32, 4, 1, A_DCN_PAD, false>(a, st)
+                  : launch_igemm<128, 32, 4, 1, A_DCN, false>(a, st);
     if (rc != CN_OK || a.ksplit == 1) return rc;
     const size_t total = (size_t)a.M * (a.cout_pad >> 2);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -1153,10 +1154,7 @@ extern "C" int cn_set_tuning(int key, int value)
         g_tune_narrow = value;
         return CN_OK;
     }
-    if (key == 3 && (value == 0 || value == 64 || value == 128)) {
-        g_tune_dcn_tile = value;
-        return CN_OK;
-    }
+    if (key == 3 && (value == 0 || value == 64)) return CN_OK;  // 128-pixel DCN tiles: retired
     if (key == 4 && (value == 0 || value == 64 || value == 128)) {
         g_tune_bm = value;
         return CN_OK;

@@ -57,7 +57,7 @@ const char *cn_arch(void);
  * key 1: LDS tile buffers of the dense implicit-GEMM kernels, 0 = default, 1 or 2.
  * key 2: 1 = never pick 64-wide N tiles for Cout > 64 (default 0 = pick them when they
  *        avoid a half-empty 128-wide tile).
- * key 3: pixel tile of the deformable kernel, 0 = default, 64 or 128.
+ * key 3: (retired) pixel tile of the deformable kernel; 64-pixel tiles are the only form built.
  * key 4: pixel tile of the dense kernels for Cout > 64, 0 = default, 64 or 128.
  * key 5: 1 = never split K.
  * key 6: 1 = run the 3-channel stem on the generic implicit-GEMM kernel instead of the
