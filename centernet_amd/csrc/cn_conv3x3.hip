@@ -2,6 +2,9 @@
 // (resnet_dcn.py:38-67 BasicBlock convs, the 3x3 of every head :155-177, conv_offset_mask of
 // DCN dcn_v2.py:52-57, DLA tree blocks pose_dla_dcn.py:31-62, hourglass residuals
 // large_hourglass.py:48-74), as an im2col-free LDS tiling on the fp32 matrix cores.
+// Template variants of the same kernel: HEADS (the whole head stack conv3x3+ReLU+conv1x1 of
+// all heads in one launch), DECONV (ConvTranspose2d 4x4/2 as four parity 2x2 convolutions over
+// the same halo, resnet_dcn.py:228-235), KSKIP (Cin % 32 != 0), fp16 (fp32 accumulate).
 //
 // Why a second kernel next to the generic implicit GEMM (cn_conv.hip): there the A tile of
 // every (tap, 32-channel chunk) is re-fetched from global memory and re-written to LDS, and
@@ -50,7 +53,11 @@ struct C3Args {
     const void *residual;        // element type T
     void *y;                     // element type T
     int B, H, W, Cin, Cout, in_pitch, out_pitch, relu;
-    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio, bm256, waves8, nkk_last, dbg, stagger, stagger_slots;
+    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio;
+    int bm256, waves8;           // tile-shape knobs (cn_set_tuning keys 14, 15)
+    int nkk_last;                // KSKIP: 8-channel K groups of the last chunk that hold data
+    int dbg;                     // ablation switches (cn_set_tuning key 9)
+    int stagger, stagger_slots;  // phase shift of co-resident workgroups (cycles per slot, slots)
 };
 
 // Fused detection heads (HEADS = true): blockIdx.y selects the head; its 64 hidden channels
