@@ -202,10 +202,17 @@ constexpr int PLDW = PKP + 4;      // LDS weight row pitch (floats)
 template <int BN, int S>
 __global__ __launch_bounds__(NT) void stem_persist_f32_kernel(const StemArgs a, int total_tiles)
 {
-    constexpr int WN = BN / 32;
+    // BN == 16 (DLA's base_layer, 3 -> 16): v_mfma_f32_16x16x4_f32 instead of the 32x32x2 form,
+    // so that no half of the N tile is padding.  K is then ordered (c, ky-quad, kx): the four
+    // lane quarters take ky = 4g .. 4g+3 of the same (c, kx) -- LDS addresses one window row
+    // apart, again `ds_read_b32 base offset:imm` -- and the lane's 42 weights live in registers
+    // for the whole persistent loop (no weight tile in LDS at all).
+    constexpr bool N16 = (BN == 16);
+    constexpr int WN = N16 ? 1 : BN / 32;
     constexpr int WM = 4 / WN;
     constexpr int TM = BM / WM;
-    constexpr int MB = TM / 32;
+    constexpr int MB = N16 ? TM / 16 : TM / 32;
+    constexpr int NE16 = 3 * 2 * PKW;  // 42 (c, ky-quad, kx) elements of the N16 form
     constexpr int WX = (BM - 1) * S + PKW;
     constexpr int WXP = WX | 1;
     constexpr int WIN_FLOATS = ((PROWS + 1) * WXP + 3) & ~3;  // + one zero row
@@ -220,8 +227,21 @@ __global__ __launch_bounds__(NT) void stem_persist_f32_kernel(const StemArgs a, 
     const int n0 = blockIdx.y * BN;
     const int tpr = a.Wo / BM;  // tiles per output row
 
+    const int l15 = lane & 15, lq = lane >> 4;
+    float wreg[N16 ? NE16 : 1];
+    if constexpr (N16) {
+#pragma unroll
+        for (int e = 0; e < NE16; ++e) {
+            const int c = e / (2 * PKW), g = (e / PKW) % 2, kx = e % PKW;
+            const int ky = 4 * g + lq;
+            const int nn = min(n0 + l15, a.cout_pad - 1);
+            wreg[e] = (ky < PKH && n0 + l15 < a.Cout)
+                          ? a.w[(size_t)nn * a.KP + (ky * PKW + kx) * 3 + c] : 0.f;
+        }
+    }
     // ---- once per workgroup: weights of this N tile, permuted from the packed
     // [cout_pad][KP] (k = tap*3 + c) layout into the (group, half, element) K order
+    if constexpr (!N16)
     for (int i = tid; i < BN * PKP; i += NT) {
         const int nrow = i / PKP, k = i - nrow * PKP;
         const int g = k >> 3, half = (k >> 2) & 1, e = k & 3;
@@ -279,9 +299,11 @@ __global__ __launch_bounds__(NT) void stem_persist_f32_kernel(const StemArgs a, 
 
     const float *abase[MB];
 #pragma unroll
-    for (int i = 0; i < MB; ++i) abase[i] = win + (wm * TM + i * 32 + l31) * S + lh * WXP;
+    for (int i = 0; i < MB; ++i)
+        abase[i] = N16 ? win + (wm * TM + i * 16 + l15) * S + lq * WXP
+                       : win + (wm * TM + i * 32 + l31) * S + lh * WXP;
     const float *wrow = Ws + (wn * 32 + l31) * PLDW + 4 * lh;
-    const int n = n0 + wn * 32 + l31;
+    const int n = N16 ? n0 + l15 : n0 + wn * 32 + l31;
     float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
     float sf = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
     asm volatile("" : "+v"(sc), "+v"(sf));  // settle these loads before the tile loop
@@ -294,6 +316,37 @@ __global__ __launch_bounds__(NT) void stem_persist_f32_kernel(const StemArgs a, 
         const int next = tile + gridDim.x;
         if (next < total_tiles) prefetch(next);  // in flight during the MFMAs below
 
+        if constexpr (N16) {
+            cn_f32x4 acc4[MB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc4[i] = cn_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < NE16; ++e) {
+                const int c = e / (2 * PKW), g = (e / PKW) % 2, kx = e % PKW;
+                const int off = (c * PKH + 4 * g) * WXP + kx;  // compile-time immediate
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    acc4[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(abase[i][off], wreg[e], acc4[i],
+                                                                   0, 0, 0);
+            }
+            // D of the 16x16 MFMA: col = lane & 15 (cout), rows 4*(lane >> 4) + r (pixels)
+            if (n < a.Cout) {
+                const int xt = tile % tpr;
+                const int rowid = tile / tpr;
+                float *yb = a.y + ((size_t)rowid * a.Wo + (size_t)xt * BM) * a.out_pitch + n;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = wm * TM + i * 16 + 4 * lq + r;
+                        float t = acc4[i][r] * sc + sf;
+                        if (a.relu) t = fmaxf(t, 0.f);
+                        yb[(size_t)m * a.out_pitch] = t;
+                    }
+            }
+            __syncthreads();  // every wave is done reading the window
+            continue;
+        }
         cn_f32x16 acc[MB];
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -342,7 +395,7 @@ template <int BN, int S>
 int launch_stem_persist(const StemArgs &a, int B, hipStream_t st)
 {
     constexpr int WXP = ((BM - 1) * S + PKW) | 1;
-    constexpr size_t lds = (size_t)((((PROWS + 1) * WXP + 3) & ~3) + NT + BN * PLDW) * 4;
+    constexpr size_t lds = (size_t)((((PROWS + 1) * WXP + 3) & ~3) + NT + (BN == 16 ? 0 : BN * PLDW)) * 4;
     const long total = (long)B * a.tiles_per_image;
     const int wgs = (int)(total < 512 ? total : 512);  // two resident workgroups per CU
     dim3 grid(wgs, cn_cdiv(a.Cout, BN));
@@ -373,6 +426,9 @@ int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, 
         if (Cout > 32)
             return stride == 2 ? launch_stem_persist<64, 2>(a, B, st)
                                : launch_stem_persist<64, 1>(a, B, st);
+        if (Cout <= 16)
+            return stride == 2 ? launch_stem_persist<16, 2>(a, B, st)
+                               : launch_stem_persist<16, 1>(a, B, st);
         return stride == 2 ? launch_stem_persist<32, 2>(a, B, st)
                            : launch_stem_persist<32, 1>(a, B, st);
     }

@@ -131,7 +131,9 @@ def test_stem_conv_nchw_input(dev):
     # B, H, W, Cout, stride, persistent-eligible (output rows a multiple of 128 px)
     (2, 20, 256, 64, 2, True),     # resnet / hourglass stem shape class (Wo = 128)
     (3, 9, 512, 128, 2, True),     # Wo = 256: two tiles per row, two N tiles (hourglass: 128 ch)
-    (2, 11, 128, 16, 1, True),     # DLA base_layer: stride 1, 16 channels (32-wide N tile)
+    (2, 11, 128, 16, 1, True),     # DLA base_layer: stride 1, 16 channels (16x16x4 MFMA form)
+    (1, 40, 256, 12, 2, True),     # <= 16 channels, stride 2, ragged channel count
+    (2, 9, 128, 24, 1, True),      # 17..32 channels: 32-wide N tile
     (4, 300, 256, 64, 2, True),    # 600 tiles > 512 persistent workgroups: the tile loop runs > 1x
     (2, 33, 200, 64, 2, False),    # not a multiple of 128: one-tile-per-workgroup kernel
 ])
