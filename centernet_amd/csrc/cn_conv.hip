@@ -679,6 +679,9 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                  int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
                  int f16, hipStream_t st);
+int cn_conv3x3_c16(const float *x, const float *w_packed, const float *scale, const float *shift,
+                   float *y, int B, int H, int W, int Ho, int Wo, int Cin, int Cout, int stride,
+                   int in_pitch, int out_pitch, int relu, hipStream_t st);
 extern int cn_tune_stagger_pct;  // cn_conv3x3.hip
 int cn_deconv4x4s2_halo(const float *x, const float *w_packed, const float *scale, const float *shift,
                         float *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
@@ -931,6 +934,16 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_STEM, false>(a, st);
         if (d->Cout > 32) return launch_igemm<128, 64, 2, 2, A_STEM, false>(a, st);
         return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
+    }
+    // 16-channel input, <= 32 output channels (DLA level0 / level1): cn_conv16.hip
+    if (!g_tune_nohalo && !f16 && !residual && a.ksplit == 1 && d->Cin == 16 && d->Cout <= 32 &&
+        d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->dil == 1 &&
+        d->oy_mul == 1 && d->ox_mul == 1 && d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho &&
+        d->OW == d->Wo && d->in_layout == CN_LAYOUT_NHWC) {
+        rc = cn_conv3x3_c16((const float *)x, (const float *)w_packed, scale, shift, (float *)y, d->B,
+                            d->H, d->W, d->Ho, d->Wo, d->Cin, d->Cout, d->stride, d->in_pitch,
+                            d->out_pitch, d->relu, st);
+        if (rc != CN_ERR_UNSUPPORTED) return rc;
     }
     // 3x3 / stride 1 / pad 1: the LDS-halo kernel (cn_conv3x3.hip) unless split-K applies
     if (!g_tune_nohalo && a.ksplit == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&

@@ -54,6 +54,12 @@ def _bn(C, seed):
     # partially filled last K chunk (DLA level0: 16 -> 16): empty 8-channel groups are skipped
     (2, 16, 64, 64, 16, 3, 1, 1, False, True, True, False),
     (1, 40, 20, 24, 24, 3, 1, 1, True, False, False, True),
+    # 16-channel input on 128-pixel-multiple rows: the 16x16x4-MFMA kernel (cn_conv16.hip)
+    (2, 16, 20, 128, 16, 3, 1, 1, False, True, True, False),    # DLA level0 form
+    (1, 16, 33, 256, 32, 3, 2, 1, False, True, True, False),    # DLA level1 form (stride 2)
+    (2, 16, 12, 256, 24, 3, 1, 1, True, False, False, False),   # two N blocks, ragged Cout
+    (3, 16, 9, 256, 9, 3, 2, 1, True, False, True, False),      # one N block, stride 2
+    (5, 16, 130, 128, 16, 3, 1, 1, False, True, True, False),   # 650 tiles > 512 workgroups
 ])
 def test_conv_bn_relu_residual(dev, cfg):
     _conv_case(dev, cfg)
