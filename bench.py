@@ -41,7 +41,7 @@ def pmc_traffic():
     for k, v in raw.items():
         if k.startswith("igemm_kernel"):
             c = "dcn" if k.rstrip(">").split(",")[5].strip() == "2" else "conv"
-        elif k.startswith(("stem_conv", "stem_persist", "splitk_reduce", "conv3x3s1_kernel")):
+        elif k.startswith(("stem_conv", "stem_persist", "splitk_reduce", "conv3x3s1_kernel", "conv16_kernel")):
             c = "conv"
         elif k.startswith(("nms_topk", "merge_topk")):
             c = "decode"
