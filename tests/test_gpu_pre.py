@@ -89,3 +89,22 @@ def test_detector_pre_process_device_equals_host(dev, shape, scale, keep, flip):
     assert np.array_equal(a.numpy().view(np.uint32), b.cpu().numpy().view(np.uint32))
     assert ma['out_height'] == mb['out_height'] and ma['out_width'] == mb['out_width']
     assert np.array_equal(ma['c'], mb['c']) and np.array_equal(np.asarray(ma['s']), np.asarray(mb['s']))
+
+
+def test_warp_random_sweep_bit_exact(dev):
+    """40 seeded random (size, matrix, flip) cases: device == scalar oracle, bit for bit."""
+    rng = np.random.RandomState(2024)
+    for case in range(40):
+        h, w = int(rng.randint(1, 40)), int(rng.randint(1, 40))
+        oh, ow = int(rng.randint(1, 48)), int(rng.randint(1, 48))
+        m = [rng.uniform(-2, 2), rng.uniform(-1, 1), rng.uniform(-20, 20),
+             rng.uniform(-1, 1), rng.uniform(-2, 2), rng.uniform(-20, 20)]
+        if case % 5 == 0:   # exact half-pixel positions: the rounding rule matters
+            m = [1.0, 0.0, float(rng.randint(-3, 3)) + 0.5, 0.0, 1.0, float(rng.randint(-3, 3)) + 0.5]
+        img = _img(h, w, 100 + case)
+        flip = bool(case & 1)
+        got = _warp_norm(dev, img, m, oh, ow, flip)
+        ref = I.normalize_chw(P.warp_bilinear_u8(img, m, (ow, oh)), MEAN, STD)[None]
+        if flip:
+            ref = np.concatenate((ref, ref[:, :, :, ::-1]), axis=0)
+        assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref).view(np.uint32)), case
