@@ -585,6 +585,7 @@ int g_tune_stem_persist = 1; // cn_set_tuning key 12: persistent, prefetching st
 int g_tune_dcn_split = 0;   // cn_set_tuning key 13: 0 = auto, 1 = never, 3 / 9 = force tap split of the deformable kernel
 int g_tune_bm256 = 0;       // cn_set_tuning key 14: 1 = 256-pixel tiles for 64-wide layers in the halo kernel (no gain, measured)
 int g_tune_waves8 = 1;      // cn_set_tuning key 15: 8-wave workgroups for the 128-wide halo tiles
+int g_tune_occ4 = 0;        // cn_set_tuning key 19: 4-workgroups-per-CU form of the 64-wide halo tiles: 0 = by rounds rule, 1 = always, 2 = never
 int g_tune_dcn_window = 0; // cn_set_tuning key 11: 1 = LDS-window DCN (cn_dcn.hip); default global gather (faster, measured)
 int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip
 int g_tune_nostem = 0;   // cn_set_tuning key 6: 1 = generic implicit-GEMM stem instead of cn_stem.hip
@@ -951,7 +952,8 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho && d->OW == d->Wo)
         return cn_conv3x3s1(x, w_packed, scale, shift, residual, y, d->B, d->H, d->W, d->Cin,
                             d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
-                            g_tune_setprio | (g_tune_bm256 << 1) | (g_tune_waves8 << 2) | (g_tune_dbgskip << 4), cls, f16 ? 1 : 0, st);
+                            g_tune_setprio | (g_tune_bm256 << 1) | (g_tune_waves8 << 2) | (g_tune_occ4 << 7) |
+                                (g_tune_dbgskip << 4), cls, f16 ? 1 : 0, st);
     if (f16) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_h<64, 128, 2, 2, A_DENSE, false>(a, st)
@@ -1218,6 +1220,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 18 && value >= 0 && value <= 255) {
         cn_tune_stagger_pct = value;
+        return CN_OK;
+    }
+    if (key == 19 && value >= 0 && value <= 2) {
+        g_tune_occ4 = value;
         return CN_OK;
     }
     if (key == 15 && (value == 0 || value == 1)) {

@@ -54,7 +54,7 @@ struct C3Args {
     void *y;                     // element type T
     int B, H, W, Cin, Cout, in_pitch, out_pitch, relu;
     int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio;
-    int bm256, waves8;           // tile-shape knobs (cn_set_tuning keys 14, 15)
+    int bm256, waves8, occ4;     // tile-shape knobs (cn_set_tuning keys 14, 15, 19)
     int nkk_last;                // KSKIP: 8-channel K groups of the last chunk that hold data
     int dbg;                     // ablation switches (cn_set_tuning key 9)
     int stagger, stagger_slots;  // phase shift of co-resident workgroups (cycles per slot, slots)
@@ -82,11 +82,11 @@ constexpr int c3_epi_rows()
     return ((size_t)BM * (BN + 4) <= 17408) ? BM : BM / WM;
 }
 
-template <int TW, int BN, int WM, bool HEADS, int BM>
+template <int TW, int BN, int WM, bool HEADS, int BM, int NBUFB = 2>
 constexpr size_t c3_union_floats()
 {
     constexpr int TH = BM / TW;
-    constexpr size_t tiles = (size_t)((TH + 2) * (TW + 2) * LDT + 2 * BN * LDT);
+    constexpr size_t tiles = (size_t)((TH + 2) * (TW + 2) * LDT + NBUFB * BN * LDT);
     // fused heads: S[128][LDS2] shares the main loop's tile space; the 1x1 weights sit behind it
     constexpr size_t cs = HEADS ? (size_t)128 * LDS2 : (size_t)c3_epi_rows<BN, WM, BM>() * (BN + 4);
     return (tiles > cs ? tiles : cs) + (HEADS ? (size_t)W2_ROWS * LDS2 : 0);
@@ -94,9 +94,11 @@ constexpr size_t c3_union_floats()
 
 // T = float: v_mfma_f32_32x32x2_f32, 32 channels per chunk; T = fp16: v_mfma_f32_32x32x16_f16
 // (fp32 accumulate), 64 channels per chunk -- same 128-byte LDS rows and read addresses.
+// NBUFB: LDS buffers of the per-tap weight tile (2: one barrier per tap; 1: two barriers per tap
+// but 9 KB less LDS -- the 4-workgroups-per-CU variant below)
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false, bool DECONV = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
+          bool KSKIP = false, bool DECONV = false, int NBUFB = 2>
+__device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &hd)
 {
     // DECONV: ConvTranspose2d(4, stride 2, pad 1) -- blockIdx.z = output parity (py, px); each
     // parity is a 2x2 convolution over the same input halo (taps (ty+py, tx+px) of the 3x3
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int A_FLOATS = HR * LDT;
-    constexpr int UNION = (int)c3_union_floats<TW, BN, WM, HEADS, BM>();
+    constexpr int UNION = (int)c3_union_floats<TW, BN, WM, HEADS, BM, NBUFB>();
     float *As = reinterpret_cast<float *>(smem);  // [HR][LDT]
     float *Bs = As + A_FLOATS;                    // [2][BN][LDT]
     int *rowoff = reinterpret_cast<int *>(As + UNION);  // [BM]
@@ -303,6 +305,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
             const bool newA = (t == NTAPS - 1) && (c + 1 < a.nchunk);
             if (more && !(a.dbg & 2)) load_B(t == NTAPS - 1 ? c + 1 : c, t == NTAPS - 1 ? 0 : t + 1);
             if (newA && !(a.dbg & 4)) load_A(c + 1);
+            if constexpr (NBUFB == 1) {
+                compute(t, 0, (KSKIP && c == a.nchunk - 1) ? a.nkk_last : 4);
+                __syncthreads();  // every wave is done with the weight tile (and the old halo)
+                if (newA) store_A();
+                if (more) store_B(0);
+                __syncthreads();
+                continue;
+            }
             compute(t, it & 1, (KSKIP && c == a.nchunk - 1) ? a.nkk_last : 4);
             if (newA) {
                 __syncthreads();  // every wave is done with the old halo
@@ -491,6 +501,39 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
 
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
           bool KSKIP = false, bool DECONV = false>
+__global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
+{
+    conv3x3s1_body<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, 2>(a, hd);
+}
+
+// 64-wide tiles at FOUR workgroups per CU (<= 128 registers, single-buffered weight tile ->
+// 39 KB of LDS): the 64-channel layers at 128^2 have 4096 tiles at B = 32, i.e. 5.33 dispatch
+// rounds at three workgroups per CU (the last one mostly empty) but exactly 4 rounds at four.
+template <typename T, int TW>
+__global__ __launch_bounds__(256, 4) void conv3x3s1_occ4_kernel(const C3Args a, const C3Heads hd)
+{
+    conv3x3s1_body<T, TW, 64, 2, 2, false, 128, false, false, 1>(a, hd);
+}
+
+template <typename T, int TW>
+int launch_c3_occ4(const C3Args &a, hipStream_t st)
+{
+    constexpr int TH = 128 / TW;
+    constexpr size_t lds = c3_union_floats<TW, 64, 2, false, 128, 1>() * 4 + 128 * 4;
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_occ4_kernel<T, TW>), lds);
+    C3Args b = a;
+    b.tiles_x = cn_cdiv(a.W, TW);
+    b.tiles_y = cn_cdiv(a.H, TH);
+    b.stagger = 0;
+    dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, 64));
+    const C3Heads none = {};
+    hipLaunchKernelGGL((conv3x3s1_occ4_kernel<T, TW>), grid, dim3(256), lds, st, b, none);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
+          bool KSKIP = false, bool DECONV = false>
 int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 {
     constexpr int TH = BM / TW;
@@ -559,6 +602,16 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
         if (kskip)
             return wide ? launch_c3<float, 32, 64, 2, 2, false, 128, true>(a, st)
                         : launch_c3<float, 16, 64, 2, 2, false, 128, true>(a, st);
+        if (sizeof(T) == 4 && a.occ4 != 2) {
+            // four workgroups per CU when that needs fewer (work-normalised) dispatch rounds than
+            // three: 4096 tiles = 5.33 rounds of 768 but exactly 4 of 1024 (resdcn_18 -1.0 %,
+            // tools/bench_knob.py 19); cn_set_tuning key 19: 0 = this rule, 1 = always, 2 = never
+            const long wgs = (long)a.B * cn_cdiv(a.H, wide ? 4 : 8) * cn_cdiv(a.W, wide ? 32 : 16) *
+                             cn_cdiv(a.Cout, 64);
+            const bool fewer = wgs > 768 && cn_cdiv((int)wgs, 1024) * 4 < cn_cdiv((int)wgs, 768) * 3;
+            if (a.occ4 == 1 || fewer)
+                return wide ? launch_c3_occ4<float, 32>(a, st) : launch_c3_occ4<float, 16>(a, st);
+        }
         return wide ? launch_c3<T, 32, 64, 2, 2>(a, st) : launch_c3<T, 16, 64, 2, 2>(a, st);
     }
     if (kskip)
@@ -578,6 +631,7 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     a.bm256 = (setprio >> 1) & 1;  // bit 1 of the knob word: cn_set_tuning key 14
     a.waves8 = (setprio >> 2) & 1; // bit 2: cn_set_tuning key 15
     a.dbg = (setprio >> 4) & 7;    // bits 4-6: ablation switches (cn_set_tuning key 9)
+    a.occ4 = (setprio >> 7) & 3;   // bits 7-8: cn_set_tuning key 19
     setprio &= 1;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_pitch = in_pitch;

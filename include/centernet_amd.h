@@ -69,6 +69,9 @@ const char *cn_arch(void);
  *         form (cn_conv.hip); kept for A/B: it measured 20-30 % slower.
  * key 7: XCD-aware tile order: 0 = deformable kernel only (default, +5-10 % there), 1 = also
  *        the dense implicit-GEMM kernels (no gain measured), 2 = nowhere.
+ * key 19: 64-wide LDS-halo tiles at four workgroups per CU (single-buffered weight tile,
+ *         <= 128 registers): 0 = when that needs fewer dispatch rounds (default), 1 = always,
+ *         2 = never.
  * key 18: phase shift of the workgroups that share a CU in the LDS-halo kernel, in percent of
  *         one tile's MFMA time (default 100, 0 = off); applied to launches of >= 4 dispatch rounds.
  * key 16 / 17: split-K: least K chunks per slice (default 8) / most slices (default 16).

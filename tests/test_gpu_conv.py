@@ -77,6 +77,19 @@ def test_conv_256_pixel_tiles(dev):
         lib.cn_set_tuning(14, 0)
 
 
+def test_conv_four_workgroups_per_cu_variant(dev):
+    """64-wide halo tiles at four workgroups per CU (single-buffered weights; key 19)."""
+    from centernet_amd import native
+    lib = native.lib()
+    try:
+        for v in (1, 2):
+            lib.cn_set_tuning(19, v)
+            _conv_case(dev, (4, 64, 64, 64, 64, 3, 1, 1, False, True, True, True))
+            _conv_case(dev, (3, 96, 19, 27, 40, 3, 1, 1, True, False, True, False))
+    finally:
+        lib.cn_set_tuning(19, 0)
+
+
 def test_conv_8_wave_tiles(dev):
     """Both workgroup shapes of the 128-wide LDS-halo tiles (key 15: 8 waves default, 4 waves)."""
     from centernet_amd import native
