@@ -854,7 +854,9 @@ static void dense_tile_class(const cn_conv_desc *d, const IgemmArgs &a, int *cls
     *cls = (d->Cout > 64 && !narrow) ? 2 : (d->Cout > 32 ? 1 : 0);
     // fewer than four workgroups per CU with 128-pixel tiles: halve the pixel tile
     const long wgs128 = (long)cn_cdiv(a.M, 128) * cn_cdiv(d->Cout, 128) * (a.zparity ? 4 : 1);
-    *bm64 = (*cls == 2) && (g_tune_bm ? (g_tune_bm == 64) : (wgs128 < 1024));
+    // ... unless the 128-pixel grid is exactly one round of two workgroups per CU (512): then the
+    // 64-pixel grid (1024 at three per CU = 1.33 rounds) loses (128->256/s2@32^2: 0.210 -> 0.183 ms)
+    *bm64 = (*cls == 2) && (g_tune_bm ? (g_tune_bm == 64) : (wgs128 < 1024 && wgs128 != 512));
 }
 
 static int dense_ksplit(const cn_conv_desc *d, const IgemmArgs &a)
