@@ -60,3 +60,28 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(native, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(native.NativeError):
         native.lib()
+
+
+def test_product_path_never_imports_the_oracle_or_the_reference():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's
+    cpu_baseline may import it; nothing under centernet_amd/ may, nor may anything read
+    /root/reference at run time."""
+    import ast
+    import glob
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "centernet_amd")
+    offenders = []
+    for path in glob.glob(os.path.join(root, "**", "*.py"), recursive=True):
+        src = open(path).read()
+        tree = ast.parse(src)
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            for n in names:
+                if n == "oracle" or n.startswith("oracle."):
+                    offenders.append((path, n))
+        if "/root/reference" in "".join(l for l in src.splitlines(True) if "open(" in l or "sys.path" in l):
+            offenders.append((path, "/root/reference"))
+    assert not offenders, offenders
