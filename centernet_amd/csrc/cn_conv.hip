@@ -1155,7 +1155,8 @@ extern "C" int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_pa
     // mostly padding (Cout <= 32)
     if (!g_tune_nohalo && Cout > 32 && a.vec_out && (in_pitch & 3) == 0)
         return cn_deconv4x4s2_halo(x_nhwc, w_packed, scale, shift, y_nhwc, B, H, W, Cin, Cout,
-                                   in_pitch, out_pitch, relu, a.vec_out, g_tune_setprio, st);
+                                   in_pitch, out_pitch, relu, a.vec_out,
+                                   g_tune_setprio | (g_tune_occ4 << 7), st);
     if (Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
     if (Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
     return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);

@@ -509,25 +509,32 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a,
 // 64-wide tiles at FOUR workgroups per CU (<= 128 registers, single-buffered weight tile ->
 // 39 KB of LDS): the 64-channel layers at 128^2 have 4096 tiles at B = 32, i.e. 5.33 dispatch
 // rounds at three workgroups per CU (the last one mostly empty) but exactly 4 rounds at four.
-template <typename T, int TW>
+template <typename T, int TW, bool DECONV = false>
 __global__ __launch_bounds__(256, 4) void conv3x3s1_occ4_kernel(const C3Args a, const C3Heads hd)
 {
-    conv3x3s1_body<T, TW, 64, 2, 2, false, 128, false, false, 1>(a, hd);
+    conv3x3s1_body<T, TW, 64, 2, 2, false, 128, false, DECONV, 1>(a, hd);
 }
 
-template <typename T, int TW>
+// does a launch of `wgs` 64-wide tiles need fewer work-normalised dispatch rounds at four
+// workgroups per CU (1024 per round) than at three (768)?
+inline bool c3_occ4_pays(long wgs)
+{
+    return wgs > 768 && cn_cdiv((int)wgs, 1024) * 4 < cn_cdiv((int)wgs, 768) * 3;
+}
+
+template <typename T, int TW, bool DECONV = false>
 int launch_c3_occ4(const C3Args &a, hipStream_t st)
 {
     constexpr int TH = 128 / TW;
     constexpr size_t lds = c3_union_floats<TW, 64, 2, false, 128, 1>() * 4 + 128 * 4;
-    CN_SET_MAX_LDS_ONCE((conv3x3s1_occ4_kernel<T, TW>), lds);
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_occ4_kernel<T, TW, DECONV>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
     b.stagger = 0;
-    dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, 64));
+    dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, 64), DECONV ? 4 : 1);
     const C3Heads none = {};
-    hipLaunchKernelGGL((conv3x3s1_occ4_kernel<T, TW>), grid, dim3(256), lds, st, b, none);
+    hipLaunchKernelGGL((conv3x3s1_occ4_kernel<T, TW, DECONV>), grid, dim3(256), lds, st, b, none);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -608,8 +615,7 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
             // tools/bench_knob.py 19); cn_set_tuning key 19: 0 = this rule, 1 = always, 2 = never
             const long wgs = (long)a.B * cn_cdiv(a.H, wide ? 4 : 8) * cn_cdiv(a.W, wide ? 32 : 16) *
                              cn_cdiv(a.Cout, 64);
-            const bool fewer = wgs > 768 && cn_cdiv((int)wgs, 1024) * 4 < cn_cdiv((int)wgs, 768) * 3;
-            if (a.occ4 == 1 || fewer)
+            if (a.occ4 == 1 || c3_occ4_pays(wgs))
                 return wide ? launch_c3_occ4<float, 32>(a, st) : launch_c3_occ4<float, 16>(a, st);
         }
         return wide ? launch_c3<T, 32, 64, 2, 2>(a, st) : launch_c3<T, 16, 64, 2, 2>(a, st);
@@ -694,6 +700,10 @@ int cn_deconv4x4s2_halo(const float *x, const float *w_packed, const float *scal
     if (Cout > 64)
         return wide ? launch_c3<float, 32, 128, 4, 2, false, 128, false, true>(a, st)
                     : launch_c3<float, 16, 128, 4, 2, false, 128, false, true>(a, st);
+    const long wgs = 4L * B * cn_cdiv(H, wide ? 4 : 8) * cn_cdiv(W, wide ? 32 : 16);
+    const int occ4 = (setprio >> 7) & 3;  // cn_set_tuning key 19
+    if (occ4 != 2 && (occ4 == 1 || c3_occ4_pays(wgs)))
+        return wide ? launch_c3_occ4<float, 32, true>(a, st) : launch_c3_occ4<float, 16, true>(a, st);
     return wide ? launch_c3<float, 32, 64, 2, 2, false, 128, false, true>(a, st)
                 : launch_c3<float, 16, 64, 2, 2, false, 128, false, true>(a, st);
 }
