@@ -1,124 +1,144 @@
-"""BaseDetector (mirror of src/lib/detectors/base_detector.py:16-143).
+"""Task API base class.
 
-Same public surface: ``pre_process``, ``process``, ``post_process``, ``merge_outputs``,
-``run(image_or_path_or_tensor, meta=None)`` returning ``{'results', 'tot', 'load',
-'pre', 'net', 'dec', 'post', 'merge'}``.  New surface (the reference is single-image
-only): ``run_batch(images)`` for device-resident batches.
+Public surface and semantics follow the reference's ``BaseDetector``
+(src/lib/detectors/base_detector.py:16-143): ``pre_process``, ``process``, ``post_process``,
+``merge_outputs`` and ``run(image_or_path_or_tensor, meta=None)`` which returns
+``{'results', 'tot', 'load', 'pre', 'net', 'dec', 'post', 'merge'}``.  The implementation is
+organised differently: the input geometry lives in one helper shared by the host and the device
+pre-process, the time buckets are kept by a small phase clock, and ``run`` sends uint8 frames
+through the device pre-process (``cn_resize_bilinear_u8`` + ``cn_warp_normalize_u8_f32``).
+New surface (the reference is single-image only): ``run_batch`` / ``run_frames`` in the task
+classes.
 """
+import collections
+import ctypes
 import time
 
 import numpy as np
 import torch
 
-from ..image import get_affine_transform, warp_affine, resize_bilinear
+from .. import native
+from ..image import get_affine_transform, invert_affine, normalize_chw, resize_bilinear, warp_affine
 from ..model import create_model, load_model
-from ..native import NativeError
+
+InputGeometry = collections.namedtuple(
+    "InputGeometry", "src_h src_w scaled_h scaled_w inp_h inp_w center extent")
+
+
+class _PhaseClock(object):
+    """Wall-clock buckets of ``run`` ('load', 'pre', 'net', 'dec', 'post', 'merge', 'tot').
+    A lap synchronises the device first -- the reference's explicit
+    ``torch.cuda.synchronize()`` calls (base_detector.py:112-134)."""
+
+    def __init__(self):
+        self.t = dict.fromkeys(("load", "pre", "net", "dec", "post", "merge", "tot"), 0.0)
+        self._start = self._last = time.time()
+
+    def lap(self, bucket, sync=True, until=None):
+        if sync:
+            torch.cuda.synchronize()
+        now = time.time() if until is None else until
+        self.t[bucket] += now - self._last
+        self._last = now
+
+    def finish(self):
+        self.t["tot"] = self._last - self._start
+        return self.t
 
 
 class BaseDetector(object):
     def __init__(self, opt):
-        if opt.gpus[0] >= 0:
-            opt.device = torch.device('cuda')
-        else:
-            raise NativeError("--gpus -1 (CPU) is not supported: centernet_amd is the MI355X "
-                              "path and has no CPU fallback")
+        if opt.gpus[0] < 0:
+            raise native.NativeError("--gpus -1 (CPU) is not supported: centernet_amd is the "
+                                     "MI355X path and has no CPU fallback")
+        opt.device = torch.device('cuda')
         print('Creating model...')
-        self.model = create_model(opt.arch, opt.heads, opt.head_conv)
+        net = create_model(opt.arch, opt.heads, opt.head_conv)
         if opt.load_model:
-            self.model = load_model(self.model, opt.load_model)
-        self.model = self.model.to(opt.device)
-        self.model.eval()
-        self.mean = np.array(opt.mean, dtype=np.float32).reshape(1, 1, 3)
-        self.std = np.array(opt.std, dtype=np.float32).reshape(1, 1, 3)
-        self.max_per_image = 100
-        self.num_classes = opt.num_classes
-        self.scales = opt.test_scales
+            net = load_model(net, opt.load_model)
+        self.model = net.to(opt.device).eval()
         self.opt = opt
+        self.mean = np.asarray(opt.mean, np.float32).reshape(1, 1, 3)
+        self.std = np.asarray(opt.std, np.float32).reshape(1, 1, 3)
+        self.scales = opt.test_scales
+        self.num_classes = opt.num_classes
+        self.max_per_image = 100
         self.pause = True
 
-    def pre_process(self, image, scale, meta=None):
-        # base_detector.py:37-65
-        height, width = image.shape[0:2]
-        new_height = int(height * scale)
-        new_width = int(width * scale)
+    # ------------------------------------------------------------------ input geometry
+    def input_geometry(self, height, width, scale):
+        """Network input size, centre and extent for one test scale (base_detector.py:38-50):
+        the fixed resolution, or the scaled image size rounded up to a multiple of pad + 1."""
+        scaled_h, scaled_w = int(height * scale), int(width * scale)
         if self.opt.fix_res:
-            inp_height, inp_width = self.opt.input_h, self.opt.input_w
-            c = np.array([new_width / 2., new_height / 2.], dtype=np.float32)
-            s = max(height, width) * 1.0
+            inp_h, inp_w = self.opt.input_h, self.opt.input_w
+            center = np.array([scaled_w / 2., scaled_h / 2.], dtype=np.float32)
+            extent = max(height, width) * 1.0
         else:
-            inp_height = (new_height | self.opt.pad) + 1
-            inp_width = (new_width | self.opt.pad) + 1
-            c = np.array([new_width // 2, new_height // 2], dtype=np.float32)
-            s = np.array([inp_width, inp_height], dtype=np.float32)
-        trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
-        resized_image = resize_bilinear(image, (new_width, new_height))
-        inp_image = warp_affine(resized_image, trans_input, (inp_width, inp_height))
-        inp_image = ((inp_image / 255. - self.mean) / self.std).astype(np.float32)
-        images = inp_image.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width)
+            inp_h, inp_w = (scaled_h | self.opt.pad) + 1, (scaled_w | self.opt.pad) + 1
+            center = np.array([scaled_w // 2, scaled_h // 2], dtype=np.float32)
+            extent = np.array([inp_w, inp_h], dtype=np.float32)
+        return InputGeometry(height, width, scaled_h, scaled_w, inp_h, inp_w, center, extent)
+
+    def _meta(self, g):
+        return {'c': g.center, 's': g.extent,
+                'out_height': g.inp_h // self.opt.down_ratio,
+                'out_width': g.inp_w // self.opt.down_ratio}
+
+    # ------------------------------------------------------------------ pre-process
+    def pre_process(self, image, scale, meta=None):
+        """Host form (base_detector.py:37-65): resize, affine warp, normalise, CHW, flip concat.
+        Usable from DataLoader workers; returns a CPU tensor and the meta dict."""
+        g = self.input_geometry(image.shape[0], image.shape[1], scale)
+        to_input = get_affine_transform(g.center, g.extent, 0, [g.inp_w, g.inp_h])
+        warped = warp_affine(resize_bilinear(image, (g.scaled_w, g.scaled_h)), to_input,
+                             (g.inp_w, g.inp_h))
+        batch = normalize_chw(warped, self.mean, self.std)[None]
         if self.opt.flip_test:
-            images = np.concatenate((images, images[:, :, :, ::-1]), axis=0)
-        images = torch.from_numpy(np.ascontiguousarray(images))
-        meta = {'c': c, 's': s, 'out_height': inp_height // self.opt.down_ratio,
-                'out_width': inp_width // self.opt.down_ratio}
-        return images, meta
+            batch = np.concatenate((batch, batch[:, :, :, ::-1]), axis=0)
+        return torch.from_numpy(np.ascontiguousarray(batch)), self._meta(g)
 
     def pre_process_device(self, image, scale, meta=None, out=None):
-        """pre_process with the resize / warp / normalise / CHW (/ flip) steps on the device
-        (cn_resize_bilinear_u8 + cn_warp_normalize_u8_f32): the uint8 frame is uploaded and the
-        fp32 (1|2,3,H,W) batch is produced in HBM.  Same arithmetic as ``pre_process``
-        (bit-identical output); used by ``run`` for ndarray / path inputs on a HIP device."""
-        import ctypes
-        from .. import native
-        from ..image import invert_affine
+        """The same steps on the device: the uint8 frame (a numpy array, or a uint8 HIP tensor
+        that is already uploaded) goes through ``cn_resize_bilinear_u8`` (scale != 1) and
+        ``cn_warp_normalize_u8_f32``; the fp32 (1|2,3,H,W) batch is produced in HBM -- into
+        ``out`` when given.  Bit-identical to ``pre_process``."""
         lib = native.lib()
-        height, width = image.shape[0:2]
-        new_height = int(height * scale)
-        new_width = int(width * scale)
-        if self.opt.fix_res:
-            inp_height, inp_width = self.opt.input_h, self.opt.input_w
-            c = np.array([new_width / 2., new_height / 2.], dtype=np.float32)
-            s = max(height, width) * 1.0
-        else:
-            inp_height = (new_height | self.opt.pad) + 1
-            inp_width = (new_width | self.opt.pad) + 1
-            c = np.array([new_width // 2, new_height // 2], dtype=np.float32)
-            s = np.array([inp_width, inp_height], dtype=np.float32)
-        trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
         dev = self.opt.device
-        if torch.is_tensor(image):   # already uploaded (run_frames: one H2D copy per batch)
+        if torch.is_tensor(image):
             if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3 or \
                     not image.is_cuda or not image.is_contiguous():
                 raise ValueError("pre_process_device needs a contiguous (H, W, 3) uint8 HIP tensor")
-            src = image
+            frame = image
         else:
             if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
                 raise ValueError("pre_process_device needs an (H, W, 3) uint8 BGR image")
-            src = torch.from_numpy(np.ascontiguousarray(image)).to(dev)
-        st = native.stream_ptr()
-        if (new_height, new_width) != (height, width):
-            resized = torch.empty((new_height, new_width, 3), device=dev, dtype=torch.uint8)
-            native.check(lib.cn_resize_bilinear_u8(native.ptr(src), height, width, width * 3,
-                                                   new_height, new_width, native.ptr(resized), st),
+            frame = torch.from_numpy(np.ascontiguousarray(image)).to(dev)
+        g = self.input_geometry(int(frame.shape[0]), int(frame.shape[1]), scale)
+        stream = native.stream_ptr()
+        if (g.scaled_h, g.scaled_w) != (g.src_h, g.src_w):
+            scaled = torch.empty((g.scaled_h, g.scaled_w, 3), device=dev, dtype=torch.uint8)
+            native.check(lib.cn_resize_bilinear_u8(native.ptr(frame), g.src_h, g.src_w, g.src_w * 3,
+                                                   g.scaled_h, g.scaled_w, native.ptr(scaled), stream),
                          "cn_resize_bilinear_u8")
-            src = resized
-        nb = 2 if self.opt.flip_test else 1
-        if out is not None:   # caller-provided slice of a batch tensor (run_frames)
-            assert tuple(out.shape) == (nb, 3, inp_height, inp_width) and out.is_contiguous()
-            images = out
-        else:
-            images = torch.empty((nb, 3, inp_height, inp_width), device=dev, dtype=torch.float32)
-        mi = (ctypes.c_double * 6)(*invert_affine(trans_input).reshape(-1))
+            frame = scaled
+        shape = (2 if self.opt.flip_test else 1, 3, g.inp_h, g.inp_w)
+        if out is None:
+            out = torch.empty(shape, device=dev, dtype=torch.float32)
+        elif tuple(out.shape) != shape or not out.is_contiguous():
+            raise ValueError("pre_process_device: `out` must be a contiguous %s tensor" % (shape,))
+        to_input = get_affine_transform(g.center, g.extent, 0, [g.inp_w, g.inp_h])
+        dst_to_src = (ctypes.c_double * 6)(*invert_affine(to_input).reshape(-1))
         mean = (ctypes.c_float * 3)(*[float(v) for v in self.mean.reshape(-1)])
         std = (ctypes.c_float * 3)(*[float(v) for v in self.std.reshape(-1)])
-        native.check(lib.cn_warp_normalize_u8_f32(native.ptr(src), new_height, new_width,
-                                                  new_width * 3, mi, inp_height, inp_width, mean,
-                                                  std, int(self.opt.flip_test), native.ptr(images),
-                                                  st),
+        native.check(lib.cn_warp_normalize_u8_f32(native.ptr(frame), g.scaled_h, g.scaled_w,
+                                                  g.scaled_w * 3, dst_to_src, g.inp_h, g.inp_w,
+                                                  mean, std, int(self.opt.flip_test),
+                                                  native.ptr(out), stream),
                      "cn_warp_normalize_u8_f32")
-        meta = {'c': c, 's': s, 'out_height': inp_height // self.opt.down_ratio,
-                'out_width': inp_width // self.opt.down_ratio}
-        return images, meta
+        return out, self._meta(g)
 
+    # ------------------------------------------------------------------ task hooks
     def process(self, images, return_time=False):
         raise NotImplementedError
 
@@ -134,63 +154,53 @@ class BaseDetector(object):
     def show_results(self, debugger, image, results):
         raise NotImplementedError("visual debugging (cv2/matplotlib) is outside the hot path")
 
-    def _load_image(self, path):
+    # ------------------------------------------------------------------ run
+    @staticmethod
+    def _read_bgr(path):
         from PIL import Image  # cv2.imread replacement: BGR uint8
         rgb = np.asarray(Image.open(path).convert('RGB'))
         return np.ascontiguousarray(rgb[:, :, ::-1])
 
+    def _inputs_for_scale(self, image, prefetched, scale, meta):
+        """(images on the device, meta) of one test scale."""
+        if prefetched is not None:   # test.py's PrefetchDataset dict (base_detector.py:104-110)
+            meta = {k: v.numpy()[0] for k, v in prefetched['meta'][scale].items()}
+            return prefetched['images'][scale][0].to(self.opt.device), meta
+        on_device = getattr(self.opt.device, 'type', str(self.opt.device)) == 'cuda'
+        if on_device and image.dtype == np.uint8 and not getattr(self.opt, 'host_pre_process', False):
+            return self.pre_process_device(image, scale, meta)
+        images, meta = self.pre_process(image, scale, meta)
+        return images.to(self.opt.device), meta
+
     def run(self, image_or_path_or_tensor, meta=None):
-        # base_detector.py:82-143 (no Debugger construction: debug==0 path only)
-        load_time, pre_time, net_time, dec_time, post_time = 0, 0, 0, 0, 0
-        merge_time, tot_time = 0, 0
-        start_time = time.time()
-        pre_processed = False
+        """One image (array, path, or the prefetch dict) through every test scale
+        (base_detector.py:82-143, debug == 0 path); returns the results and the time buckets."""
+        clock = _PhaseClock()
+        prefetched = None
         if isinstance(image_or_path_or_tensor, np.ndarray):
             image = image_or_path_or_tensor
-        elif type(image_or_path_or_tensor) == type(''):
-            image = self._load_image(image_or_path_or_tensor)
+        elif isinstance(image_or_path_or_tensor, str):
+            image = self._read_bgr(image_or_path_or_tensor)
         else:
-            image = image_or_path_or_tensor['image'][0].numpy()
-            pre_processed_images = image_or_path_or_tensor
-            pre_processed = True
-        loaded_time = time.time()
-        load_time += (loaded_time - start_time)
-        detections = []
+            prefetched = image_or_path_or_tensor
+            image = prefetched['image'][0].numpy()
+        clock.lap("load", sync=False)
+
+        per_scale = []
         for scale in self.scales:
-            scale_start_time = time.time()
-            if not pre_processed:
-                on_device = getattr(self.opt.device, 'type', str(self.opt.device)) == 'cuda'
-                if on_device and not getattr(self.opt, 'host_pre_process', False) and \
-                        image.dtype == np.uint8:
-                    images, meta = self.pre_process_device(image, scale, meta)
-                else:
-                    images, meta = self.pre_process(image, scale, meta)
-            else:
-                images = pre_processed_images['images'][scale][0]
-                meta = pre_processed_images['meta'][scale]
-                meta = {k: v.numpy()[0] for k, v in meta.items()}
-            images = images.to(self.opt.device)
-            torch.cuda.synchronize()
-            pre_process_time = time.time()
-            pre_time += pre_process_time - scale_start_time
-            output, dets, forward_time = self.process(images, return_time=True)
-            torch.cuda.synchronize()
-            net_time += forward_time - pre_process_time
-            decode_time = time.time()
-            dec_time += decode_time - forward_time
+            images, meta = self._inputs_for_scale(image, prefetched, scale, meta)
+            clock.lap("pre")
+            output, dets, forward_done = self.process(images, return_time=True)
+            clock.lap("net", until=forward_done)   # process() took this stamp after its own sync
+            clock.lap("dec")
             if self.opt.debug >= 2:
                 self.debug(None, images, dets, output, scale)
-            dets = self.post_process(dets, meta, scale)
-            torch.cuda.synchronize()
-            post_process_time = time.time()
-            post_time += post_process_time - decode_time
-            detections.append(dets)
-        results = self.merge_outputs(detections)
-        torch.cuda.synchronize()
-        end_time = time.time()
-        merge_time += end_time - post_process_time
-        tot_time += end_time - start_time
+            per_scale.append(self.post_process(dets, meta, scale))
+            clock.lap("post")
+        results = self.merge_outputs(per_scale)
+        clock.lap("merge")
         if self.opt.debug >= 1:
             self.show_results(None, image, results)
-        return {'results': results, 'tot': tot_time, 'load': load_time, 'pre': pre_time,
-                'net': net_time, 'dec': dec_time, 'post': post_time, 'merge': merge_time}
+        out = {'results': results}
+        out.update(clock.finish())
+        return out

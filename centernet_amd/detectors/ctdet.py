@@ -1,4 +1,6 @@
-"""CtdetDetector (mirror of src/lib/detectors/ctdet.py:23-73)."""
+"""ctdet task (public behaviour of src/lib/detectors/ctdet.py:23-73): centre heat-map, box size
+and sub-pixel offset decoded by the fused ``cn_ctdet_decode_f32`` kernels.  New surface:
+``run_batch`` (device-resident batches) and ``run_frames`` (lists of uint8 frames)."""
 import time
 
 import numpy as np
@@ -14,85 +16,86 @@ class CtdetDetector(BaseDetector):
     def __init__(self, opt):
         super(CtdetDetector, self).__init__(opt)
 
+    def _decode(self, hm, wh, reg, logits):
+        return ctdet_decode(hm, wh, reg=reg, cat_spec_wh=self.opt.cat_spec_wh, K=self.opt.K,
+                            apply_sigmoid=logits)
+
     def process(self, images, return_time=False):
-        # ctdet.py:28-45.  hm.sigmoid_() is fused into the decode kernel unless the
-        # flip-test average (which needs the sigmoid values) is requested.
+        """Network + decode of one pre-processed batch (ctdet.py:28-45).  Without flip-test the
+        sigmoid of ctdet.py:31 is fused into the decode kernel (``hm`` stays logits); with it,
+        the mirrored frame (image 1) is averaged in after the sigmoid, as in the reference."""
         with torch.no_grad():
             output = self.model(images)[-1]
-            hm = output['hm']
-            wh = output['wh']
+            hm, wh = output['hm'], output['wh']
             reg = output['reg'] if self.opt.reg_offset else None
-            fused_sigmoid = not self.opt.flip_test
+            logits = not self.opt.flip_test
             if self.opt.flip_test:
                 hm = hm.sigmoid_()
                 hm = (hm[0:1] + flip_tensor(hm[1:2])) / 2
                 wh = (wh[0:1] + flip_tensor(wh[1:2])) / 2
-                reg = reg[0:1] if reg is not None else None
+                reg = None if reg is None else reg[0:1]
             torch.cuda.synchronize()
             forward_time = time.time()
-            dets = ctdet_decode(hm, wh, reg=reg, cat_spec_wh=self.opt.cat_spec_wh, K=self.opt.K,
-                                apply_sigmoid=fused_sigmoid)
-        if return_time:
-            return output, dets, forward_time
-        return output, dets
+            dets = self._decode(hm, wh, reg, logits)
+        return (output, dets, forward_time) if return_time else (output, dets)
 
     def post_process(self, dets, meta, scale=1):
-        # ctdet.py:47-56
-        dets = dets.detach().cpu().numpy()
-        dets = dets.reshape(1, -1, dets.shape[2])
-        dets = ctdet_post_process(dets.copy(), [meta['c']], [meta['s']], meta['out_height'],
-                                  meta['out_width'], self.opt.num_classes)
-        for j in range(1, self.num_classes + 1):
-            dets[0][j] = np.array(dets[0][j], dtype=np.float32).reshape(-1, 5)
-            dets[0][j][:, :4] /= scale
-        return dets[0]
+        """(1, K, 6) in output-grid units -> {class: (n, 5) float32} in the coordinates of the
+        unscaled frame (ctdet.py:47-56)."""
+        host = dets.detach().cpu().numpy()
+        host = host.reshape(1, -1, host.shape[2])
+        per_class = ctdet_post_process(host.copy(), [meta['c']], [meta['s']], meta['out_height'],
+                                       meta['out_width'], self.opt.num_classes)[0]
+        for cls in range(1, self.num_classes + 1):
+            rows = np.array(per_class[cls], dtype=np.float32).reshape(-1, 5)
+            rows[:, :4] /= scale
+            per_class[cls] = rows
+        return per_class
 
     def merge_outputs(self, detections):
-        # ctdet.py:58-73
-        results = {}
-        for j in range(1, self.num_classes + 1):
-            results[j] = np.concatenate([d[j] for d in detections], axis=0).astype(np.float32)
-            if len(self.scales) > 1 or self.opt.nms:
-                from ..soft_nms import soft_nms
-                soft_nms(results[j], Nt=0.5, method=2)
-        scores = np.hstack([results[j][:, 4] for j in range(1, self.num_classes + 1)])
+        """Concatenate the test scales per class, soft-NMS when asked or when there are several,
+        then keep the ``max_per_image`` best over all classes by score threshold -- ``>=``, so
+        ties may exceed the cap, as in the reference (ctdet.py:58-73)."""
+        classes = range(1, self.num_classes + 1)
+        results = {c: np.concatenate([d[c] for d in detections], axis=0).astype(np.float32)
+                   for c in classes}
+        if len(self.scales) > 1 or self.opt.nms:
+            from ..soft_nms import soft_nms
+            for c in classes:
+                soft_nms(results[c], Nt=0.5, method=2)
+        scores = np.hstack([results[c][:, 4] for c in classes])
         if len(scores) > self.max_per_image:
             kth = len(scores) - self.max_per_image
             thresh = np.partition(scores, kth)[kth]
-            for j in range(1, self.num_classes + 1):
-                keep_inds = (results[j][:, 4] >= thresh)
-                results[j] = results[j][keep_inds]
+            for c in classes:
+                results[c] = results[c][results[c][:, 4] >= thresh]
         return results
 
+    # ------------------------------------------------------------------ new surface
     def run_batch(self, images):
-        """NEW surface: ``images`` (B,3,H,W) fp32 already normalised, on the device.
-        Returns the raw (B,K,6) detections in output-grid units (device tensor)."""
+        """``images`` (B,3,H,W) fp32, already normalised, on the device -> raw (B,K,6)
+        detections in output-grid units (device tensor)."""
         with torch.no_grad():
-            output = self.model(images)[-1]
-            return ctdet_decode(output['hm'], output['wh'],
-                                reg=output['reg'] if self.opt.reg_offset else None,
-                                cat_spec_wh=self.opt.cat_spec_wh, K=self.opt.K, apply_sigmoid=True)
+            out = self.model(images)[-1]
+            return self._decode(out['hm'], out['wh'], out['reg'] if self.opt.reg_offset else None,
+                                True)
 
     def run_frames(self, frames):
-        """NEW surface (the reference's test loop is batch_size=1, test.py:60-62): a list of
-        (H, W, 3) uint8 BGR frames of one size -> list of per-image result dicts, exactly what
-        ``run(frame)['results']`` returns for each (single scale, no flip).  The frames are
-        uploaded as uint8, pre-processed on the device straight into one batch tensor, and the
-        whole batch goes through the network + decode once."""
-        assert len(self.scales) == 1 and not self.opt.flip_test, "run_frames is single-scale, no flip"
-        scale = self.scales[0]
-        batch, metas = None, []
+        """A list of (H, W, 3) uint8 BGR frames of one size -> list of per-image result dicts,
+        what ``run(frame)['results']`` returns for each (single scale, no flip).  The reference's
+        test loop is batch_size = 1 (test.py:60-62); here the frames are uploaded as ONE uint8
+        copy, pre-processed on the device straight into one batch tensor, and the whole batch
+        goes through the network + decode once; the host tail is vectorised."""
+        if len(self.scales) != 1 or self.opt.flip_test:
+            raise ValueError("run_frames is single-scale, no flip")
         if len({tuple(f.shape) for f in frames}) != 1:
             raise ValueError("run_frames needs frames of one size")
-        stacked = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).to(self.opt.device)
-        for i, f in enumerate(stacked):
-            if batch is None:
-                probe, meta = self.pre_process_device(f, scale)
-                batch = torch.empty((len(frames),) + tuple(probe.shape[1:]), device=probe.device,
-                                    dtype=torch.float32)
-                batch[0:1].copy_(probe)
-            else:
-                _, meta = self.pre_process_device(f, scale, out=batch[i:i + 1])
-            metas.append(meta)
+        scale = self.scales[0]
+        uploaded = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).to(self.opt.device)
+        g = self.input_geometry(uploaded.shape[1], uploaded.shape[2], scale)
+        batch = torch.empty((len(frames), 3, g.inp_h, g.inp_w), device=self.opt.device,
+                            dtype=torch.float32)
+        metas = [self.pre_process_device(frame, scale, out=batch[i:i + 1])[1]
+                 for i, frame in enumerate(uploaded)]
         dets = self.run_batch(batch).detach().cpu().numpy()
         return ctdet_results_batch(dets, metas, self.opt.num_classes, scale, self.max_per_image)

@@ -1,9 +1,7 @@
-"""detector_factory (mirror of src/lib/detectors/detector_factory.py:10-15).
-'exdet' and 'ddd' are outside the MI355X hot path."""
-from .ctdet import CtdetDetector
-from .multi_pose import MultiPoseDetector
+"""Task name -> detector class, the lookup the reference's users go through
+(``detector_factory[opt.task](opt)``, src/lib/detectors/detector_factory.py:10-15).
+Only the tasks on the MI355X hot path are registered; the decoders of 'ddd' and 'exdet' exist
+(centernet_amd.decode) but their detector classes are not built."""
+from . import ctdet, multi_pose
 
-detector_factory = {
-    'ctdet': CtdetDetector,
-    'multi_pose': MultiPoseDetector,
-}
+detector_factory = dict(ctdet=ctdet.CtdetDetector, multi_pose=multi_pose.MultiPoseDetector)

@@ -1,4 +1,6 @@
-"""MultiPoseDetector (mirror of src/lib/detectors/multi_pose.py:24-81)."""
+"""multi_pose task (public behaviour of src/lib/detectors/multi_pose.py:24-81): centre
+heat-map + box size + 17 joint offsets, optional joint heat-maps / sub-pixel offsets, decoded
+by the fused ``cn_multi_pose_decode_f32`` kernels."""
 import time
 
 import numpy as np
@@ -9,57 +11,73 @@ from ..post_process import multi_pose_post_process
 from ..utils import flip_tensor, flip_lr, flip_lr_off
 from .base_detector import BaseDetector
 
+ROW = 39  # [x1, y1, x2, y2, score, 17 x (x, y)]
+
+
+def _mean_with_mirror(first, mirrored):
+    return (first + mirrored) / 2
+
 
 class MultiPoseDetector(BaseDetector):
     def __init__(self, opt):
         super(MultiPoseDetector, self).__init__(opt)
         self.flip_idx = opt.flip_idx
 
+    def _head_maps(self, out):
+        """Post-sigmoid centre map and the optional branches, as the decode expects them."""
+        hm = out['hm'].sigmoid_()
+        hm_hp = None
+        if self.opt.hm_hp:
+            hm_hp = out['hm_hp'] if self.opt.mse_loss else out['hm_hp'].sigmoid_()
+        reg = out['reg'] if self.opt.reg_offset else None
+        hp_offset = out['hp_offset'] if self.opt.reg_hp_offset else None
+        return hm, out['wh'], out['hps'], reg, hm_hp, hp_offset
+
+    def _average_flip(self, hm, wh, hps, reg, hm_hp, hp_offset):
+        """Flip-test (multi_pose.py:44-55): image 1 of the batch is the mirrored frame; maps are
+        averaged after un-mirroring, offsets of the un-mirrored frame are kept."""
+        hm = _mean_with_mirror(hm[0:1], flip_tensor(hm[1:2]))
+        wh = _mean_with_mirror(wh[0:1], flip_tensor(wh[1:2]))
+        hps = _mean_with_mirror(hps[0:1], flip_lr_off(hps[1:2], self.flip_idx))
+        if hm_hp is not None:
+            hm_hp = _mean_with_mirror(hm_hp[0:1], flip_lr(hm_hp[1:2], self.flip_idx))
+        reg = None if reg is None else reg[0:1]
+        hp_offset = None if hp_offset is None else hp_offset[0:1]
+        return hm, wh, hps, reg, hm_hp, hp_offset
+
     def process(self, images, return_time=False):
-        # multi_pose.py:29-60
         with torch.no_grad():
             torch.cuda.synchronize()
             output = self.model(images)[-1]
-            output['hm'] = output['hm'].sigmoid_()
-            if self.opt.hm_hp and not self.opt.mse_loss:
-                output['hm_hp'] = output['hm_hp'].sigmoid_()
-            reg = output['reg'] if self.opt.reg_offset else None
-            hm_hp = output['hm_hp'] if self.opt.hm_hp else None
-            hp_offset = output['hp_offset'] if self.opt.reg_hp_offset else None
+            maps = self._head_maps(output)
             torch.cuda.synchronize()
             forward_time = time.time()
             if self.opt.flip_test:
-                output['hm'] = (output['hm'][0:1] + flip_tensor(output['hm'][1:2])) / 2
-                output['wh'] = (output['wh'][0:1] + flip_tensor(output['wh'][1:2])) / 2
-                output['hps'] = (output['hps'][0:1] +
-                                 flip_lr_off(output['hps'][1:2], self.flip_idx)) / 2
-                hm_hp = (hm_hp[0:1] + flip_lr(hm_hp[1:2], self.flip_idx)) / 2 \
-                    if hm_hp is not None else None
-                reg = reg[0:1] if reg is not None else None
-                hp_offset = hp_offset[0:1] if hp_offset is not None else None
-            dets = multi_pose_decode(output['hm'], output['wh'], output['hps'], reg=reg,
-                                     hm_hp=hm_hp, hp_offset=hp_offset, K=self.opt.K)
-        if return_time:
-            return output, dets, forward_time
-        return output, dets
+                maps = self._average_flip(*maps)
+                output['hm'], output['wh'], output['hps'] = maps[0], maps[1], maps[2]
+            hm, wh, hps, reg, hm_hp, hp_offset = maps
+            dets = multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset,
+                                     K=self.opt.K)
+        return (output, dets, forward_time) if return_time else (output, dets)
 
     def post_process(self, dets, meta, scale=1):
-        # multi_pose.py:62-72
-        dets = dets.detach().cpu().numpy().reshape(1, -1, dets.shape[2])
-        dets = multi_pose_post_process(dets.copy(), [meta['c']], [meta['s']], meta['out_height'],
-                                       meta['out_width'])
-        for j in range(1, self.num_classes + 1):
-            dets[0][j] = np.array(dets[0][j], dtype=np.float32).reshape(-1, 39)
-            dets[0][j][:, :4] /= scale
-            dets[0][j][:, 5:] /= scale
-        return dets[0]
+        """Output-grid units -> image coordinates of the unscaled frame (multi_pose.py:62-72)."""
+        host = dets.detach().cpu().numpy()
+        host = host.reshape(1, -1, host.shape[2])
+        per_class = multi_pose_post_process(host.copy(), [meta['c']], [meta['s']],
+                                            meta['out_height'], meta['out_width'])[0]
+        for cls in range(1, self.num_classes + 1):
+            rows = np.array(per_class[cls], dtype=np.float32).reshape(-1, ROW)
+            rows[:, :4] /= scale
+            rows[:, 5:] /= scale
+            per_class[cls] = rows
+        return per_class
 
     def merge_outputs(self, detections):
-        # multi_pose.py:74-81
-        results = {}
-        results[1] = np.concatenate([d[1] for d in detections], axis=0).astype(np.float32)
+        """Concatenate the test scales; soft-NMS when asked or when there are several
+        (multi_pose.py:74-81).  The person class is the only one."""
+        people = np.concatenate([d[1] for d in detections], axis=0).astype(np.float32)
         if self.opt.nms or len(self.opt.test_scales) > 1:
             from ..soft_nms import soft_nms_39
-            soft_nms_39(results[1], Nt=0.5, method=2)
-        results[1] = results[1].tolist()
-        return results
+            soft_nms_39(people, Nt=0.5, method=2)
+        return {1: people.tolist()}

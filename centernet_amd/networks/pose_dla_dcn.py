@@ -7,24 +7,19 @@ DLAUp (:390-413), DLASeg (:427-482).  State-dict names follow that file
 ida_up.node_2.actf.0.running_var, hm.0.weight, ...).
 """
 import numpy as np
-import torch
 from torch import nn
 
 from ..dcn_v2 import DCN
 from ..engine import PlannedModule
-
-BN_MOMENTUM = 0.1
+from .common import bn, conv, bilinear_upsample_init_, detection_head
 
 
 class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, dilation=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, dilation, dilation, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, dilation, dilation, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
-        self.stride = stride
-        self.dilation = dilation
+        self.stride, self.dilation = stride, dilation
+        self.conv1, self.bn1 = conv(inplanes, planes, 3, stride, dilation=dilation), bn(planes)
+        self.conv2, self.bn2 = conv(planes, planes, 3, dilation=dilation), bn(planes)
 
     def describe(self, pb, x, residual=None):
         # pose_dla_dcn.py:45-62
@@ -39,10 +34,9 @@ class BasicBlock(nn.Module):
 class Root(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, residual):
         super().__init__()
-        self.conv = nn.Conv2d(in_channels, out_channels, 1, stride=1, bias=False,
-                              padding=(kernel_size - 1) // 2)
-        self.bn = nn.BatchNorm2d(out_channels, momentum=BN_MOMENTUM)
         self.residual = residual
+        self.conv = conv(in_channels, out_channels, 1, pad=(kernel_size - 1) // 2)
+        self.bn = bn(out_channels)
 
     def describe(self, pb, *children):
         # pose_dla_dcn.py:157-165: conv1x1(cat(children)) + BN (+ children[0]) + ReLU
@@ -53,37 +47,32 @@ class Root(nn.Module):
 
 
 class Tree(nn.Module):
+    """A node of the aggregation tree: two sub-trees (blocks at depth 1) whose outputs, plus the
+    outputs handed down by the ancestors, are merged by a Root."""
+
     def __init__(self, levels, block, in_channels, out_channels, stride=1, level_root=False,
                  root_dim=0, root_kernel_size=1, dilation=1, root_residual=False):
         super().__init__()
-        if root_dim == 0:
-            root_dim = 2 * out_channels
+        self.levels, self.stride, self.level_root = levels, stride, level_root
+        root_dim = root_dim or 2 * out_channels
         if level_root:
             root_dim += in_channels
+        self.root_dim = root_dim
         if levels == 1:
             self.tree1 = block(in_channels, out_channels, stride, dilation=dilation)
             self.tree2 = block(out_channels, out_channels, 1, dilation=dilation)
             self.root = Root(root_dim, out_channels, root_kernel_size, root_residual)
         else:
+            shared = dict(root_kernel_size=root_kernel_size, dilation=dilation,
+                          root_residual=root_residual)
             self.tree1 = Tree(levels - 1, block, in_channels, out_channels, stride, root_dim=0,
-                              root_kernel_size=root_kernel_size, dilation=dilation,
-                              root_residual=root_residual)
+                              **shared)
             self.tree2 = Tree(levels - 1, block, out_channels, out_channels,
-                              root_dim=root_dim + out_channels,
-                              root_kernel_size=root_kernel_size, dilation=dilation,
-                              root_residual=root_residual)
-        self.level_root = level_root
-        self.root_dim = root_dim
-        self.downsample = None
+                              root_dim=root_dim + out_channels, **shared)
+        self.downsample = nn.MaxPool2d(stride, stride=stride) if stride > 1 else None
         self.project = None
-        self.levels = levels
-        self.stride = stride
-        if stride > 1:
-            self.downsample = nn.MaxPool2d(stride, stride=stride)
         if in_channels != out_channels:
-            self.project = nn.Sequential(
-                nn.Conv2d(in_channels, out_channels, 1, 1, bias=False),
-                nn.BatchNorm2d(out_channels, momentum=BN_MOMENTUM))
+            self.project = nn.Sequential(conv(in_channels, out_channels, 1), bn(out_channels))
 
     def describe(self, pb, x, residual=None, children=None):
         # pose_dla_dcn.py:206-221
@@ -105,32 +94,26 @@ class DLA(nn.Module):
     def __init__(self, levels, channels, block=BasicBlock, residual_root=False, with_fc=True):
         super().__init__()
         self.channels = channels
-        self.base_layer = nn.Sequential(
-            nn.Conv2d(3, channels[0], 7, 1, 3, bias=False),
-            nn.BatchNorm2d(channels[0], momentum=BN_MOMENTUM), nn.ReLU(inplace=True))
-        self.level0 = self._make_conv_level(channels[0], channels[0], levels[0])
-        self.level1 = self._make_conv_level(channels[0], channels[1], levels[1], stride=2)
-        self.level2 = Tree(levels[2], block, channels[1], channels[2], 2, level_root=False,
-                           root_residual=residual_root)
-        self.level3 = Tree(levels[3], block, channels[2], channels[3], 2, level_root=True,
-                           root_residual=residual_root)
-        self.level4 = Tree(levels[4], block, channels[3], channels[4], 2, level_root=True,
-                           root_residual=residual_root)
-        self.level5 = Tree(levels[5], block, channels[4], channels[5], 2, level_root=True,
-                           root_residual=residual_root)
+        self.base_layer = nn.Sequential(conv(3, channels[0], 7), bn(channels[0]),
+                                        nn.ReLU(inplace=True))
+        self.level0 = self._plain_level(channels[0], channels[0], levels[0], stride=1)
+        self.level1 = self._plain_level(channels[0], channels[1], levels[1], stride=2)
+        for lv in range(2, 6):  # the aggregation stages: every one halves the resolution
+            setattr(self, 'level%d' % lv,
+                    Tree(levels[lv], block, channels[lv - 1], channels[lv], 2,
+                         level_root=lv > 2, root_residual=residual_root))
         if with_fc:
             # the reference's pretrained loader attaches the ImageNet classifier
             # (pose_dla_dcn.py:294-305), so zoo checkpoints carry base.fc.*; unused in forward
-            self.fc = nn.Conv2d(channels[-1], 1000, 1, 1, 0, bias=True)
+            self.fc = conv(channels[-1], 1000, 1, bias=True)
 
     @staticmethod
-    def _make_conv_level(inplanes, planes, convs, stride=1, dilation=1):
+    def _plain_level(cin, cout, count, stride):
+        """``count`` x (conv3x3, BN, ReLU); only the first conv changes stride / width."""
         mods = []
-        for i in range(convs):
-            mods.extend([nn.Conv2d(inplanes, planes, 3, stride if i == 0 else 1, dilation,
-                                   dilation, bias=False),
-                         nn.BatchNorm2d(planes, momentum=BN_MOMENTUM), nn.ReLU(inplace=True)])
-            inplanes = planes
+        for i in range(count):
+            mods += [conv(cin if i == 0 else cout, cout, 3, stride if i == 0 else 1), bn(cout),
+                     nn.ReLU(inplace=True)]
         return nn.Sequential(*mods)
 
     def describe(self, pb, x):
@@ -159,7 +142,7 @@ def dla34(with_fc=True):
 class DeformConv(nn.Module):
     def __init__(self, chi, cho):
         super().__init__()
-        self.actf = nn.Sequential(nn.BatchNorm2d(cho, momentum=BN_MOMENTUM), nn.ReLU(inplace=True))
+        self.actf = nn.Sequential(bn(cho), nn.ReLU(inplace=True))
         self.conv = DCN(chi, cho, kernel_size=(3, 3), stride=1, padding=1, dilation=1,
                         deformable_groups=1)
 
@@ -168,30 +151,22 @@ class DeformConv(nn.Module):
         return pb.dcn(x, self.conv, bn=self.actf[0], relu=True)
 
 
-def _fill_up_weights(up):
-    import math
-    w = up.weight.data
-    f = math.ceil(w.size(2) / 2)
-    c = (2 * f - 1 - f % 2) / (2. * f)
-    for i in range(w.size(2)):
-        for j in range(w.size(3)):
-            w[0, 0, i, j] = (1 - math.fabs(i / f - c)) * (1 - math.fabs(j / f - c))
-    for ch in range(1, w.size(0)):
-        w[ch, 0, :, :] = w[0, 0, :, :]
-
-
 class IDAUp(nn.Module):
+    """Iterative deep aggregation: every deeper level is projected to ``o`` channels (DCN),
+    up-sampled by its factor (depthwise bilinear transposed conv), added to the level above and
+    refined (DCN)."""
+
     def __init__(self, o, channels, up_f):
         super().__init__()
-        for i in range(1, len(channels)):
-            c = channels[i]
-            f = int(up_f[i])
-            setattr(self, 'proj_' + str(i), DeformConv(c, o))
-            up = nn.ConvTranspose2d(o, o, f * 2, stride=f, padding=f // 2, output_padding=0,
+        for i, (c, factor) in enumerate(zip(channels, up_f)):
+            if i == 0:
+                continue  # the shallowest level is the aggregation target itself
+            f = int(factor)
+            up = nn.ConvTranspose2d(o, o, 2 * f, stride=f, padding=f // 2, output_padding=0,
                                     groups=o, bias=False)
-            _fill_up_weights(up)
-            setattr(self, 'up_' + str(i), up)
-            setattr(self, 'node_' + str(i), DeformConv(o, o))
+            setattr(self, 'proj_%d' % i, DeformConv(c, o))
+            setattr(self, 'up_%d' % i, bilinear_upsample_init_(up))
+            setattr(self, 'node_%d' % i, DeformConv(o, o))
 
     def describe(self, pb, layers, startp, endp):
         # pose_dla_dcn.py:379-386; the "+ layers[i-1]" is fused into the up-sampling kernel
@@ -208,18 +183,16 @@ class DLAUp(nn.Module):
     def __init__(self, startp, channels, scales, in_channels=None):
         super().__init__()
         self.startp = startp
-        if in_channels is None:
-            in_channels = channels
         self.channels = channels
-        channels = list(channels)
-        in_channels = list(in_channels)
-        scales = np.array(scales, dtype=int)
-        for i in range(len(channels) - 1):
-            j = -i - 2
-            setattr(self, 'ida_{}'.format(i),
-                    IDAUp(channels[j], in_channels[j:], scales[j:] // scales[j]))
-            scales[j + 1:] = scales[j]
-            in_channels[j + 1:] = [channels[j] for _ in channels[j + 1:]]
+        widths = list(channels)
+        inputs = list(channels if in_channels is None else in_channels)
+        rel = np.array(scales, dtype=int)
+        # from the deepest pair upwards: ida_i aggregates levels [j:] into level j, after which
+        # those levels all carry widths[j] channels at level j's resolution
+        for i, j in enumerate(range(len(widths) - 2, -1, -1)):
+            setattr(self, 'ida_%d' % i, IDAUp(widths[j], inputs[j:], rel[j:] // rel[j]))
+            rel[j + 1:] = rel[j]
+            inputs[j + 1:] = [widths[j]] * (len(widths) - j - 1)
 
     def describe(self, pb, layers):
         # pose_dla_dcn.py:407-413
@@ -236,39 +209,20 @@ class DLASeg(PlannedModule):
     def __init__(self, base_name, heads, down_ratio, final_kernel, last_level, head_conv,
                  out_channel=0, with_fc=True):
         super().__init__()
-        assert down_ratio in [2, 4, 8, 16]
-        assert base_name == 'dla34', "only DLA-34 is on the MI355X hot path"
-        self.first_level = int(np.log2(down_ratio))
-        self.last_level = last_level
-        self.base = dla34(with_fc=with_fc)
-        channels = self.base.channels
-        scales = [2 ** i for i in range(len(channels[self.first_level:]))]
-        self.dla_up = DLAUp(self.first_level, channels[self.first_level:], scales)
-        if out_channel == 0:
-            out_channel = channels[self.first_level]
-        self.ida_up = IDAUp(out_channel, channels[self.first_level:self.last_level],
-                            [2 ** i for i in range(self.last_level - self.first_level)])
+        if down_ratio not in (2, 4, 8, 16):
+            raise ValueError("down_ratio must be 2, 4, 8 or 16")
+        if base_name != 'dla34':
+            raise KeyError("only DLA-34 is on the MI355X hot path")
         self.heads = heads
-        for head in self.heads:
-            classes = self.heads[head]
-            if head_conv > 0:
-                fc = nn.Sequential(
-                    nn.Conv2d(channels[self.first_level], head_conv, 3, padding=1, bias=True),
-                    nn.ReLU(inplace=True),
-                    nn.Conv2d(head_conv, classes, final_kernel, stride=1,
-                              padding=final_kernel // 2, bias=True))
-                last = fc[-1]
-            else:
-                fc = nn.Conv2d(channels[self.first_level], classes, final_kernel, stride=1,
-                               padding=final_kernel // 2, bias=True)
-                last = fc
-            if 'hm' in head:
-                last.bias.data.fill_(-2.19)
-            else:
-                for m in fc.modules():
-                    if isinstance(m, nn.Conv2d) and m.bias is not None:
-                        nn.init.constant_(m.bias, 0)
-            self.__setattr__(head, fc)
+        self.first_level, self.last_level = int(np.log2(down_ratio)), last_level
+        self.base = dla34(with_fc=with_fc)
+        used = self.base.channels[self.first_level:]
+        self.dla_up = DLAUp(self.first_level, used, [2 ** i for i in range(len(used))])
+        fused = self.base.channels[self.first_level:self.last_level]
+        self.ida_up = IDAUp(out_channel or used[0], fused, [2 ** i for i in range(len(fused))])
+        for name, classes in heads.items():
+            setattr(self, name, detection_head(used[0], head_conv, classes, final_kernel,
+                                               is_heatmap='hm' in name))
 
     def describe(self, pb, x):
         # pose_dla_dcn.py:470-482 (the .clone() there only protects x from in-place edits)

@@ -6,15 +6,11 @@ Two reference files are covered by one class:
 Parameter names/shapes follow those files exactly (conv1, bn1, layer{1..4}.{i}.conv{1,2,3},
 layer*.0.downsample.{0,1}, deconv_layers.{i}, <head>.{0,2}).
 """
-import math
-
-import torch
 import torch.nn as nn
 
 from ..dcn_v2 import DCN
 from ..engine import PlannedModule
-
-BN_MOMENTUM = 0.1
+from .common import bn, conv, bilinear_upsample_init_, detection_head
 
 
 class BasicBlock(nn.Module):
@@ -22,12 +18,9 @@ class BasicBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
-        self.downsample = downsample
-        self.stride = stride
+        self.stride, self.downsample = stride, downsample
+        self.conv1, self.bn1 = conv(inplanes, planes, 3, stride), bn(planes)
+        self.conv2, self.bn2 = conv(planes, planes, 3), bn(planes)
 
     def describe(self, pb, x):
         # resnet_dcn.py:49-67
@@ -44,14 +37,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes, momentum=BN_MOMENTUM)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4, momentum=BN_MOMENTUM)
-        self.downsample = downsample
-        self.stride = stride
+        wide = planes * self.expansion
+        self.stride, self.downsample = stride, downsample
+        self.conv1, self.bn1 = conv(inplanes, planes, 1), bn(planes)
+        self.conv2, self.bn2 = conv(planes, planes, 3, stride), bn(planes)
+        self.conv3, self.bn3 = conv(planes, wide, 1), bn(wide)
 
     def describe(self, pb, x):
         # resnet_dcn.py:88-108
@@ -64,87 +54,53 @@ class Bottleneck(nn.Module):
         return pb.conv(out, self.conv3.weight, bn=self.bn3, relu=True, residual=res)
 
 
-def _bilinear_up_init(up):
-    # resnet_dcn.py:110-119 (fill_up_weights): only w[:, 0] is filled
-    w = up.weight.data
-    f = math.ceil(w.size(2) / 2)
-    c = (2 * f - 1 - f % 2) / (2.0 * f)
-    for i in range(w.size(2)):
-        for j in range(w.size(3)):
-            w[0, 0, i, j] = (1 - math.fabs(i / f - c)) * (1 - math.fabs(j / f - c))
-    for ch in range(1, w.size(0)):
-        w[ch, 0, :, :] = w[0, 0, :, :]
-
-
 class PoseResNet(PlannedModule):
+    STAGE_WIDTHS = (64, 128, 256, 512)
+
     def __init__(self, block, layers, heads, head_conv, dcn=True):
         super().__init__()
-        self.inplanes = 64
-        self.heads = heads
+        self.heads, self.use_dcn = heads, dcn
         self.deconv_with_bias = False
-        self.use_dcn = dcn
-        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
-        self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(3, 2, 1)
-        self.layer1 = self._make_layer(block, 64, layers[0])
-        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
-        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
-        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
-        filters = [256, 128, 64] if dcn else [256, 256, 256]
-        self.deconv_layers = self._make_deconv_layer(filters)
-        feat = filters[-1]
-        # msra_resnet.py:133 creates heads in sorted() order, resnet_dcn.py:155 in dict order;
-        # only RNG-dependent init differs, the names are the same.
-        for head in (self.heads if dcn else sorted(self.heads)):
-            classes = self.heads[head]
-            if head_conv > 0:
-                fc = nn.Sequential(nn.Conv2d(feat, head_conv, 3, padding=1, bias=True),
-                                   nn.ReLU(inplace=True),
-                                   nn.Conv2d(head_conv, classes, 1, bias=True))
-                last = fc[-1]
-            else:
-                fc = nn.Conv2d(feat, classes, 1, bias=True)
-                last = fc
-            if 'hm' in head:
-                last.bias.data.fill_(-2.19)  # resnet_dcn.py:165-166
-            elif dcn:
-                for m in fc.modules():       # fill_fc_weights, resnet_dcn.py:121-128
-                    if isinstance(m, nn.Conv2d):
-                        nn.init.normal_(m.weight, std=0.001)
-                        nn.init.constant_(m.bias, 0)
-            self.__setattr__(head, fc)
+        self.conv1, self.bn1 = conv(3, 64, 7, 2), bn(64)
+        self.relu, self.maxpool = nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)
+        width = 64
+        for stage, (planes, count) in enumerate(zip(self.STAGE_WIDTHS, layers), start=1):
+            blocks, width = self._stage(block, width, planes, count, stride=1 if stage == 1 else 2)
+            setattr(self, 'layer%d' % stage, blocks)
+        up_widths = (256, 128, 64) if dcn else (256, 256, 256)
+        self.deconv_layers = self._up_path(width, up_widths)
+        # msra_resnet.py:133 creates the heads in sorted() order, resnet_dcn.py:155 in dict order;
+        # only RNG-dependent initialisation differs, the names are the same
+        for name in (heads if dcn else sorted(heads)):
+            setattr(self, name, detection_head(up_widths[-1], head_conv, heads[name],
+                                               is_heatmap='hm' in name, normal_init=dcn))
 
-    def _make_layer(self, block, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
-                nn.BatchNorm2d(planes * block.expansion, momentum=BN_MOMENTUM))
-        layers = [block(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes))
-        return nn.Sequential(*layers)
+    @staticmethod
+    def _stage(block, width_in, planes, count, stride):
+        """One residual stage: the first block changes stride / width (with a 1x1 projection on
+        the identity branch when needed), the others keep both."""
+        width_out = planes * block.expansion
+        project = None
+        if stride != 1 or width_in != width_out:
+            project = nn.Sequential(conv(width_in, width_out, 1, stride), bn(width_out))
+        blocks = [block(width_in, planes, stride, project)]
+        blocks += [block(width_out, planes) for _ in range(count - 1)]
+        return nn.Sequential(*blocks), width_out
 
-    def _make_deconv_layer(self, filters):
-        layers = []
-        for planes in filters:
+    def _up_path(self, width, up_widths):
+        """Three x2 up-sampling steps: [DCN, BN, ReLU,] ConvTranspose 4x4/2, BN, ReLU."""
+        mods = []
+        for planes in up_widths:
             if self.use_dcn:
-                layers.append(DCN(self.inplanes, planes, kernel_size=(3, 3), stride=1, padding=1,
-                                  dilation=1, deformable_groups=1))
-                layers.append(nn.BatchNorm2d(planes, momentum=BN_MOMENTUM))
-                layers.append(nn.ReLU(inplace=True))
-                up = nn.ConvTranspose2d(planes, planes, 4, 2, 1, 0, bias=self.deconv_with_bias)
-                _bilinear_up_init(up)
-            else:
-                up = nn.ConvTranspose2d(self.inplanes, planes, 4, 2, 1, 0,
-                                        bias=self.deconv_with_bias)
-            layers.append(up)
-            layers.append(nn.BatchNorm2d(planes, momentum=BN_MOMENTUM))
-            layers.append(nn.ReLU(inplace=True))
-            self.inplanes = planes
-        return nn.Sequential(*layers)
+                mods += [DCN(width, planes, kernel_size=(3, 3), stride=1, padding=1, dilation=1,
+                             deformable_groups=1), bn(planes), nn.ReLU(inplace=True)]
+                width = planes
+            up = nn.ConvTranspose2d(width, planes, 4, 2, 1, 0, bias=self.deconv_with_bias)
+            if self.use_dcn:
+                bilinear_upsample_init_(up)
+            mods += [up, bn(planes), nn.ReLU(inplace=True)]
+            width = planes
+        return nn.Sequential(*mods)
 
     def describe(self, pb, x):
         # resnet_dcn.py:248-263 / msra_resnet.py forward

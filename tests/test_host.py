@@ -136,3 +136,39 @@ def test_ctdet_results_batch_equals_per_image_loop():
             for j in range(1, 81):
                 assert got[i][j].dtype == np.float32 and got[i][j].shape == ref[j].shape
                 assert np.array_equal(got[i][j], ref[j])
+
+
+def test_load_model_tolerant_like_the_reference(tmp_path, capsys):
+    """model.py:31-67 behaviour: DataParallel prefixes stripped, shape mismatches skipped with a
+    message, unknown keys dropped, missing keys keep the model's value; save_model round trip."""
+    import torch
+    from centernet_amd import synth
+    from centernet_amd.model import create_model, load_model, save_model
+    heads = {'hm': 80, 'wh': 2, 'reg': 2}
+    src = create_model('res_18', heads, 64)
+    synth.fill_state_dict_(src, 5)
+    sd = {('module.' + k): v.clone() for k, v in src.state_dict().items()}
+    sd['module.hm.2.weight'] = torch.zeros(3, 64, 1, 1)          # other --num_classes: skipped
+    sd['module.not_in_model'] = torch.zeros(1)                    # dropped
+    missing = 'module.wh.2.bias'
+    del sd[missing]                                                # kept from the target model
+    path = str(tmp_path / 'ckpt.pth')
+    torch.save({'epoch': 7, 'state_dict': sd}, path)
+    dst = create_model('res_18', heads, 64)
+    synth.fill_state_dict_(dst, 9)
+    keep_hm = dst.state_dict()['hm.2.weight'].clone()
+    keep_wh = dst.state_dict()['wh.2.bias'].clone()
+    load_model(dst, path)
+    out = capsys.readouterr().out
+    assert 'epoch 7' in out and 'Skip loading parameter hm.2.weight' in out
+    assert 'Drop parameter not_in_model' in out and 'No param wh.2.bias' in out
+    got = dst.state_dict()
+    assert torch.equal(got['hm.2.weight'], keep_hm) and torch.equal(got['wh.2.bias'], keep_wh)
+    for k, v in src.state_dict().items():
+        if k not in ('hm.2.weight', 'wh.2.bias'):
+            assert torch.equal(got[k], v), k
+    save_model(str(tmp_path / 'again.pth'), 3, dst)
+    again = torch.load(str(tmp_path / 'again.pth'), weights_only=False)
+    assert again['epoch'] == 3 and set(again['state_dict']) == set(got)
+    with pytest.raises(KeyError):
+        create_model('dlav0_34', heads, 64)
