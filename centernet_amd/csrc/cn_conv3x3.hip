@@ -159,8 +159,8 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const unsigned slot = lin / 256;
         if (slot >= 1 && slot < (unsigned)a.stagger_slots) {
-            const long long t0 = __builtin_readcyclecounter();
-            const long long wait = (long long)slot * a.stagger;
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            const unsigned long long wait = (unsigned long long)slot * (unsigned)a.stagger;
             while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
         }
     }
