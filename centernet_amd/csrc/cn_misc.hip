@@ -280,11 +280,27 @@ DcnWs dcn_ws_plan(int B, int Cin, int H, int W, int Cout, int kh, int kw)
 }
 }  // namespace
 
+// cn_dcn_general.hip
+int cn_dcn_general_launch(const float *input, const float *weight, const float *bias,
+                          const float *offset, const float *mask, float *output, int B, int Cin,
+                          int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                          int dh, int dw, int dg, int mask_sigmoid, hipStream_t st);
+
+// The tuned CenterNet path (NHWC implicit GEMM on MFMA) takes 3x3 kernels at 4-aligned channel
+// counts; whether a call also has stride 1 / pad 1 / dilation 1 / one group is only known at
+// the forward call, so the query sizes for it whenever the kernel is 3x3 (an upper bound).
+static bool dcn_tuned_shape(int Cin, int kh, int kw)
+{
+    return kh == 3 && kw == 3 && Cin != 3 && (Cin & 3) == 0;
+}
+
 extern "C" size_t cn_dcn_v2_forward_workspace_bytes(int B, int Cin, int H, int W, int Cout,
                                                     int kernel_h, int kernel_w, int layout)
 {
     if (layout != CN_LAYOUT_NCHW) return 0;
-    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || kernel_h <= 0 || kernel_w <= 0)
+        return 0;
+    if (!dcn_tuned_shape(Cin, kernel_h, kernel_w)) return 256;   // general kernel: no scratch
     return dcn_ws_plan(B, Cin, H, W, Cout, kernel_h, kernel_w).total;
 }
 
@@ -296,12 +312,21 @@ extern "C" int cn_dcn_v2_forward_f32(const float *input, const float *weight, co
                                      int apply_mask_sigmoid, void *workspace,
                                      size_t workspace_bytes, void *stream)
 {
-    if (!input || !weight || !bias || !offset || !mask || !output || !workspace) return CN_ERR_NULL;
+    if (!input || !weight || !bias || !offset || !mask || !output) return CN_ERR_NULL;
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return CN_ERR_SHAPE;
-    if (kernel_h != 3 || kernel_w != 3 || stride_h != 1 || stride_w != 1 || pad_h != 1 ||
-        pad_w != 1 || dilation_h != 1 || dilation_w != 1 || deformable_group != 1)
-        return CN_ERR_UNSUPPORTED;
-    if (Cin == 3 || (Cin & 3)) return CN_ERR_UNSUPPORTED;
+    if (kernel_h <= 0 || kernel_w <= 0 || stride_h <= 0 || stride_w <= 0 || pad_h < 0 ||
+        pad_w < 0 || dilation_h <= 0 || dilation_w <= 0 || deformable_group <= 0 ||
+        Cin % deformable_group != 0)
+        return CN_ERR_SHAPE;
+    const bool tuned = dcn_tuned_shape(Cin, kernel_h, kernel_w) && stride_h == 1 &&
+                       stride_w == 1 && pad_h == 1 && pad_w == 1 && dilation_h == 1 &&
+                       dilation_w == 1 && deformable_group == 1;
+    if (!tuned)   // the rest of the reference operator's domain (cn_dcn_general.hip)
+        return cn_dcn_general_launch(input, weight, bias, offset, mask, output, B, Cin, H, W, Cout,
+                                     kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+                                     dilation_h, dilation_w, deformable_group,
+                                     apply_mask_sigmoid, (hipStream_t)stream);
+    if (!workspace) return CN_ERR_NULL;
     if (!cn_aligned16(workspace)) return CN_ERR_ALIGN;
     const DcnWs p = dcn_ws_plan(B, Cin, H, W, Cout, 3, 3);
     if (workspace_bytes < p.total) return CN_ERR_WORKSPACE;
@@ -412,12 +437,16 @@ extern "C" int cn_upsample2x_add_f16(const void *x, const void *add, void *y, in
 
 // ---- soft-NMS on a small host array (merge_outputs, detectors/ctdet.py:63-64) -------------
 // Host-side, in place, same greedy/swap/discard order as src/lib/external/nms.pyx:77-170
-// (soft_nms) and :172-275 (soft_nms_39): `stride` floats per row, box in [0..3], score in [4];
-// rows swap as a whole.  Returns the number of boxes kept (the rows [0, N) at exit); rows
-// beyond N keep their decayed scores, exactly like the reference's in-place array.
+// (soft_nms) and :172-275 (soft_nms_39): `stride` floats per row, box in [0..3], score in [4].
+// The max box swaps with row i as a whole; a discarded box takes columns 0..4 of row N-1 and
+// SWAPS columns 5.. with it (nms.pyx:260-268), so the whole in-place array -- rows past N
+// included, which MultiPoseDetector.merge_outputs returns -- equals the reference's.  Returns
+// the number of boxes kept (the rows [0, N) at exit).  Pinned bit-for-bit against the
+// reference's own cython build (oracle/_ref, tests/test_oracle_ref.py).
 extern "C" int cn_soft_nms_f32(float *boxes, int n, int stride, float sigma, float Nt,
                                float threshold, int method)
 {
+#pragma clang fp contract(off)
     if (!boxes || n < 0 || stride < 5) return CN_ERR_SHAPE;
     int N = n;
     float *tmp = (float *)alloca(sizeof(float) * (size_t)stride);
@@ -440,16 +469,20 @@ extern "C" int cn_soft_nms_f32(float *boxes, int n, int stride, float sigma, flo
         while (pos < N) {
             float *bp = boxes + (size_t)pos * stride;
             const float x1 = bp[0], y1 = bp[1], x2 = bp[2], y2 = bp[3];
-            const float area = (x2 - x1 + 1) * (y2 - y1 + 1);
-            const float iw = (fminf(tx2, x2) - fmaxf(tx1, x1) + 1);
+            // Cython writes the integer literals of nms.pyx:133-143 as the double constant 1.0, so
+            // `x2 - x1 + 1` is a float difference widened to double; each assignment to a `cdef
+            // float` rounds once.  Reproduced here term by term.
+            const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
+            const float iw = (float)((double)(fminf(tx2, x2) - fmaxf(tx1, x1)) + 1.0);
             if (iw > 0) {
-                const float ih = (fminf(ty2, y2) - fmaxf(ty1, y1) + 1);
+                const float ih = (float)((double)(fminf(ty2, y2) - fmaxf(ty1, y1)) + 1.0);
                 if (ih > 0) {
-                    const float ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih;
-                    const float ov = iw * ih / ua;
+                    const float ua = (float)((((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0) +
+                                              (double)area) - (double)(iw * ih));
+                    const float ov = (iw * ih) / ua;
                     float weight;
                     if (method == 1)
-                        weight = ov > Nt ? 1 - ov : 1;
+                        weight = ov > Nt ? (float)(1.0 - (double)ov) : 1.0f;
                     else if (method == 2)
                         weight = (float)exp((double)(-(ov * ov) / sigma));  // np.exp on a C float
                     else
@@ -457,7 +490,12 @@ extern "C" int cn_soft_nms_f32(float *boxes, int n, int stride, float sigma, flo
                     bp[4] = weight * bp[4];
                     if (bp[4] < threshold) {
                         float *bl = boxes + (size_t)(N - 1) * stride;
-                        for (int c = 0; c < stride; ++c) bp[c] = bl[c];
+                        for (int c = 0; c < 5; ++c) bp[c] = bl[c];
+                        for (int c = 5; c < stride; ++c) {
+                            const float t = bp[c];
+                            bp[c] = bl[c];
+                            bl[c] = t;
+                        }
                         N = N - 1;
                         pos = pos - 1;
                     }

@@ -100,6 +100,12 @@ class DCN(DCNv2):
             self.conv_offset_mask.weight.zero_()
             self.conv_offset_mask.bias.zero_()
 
+    def _tuned(self, cin):
+        """The configuration CenterNet instantiates (resnet_dcn.py:221-223, pose_dla_dcn.py:352):
+        served by the NHWC MFMA kernel; everything else by the general-domain kernel."""
+        return (tuple(self.kernel_size) == (3, 3) and self.stride == 1 and self.padding == 1 and
+                self.dilation == 1 and self.deformable_groups == 1 and cin % 4 == 0)
+
     def forward(self, input):
         """Stand-alone use (NCHW in/out).  Inside a network the plan fuses this with the
         following BatchNorm+ReLU and stays in NHWC (engine.PlanBuilder.dcn)."""
@@ -108,8 +114,26 @@ class DCN(DCNv2):
             raise NotImplementedError
         B, C, H, W = input.shape
         pb = PlanBuilder(input.device, B, H, W)
-        x_nhwc = input.permute(0, 2, 3, 1).contiguous()
-        y = pb.dcn(Act(x_nhwc, B, H, W, C), self)
+        if self._tuned(C):
+            x_nhwc = input.permute(0, 2, 3, 1).contiguous()
+            y = pb.dcn(Act(x_nhwc, B, H, W, C), self)
+            for op in pb.ops:
+                op()
+            return y.t.permute(0, 3, 1, 2).contiguous()
+        # general domain (dcn_v2.py:64-70 literally): conv_offset_mask as one implicit-GEMM launch
+        # (channels zero-padded to the kernel's 4-channel granule), then chunk / cat / sigmoid
+        # folded into the operator call (the first 2/3 of the channels ARE cat(o1, o2)).
+        cp = (C + 3) // 4 * 4
+        x_nhwc = input.new_zeros((B, H, W, cp))
+        x_nhwc[..., :C] = input.permute(0, 2, 3, 1)
+        com = self.conv_offset_mask
+        w = com.weight.detach().new_zeros((com.weight.shape[0], cp) + tuple(com.weight.shape[2:]))
+        w[:, :C] = com.weight.detach()
+        om = pb.conv(Act(x_nhwc, B, H, W, cp), w, bias=com.bias, stride=self.stride,
+                     padding=self.padding, out_nchw=True)
         for op in pb.ops:
             op()
-        return y.t.permute(0, 3, 1, 2).contiguous()
+        n_off = 2 * self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
+        return dcn_v2_forward(input, om.t[:, :n_off], om.t[:, n_off:], self.weight, self.bias,
+                              self.stride, self.padding, self.dilation, self.deformable_groups,
+                              apply_mask_sigmoid=True)

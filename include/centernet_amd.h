@@ -110,9 +110,14 @@ int cn_set_tuning(int key, int value);
  *
  * weight is always the reference's (Cout,Cin,kh,kw) tensor here; use
  * cn_pack_conv_weight_f32 + the *_packed entry points to skip the repack.
- * Supported: kh=kw=3, stride 1, dilation 1, pad 1, deformable_group 1
- * (the only configuration CenterNet instantiates: resnet_dcn.py:221-223,
- * pose_dla_dcn.py:352); anything else returns CN_ERR_UNSUPPORTED.
+ * Domain: the reference operator's -- any kernel size, stride, padding, dilation,
+ * deformable_group (Cin % deformable_group == 0) and channel count.  The configuration
+ * CenterNet instantiates (3x3, stride 1, pad 1, dilation 1, one group, Cin % 4 == 0:
+ * resnet_dcn.py:221-223, pose_dla_dcn.py:352) runs on the NHWC MFMA kernel and needs
+ * cn_dcn_v2_forward_workspace_bytes() of 16-byte aligned scratch (layout change + tap
+ * split); every other configuration (e.g. DCNv2/test.py:16-19 inC = 2, :169-179
+ * deformable_groups = 2) runs on the general-domain NCHW kernel (cn_dcn_general.hip),
+ * which takes no workspace (NULL / 0 accepted).  Invalid geometry -> CN_ERR_SHAPE.
  * ------------------------------------------------------------------------ */
 size_t cn_dcn_v2_forward_workspace_bytes(int B, int Cin, int H, int W, int Cout,
                                          int kernel_h, int kernel_w, int layout);

@@ -26,15 +26,16 @@ def _bn(x, sd, p):
                         sd[p + ".bias"], False, 0.0, EPS)
 
 
-def dcn(x, sd, p):
-    """DCN.forward, DCNv2/dcn_v2.py:64-70."""
+def dcn(x, sd, p, stride=1, padding=1, dilation=1, deformable_groups=1):
+    """DCN.forward, DCNv2/dcn_v2.py:64-70 (conv_offset_mask has the DCN's stride and padding,
+    :52-57)."""
     out = F.conv2d(x, sd[p + ".conv_offset_mask.weight"], sd[p + ".conv_offset_mask.bias"],
-                   stride=1, padding=1)
+                   stride=stride, padding=padding)
     o1, o2, mask = torch.chunk(out, 3, dim=1)
     offset = torch.cat((o1, o2), dim=1)
     mask = torch.sigmoid(mask)
     y = cref.dcn_v2_forward(x.numpy(), offset.numpy(), mask.numpy(), sd[p + ".weight"].numpy(),
-                            sd[p + ".bias"].numpy(), 1, 1, 1, 1)
+                            sd[p + ".bias"].numpy(), stride, padding, dilation, deformable_groups)
     return torch.from_numpy(y)
 
 

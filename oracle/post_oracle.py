@@ -104,8 +104,8 @@ def ctdet_results(dets, meta, num_classes, scale=1, max_per_image=100):
 def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
     """external/nms.pyx:77-170 (and :172-275 for 39-column rows), statement by statement;
     ``boxes`` float32 (N, 5|39) modified in place; returns the kept indices.  The reference's
-    Cython source does not compile against NumPy 2 (np.int / np.float), so this restatement
-    is pinned only by hand-checked cases in tests/test_host.py."""
+    pinned bit-for-bit (kept count and the whole in-place array, rows past N included) against
+    the reference's own cython build, oracle/_ref (tests/test_oracle_ref.py)."""
     f = np.float32
     N = boxes.shape[0]
     ncol = boxes.shape[1]
@@ -127,22 +127,29 @@ def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
         pos = i + 1
         while pos < N:
             x1, y1, x2, y2 = boxes[pos, 0], boxes[pos, 1], boxes[pos, 2], boxes[pos, 3]
-            area = f(f(x2 - x1 + f(1)) * f(y2 - y1 + f(1)))
-            iw = f(min(tx2, x2) - max(tx1, x1) + f(1))
+            # cython emits the integer literals as the double 1.0: float differences widen to
+            # double, every assignment to a `cdef float` rounds once (generated C of nms.pyx:133-143)
+            d = np.float64
+            area = f((d(f(x2 - x1)) + 1.0) * (d(f(y2 - y1)) + 1.0))
+            iw = f(d(f(min(tx2, x2) - max(tx1, x1))) + 1.0)
             if iw > 0:
-                ih = f(min(ty2, y2) - max(ty1, y1) + f(1))
+                ih = f(d(f(min(ty2, y2) - max(ty1, y1))) + 1.0)
                 if ih > 0:
-                    ua = f(f(f(tx2 - tx1 + f(1)) * f(ty2 - ty1 + f(1))) + area - f(iw * ih))
+                    ua = f(((d(f(tx2 - tx1)) + 1.0) * (d(f(ty2 - ty1)) + 1.0) + d(area)) - d(f(iw * ih)))
                     ov = f(f(iw * ih) / ua)
                     if method == 1:
-                        weight = f(1) - ov if ov > Nt else f(1)
+                        weight = f(1.0 - d(ov)) if ov > Nt else f(1)
                     elif method == 2:
                         weight = f(np.exp(float(f(-f(ov * ov) / f(sigma)))))
                     else:
                         weight = f(0) if ov > Nt else f(1)
                     boxes[pos, 4] = f(weight * boxes[pos, 4])
                     if boxes[pos, 4] < threshold:
-                        boxes[pos, :ncol] = boxes[N - 1, :ncol]
+                        boxes[pos, :5] = boxes[N - 1, :5]
+                        if ncol > 5:                      # nms.pyx:260-268: columns 5.. swap
+                            t = boxes[pos, 5:].copy()
+                            boxes[pos, 5:] = boxes[N - 1, 5:]
+                            boxes[N - 1, 5:] = t
                         N -= 1
                         pos -= 1
             pos += 1

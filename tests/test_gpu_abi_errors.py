@@ -60,9 +60,12 @@ def test_dcn_error_codes(dev):
     assert call() == OK
     assert call(nbytes=need - 1) == WS
     assert call(x_=None) == NULL
-    # only the configuration CenterNet instantiates is built (resnet_dcn.py:221-223)
-    assert call(stride=2) == UNSUP and call(k=5) == UNSUP and call(dil=2) == UNSUP and call(dg=2) == UNSUP
+    # invalid geometry (the reference raises THError, dcn_v2_cuda.c:33-38): return codes
+    assert call(stride=0) == SHAPE and call(dil=0) == SHAPE and call(dg=0) == SHAPE
+    assert call(dg=3) == SHAPE                      # Cin % deformable_group != 0
+    assert call(pad=-1) == SHAPE and call(k=0) == SHAPE
     assert call(cin=0) == SHAPE
+    assert call(k=9, pad=0) == SHAPE                # kernel larger than the padded map: Ho <= 0
     torch.cuda.synchronize()
 
 

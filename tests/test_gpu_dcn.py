@@ -1,12 +1,20 @@
-"""Fused HIP DCNv2 (through the C ABI, NCHW drop-in entry and NHWC native entry) vs the C
-oracle.  fp32 tolerance: |diff| <= 2e-5 * (1 + |ref|) (fp32 MFMA, different summation
-order than the oracle's double accumulation)."""
+"""Fused HIP DCNv2 (through the C ABI, NCHW drop-in entry and NHWC native entry) vs
+  * the reference's own sampling kernel built test-only (oracle/_ref, when present) and the
+    committed fixtures made from it (tests/golden/ref_golden.npz), and
+  * the C oracle, itself bit-identical to oracle/_ref (tests/test_oracle_ref.py).
+fp32 tolerance: |diff| <= 2e-5 * (1 + |ref|) (fp32 MFMA, different summation order than the
+checker's double accumulation)."""
+import importlib.util
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from centernet_amd import synth
-from oracle import cref
+from oracle import cref, ref
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -32,16 +40,118 @@ def _case(B, Cin, H, W, Cout, seed, off_std=2.0):
 def test_dcn_nchw_entry_vs_oracle(dev, shape):
     from centernet_amd.dcn_v2 import dcn_v2_forward
     B, Cin, H, W, Cout = shape
-    if Cin % 4:
-        pytest.skip("HIP path needs Cin % 4 == 0")
     x, off, mask, w, b = _case(B, Cin, H, W, Cout, 20 + Cin)
-    ref = cref.dcn_v2_forward(x, off, mask, w, b)
+    want = cref.dcn_v2_forward(x, off, mask, w, b)
     y = dcn_v2_forward(*[torch.from_numpy(a).to(dev) for a in (x, off, mask, w, b)])
-    _check(y.cpu().numpy(), ref)
+    _check(y.cpu().numpy(), want)
+    if ref.available():       # the reference's own kernel on the same inputs
+        _check(y.cpu().numpy(), ref.dcn_v2_forward(x, off, mask, w, b))
+
+
+def _gen_ref():
+    spec = importlib.util.spec_from_file_location("gen_golden_ref", os.path.join(GOLDEN, "gen_golden_ref.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_dcn_vs_reference_kernel_fixtures(dev):
+    """Outputs of the REFERENCE's kernel (oracle/_ref at fixture-generation time) for tuned and
+    general-domain configurations: deformable groups, stride 2, dilation 2, 5x5, Cin = 2 / 6 / 7,
+    stress offsets."""
+    from centernet_amd.dcn_v2 import dcn_v2_forward
+    gen = _gen_ref()
+    z = np.load(os.path.join(GOLDEN, "ref_golden.npz"))
+    for name, cfg in gen.DCN_CASES.items():
+        x, off, mask, w, b, kw = gen.dcn_inputs(cfg)
+        y = dcn_v2_forward(*[torch.from_numpy(a).to(dev) for a in (x, off, mask, w, b)],
+                           stride=kw["stride"], padding=kw["pad"], dilation=kw["dil"],
+                           deformable_groups=kw["dg"])
+        err = np.abs(y.cpu().numpy() - z["dcn_" + name + "_y"]) / (1 + np.abs(z["dcn_" + name + "_y"]))
+        assert err.max() < TOL, (name, err.max())
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, Cin=64, H=24, W=20, Cout=64, dg=2),
+    dict(B=2, Cin=12, H=15, W=17, Cout=9, dg=3),
+    dict(B=1, Cin=6, H=17, W=13, Cout=70, stride=2),
+    dict(B=1, Cin=6, H=17, W=13, Cout=5, stride=2, pad=0),
+    dict(B=2, Cin=6, H=19, W=16, Cout=8, dil=2, pad=2),
+    dict(B=1, Cin=4, H=14, W=18, Cout=4, k=5, pad=2, dg=2),
+    dict(B=1, Cin=5, H=9, W=9, Cout=3, k=1, pad=0),
+    dict(B=1, Cin=3, H=33, W=9, Cout=130, k=3),
+])
+def test_dcn_general_domain_vs_oracle(dev, cfg):
+    """Everything outside the tuned configuration (dcn_v2_cuda.c:10-102 takes any kernel /
+    stride / pad / dilation / deformable_group): cn_dcn_general.hip through the same entry."""
+    from centernet_amd.dcn_v2 import dcn_v2_forward
+    B, Cin, H, W, Cout = cfg["B"], cfg["Cin"], cfg["H"], cfg["W"], cfg["Cout"]
+    k, stride, pad, dil, dg = cfg.get("k", 3), cfg.get("stride", 1), cfg.get("pad", 1), cfg.get("dil", 1), cfg.get("dg", 1)
+    Ho, Wo = cref.out_hw(H, W, k, k, stride, pad, dil)
+    x = synth.normal((B, Cin, H, W), 1.0, 3)
+    w = synth.normal((Cout, Cin, k, k), (2.0 / (Cin * k * k)) ** 0.5, 4)
+    b = synth.normal((Cout,), 0.1, 5)
+    off = synth.normal((B, dg * 2 * k * k, Ho, Wo), 2.0, 6)
+    off[0, :, 0, :] = -1.0
+    mask = synth.uniform((B, dg * k * k, Ho, Wo), 0, 1, 7)
+    want = cref.dcn_v2_forward(x, off, mask, w, b, stride, pad, dil, dg)
+    y = dcn_v2_forward(*[torch.from_numpy(a).to(dev) for a in (x, off, mask, w, b)], stride=stride,
+                       padding=pad, dilation=dil, deformable_groups=dg)
+    assert tuple(y.shape) == want.shape
+    _check(y.cpu().numpy(), want)
+    # mask sigmoid fused (DCN.forward, dcn_v2.py:67)
+    logit = synth.normal(mask.shape, 1.0, 8)
+    want = cref.dcn_v2_forward(x, off, (1 / (1 + np.exp(-logit.astype(np.float64)))).astype(np.float32),
+                               w, b, stride, pad, dil, dg)
+    y = dcn_v2_forward(*[torch.from_numpy(a).to(dev) for a in (x, off, logit, w, b)], stride=stride,
+                       padding=pad, dilation=dil, deformable_groups=dg, apply_mask_sigmoid=True)
+    _check(y.cpu().numpy(), want)
+
+
+def test_reference_example_dcn_module_two_deformable_groups(dev):
+    """DCNv2/test.py:169-179: DCN(64, 64, 3x3, stride 1, padding 1, deformable_groups=2) on a
+    (2, 64, 128, 128) input, un-skipped, vs the oracle chain."""
+    from centernet_amd.dcn_v2 import DCN
+    from oracle import net_oracle
+    m = DCN(64, 64, kernel_size=(3, 3), stride=1, padding=1, deformable_groups=2)
+    synth.fill_state_dict_(m, 11)
+    x = torch.from_numpy(synth.normal((2, 64, 128, 128), 1.0, 12))
+    sd = {"d." + k: v for k, v in m.state_dict().items()}
+    want = net_oracle.dcn(x, sd, "d", deformable_groups=2).numpy()
+    y = m.eval()(x.to(dev)).cpu().numpy()
+    assert y.shape == (2, 64, 128, 128)
+    _check(y, want)
+
+
+def test_dcn_module_general_stride_and_odd_channels(dev):
+    from centernet_amd.dcn_v2 import DCN
+    from oracle import net_oracle
+    m = DCN(6, 10, kernel_size=(3, 3), stride=2, padding=1, deformable_groups=3)
+    synth.fill_state_dict_(m, 13)
+    x = torch.from_numpy(synth.normal((2, 6, 21, 18), 1.0, 14))
+    sd = {"d." + k: v for k, v in m.state_dict().items()}
+    want = net_oracle.dcn(x, sd, "d", stride=2, deformable_groups=3).numpy()
+    y = m.eval()(x.to(dev)).cpu().numpy()
+    _check(y, want)
+
+
+def test_reference_zero_offset_identity_kat_exact_shape(dev):
+    """DCNv2/test.py:16-19,32-65 at the reference's own shape N, inC, inH, inW = 2, 2, 4, 4."""
+    from centernet_amd.dcn_v2 import DCNv2
+    N, C, H, W = 2, 2, 4, 4
+    x = synth.normal((N, C, H, W), 1.0, 0)
+    m = DCNv2(C, C, (3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(dev)
+    with torch.no_grad():
+        m.weight.zero_()
+        m.weight[torch.arange(C), torch.arange(C), 1, 1] = 1.0
+        m.bias.zero_()
+    y = m(torch.from_numpy(x).to(dev), torch.zeros((N, 18, H, W), device=dev),
+          torch.full((N, 9, H, W), 0.5, device=dev))
+    assert np.abs(2 * y.cpu().numpy() - x).max() < 1e-6
 
 
 def test_reference_zero_offset_identity_kat(dev):
-    """DCNv2/test.py:32-65 (shapes widened to Cin=4 for the 16-byte channel vectors)."""
+    """DCNv2/test.py:32-65 on the tuned path (Cin = 4: 16-byte channel vectors)."""
     from centernet_amd.dcn_v2 import dcn_v2_forward
     N, C, H, W = 2, 4, 4, 4
     x = synth.normal((N, C, H, W), 1.0, 0)
@@ -64,9 +174,10 @@ def test_stress_offsets_far_outside(dev):
     off[0, :, 0, :] = -1.0
     off[0, :, 1, :] = float(H)
     off[1, :, 2, :] = np.round(off[1, :, 2, :])
-    ref = cref.dcn_v2_forward(x, off, mask, w, b)
+    want = ref.dcn_v2_forward(x, off, mask, w, b) if ref.available() else \
+        cref.dcn_v2_forward(x, off, mask, w, b)
     y = dcn_v2_forward(*[torch.from_numpy(a).to(dev) for a in (x, off, mask, w, b)])
-    _check(y.cpu().numpy(), ref)
+    _check(y.cpu().numpy(), want)
 
 
 def test_dcn_module_with_offset_conv(dev):
@@ -79,9 +190,9 @@ def test_dcn_module_with_offset_conv(dev):
     x = synth.images(2, 16, 16, 3)[:, :1].repeat(1, 64, 1, 1) * synth.normal((1, 64, 1, 1), 1.0, 9)
     x = x.contiguous()
     sd = {"d." + k: v for k, v in m.state_dict().items()}
-    ref = net_oracle.dcn(x, sd, "d").numpy()
+    want = net_oracle.dcn(x, sd, "d").numpy()
     y = m.eval()(x.to(dev)).cpu().numpy()
-    _check(y, ref)
+    _check(y, want)
 
 
 def test_full_size_linearity(dev):
@@ -115,8 +226,8 @@ def test_lds_window_variant_matches_oracle(dev):
         for (B, Cin, H, W, Cout, std) in [(2, 64, 16, 16, 64, 2.0), (1, 128, 20, 12, 128, 6.0),
                                           (1, 36, 9, 11, 40, 1.0)]:
             x, off, mask, w, b = _case(B, Cin, H, W, Cout, 50 + Cin, off_std=std)
-            ref = cref.dcn_v2_forward(x, off, mask, w, b)
+            want = cref.dcn_v2_forward(x, off, mask, w, b)
             y = dcn_v2_forward(*[torch.from_numpy(a).to(dev) for a in (x, off, mask, w, b)])
-            _check(y.cpu().numpy(), ref)
+            _check(y.cpu().numpy(), want)
     finally:
         lib.cn_set_tuning(11, 0)
