@@ -1,17 +1,22 @@
 #!/usr/bin/env python
-"""Headline benchmark: images/s of the CenterNet ctdet hot path (network + decode) on
-512x512 synthetic input, ResNet-18-DCN, batch 32 per GPU, fp32.
+"""Headline benchmark: images/s of the CenterNet hot path (network + decode) on 512x512
+synthetic input.  Default = BASELINE configs[1]: ctdet ResNet-18-DCN, batch 32 per GPU, fp32.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                   # 1 GPU, configs[1]
+    python bench.py --gpus 8 --steps 50 --warmup 5    # spawns 8 ranks itself (torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # or launched by the driver
 
-One step = detector.run_batch(images): backbone + DCN + heads + fused sigmoid/decode over
-one device-resident batch.  Images shard over ranks (weak scaling, no collective in the
-loop); rank 0 broadcasts the flat weight buffer once at start-up over RCCL.
-Prints ONE JSON line (rank 0).
+    --config 2|3|4 selects the other BASELINE configurations (dla_34 ctdet, dla_34 multi_pose,
+    hourglass fp16 batch 8); --arch / --task / --batch / --fp16 override piecewise.
+
+One step = detector.run_batch(images): backbone + DCN + heads + fused sigmoid / peak-NMS /
+top-K decode over one device-resident batch -- the same entry point in warm-up and in the
+timed loop.  Images shard over ranks (weak scaling, no collective in the loop); rank 0
+broadcasts the flat weight buffer once at start-up over RCCL.  Prints ONE JSON line (rank 0).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -20,30 +25,43 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md)
 
+DECODE_LAUNCHES = {"ctdet": 2, "multi_pose": 4}   # kernels per decode call (cn_decode.hip)
 
-def pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (tools/pmc_traffic.py,
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); summed per kernel class."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return {}
-    with open(path) as f:
+# BASELINE.json configs[1..4] (configs[0] is the reference's CPU plumbing case: cpu_baseline)
+CONFIGS = {
+    1: dict(task="ctdet", arch="resdcn_18", batch=32, fp16=False),
+    2: dict(task="ctdet", arch="dla_34", batch=32, fp16=False),       # 256 over 8 GPUs = 32/GPU
+    3: dict(task="multi_pose", arch="dla_34", batch=32, fp16=False),
+    4: dict(task="ctdet", arch="hourglass", batch=8, fp16=True),
+}
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC summary of this
+    configuration (tools/pmc_traffic.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), summed
+    per kernel class; {} when no profile of this configuration is committed."""
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % tag)))
+    if not hits and tag == "cfg1":
+        hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not hits:
+        return {}, None
+    with open(hits[-1]) as f:
         raw = json.load(f)
     cls = {"conv": 0.0, "dcn": 0.0, "decode": 0.0, "maxpool": 0.0}
     n = {"conv": 0, "dcn": 0, "decode": 0, "maxpool": 0}
     steps = max(1, raw.get("nms_topk_kernel", {}).get("launches", 1))
     for k, v in raw.items():
+        if not isinstance(v, dict) or "hbm_bytes_per_launch" not in v:
+            continue
         if k.startswith("igemm_kernel"):
             c = "dcn" if k.rstrip(">").split(",")[5].strip() == "2" else "conv"
-        elif k.startswith(("stem_conv", "stem_persist", "splitk_reduce", "conv3x3s1_kernel", "conv16_kernel")):
+        elif k.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_")):
             c = "conv"
-        elif k.startswith(("nms_topk", "merge_topk")):
+        elif k.startswith(("nms_topk", "merge_topk", "peak_", "pose_match", "decode_")):
             c = "decode"
         elif k.startswith("maxpool"):
             c = "maxpool"
@@ -51,54 +69,119 @@ def pmc_traffic():
             continue
         cls[c] += v["hbm_bytes_per_launch"] * v["launches"] / steps   # bytes per forward step
         n[c] += v["launches"] // steps
-    return {c: (cls[c], n[c]) for c in cls if n[c]}
+    return {c: (cls[c], n[c]) for c in cls if n[c]}, os.path.basename(hits[-1])
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS),
+                   help="BASELINE.json configs[i]")
+    p.add_argument("--task", default=None, choices=["ctdet", "multi_pose"])
+    p.add_argument("--arch", default=None)
+    p.add_argument("--batch", type=int, default=None, help="images per GPU per step")
+    p.add_argument("--res", type=int, default=512)
+    p.add_argument("--fp16", action="store_true", default=None,
+                   help="fp16 activations/weights, fp32 accumulate (configs[4], hourglass only)")
     p.add_argument("--tune", action="append", default=[],
                    help="KEY=VALUE for cn_set_tuning (A/B experiments; not used by the driver)")
-    p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    p.add_argument("--arch", default="resdcn_18")
-    p.add_argument("--res", type=int, default=512)
-    p.add_argument("--fp16", action="store_true",
-                   help="fp16 activations/weights, fp32 accumulate (configs[4], hourglass only)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-images", type=int, default=16)
+    p.add_argument("--cpu-seconds", type=float, default=15.0,
+                   help="bound of the CPU-baseline sample (seconds of CPU work)")
     p.add_argument("--per-op", action="store_true", help="print per-launch timings to stderr")
-    return p.parse_args()
+    a = p.parse_args(argv)
+    cfg = CONFIGS[a.config]
+    for k, v in cfg.items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    return a
 
 
-def cpu_baseline(arch, state_dict, heads, res, n_images):
-    """The CPU restatement of the same path (oracle/: torch-CPU dense ops, i.e. the
-    reference's own arithmetic, + C DCNv2 + C decode) timed on the host cores."""
+def _time_images(fn, make_input, seconds):
+    fn(make_input(0))   # warm-up
+    t0 = time.time()
+    done = 0
+    while (time.time() - t0) < seconds:
+        fn(make_input(1 + done))
+        done += 1
+    return done, time.time() - t0
+
+
+def cpu_baseline(task, arch, state_dict, heads, res, seconds):
+    """CPU leg, timed on this host's cores in the same run.
+
+    kind "port": oracle/net_oracle (torch-CPU dense ops -- the reference's own third-party
+    arithmetic -- + C DCNv2 + C decode) on the SAME architecture; the reference's DCNv2 has no
+    CPU implementation (DCNv2/src/dcn_v2.c:5-16 only prints), so a port is the only CPU form of
+    the DCN networks.  Where /root/reference is present (build container; never on the GPU box)
+    the reference's OWN msra_resnet.PoseResNet + models/decode.ctdet_decode (BASELINE
+    configs[0]: ResNet-18 without DCN, batch 1) is timed beside it as `reference_res18`."""
+    import torch
     from centernet_amd import synth
     from oracle import net_oracle, cref
     cref.lib()
     cores = min(os.cpu_count() or 1, 64)   # more threads than this slows batch-1 convs down
     torch.set_num_threads(cores)
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    x = synth.images(1, res, res, seed=1)
-    net_oracle.ctdet_process(arch, state_dict, x, heads)  # warm-up
-    t0 = time.time()
-    done = 0
-    while done < n_images and (time.time() - t0) < 20.0:   # bounded sample: <= ~20 s of CPU work
-        net_oracle.ctdet_process(arch, state_dict, synth.images(1, res, res, seed=2 + done), heads)
-        done += 1
-    dt = time.time() - t0
-    return {"value": done / dt, "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "%d images %dx%d batch 1, oracle/net_oracle.ctdet_process (torch-CPU convs "
-                      "+ C DCNv2 + C decode), %.1f s" % (done, res, res, dt)}
+    if task == "ctdet":
+        fn = lambda x: net_oracle.ctdet_process(arch, state_dict, x, heads)      # noqa: E731
+    else:
+        fn = lambda x: net_oracle.multi_pose_process(arch, state_dict, x, heads)  # noqa: E731
+    done, dt = _time_images(fn, lambda i: synth.images(1, res, res, seed=1 + i), seconds)
+    out = {"value": done / dt, "unit": "img/s", "cores": cores, "kind": "port",
+           "sample": "%d images %dx%d batch 1 in %.1f s: oracle/net_oracle %s %s -- a PORT (torch-CPU "
+                     "convs + C DCNv2 + C decode), not the reference's code: the reference has no "
+                     "CPU DCNv2" % (done, res, res, dt, task, arch)}
+    ref_src = "/root/reference/src/lib"
+    if os.path.isdir(ref_src):
+        try:
+            out["reference_res18"] = _reference_cpu_res18(ref_src, res, min(seconds, 10.0), cores)
+        except Exception as e:   # the reference tree is optional, never fatal
+            out["reference_res18"] = {"error": repr(e)[:200]}
+    return out
+
+
+def _reference_cpu_res18(ref_src, res, seconds, cores):
+    """The reference's own CPU PyTorch path: msra_resnet.PoseResNet(BasicBlock,
+    [2,2,2,2]) -> sigmoid_ -> models/decode.ctdet_decode at batch 1, imported from
+    /root/reference (no bytecode written there)."""
+    import importlib
+    import torch
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, ref_src)
+    try:
+        mr = importlib.import_module("models.networks.msra_resnet")
+        dec = importlib.import_module("models.decode")
+    finally:
+        sys.path.remove(ref_src)
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    torch.manual_seed(317)
+    m = mr.PoseResNet(mr.BasicBlock, [2, 2, 2, 2], heads, head_conv=64).eval()
+
+    def fn(x):
+        with torch.no_grad():
+            o = m(x)[-1]
+            return dec.ctdet_decode(o["hm"].sigmoid_(), o["wh"], reg=o["reg"], K=100)
+    g = torch.Generator().manual_seed(0)
+    done, dt = _time_images(fn, lambda i: torch.randn((1, 3, res, res), generator=g), seconds)
+    return {"value": done / dt, "unit": "img/s", "cores": cores, "kind": "reference",
+            "sample": "%d images %dx%d batch 1 in %.1f s: reference msra_resnet res_18 (no DCN) + "
+                      "models/decode.ctdet_decode, torch CPU" % (done, res, res, dt)}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the ranks ourselves (one process per GPU)
+        from centernet_amd.sharding import launch_ranks
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # BENCH_DEVICE / BENCH_BACKEND exist only so the multi-rank control flow can be exercised on
     # a single-GPU box (two ranks sharing cuda:0 over gloo); the driver never sets them.
@@ -107,13 +190,19 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    world = 1
+    if env_world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=dev)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=env_world)
+        world = dist.get_world_size()
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s); launch with "
+                         "`python bench.py --gpus N` (self-spawning) or torchrun --nproc-per-node N"
+                         % (a.gpus, world))
 
     from centernet_amd import synth, native
     for kv in a.tune:
@@ -123,14 +212,15 @@ def main():
     from centernet_amd.detectors import detector_factory
     from centernet_amd.sharding import broadcast_weights
 
-    opt = opts().init(["ctdet", "--arch", a.arch, "--input_res", str(a.res)])
+    opt = opts().init([a.task, "--arch", a.arch, "--input_res", str(a.res)])
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):   # the detector prints 'Creating model...'
         det = detector_factory[opt.task](opt)
     if rank == 0:
         synth.fill_state_dict_(det.model, 317)
+    bcast_bytes = 0
     if world > 1:
-        broadcast_weights(det.model, src=0)      # one flat RCCL broadcast, then no collectives
+        bcast_bytes = broadcast_weights(det.model, src=0)   # ONE flat RCCL broadcast, then none
     det.model.invalidate_plans()
     if a.fp16:
         det.model.half_compute()
@@ -146,8 +236,8 @@ def main():
 
     plan = det.model.plan_for(B, a.res, a.res, dev)
     # HIP events on the launch stream, inside the timed region.  A marker after every launch
-    # costs ~7 us of bubble each (35 per step), so by default events sit only where the kernel
-    # class changes (the per-class sums stay exact); --per-op records one after every launch.
+    # costs ~7 us of bubble each, so by default events sit only where the kernel class changes
+    # (the per-class sums stay exact); --per-op records one after every launch.
     metas = plan.b.meta
     nops = len(metas)
     if a.per_op:
@@ -156,18 +246,12 @@ def main():
         bounds = [i for i in range(nops) if i == nops - 1 or metas[i]["kind"] != metas[i + 1]["kind"]]
     bset = set(bounds)
     seg_first = [0] + [b + 1 for b in bounds[:-1]]   # first op of every segment
-    ev_all = []
-    e_dec0, e_dec1 = [], []
+    probes = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        evs = []
-        with torch.no_grad():
-            out = plan.run(images, events=evs, event_after=bset)
-            e0 = torch.cuda.Event(enable_timing=True); e0.record()
-            from centernet_amd.decode import ctdet_decode
-            dets = ctdet_decode(out["hm"], out["wh"], reg=out["reg"], K=opt.K, apply_sigmoid=True)
-            e1 = torch.cuda.Event(enable_timing=True); e1.record()
-        ev_all.append(evs); e_dec0.append(e0); e_dec1.append(e1)
+        probe = {"event_after": bset}
+        dets = det.run_batch(images, probe=probe)    # same entry point as the warm-up
+        probes.append(probe)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -181,7 +265,8 @@ def main():
     if rank == 0:
         # ---- per-kernel-class time from the HIP events recorded inside the timed region
         kinds = {}
-        for evs in ev_all:
+        for pr in probes:
+            evs = pr["net_events"]
             for si, (first, last) in enumerate(zip(seg_first, bounds)):
                 ms = evs[si].elapsed_time(evs[si + 1])
                 k = kinds.setdefault(metas[first]["kind"], {"ms": 0.0, "flops": 0, "bytes": 0, "launches": 0})
@@ -190,64 +275,75 @@ def main():
                     k["flops"] += m["flops"]; k["bytes"] += m["bytes"]; k["launches"] += 1
         if a.per_op:
             for i, m in enumerate(plan.b.meta):
-                ms = sum(evs[i].elapsed_time(evs[i + 1]) for evs in ev_all) / a.steps
+                ms = sum(pr["net_events"][i].elapsed_time(pr["net_events"][i + 1]) for pr in probes) / a.steps
                 kind, act = plan.b.trace[i]
                 print("op %2d %-7s out(B,H,W,C)=(%d,%d,%d,%d) %8.3f ms  %7.2f TF/s  %7.1f GB/s" % (
                     i, kind, act.B, act.H, act.W, act.C, ms, m["flops"] / ms / 1e9 if ms else 0,
                     m["bytes"] / ms / 1e6 if ms else 0), file=sys.stderr)
-        dec_ms = sum(s.elapsed_time(e) for s, e in zip(e_dec0, e_dec1))
-        C, Ho = opt.num_classes, a.res // 4
-        dec_bytes = B * (C * Ho * Ho * 4 + 2 * 2 * Ho * Ho * 4 + opt.K * 6 * 4)
+        dec_ms = sum(pr["dec_events"][0].elapsed_time(pr["dec_events"][1]) for pr in probes)
+        Ho = a.res // 4
+        if a.task == "ctdet":   # hm + wh + reg read once, (K,6) written
+            dec_bytes = B * (opt.num_classes * Ho * Ho * 4 + 2 * 2 * Ho * Ho * 4 + opt.K * 6 * 4)
+        else:                   # hm 1 + wh 2 + hps 34 + reg 2 + hm_hp 17 + hp_offset 2, (K,40)
+            dec_bytes = B * ((1 + 2 + 34 + 2 + 17 + 2) * Ho * Ho * 4 + opt.K * 40 * 4)
         kinds["decode"] = {"ms": dec_ms, "flops": 0, "bytes": dec_bytes * a.steps,
-                           "launches": 2 * a.steps}
+                           "launches": DECODE_LAUNCHES[a.task] * a.steps}
         dom = max(kinds, key=lambda k: kinds[k]["ms"])
-        pmc = pmc_traffic() if (a.arch == "resdcn_18" and B == 32 and a.res == 512 and not a.fp16) else {}
+        standard = (a.res == 512 and not a.tune and
+                    all(getattr(a, k) == v for k, v in CONFIGS[a.config].items()))
+        pmc, pmc_file = pmc_traffic("cfg%d" % a.config) if standard else ({}, None)
 
         def traffic(k):
             # measured HBM bytes per launch of this kernel class (committed PMC profile of the
-            # same command), or null when the profile does not cover this configuration
+            # same command), or null when no profile covers this configuration
             if k not in pmc:
                 return None
             byts, launches = pmc[k]
             return byts / max(launches, 1)
 
-        def mfma_roof(k):
+        def roof(k, bound):
             s = kinds[k]
-            ach = s["flops"] / (s["ms"] * 1e-3) / 1e12 if s["ms"] > 0 else 0.0
-            peak = F16_MFMA_PEAK_TF if a.fp16 else F32_MFMA_PEAK_TF
-            return {"kernel": k, "bound": "mfma", "achieved": ach, "peak": peak,
-                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic(k),
-                    "avg_launch_ms": s["ms"] / max(s["launches"], 1), "launches_per_step": s["launches"] // a.steps}
+            sec = s["ms"] * 1e-3
+            if bound == "mfma":
+                ach = s["flops"] / sec / 1e12 if sec > 0 else 0.0
+                peak, unit = (F16_MFMA_PEAK_TF if a.fp16 else F32_MFMA_PEAK_TF), "TFLOP/s"
+            else:
+                ach = s["bytes"] / sec / 1e9 if sec > 0 else 0.0
+                peak, unit = HBM_PEAK_GBS, "GB/s"
+            return {"kernel": k, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                    "frac": ach / peak, "traffic": traffic(k),
+                    "algorithmic_bytes_per_launch": s["bytes"] / max(s["launches"], 1),
+                    "avg_launch_ms": s["ms"] / max(s["launches"], 1),
+                    "launches_per_step": s["launches"] // a.steps}
 
-        def hbm_roof(k):
-            s = kinds[k]
-            ach = s["bytes"] / (s["ms"] * 1e-3) / 1e9 if s["ms"] > 0 else 0.0
-            return {"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic(k),
-                    "avg_launch_ms": s["ms"] / max(s["launches"], 1), "launches_per_step": s["launches"] // a.steps}
-
-        roofline = mfma_roof(dom) if kinds[dom]["flops"] > 0 else hbm_roof(dom)
         total_imgs = B * a.steps * world
         res = {
             "metric": "images/sec whole-node, 512x512 ctdet", "value": total_imgs / dt,
             "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if a.fp16 else "f32", "data": "synthetic",
-            "config": {"workload": "ctdet %s %dx%d, batch %d per GPU (BASELINE configs[1]), "
-                                   "network + fused sigmoid/peak-NMS/top-K decode, K=%d"
-                                   % (a.arch, a.res, a.res, B, opt.K),
+            "config": {"workload": "%s %s %dx%d, batch %d per GPU (BASELINE configs[%d]%s), network "
+                                   "+ fused sigmoid/peak-NMS/top-K decode, K=%d"
+                                   % (a.task, a.arch, a.res, a.res, B, a.config,
+                                      "" if standard else ", modified", opt.K),
                        "global_batch": B * world, "parallelism": "image-sharded x%d" % world,
                        "gflop_per_image": plan.flops / B / 1e9},
-            "roofline": roofline,
-            "roofline_dcn_mfma": mfma_roof("dcn") if "dcn" in kinds else None,
-            "roofline_dcn_hbm": hbm_roof("dcn") if "dcn" in kinds else None,
-            "roofline_decode_hbm": hbm_roof("decode"),
+            "world_size_seen": world,
+            "backend": ("%s (RCCL over xGMI)" % backend if backend == "nccl" else backend) if dist is not None else None,
+            "weight_broadcast_bytes": bcast_bytes,
+            "roofline": roof(dom, "mfma" if kinds[dom]["flops"] > 0 else "hbm"),
+            "roofline_dcn_mfma": roof("dcn", "mfma") if "dcn" in kinds else None,
+            "roofline_dcn_hbm": roof("dcn", "hbm") if "dcn" in kinds else None,
+            "roofline_decode_hbm": roof("decode", "hbm"),
+            "pmc_profile": pmc_file,
             "time_share": {k: round(v["ms"] / (dt * 1e3), 4) for k, v in kinds.items()},
         }
         if world == 1 and not a.no_cpu_baseline:
             sd = {k: v.detach().cpu() for k, v in det.model.state_dict().items()}
-            res["cpu_baseline"] = cpu_baseline(a.arch, sd, list(opt.heads), a.res, a.cpu_images)
+            res["cpu_baseline"] = cpu_baseline(a.task, a.arch, sd, list(opt.heads), a.res,
+                                               a.cpu_seconds)
         print(json.dumps(res))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
     const float NEG_INF = -__builtin_huge_valf();
     // ablation bits for tools/bench_decode.py (never set through the Python API)
     const bool dbg_noselect = (apply_sigmoid & 256) != 0;
-    const bool dbg_nonms = (apply_sigmoid & 512) != 0;
+    const bool dbg_nonms = (apply_sigmoid & CN_DECODE_NO_PEAK_TEST) != 0;  // plain topk
     const bool dbg_slow = (apply_sigmoid & 1024) != 0;
     apply_sigmoid &= 1;
     if (tid == 0) sh.ncand = 0;
@@ -783,7 +783,11 @@ __global__ void gather_feat_kernel(const float *__restrict__ feat, const int32_t
     const int c = (int)(i % C);
     const size_t bk = i / C;
     const size_t b = bk / K;
-    out[i] = feat[(b * C + c) * HW + inds[bk]];
+    // an index outside the map never reads out of bounds (the Python wrapper raises for it, as
+    // torch.gather does; a raw C-ABI caller gets NaN in that row)
+    const int32_t ind = inds[bk];
+    out[i] = ((uint32_t)ind < (uint32_t)HW) ? feat[(b * C + c) * HW + ind]
+                                             : __builtin_nanf("");
 }
 
 // one thread per (b,k): [xs, ys, score, rot(8), depth, dim(3), (wh(2),) cls]  (decode.py:433-460)

@@ -37,11 +37,26 @@ def _prep(*ts):
     return out
 
 
+def _expect(name, t, B, C, H, W, device):
+    """The decoders read their maps through raw pointers: a map of the wrong size would be a
+    silent out-of-bounds device read, where the reference's torch ops raise."""
+    if t is None:
+        return
+    if t.dim() != 4 or tuple(t.shape) != (B, C, H, W):
+        raise RuntimeError("%s must have shape %s, got %s" % (name, (B, C, H, W), tuple(t.shape)))
+    if t.device != device:
+        raise RuntimeError("%s is on %s, the heat-map on %s" % (name, t.device, device))
+
+
 def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=False,
                  return_inds=False, _debug_flags=0):
     heat, wh, reg = _prep(heat, wh, reg)
     lib = native.lib()
+    if heat.dim() != 4:
+        raise RuntimeError("heat must be (B, C, H, W)")
     B, C, H, W = heat.shape
+    _expect("wh", wh, B, 2 * C if cat_spec_wh else 2, H, W, heat.device)
+    _expect("reg", reg, B, 2, H, W, heat.device)
     if K > H * W:
         raise RuntimeError("selected index k out of range")  # torch.topk's error
     dets = torch.empty((B, K, 6), device=heat.device, dtype=torch.float32)
@@ -56,21 +71,24 @@ def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=Fal
     return (dets, inds.long()) if return_inds else dets
 
 
+_NO_PEAK_TEST = 512   # flag bit of the decode entry points: rank every cell (plain topk)
+
+
 def _topk_channel(scores, K=40, apply_sigmoid=False, nms=False):
-    """decode.py:92-101.  With ``nms=True`` the 3x3 peak test is fused in front (the only
-    way the reference ever calls it, decode.py:528-533)."""
+    """decode.py:92-101: per-channel top-K -> (scores, inds, ys, xs), each (B, C, K).  With
+    ``nms=True`` the 3x3 peak test of ``_nms`` is fused in front (how the reference chains
+    them, decode.py:528-533); ``nms=False`` is the plain function on any float map."""
     (scores,) = _prep(scores)
     lib = native.lib()
     B, C, H, W = scores.shape
     if K > H * W:
         raise RuntimeError("selected index k out of range")
-    if not nms:
-        raise native.NativeError("the HIP kernel fuses _nms with _topk_channel; call with nms=True")
+    flags = int(bool(apply_sigmoid)) | (0 if nms else _NO_PEAK_TEST)
     s = torch.empty((B, C, K), device=scores.device, dtype=torch.float32)
     i = torch.empty((B, C, K), device=scores.device, dtype=torch.int32)
     nbytes = lib.cn_ctdet_decode_workspace_bytes(B, C, H, W, K)
     ws = _workspace(nbytes, scores.device)
-    rc = lib.cn_nms_topk_channel_f32(native.ptr(scores), B, C, H, W, K, int(bool(apply_sigmoid)),
+    rc = lib.cn_nms_topk_channel_f32(native.ptr(scores), B, C, H, W, K, flags,
                                      native.ptr(s), native.ptr(i), native.ptr(ws), ws.numel(),
                                      native.stream_ptr())
     native.check(rc, "cn_nms_topk_channel_f32")
@@ -84,8 +102,15 @@ def multi_pose_decode(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100
                       apply_sigmoid=False):
     heat, wh, kps, reg, hm_hp, hp_offset = _prep(heat, wh, kps, reg, hm_hp, hp_offset)
     lib = native.lib()
+    if heat.dim() != 4 or kps.dim() != 4 or kps.shape[1] % 2:
+        raise RuntimeError("heat must be (B, C, H, W) and kps (B, 2J, H, W)")
     B, C, H, W = heat.shape
     J = kps.shape[1] // 2
+    _expect("wh", wh, B, 2, H, W, heat.device)
+    _expect("kps", kps, B, 2 * J, H, W, heat.device)
+    _expect("reg", reg, B, 2, H, W, heat.device)
+    _expect("hm_hp", hm_hp, B, J, H, W, heat.device)
+    _expect("hp_offset", hp_offset, B, 2, H, W, heat.device)
     if K > H * W:
         raise RuntimeError("selected index k out of range")
     dets = torch.empty((B, K, 4 + 1 + 2 * J + 1), device=heat.device, dtype=torch.float32)
@@ -100,20 +125,20 @@ def multi_pose_decode(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100
 
 
 def _topk(scores, K=40, apply_sigmoid=False, nms=False):
-    """decode.py:103-119 with the 3x3 peak test fused in front (``nms=True``: the only way
-    the reference calls it): (scores, inds, clses, ys, xs), each (B, K)."""
+    """decode.py:103-119: (scores, inds, clses, ys, xs), each (B, K); ``nms=True`` fuses the
+    3x3 peak test of ``_nms`` in front (how the reference chains them), ``nms=False`` is the
+    plain function."""
     (scores,) = _prep(scores)
     lib = native.lib()
     B, C, H, W = scores.shape
     if K > H * W:
         raise RuntimeError("selected index k out of range")
-    if not nms:
-        raise native.NativeError("the HIP kernel fuses _nms with _topk; call with nms=True")
+    flags = int(bool(apply_sigmoid)) | (0 if nms else _NO_PEAK_TEST)
     s = torch.empty((B, K), device=scores.device, dtype=torch.float32)
     i = torch.empty((B, K), device=scores.device, dtype=torch.int32)
     c = torch.empty((B, K), device=scores.device, dtype=torch.int32)
     ws = _workspace(lib.cn_ctdet_decode_workspace_bytes(B, C, H, W, K), scores.device)
-    rc = lib.cn_topk_f32(native.ptr(scores), B, C, H, W, K, int(bool(apply_sigmoid)), native.ptr(s),
+    rc = lib.cn_topk_f32(native.ptr(scores), B, C, H, W, K, flags, native.ptr(s),
                          native.ptr(i), native.ptr(c), native.ptr(ws), ws.numel(),
                          native.stream_ptr())
     native.check(rc, "cn_topk_f32")
@@ -126,7 +151,11 @@ def _transpose_and_gather_feat(feat, ind):
     (feat,) = _prep(feat)
     lib = native.lib()
     B, C, H, W = feat.shape
+    if ind.dim() != 2 or ind.shape[0] != B or ind.device != feat.device:
+        raise RuntimeError("ind must be (B, K) on the device of feat")
     K = ind.shape[1]
+    if ind.numel() and (int(ind.min()) < 0 or int(ind.max()) >= H * W):   # torch.gather raises
+        raise RuntimeError("index out of range for a %dx%d map" % (H, W))
     ind32 = ind.to(torch.int32).contiguous()
     out = torch.empty((B, K, C), device=feat.device, dtype=torch.float32)
     rc = lib.cn_gather_feat_f32(native.ptr(feat), native.ptr(ind32), native.ptr(out), B, C, H, W, K,
@@ -142,7 +171,11 @@ def ddd_decode(heat, rot, depth, dim, wh=None, reg=None, K=40, apply_sigmoid=Fal
     B, C, H, W = heat.shape
     if K > H * W:
         raise RuntimeError("selected index k out of range")
-    assert rot.shape[1] == 8 and depth.shape[1] == 1 and dim.shape[1] == 3
+    _expect("rot", rot, B, 8, H, W, heat.device)
+    _expect("depth", depth, B, 1, H, W, heat.device)
+    _expect("dim", dim, B, 3, H, W, heat.device)
+    _expect("wh", wh, B, 2, H, W, heat.device)
+    _expect("reg", reg, B, 2, H, W, heat.device)
     dets = torch.empty((B, K, 18 if wh is not None else 16), device=heat.device, dtype=torch.float32)
     ws = _workspace(lib.cn_ddd_decode_workspace_bytes(B, C, H, W, K), heat.device)
     rc = lib.cn_ddd_decode_f32(native.ptr(heat), native.ptr(rot), native.ptr(depth), native.ptr(dim),
@@ -164,6 +197,10 @@ def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=Non
         t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr, l_regr, b_regr, r_regr)
     lib = native.lib()
     B, C, H, W = t_heat.shape
+    for name, t in (("l_heat", l_heat), ("b_heat", b_heat), ("r_heat", r_heat), ("ct_heat", ct_heat)):
+        _expect(name, t, B, C, H, W, t_heat.device)
+    for name, t in (("t_regr", t_regr), ("l_regr", l_regr), ("b_regr", b_regr), ("r_regr", r_regr)):
+        _expect(name, t, B, 2, H, W, t_heat.device)
     if K > H * W or num_dets > K ** 4:
         raise RuntimeError("selected index k out of range")
     dets = torch.empty((B, num_dets, 14), device=t_heat.device, dtype=torch.float32)

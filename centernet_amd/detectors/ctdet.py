@@ -25,7 +25,7 @@ class CtdetDetector(BaseDetector):
         sigmoid of ctdet.py:31 is fused into the decode kernel (``hm`` stays logits); with it,
         the mirrored frame (image 1) is averaged in after the sigmoid, as in the reference."""
         with torch.no_grad():
-            output = self.model(images)[-1]
+            output = self.model(images, borrow=True)[-1]   # consumed before the next run
             hm, wh = output['hm'], output['wh']
             reg = output['reg'] if self.opt.reg_offset else None
             logits = not self.opt.flip_test
@@ -72,13 +72,27 @@ class CtdetDetector(BaseDetector):
         return results
 
     # ------------------------------------------------------------------ new surface
-    def run_batch(self, images):
+    def run_batch(self, images, probe=None):
         """``images`` (B,3,H,W) fp32, already normalised, on the device -> raw (B,K,6)
-        detections in output-grid units (device tensor)."""
+        detections in output-grid units (device tensor).  ``probe``: optional dict for
+        measurement (bench.py): ``event_after`` (set of launch indices) in, ``net_events`` (HIP
+        events at those launch boundaries) and ``dec_events`` (before / after the decode) out."""
         with torch.no_grad():
-            out = self.model(images)[-1]
-            return self._decode(out['hm'], out['wh'], out['reg'] if self.opt.reg_offset else None,
+            if probe is None:
+                out = self.model(images, borrow=True)[-1]
+                return self._decode(out['hm'], out['wh'],
+                                    out['reg'] if self.opt.reg_offset else None, True)
+            probe['net_events'] = []
+            out = self.model(images, borrow=True, events=probe['net_events'],
+                             event_after=probe.get('event_after'))[-1]
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dets = self._decode(out['hm'], out['wh'], out['reg'] if self.opt.reg_offset else None,
                                 True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            probe['dec_events'] = (e0, e1)
+            return dets
 
     def run_frames(self, frames):
         """A list of (H, W, 3) uint8 BGR frames of one size -> list of per-image result dicts,

@@ -48,7 +48,7 @@ class MultiPoseDetector(BaseDetector):
     def process(self, images, return_time=False):
         with torch.no_grad():
             torch.cuda.synchronize()
-            output = self.model(images)[-1]
+            output = self.model(images, borrow=True)[-1]   # consumed before the next run
             maps = self._head_maps(output)
             torch.cuda.synchronize()
             forward_time = time.time()
@@ -59,6 +59,31 @@ class MultiPoseDetector(BaseDetector):
             dets = multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset,
                                      K=self.opt.K)
         return (output, dets, forward_time) if return_time else (output, dets)
+
+    def run_batch(self, images, probe=None):
+        """New surface (as CtdetDetector.run_batch): a device-resident, normalised batch ->
+        raw (B,K,40) detections in output-grid units; sigmoids fused into the decode kernels."""
+        with torch.no_grad():
+            ev = None
+            if probe is not None:
+                ev = probe['net_events'] = []
+            o = self.model(images, borrow=True, events=ev,
+                           event_after=None if probe is None else probe.get('event_after'))[-1]
+            if probe is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if self.opt.mse_loss and self.opt.hm_hp:
+                raise NotImplementedError("run_batch: mse_loss joint heat-maps are not logits")
+            dets = multi_pose_decode(o['hm'], o['wh'], o['hps'],
+                                     reg=o['reg'] if self.opt.reg_offset else None,
+                                     hm_hp=o['hm_hp'] if self.opt.hm_hp else None,
+                                     hp_offset=o['hp_offset'] if self.opt.reg_hp_offset else None,
+                                     K=self.opt.K, apply_sigmoid=True)
+            if probe is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                probe['dec_events'] = (e0, e1)
+            return dets
 
     def post_process(self, dets, meta, scale=1):
         """Output-grid units -> image coordinates of the unscaled frame (multi_pose.py:62-72)."""

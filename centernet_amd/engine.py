@@ -65,9 +65,12 @@ def fold_bn(conv_bias, bn, cout, device):
 class PlanBuilder:
     """Records launches for one (B, H, W) input shape."""
 
-    def __init__(self, device, B, H, W, dtype=torch.float32):
+    def __init__(self, device, B, H, W, dtype=torch.float32, wcache=None):
         assert dtype in (torch.float32, torch.float16)
         self.device = device
+        # packed weights shared by every plan of one module (keyed by source storage, packing
+        # and dtype): a new input shape re-uses them instead of re-packing the whole network
+        self.wcache = wcache if wcache is not None else {}
         self.dtype = dtype           # element type of NHWC activations and packed weights
         self.cdtype = DTYPE_F16 if dtype == torch.float16 else DTYPE_F32
         self.B, self.H, self.W = B, H, W
@@ -88,15 +91,31 @@ class PlanBuilder:
         t = torch.empty((B, H, W, pitch), device=self.device, dtype=self.dtype)
         return Act(t, B, H, W, C, pitch)
 
-    def _pack(self, w_oihw):
-        w = w_oihw.detach().to(device=self.device, dtype=torch.float32).contiguous()
-        co, ci, kh, kw = w.shape
-        n = self.lib.cn_packed_conv_weight_elems(co, ci, kh, kw, self.cdtype)
-        wp = torch.empty(n, device=self.device, dtype=self.dtype)
-        native.check(self.lib.cn_pack_conv_weight(native.ptr(w), native.ptr(wp), co, ci, kh, kw,
-                                                  self.cdtype, native.stream_ptr()),
-                     "cn_pack_conv_weight")
-        torch.cuda.current_stream().synchronize()
+    def _wkey(self, kind, sources):
+        return (kind, self.cdtype, str(self.device)) + tuple(
+            (t.data_ptr(), tuple(t.shape)) for t in sources)
+
+    def _pack(self, w_oihw, sources=None):
+        """Packed copy of a (Cout,Cin,KH,KW) weight.  ``sources``: the parameter tensors the
+        weight was assembled from (defaults to the weight itself) -- the cache key.  The pack
+        kernel runs on the current stream, which also orders the temporary's release: no
+        host synchronisation."""
+        if sources is None:
+            sources = [w_oihw]
+        # only module parameters have storage that outlives the plan: temporaries are not cached
+        cacheable = all(isinstance(t, torch.nn.Parameter) for t in sources)
+        key = self._wkey("conv", sources) if cacheable else None
+        wp = self.wcache.get(key) if cacheable else None
+        if wp is None:
+            w = w_oihw.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            co, ci, kh, kw = w.shape
+            n = self.lib.cn_packed_conv_weight_elems(co, ci, kh, kw, self.cdtype)
+            wp = torch.empty(n, device=self.device, dtype=self.dtype)
+            native.check(self.lib.cn_pack_conv_weight(native.ptr(w), native.ptr(wp), co, ci, kh,
+                                                      kw, self.cdtype, native.stream_ptr()),
+                         "cn_pack_conv_weight")
+            if cacheable:
+                self.wcache[key] = wp
         self.keep.append(wp)
         return wp
 
@@ -113,13 +132,13 @@ class PlanBuilder:
 
     # ---- ops -------------------------------------------------------------------
     def conv(self, x, weight, bias=None, bn=None, relu=False, residual=None, stride=1,
-             padding=0, dilation=1, out_nchw=False, out=None):
+             padding=0, dilation=1, out_nchw=False, out=None, wsources=None):
         """conv2d (+bias) (+BN eval) (+residual) (+ReLU) as one implicit-GEMM launch."""
         co, ci, kh, kw = weight.shape
         assert ci == x.C, (ci, x.C)
         Ho = _out_size(x.H, kh, stride, padding, dilation)
         Wo = _out_size(x.W, kw, stride, padding, dilation)
-        wp = self._pack(weight)
+        wp = self._pack(weight, wsources)
         scale, shift = fold_bn(bias, bn, co, self.device)
         self.keep += [scale, shift]
         if out is None:
@@ -170,14 +189,19 @@ class PlanBuilder:
         assert self.dtype == torch.float32, "ConvTranspose is built for fp32 only"
         out = self._new(x.B, 2 * x.H, 2 * x.W, co)
         scale, shift = fold_bn(None, bn, co, self.device)
-        w = weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
         lib = self.lib
-        wp = torch.empty(lib.cn_packed_deconv4x4s2_weight_floats(ci, co), device=self.device,
-                         dtype=torch.float32)
-        native.check(lib.cn_pack_deconv4x4s2_weight_f32(native.ptr(w), native.ptr(wp), ci, co,
-                                                        native.stream_ptr()),
-                     "cn_pack_deconv4x4s2_weight_f32")
-        torch.cuda.current_stream().synchronize()
+        cacheable = isinstance(weight, torch.nn.Parameter)
+        key = self._wkey("deconv4x4s2", [weight])
+        wp = self.wcache.get(key) if cacheable else None
+        if wp is None:
+            w = weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            wp = torch.empty(lib.cn_packed_deconv4x4s2_weight_floats(ci, co), device=self.device,
+                             dtype=torch.float32)
+            native.check(lib.cn_pack_deconv4x4s2_weight_f32(native.ptr(w), native.ptr(wp), ci, co,
+                                                            native.stream_ptr()),
+                         "cn_pack_deconv4x4s2_weight_f32")
+            if cacheable:
+                self.wcache[key] = wp
         self.keep += [scale, shift, wp]
         sp, hp, wpp = native.ptr(scale), native.ptr(shift), native.ptr(wp)
 
@@ -346,7 +370,8 @@ class PlanBuilder:
                     for c in firsts) and
                 all(tuple(pairs[n][1].kernel_size) == (1, 1) for n in names)):
             return self._heads_fused(x, names, pairs, w, b)
-        mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2)
+        mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2,
+                        wsources=[c.weight for c in firsts])
         outs = {}
         off = 0
         for n in names:
@@ -364,7 +389,7 @@ class PlanBuilder:
         stay in LDS between its 3x3 and its 1x1 convolution."""
         lib = self.lib
         nh = len(names)
-        wp = self._pack(w1)
+        wp = self._pack(w1, [pairs[n][0].weight for n in names])
         b1 = b1.to(device=self.device, dtype=torch.float32).contiguous()
         arr = (native.HeadOut * nh)()
         outs = {}
@@ -415,11 +440,16 @@ class Plan:
     def flops(self):
         return self.b.flops
 
-    def run(self, images, events=None, event_after=None):
+    def run(self, images, events=None, event_after=None, borrow=False):
         """Replay the launch list.  ``events``: optional list that receives one
         torch.cuda.Event per op boundary (len(ops)+1), recorded on the launch stream; with
         ``event_after`` (a set of op indices) events are recorded only at the start and after
-        those ops (segment timing with fewer stream markers)."""
+        those ops (segment timing with fewer stream markers).
+
+        Returns fresh head tensors, like the reference's nn.Module.  ``borrow=True`` returns the
+        plan's own persistent head buffers instead (zero-copy): they are OVERWRITTEN by the next
+        run of this plan (same B, H, W) -- only for callers that consume them at once, as the
+        detectors do."""
         if not images.is_cuda:
             raise native.NativeError("input batch must be on a HIP device; there is no CPU path")
         native.require_f32(images)
@@ -443,7 +473,9 @@ class Plan:
                         e = torch.cuda.Event(enable_timing=True)
                         e.record()
                         events.append(e)
-        return {k: v.t for k, v in self.outputs.items()}
+        if borrow:
+            return {k: v.t for k, v in self.outputs.items()}
+        return {k: v.t.clone() for k, v in self.outputs.items()}
 
     def capture(self):
         """Capture the launch list in a HIP graph (launch-bound small batches)."""
@@ -480,27 +512,41 @@ class PlannedModule(torch.nn.Module):
         self.invalidate_plans()
         return self
 
+    max_plans = int(os.environ.get("CN_PLAN_CACHE", "8"))   # LRU bound on cached input shapes
+
     def plan_for(self, B, H, W, device):
+        """The plan of one input shape.  Plans (activations + launch list) are kept in an LRU of
+        ``max_plans`` shapes -- --keep_res / multi-scale evaluation sees many (H, W) -- while the
+        packed weights live in one per-module cache shared by all of them."""
         cache = self.__dict__.setdefault("_plans", {})
         key = (B, H, W, str(device), self.compute_dtype)
-        if key not in cache:
+        plan = cache.pop(key, None)
+        if plan is None:
             native.lib()  # raises if the HIP library is missing
             with torch.no_grad():
-                pb = PlanBuilder(device, B, H, W, dtype=self.compute_dtype)
+                pb = PlanBuilder(device, B, H, W, dtype=self.compute_dtype,
+                                 wcache=self.__dict__.setdefault("_wcache", {}))
                 x = pb.set_input(3)
                 outs = self.describe(pb, x)
-            cache[key] = Plan(pb, outs)
-        return cache[key]
+            plan = Plan(pb, outs)
+            while len(cache) >= max(1, self.max_plans):
+                cache.pop(next(iter(cache)))          # least recently used
+        cache[key] = plan                             # most recently used last
+        return plan
 
     def invalidate_plans(self):
+        """Drop every plan and packed weight (call after changing parameters in place)."""
         self.__dict__["_plans"] = {}
+        self.__dict__["_wcache"] = {}
 
     def load_state_dict(self, *a, **kw):
         r = super().load_state_dict(*a, **kw)
         self.invalidate_plans()
         return r
 
-    def forward(self, x):
+    def forward(self, x, borrow=False, events=None, event_after=None):
+        """[{head: (B,C,H/4,W/4)}] like the reference modules (fresh tensors).  ``borrow`` /
+        ``events``: see Plan.run."""
         if self.training:
             raise native.NativeError("centernet_amd implements the inference path only; call .eval()")
         if not x.is_cuda:
@@ -509,4 +555,4 @@ class PlannedModule(torch.nn.Module):
                 "CPU restatement under oracle/ is test infrastructure." % x.device)
         B, C, H, W = x.shape
         plan = self.plan_for(B, H, W, x.device)
-        return [plan.run(x)]
+        return [plan.run(x, events=events, event_after=event_after, borrow=borrow)]

@@ -1,7 +1,8 @@
 """Host-side geometry helpers (mirror of src/lib/utils/image.py:19-66).
 
 OpenCV is not available in this image, so the cv2 calls the reference makes are restated:
-``cv2.getAffineTransform`` (exact 3-point solve, float64), ``cv2.warpAffine(..., INTER_LINEAR)``
+``cv2.getAffineTransform`` of the reference's three-point construction (a similarity, written
+in closed form in float64), ``cv2.warpAffine(..., INTER_LINEAR)``
 and ``cv2.resize`` (float64 bilinear, round-half-even to uint8; the same arithmetic, operation for
 operation, as the device kernels in csrc/cn_pre.hip).  For the benchmark configuration
 (512x512 input, fix_res) the warp is the identity.
@@ -9,63 +10,63 @@ operation, as the device kernels in csrc/cn_pre.hip).  For the benchmark configu
 import numpy as np
 
 
-def get_dir(src_point, rot_rad):
-    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
-    return [src_point[0] * cs - src_point[1] * sn, src_point[0] * sn + src_point[1] * cs]
+def _rotation(rot_deg):
+    """(cos, sin) of the augmentation angle; exactly (1, 0) for the inference case rot = 0."""
+    theta = np.pi * rot_deg / 180
+    return float(np.cos(theta)), float(np.sin(theta))
 
 
-def get_3rd_point(a, b):
-    direct = a - b
-    return b + np.array([-direct[1], direct[0]], dtype=np.float32)
+def get_affine_transform(center, scale, rot, output_size, shift=(0.0, 0.0), inv=0):
+    """2x3 float64 matrix between the source frame and an ``output_size`` = (w, h) crop
+    (call-compatible with utils/image.py:27-60).
 
+    The reference pins the map with three point pairs -- the crop centre, a point half the
+    source extent above it (turned by ``rot``), and a third at a right angle -- and asks OpenCV
+    for the affine through them.  Right-angle constructions on both sides make that map a
+    similarity, so it is written down directly here:
 
-def solve_affine(src, dst):
-    """2x3 float64 matrix M with M @ [x, y, 1] = dst for the three point pairs
-    (what cv2.getAffineTransform returns)."""
-    src = np.asarray(src, dtype=np.float64)
-    dst = np.asarray(dst, dtype=np.float64)
-    A = np.concatenate([src, np.ones((3, 1))], axis=1)  # 3x3
-    return np.linalg.solve(A, dst).T.copy()            # 2x3
+        dst = q0 + k * R(-rot) * (src - p0),      k = dst_w / src_w
 
-
-def get_affine_transform(center, scale, rot, output_size,
-                         shift=np.array([0, 0], dtype=np.float32), inv=0):
-    # utils/image.py:27-60
-    if not isinstance(scale, np.ndarray) and not isinstance(scale, list):
-        scale = np.array([scale, scale], dtype=np.float32)
-    scale_tmp = scale
-    src_w = scale_tmp[0]
-    dst_w, dst_h = output_size[0], output_size[1]
-    rot_rad = np.pi * rot / 180
-    src_dir = get_dir([0, src_w * -0.5], rot_rad)
-    dst_dir = np.array([0, dst_w * -0.5], np.float32)
-    src = np.zeros((3, 2), dtype=np.float32)
-    dst = np.zeros((3, 2), dtype=np.float32)
-    src[0, :] = center + scale_tmp * shift
-    src[1, :] = center + src_dir + scale_tmp * shift
-    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
-    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + dst_dir
-    src[2:, :] = get_3rd_point(src[0, :], src[1, :])
-    dst[2:, :] = get_3rd_point(dst[0, :], dst[1, :])
+    with p0 = centre + scale * shift (held in float32, as the reference's point array holds
+    it), q0 = the crop centre, and src_w = scale[0] (the reference uses the x extent for both
+    axes).  ``inv`` returns the opposite direction, src = p0 + R(rot) * (dst - q0) / k.  For
+    rot = 0 -- every call on the inference path -- the entries are exact ratios of the inputs.
+    """
+    extent = np.asarray(scale, np.float32).reshape(-1)
+    if extent.size == 1:
+        extent = np.repeat(extent, 2)
+    p0 = (np.asarray(center, np.float32).reshape(2) +
+          extent * np.asarray(shift, np.float32).reshape(2)).astype(np.float64)
+    q0 = np.array([output_size[0] * 0.5, output_size[1] * 0.5], np.float64)
+    cs, sn = _rotation(rot)
     if inv:
-        return solve_affine(dst, src)
-    return solve_affine(src, dst)
+        k = float(extent[0]) / float(output_size[0])
+        lin = k * np.array([[cs, -sn], [sn, cs]], np.float64)
+        return np.concatenate([lin, (p0 - lin @ q0)[:, None]], axis=1)
+    k = float(output_size[0]) / float(extent[0])
+    lin = k * np.array([[cs, sn], [-sn, cs]], np.float64)
+    return np.concatenate([lin, (q0 - lin @ p0)[:, None]], axis=1)
+
+
+def apply_affine(points, trans):
+    """(N, 2) points through a 2x3 matrix: float32 homogeneous coordinates, float64 product
+    (the arithmetic of utils/image.py:63-66 for a whole array at once)."""
+    pts = np.concatenate([np.asarray(points, np.float32).reshape(-1, 2),
+                          np.ones((len(points), 1), np.float32)], axis=1)
+    return pts.astype(np.float64) @ np.asarray(trans, np.float64).T
 
 
 def affine_transform(pt, t):
-    # utils/image.py:63-66
-    new_pt = np.array([pt[0], pt[1], 1.], dtype=np.float32).T
-    new_pt = np.dot(t, new_pt)
-    return new_pt[:2]
+    """One point (utils/image.py:63-66)."""
+    return apply_affine(np.asarray(pt, np.float32).reshape(1, 2), t)[0]
 
 
 def transform_preds(coords, center, scale, output_size):
-    # utils/image.py:19-24 (vectorised: the per-point loop is a (K,3)x(3,2) product)
-    trans = get_affine_transform(center, scale, 0, output_size, inv=1)
-    pts = np.concatenate([np.asarray(coords[:, 0:2], dtype=np.float32),
-                          np.ones((coords.shape[0], 1), np.float32)], axis=1)
+    """Output-grid coordinates -> source-frame coordinates (utils/image.py:19-24): one inverse
+    map for the whole (K, 2) array instead of the reference's per-point loop."""
+    to_source = get_affine_transform(center, scale, 0, output_size, inv=1)
     target = np.zeros(coords.shape)
-    target[:, 0:2] = pts.astype(np.float64) @ trans.T
+    target[:, 0:2] = apply_affine(coords[:, 0:2], to_source)
     return target
 
 

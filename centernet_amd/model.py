@@ -63,14 +63,49 @@ def _reconcile(loaded, own):
     return merged
 
 
+def _read_checkpoint(model_path):
+    """Zoo checkpoints are plain {'epoch', 'state_dict', 'optimizer'} dicts of tensors, so the
+    safe tensors-only unpickler is enough.  Files that need full unpickling (arbitrary code
+    execution from a downloaded file) load only with CENTERNET_UNSAFE_LOAD=1, with a warning."""
+    import os
+    try:
+        return torch.load(model_path, map_location='cpu', weights_only=True)
+    except Exception as err:
+        if os.environ.get('CENTERNET_UNSAFE_LOAD') != '1':
+            raise RuntimeError(
+                "%s does not load with weights_only=True (%s). If you trust the file, set "
+                "CENTERNET_UNSAFE_LOAD=1 to unpickle it fully." % (model_path, err)) from err
+        print('WARNING: unpickling {} without weights_only (CENTERNET_UNSAFE_LOAD=1)'.format(model_path))
+        return torch.load(model_path, map_location='cpu', weights_only=False)
+
+
+def _decayed_lr(lr, lr_step, epoch):
+    """Base rate divided by ten for every schedule step already behind ``epoch``."""
+    return lr * (0.1 ** sum(1 for step in (lr_step or ()) if epoch >= step))
+
+
 def load_model(model, model_path, optimizer=None, resume=False, lr=None, lr_step=None):
-    if optimizer is not None:
-        raise NotImplementedError("training state (optimizer / resume, model.py:69-84) is out of scope")
-    checkpoint = torch.load(model_path, map_location='cpu', weights_only=False)
+    """models/model.py:31-84: tolerant state-dict load; with ``optimizer`` the return value is
+    ``(model, optimizer, start_epoch)`` and, when resuming, the optimizer state and the
+    step-decayed learning rate are restored."""
+    checkpoint = _read_checkpoint(model_path)
     print('loaded {}, epoch {}'.format(model_path, checkpoint.get('epoch', '?')))
     loaded = _without_dataparallel_prefix(checkpoint['state_dict'])
     model.load_state_dict(_reconcile(loaded, model.state_dict()), strict=False)
-    return model
+    if optimizer is None:
+        return model
+    start_epoch = 0
+    if resume:
+        if 'optimizer' in checkpoint:
+            optimizer.load_state_dict(checkpoint['optimizer'])
+            start_epoch = checkpoint['epoch']
+            rate = _decayed_lr(lr, lr_step, start_epoch)
+            for group in optimizer.param_groups:
+                group['lr'] = rate
+            print('Resumed optimizer with start lr', rate)
+        else:
+            print('No optimizer parameters in checkpoint.')
+    return model, optimizer, start_epoch
 
 
 def save_model(path, epoch, model, optimizer=None):

@@ -8,7 +8,6 @@ task, --arch, --head_conv, --down_ratio, --input_res/_h/_w, --load_model, --gpus
 --not_hm_hp, --not_reg_hp_offset, --debug, --vis_thresh.
 """
 import argparse
-import os
 
 # (flag, kwargs) -- table form; names and defaults as in opts.py:13-225
 _FLAGS = [
@@ -97,30 +96,8 @@ class opts(object):
             opt.head_conv = 256 if 'dla' in opt.arch else 64
         opt.pad = 127 if 'hourglass' in opt.arch else 31
         opt.num_stacks = 2 if opt.arch == 'hourglass' else 1
-        if opt.trainval:
-            opt.val_intervals = 100000000
-        if opt.debug > 0:
-            opt.num_workers = 0
-            opt.batch_size = 1
-            opt.gpus = [opt.gpus[0]]
-            opt.master_batch_size = -1
-        if opt.master_batch_size == -1:
-            opt.master_batch_size = opt.batch_size // len(opt.gpus)
-        rest = opt.batch_size - opt.master_batch_size
-        opt.chunk_sizes = [opt.master_batch_size]
-        for i in range(len(opt.gpus) - 1):
-            c = rest // (len(opt.gpus) - 1)
-            if i < rest % (len(opt.gpus) - 1):
-                c += 1
-            opt.chunk_sizes.append(c)
-        opt.root_dir = os.path.join(os.path.dirname(__file__), '..')
-        opt.data_dir = os.path.join(opt.root_dir, 'data')
-        opt.exp_dir = os.path.join(opt.root_dir, 'exp', opt.task)
-        opt.save_dir = os.path.join(opt.exp_dir, opt.exp_id)
-        opt.debug_dir = os.path.join(opt.save_dir, 'debug')
-        if opt.resume and opt.load_model == '':
-            model_path = opt.save_dir[:-4] if opt.save_dir.endswith('TEST') else opt.save_dir
-            opt.load_model = os.path.join(model_path, 'model_last.pth')
+        # training / experiment-directory bookkeeping of the reference's parse() (chunk sizes,
+        # save_dir, resume paths) is not derived: nothing on the inference path reads it
         return opt
 
     def update_dataset_info_and_set_heads(self, opt, dataset):

@@ -58,3 +58,32 @@ def gather_detections(dets, group=None):
     outs = [torch.empty_like(dets) for _ in range(world)]
     dist.all_gather(outs, dets.contiguous(), group=group)
     return torch.cat(outs, 0)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(script, argv, n_ranks, port=None, python=None):
+    """The torchrun command line that starts ``n_ranks`` processes of ``script`` on this node
+    (one per GPU; rendezvous on 127.0.0.1 -- the container hostname may not resolve)."""
+    import sys
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            "--nproc-per-node", str(int(n_ranks)), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), script] + list(argv)
+
+
+def launch_ranks(script, argv, n_ranks, env=None):
+    """Start the ranks and wait; returns the launcher's exit status.  stdout / stderr are
+    inherited, so rank 0's JSON line is this process's output.  The role of the reference's
+    ``DataParallel`` device loop (src/lib/models/data_parallel.py:119-128) -- one replica per
+    GPU -- played by processes instead of threads."""
+    import os
+    import subprocess
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC, required by RCCL here
+    e.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(launch_command(script, argv, n_ranks), env=e)

@@ -323,6 +323,12 @@ int cn_ctdet_decode_f32(const float *heat, const float *wh, const float *reg,
                         int apply_sigmoid, float *dets, int32_t *inds,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* Flag bits of the `apply_sigmoid` argument of cn_nms_topk_channel_f32 / cn_topk_f32:
+ * bit 0 = apply the logistic first (detectors/ctdet.py:31); CN_DECODE_NO_PEAK_TEST = rank every
+ * cell, i.e. the plain _topk_channel / _topk without the _nms in front. */
+#define CN_DECODE_SIGMOID 1
+#define CN_DECODE_NO_PEAK_TEST 512
+
 /* _nms + _topk_channel (models/decode.py:9-15, 92-101) as one kernel: per
  * (b,c) plane the K best peaks; scores (B,C,K) desc, inds (B,C,K) int32. */
 int cn_nms_topk_channel_f32(const float *heat, int B, int C, int H, int W, int K,

@@ -267,11 +267,65 @@ def forward(arch, sd, x, heads):
     raise NotImplementedError(arch)
 
 
-def ctdet_process(arch, sd, images, heads, K=100, reg_offset=True, cat_spec_wh=False):
-    """CtdetDetector.process without flip (detectors/ctdet.py:28-45): returns (output, dets)."""
+def _flip_w(t):
+    """flip_tensor, models/utils.py:28-29."""
+    return torch.flip(t, [3])
+
+
+def _flip_lr(x, flip_idx):
+    """models/utils.py:33-39 (NumPy round trip, as the reference does it)."""
+    tmp = x.numpy()[..., ::-1].copy()
+    shape = tmp.shape
+    for e in flip_idx:
+        tmp[:, e[0], ...], tmp[:, e[1], ...] = tmp[:, e[1], ...].copy(), tmp[:, e[0], ...].copy()
+    return torch.from_numpy(tmp.reshape(shape))
+
+
+def _flip_lr_off(x, flip_idx):
+    """models/utils.py:41-50."""
+    tmp = x.numpy()[..., ::-1].copy()
+    shape = tmp.shape
+    tmp = tmp.reshape(tmp.shape[0], 17, 2, tmp.shape[2], tmp.shape[3])
+    tmp[:, :, 0, :, :] *= -1
+    for e in flip_idx:
+        tmp[:, e[0], ...], tmp[:, e[1], ...] = tmp[:, e[1], ...].copy(), tmp[:, e[0], ...].copy()
+    return torch.from_numpy(tmp.reshape(shape))
+
+
+def ctdet_process(arch, sd, images, heads, K=100, reg_offset=True, cat_spec_wh=False,
+                  flip_test=False):
+    """CtdetDetector.process (detectors/ctdet.py:28-45): returns (output, dets).  With
+    ``flip_test`` the batch is [frame, mirrored frame] (base_detector.py:59-60)."""
     out = forward(arch, sd, images, heads)
     hm = out["hm"].sigmoid_()
-    dets = cref.ctdet_decode(hm.numpy(), out["wh"].numpy(),
-                             out["reg"].numpy() if reg_offset and "reg" in out else None,
+    wh = out["wh"]
+    reg = out["reg"] if reg_offset and "reg" in out else None
+    if flip_test:
+        hm = (hm[0:1] + _flip_w(hm[1:2])) / 2
+        wh = (wh[0:1] + _flip_w(wh[1:2])) / 2
+        reg = reg[0:1] if reg is not None else None
+    dets = cref.ctdet_decode(hm.numpy(), wh.numpy(), None if reg is None else reg.numpy(),
                              cat_spec_wh=cat_spec_wh, K=K)
+    return out, dets
+
+
+COCO_FLIP_IDX = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+
+
+def multi_pose_process(arch, sd, images, heads, K=100, flip_test=False, flip_idx=None):
+    """MultiPoseDetector.process (detectors/multi_pose.py:29-60) with the default options
+    (reg_offset, hm_hp, reg_hp_offset on; mse_loss off): returns (output, dets)."""
+    flip_idx = COCO_FLIP_IDX if flip_idx is None else flip_idx
+    out = forward(arch, sd, images, heads)
+    out["hm"] = out["hm"].sigmoid_()
+    out["hm_hp"] = out["hm_hp"].sigmoid_()
+    reg, hm_hp, hp_offset = out["reg"], out["hm_hp"], out["hp_offset"]
+    if flip_test:
+        out["hm"] = (out["hm"][0:1] + _flip_w(out["hm"][1:2])) / 2
+        out["wh"] = (out["wh"][0:1] + _flip_w(out["wh"][1:2])) / 2
+        out["hps"] = (out["hps"][0:1] + _flip_lr_off(out["hps"][1:2], flip_idx)) / 2
+        hm_hp = (hm_hp[0:1] + _flip_lr(hm_hp[1:2], flip_idx)) / 2
+        reg, hp_offset = reg[0:1], hp_offset[0:1]
+    dets = cref.multi_pose_decode(out["hm"].numpy(), out["wh"].numpy(), out["hps"].numpy(),
+                                  reg.numpy(), hm_hp.numpy(), hp_offset.numpy(), K=K)
     return out, dets

@@ -154,3 +154,55 @@ def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
                         pos -= 1
             pos += 1
     return list(range(N))
+
+
+def multi_pose_post_process(dets, c, s, h, w):
+    """utils/post_process.py:103-114, statement by statement."""
+    ret = []
+    for i in range(dets.shape[0]):
+        bbox = transform_preds(dets[i, :, :4].reshape(-1, 2), c[i], s[i], (w, h))
+        pts = transform_preds(dets[i, :, 5:39].reshape(-1, 2), c[i], s[i], (w, h))
+        top_preds = np.concatenate([bbox.reshape(-1, 4), dets[i, :, 4:5], pts.reshape(-1, 34)],
+                                   axis=1).astype(np.float32).tolist()
+        ret.append({np.ones(1, dtype=np.int32)[0]: top_preds})
+    return ret
+
+
+def multi_pose_results(dets, meta, scale=1):
+    """detectors/multi_pose.py:62-81 for one image, single scale, no NMS."""
+    d = dets.reshape(1, -1, dets.shape[2])
+    d = multi_pose_post_process(d.copy(), [meta['c']], [meta['s']], meta['out_height'],
+                                meta['out_width'])
+    rows = np.array(d[0][1], dtype=np.float32).reshape(-1, 39)
+    rows[:, :4] /= scale
+    rows[:, 5:] /= scale
+    return {1: rows.tolist()}
+
+
+def ctdet_post_process_scale(dets, meta, num_classes, scale=1):
+    """CtdetDetector.post_process, detectors/ctdet.py:47-56."""
+    d = dets.reshape(1, -1, dets.shape[2])
+    d = ctdet_post_process(d.copy(), [meta['c']], [meta['s']], meta['out_height'],
+                           meta['out_width'], num_classes)
+    for j in range(1, num_classes + 1):
+        d[0][j] = np.array(d[0][j], dtype=np.float32).reshape(-1, 5)
+        d[0][j][:, :4] /= scale
+    return d[0]
+
+
+def ctdet_merge_outputs(detections, num_classes, n_scales, nms=False, max_per_image=100):
+    """CtdetDetector.merge_outputs, detectors/ctdet.py:58-73 (the list soft_nms returns is
+    discarded there: only its in-place score decay and row swaps matter)."""
+    results = {}
+    for j in range(1, num_classes + 1):
+        results[j] = np.concatenate([d[j] for d in detections], axis=0).astype(np.float32)
+        if n_scales > 1 or nms:
+            soft_nms(results[j], Nt=0.5, method=2)
+    scores = np.hstack([results[j][:, 4] for j in range(1, num_classes + 1)])
+    if len(scores) > max_per_image:
+        kth = len(scores) - max_per_image
+        thresh = np.partition(scores, kth)[kth]
+        for j in range(1, num_classes + 1):
+            keep_inds = (results[j][:, 4] >= thresh)
+            results[j] = results[j][keep_inds]
+    return results

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from centernet_amd import synth
-from oracle import net_oracle, post_oracle
+from oracle import net_oracle, post_oracle, pre_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -45,6 +45,67 @@ def test_run_on_image_matches_oracle_pipeline(dev):
     assert n_same >= 95
 
 
+def _oracle_inputs(image, scale, opt, flip_test=False):
+    """base_detector.py:37-65 through the scalar oracle (bit-identical to the product's host
+    and device pre-process, tests/test_oracle_pre.py / test_gpu_pre.py)."""
+    images, meta = pre_oracle.pre_process(image, scale, opt.mean, opt.std, fix_res=opt.fix_res,
+                                          input_h=opt.input_h, input_w=opt.input_w, pad=opt.pad,
+                                          flip_test=flip_test, down_ratio=opt.down_ratio)
+    return torch.from_numpy(images), meta
+
+
+def _compare_class_rows(res, ref, n_min, score_tol=1e-4, box_tol=2e-3):
+    """Per class: same number of rows, rows paired by position, scores / boxes within
+    tolerance; returns how many rows were compared (classes whose row count differs -- a
+    detection at the top-100 threshold that flipped -- are skipped and bounded by n_min)."""
+    n_same = 0
+    for j in sorted(ref):
+        if len(ref[j]) == len(res[j]) and len(ref[j]):
+            a = res[j][np.lexsort((res[j][:, 1], np.round(res[j][:, 0])))]
+            b = ref[j][np.lexsort((ref[j][:, 1], np.round(ref[j][:, 0])))]
+            assert np.abs(a[:, 4] - b[:, 4]).max() < score_tol, j
+            assert np.abs(a[:, :4] - b[:, :4]).max() < box_tol, j
+            n_same += len(a)
+    assert n_same >= n_min, n_same
+    return n_same
+
+
+def test_flip_test_matches_oracle_pipeline(dev):
+    """--flip_test (detectors/ctdet.py:34-37): the mirrored frame is averaged in after the
+    sigmoid -- against the oracle's flip pipeline, not against the product itself."""
+    det, opt = _detector("resdcn_18", ["--flip_test"])
+    image = np.random.RandomState(1).randint(0, 256, (512, 512, 3)).astype(np.uint8)
+    res = det.run(image)["results"]
+    images, meta = _oracle_inputs(image, 1.0, opt, flip_test=True)
+    assert tuple(images.shape) == (2, 3, 512, 512)
+    _, dets = net_oracle.ctdet_process("resdcn_18", det.model.state_dict(), images, list(opt.heads),
+                                       K=opt.K, flip_test=True)
+    ref = post_oracle.ctdet_results(dets, meta, opt.num_classes)
+    assert sum(len(v) for v in res.values()) == 100
+    _compare_class_rows(res, ref, 95)
+
+
+def test_multi_scale_soft_nms_matches_oracle_pipeline(dev):
+    """--test_scales 1,0.75 --nms (detectors/ctdet.py:58-73, base_detector.py:99-127): per-scale
+    pre-process / network / decode / post-process, merge, soft-NMS (pinned to the reference's
+    cython, tests/test_oracle_ref.py), top-100 threshold -- every stage from the oracle."""
+    det, opt = _detector("resdcn_18", ["--test_scales", "1,0.75", "--nms", "--keep_res"])
+    image = np.random.RandomState(3).randint(0, 256, (200, 264, 3)).astype(np.uint8)
+    res = det.run(image)["results"]
+    per_scale = []
+    for scale in opt.test_scales:
+        images, meta = _oracle_inputs(image, scale, opt)
+        _, dets = net_oracle.ctdet_process("resdcn_18", det.model.state_dict(), images,
+                                           list(opt.heads), K=opt.K)
+        per_scale.append(post_oracle.ctdet_post_process_scale(dets, meta, opt.num_classes, scale))
+    ref = post_oracle.ctdet_merge_outputs(per_scale, opt.num_classes, len(opt.test_scales), nms=True)
+    n_ref = sum(len(v) for v in ref.values())
+    n_res = sum(len(v) for v in res.values())
+    assert 100 <= n_ref <= 200 and abs(n_res - n_ref) <= 2
+    # soft-NMS decays scores by overlap, so score agreement also checks the box agreement
+    _compare_class_rows(res, ref, int(0.9 * n_ref), score_tol=2e-4, box_tol=4e-3)
+
+
 def test_prefetch_dict_branch_and_flip_test(dev):
     det, opt = _detector("resdcn_18", ["--flip_test"])
     image = np.random.RandomState(1).randint(0, 256, (512, 512, 3)).astype(np.uint8)
@@ -71,19 +132,6 @@ def test_run_batch(dev):
     assert torch.equal(det.run_batch(x), d)            # same batch: bit-identical replay
 
 
-def test_multi_scale_with_soft_nms(dev):
-    """--test_scales 1,0.75 --nms: two passes at different resolutions, detections merged per
-    class and decayed by the native soft-NMS (detectors/ctdet.py:58-73)."""
-    det, opt = _detector("resdcn_18", ["--test_scales", "1,0.75", "--nms"])
-    image = np.random.RandomState(3).randint(0, 256, (384, 512, 3)).astype(np.uint8)
-    res = det.run(image)["results"]
-    assert sorted(res) == list(range(1, 81))
-    n = sum(len(v) for v in res.values())
-    assert 100 <= n <= 200          # top-100 threshold keeps ties, at most 2x100 candidates
-    allb = np.concatenate([v for v in res.values() if len(v)], 0)
-    assert np.isfinite(allb).all() and (allb[:, 4] > 0).all() and (allb[:, 4] <= 1).all()
-
-
 def test_multi_pose_detector_matches_oracle(dev):
     """multi_pose task on DLA-34 (BASELINE configs[3]): run(img) -> {1: [[39 floats], ...]};
     compared with the CPU restatement of network + multi_pose_decode + post-process."""
@@ -104,19 +152,42 @@ def test_multi_pose_detector_matches_oracle(dev):
     hm_hp = out["hm_hp"].sigmoid_().numpy()
     dets = cref.multi_pose_decode(hm, out["wh"].numpy(), out["hps"].numpy(), out["reg"].numpy(),
                                   hm_hp, out["hp_offset"].numpy(), K=opt.K)
-    from centernet_amd.post_process import multi_pose_post_process
-    ref = np.array(multi_pose_post_process(dets.copy(), [meta["c"]], [meta["s"]], meta["out_height"],
-                                           meta["out_width"])[0][1], np.float32)
+    ref = np.array(post_oracle.multi_pose_results(dets, meta)[1], np.float32)
     assert np.abs(got[:, 4] - ref[:, 4]).max() < 1e-4            # scores
     same = np.abs(got[:, 4] - ref[:, 4]) < 1e-6
     gap = np.minimum(np.abs(np.diff(ref[:, 4], prepend=np.inf)), np.abs(np.diff(ref[:, 4], append=-np.inf)))
     safe = gap > 2e-6
-    assert safe.mean() > 0.8
+    print("multi_pose detector: safe fraction %.3f" % safe.mean())
+    assert safe.mean() >= 0.95
     assert np.abs(got[safe, :4] - ref[safe, :4]).max() < 5e-3    # boxes, image pixels
     # keypoints: regression branch within 5e-3 px; the heat-map-snapped ones are discrete
     # choices, so allow a few to differ where the reject rule sits on its threshold
     kd = np.abs(got[safe, 5:] - ref[safe, 5:])
     assert (kd < 5e-3).mean() > 0.97
+
+
+def test_multi_pose_flip_test_matches_oracle_pipeline(dev):
+    """multi_pose --flip_test (detectors/multi_pose.py:44-55): flip_lr / flip_lr_off on the
+    device (index permutation) vs the reference's NumPy round trip restated in the oracle."""
+    from centernet_amd.detectors import detector_factory
+    from centernet_amd.opts import opts
+    opt = opts().init(["multi_pose", "--arch", "dla_34", "--flip_test", "--input_res", "256"])
+    det = detector_factory[opt.task](opt)
+    synth.fill_state_dict_(det.model, 317)
+    image = np.random.RandomState(7).randint(0, 256, (256, 256, 3)).astype(np.uint8)
+    got = np.array(det.run(image)["results"][1], np.float32)
+    images, meta = _oracle_inputs(image, 1.0, opt, flip_test=True)
+    _, dets = net_oracle.multi_pose_process("dla_34", det.model.state_dict(), images,
+                                            list(opt.heads), K=opt.K, flip_test=True,
+                                            flip_idx=opt.flip_idx)
+    ref = np.array(post_oracle.multi_pose_results(dets, meta)[1], np.float32)
+    assert got.shape == ref.shape == (100, 39)
+    assert np.abs(got[:, 4] - ref[:, 4]).max() < 1e-4
+    gap = np.minimum(np.abs(np.diff(ref[:, 4], prepend=np.inf)), np.abs(np.diff(ref[:, 4], append=-np.inf)))
+    safe = gap > 2e-6
+    assert safe.mean() >= 0.9
+    assert np.abs(got[safe, :4] - ref[safe, :4]).max() < 5e-3
+    assert (np.abs(got[safe, 5:] - ref[safe, 5:]) < 5e-3).mean() > 0.97
 
 
 def test_run_frames_equals_run(dev):

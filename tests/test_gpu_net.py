@@ -69,10 +69,157 @@ def test_end_to_end_boxes_512(dev, arch, B):
     s = ref[..., 4]
     gap = np.minimum(np.abs(np.diff(s, axis=1, prepend=np.inf)), np.abs(np.diff(s, axis=1, append=-np.inf)))
     safe = gap > 2e-6
-    assert safe.mean() > 0.9
+    print("%s B=%d: safe fraction %.4f" % (arch, B, safe.mean()))
+    assert safe.mean() >= 0.99
     assert np.array_equal(inds[safe], ref_inds[safe])
     assert np.array_equal(dets[..., 5][safe], ref[..., 5][safe])
     assert np.abs(dets[safe] - ref[safe]).max() < 1e-4 * max(1.0, np.abs(ref[safe][:, :4]).max())
+
+
+def _safe_positions(scores, gap_min=2e-6):
+    """Ranks whose oracle score is separated from both neighbours by more than ``gap_min``: an
+    fp32 implementation can only swap detections whose scores are closer than its own rounding."""
+    gap = np.minimum(np.abs(np.diff(scores, axis=1, prepend=np.inf)),
+                     np.abs(np.diff(scores, axis=1, append=-np.inf)))
+    return gap > gap_min
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("arch,B", [("resdcn_18", 32), ("dla_34", 32)])
+def test_end_to_end_boxes_at_benchmark_batch(dev, arch, B):
+    """BASELINE configs[1] / [2] at their stated size: 512x512, batch 32 on one GPU -- the tile
+    shapes, split-K plans, tap splits and dispatch-round fits the bench uses -- against the CPU
+    oracle of the whole path (detectors/ctdet.py:28-45).  Reports the fraction of ranks that
+    are comparable (`safe`) and holds indices / classes identical and boxes within 1e-4 there."""
+    from centernet_amd.decode import ctdet_decode
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    m = _model(arch, heads, 317, dev)
+    x = synth.images(B, 512, 512, seed=0)
+    with torch.no_grad():
+        out = m(x.to(dev))[-1]
+        dets, inds = ctdet_decode(out["hm"], out["wh"], out["reg"], K=100, apply_sigmoid=True,
+                                  return_inds=True)
+    dets, inds = dets.cpu().numpy(), inds.cpu().numpy()
+    hm_dev = torch.sigmoid(out["hm"]).cpu().numpy()
+    torch.set_num_threads(min(64, torch.get_num_threads() * 4 or 8))
+    ref = np.empty_like(dets)
+    ref_inds = np.empty_like(inds)
+    hm_err = 0.0
+    for b0 in range(0, B, 8):          # oracle in chunks of 8 images (memory of the C DCN columns)
+        ro, rd = net_oracle.ctdet_process(arch, m.state_dict(), x[b0:b0 + 8], list(heads), K=100)
+        ref[b0:b0 + 8] = rd
+        ref_inds[b0:b0 + 8] = cref.ctdet_decode(ro["hm"].numpy(), ro["wh"].numpy(), ro["reg"].numpy(),
+                                                K=100, return_inds=True)[1]
+        hm_err = max(hm_err, float(np.abs(hm_dev[b0:b0 + 8] - ro["hm"].numpy()).max()))
+    assert hm_err < 1e-4, hm_err
+    assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-4
+    safe = _safe_positions(ref[..., 4])
+    print("%s B=%d: safe fraction %.4f, heat-map max err %.2e, score max err %.2e" % (
+        arch, B, safe.mean(), hm_err, np.abs(dets[..., 4] - ref[..., 4]).max()))
+    assert safe.mean() >= 0.99
+    assert np.array_equal(inds[safe], ref_inds[safe])
+    assert np.array_equal(dets[..., 5][safe], ref[..., 5][safe])
+    assert np.abs(dets[safe] - ref[safe]).max() < 1e-4 * max(1.0, np.abs(ref[safe][:, :4]).max())
+
+
+@pytest.mark.slow
+def test_end_to_end_pose_at_benchmark_batch(dev):
+    """BASELINE configs[3]: dla_34 multi_pose 512x512, batch 32, whole path vs the CPU oracle."""
+    from centernet_amd.decode import multi_pose_decode
+    heads = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
+    B = 32
+    m = _model("dla_34", heads, 317, dev)
+    x = synth.images(B, 512, 512, seed=0)
+    with torch.no_grad():
+        o = m(x.to(dev))[-1]
+        dets = multi_pose_decode(o["hm"], o["wh"], o["hps"], reg=o["reg"], hm_hp=o["hm_hp"],
+                                 hp_offset=o["hp_offset"], K=100, apply_sigmoid=True).cpu().numpy()
+    ref = np.empty_like(dets)
+    for b0 in range(0, B, 8):
+        ref[b0:b0 + 8] = net_oracle.multi_pose_process("dla_34", m.state_dict(), x[b0:b0 + 8],
+                                                       list(heads), K=100)[1]
+    assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-4
+    safe = _safe_positions(ref[..., 4])
+    print("dla_34 multi_pose B=32: safe fraction %.4f" % safe.mean())
+    assert safe.mean() >= 0.97      # one class: scores crowd more than in the 80-class case
+    assert np.abs(dets[safe][:, :4] - ref[safe][:, :4]).max() < 1e-3
+    assert np.array_equal(dets[..., 39][safe], ref[..., 39][safe])
+    # keypoints: regression branch to 1e-3 grid cells; the heat-map-snapped ones are discrete
+    # choices that may flip where the reject rule sits on its threshold
+    kd = np.abs(dets[safe][:, 5:39] - ref[safe][:, 5:39])
+    assert (kd < 1e-3).mean() > 0.995, (kd < 1e-3).mean()
+
+
+@pytest.mark.slow
+def test_end_to_end_hourglass_512_batch8(dev):
+    """BASELINE configs[4] network at its stated size (512x512, batch 8): fp32 against the
+    oracle (indices / boxes), and the fp16 deltas the benchmark's precision produces."""
+    from centernet_amd.decode import ctdet_decode
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    B = 8
+    m = _model("hourglass", heads, 317, dev)
+    x = synth.images(B, 512, 512, seed=0)
+    with torch.no_grad():
+        out = m(x.to(dev))[-1]
+        dets, inds = ctdet_decode(out["hm"], out["wh"], out["reg"], K=100, apply_sigmoid=True,
+                                  return_inds=True)
+    dets, inds = dets.cpu().numpy(), inds.cpu().numpy()
+    ref = np.empty_like(dets)
+    ref_inds = np.empty_like(inds)
+    for b0 in range(0, B, 2):
+        ro, rd = net_oracle.ctdet_process("hourglass", m.state_dict(), x[b0:b0 + 2], list(heads), K=100)
+        ref[b0:b0 + 2] = rd
+        ref_inds[b0:b0 + 2] = cref.ctdet_decode(ro["hm"].numpy(), ro["wh"].numpy(), ro["reg"].numpy(),
+                                                K=100, return_inds=True)[1]
+    assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-4
+    safe = _safe_positions(ref[..., 4])
+    print("hourglass fp32 B=8 512^2: safe fraction %.4f" % safe.mean())
+    assert safe.mean() >= 0.99
+    assert np.array_equal(inds[safe], ref_inds[safe])
+    assert np.abs(dets[safe] - ref[safe]).max() < 1e-4 * max(1.0, np.abs(ref[safe][:, :4]).max())
+    m.half_compute()
+    with torch.no_grad():
+        o16 = m(x.to(dev))[-1]
+        d16 = ctdet_decode(o16["hm"], o16["wh"], o16["reg"], K=100, apply_sigmoid=True).cpu().numpy()
+    e = np.abs(d16[..., 4] - ref[..., 4])
+    same_cls = (d16[..., 5] == ref[..., 5]).mean()
+    print("hourglass fp16 B=8 512^2: score delta max %.2e mean %.2e, class agreement %.3f" % (
+        e.max(), e.mean(), same_cls))
+    assert e.max() < 2e-2      # relaxed: the reference has no half path
+
+
+def test_forward_returns_fresh_tensors(dev):
+    """Like the reference nn.Module, `model(x)` hands out tensors the next call does not
+    overwrite (borrow=True is the zero-copy form the detectors use)."""
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    m = _model("resdcn_18", heads, 317, dev)
+    a = synth.images(1, 128, 128, seed=1).to(dev)
+    b = synth.images(1, 128, 128, seed=2).to(dev)
+    with torch.no_grad():
+        o1 = m(a)[-1]["hm"]
+        keep = o1.clone()
+        o2 = m(b)[-1]["hm"]
+        assert torch.equal(o1, keep) and not torch.equal(o1, o2)
+        z1 = m(a, borrow=True)[-1]["hm"]
+        z2 = m(b, borrow=True)[-1]["hm"]
+        assert z1.data_ptr() == z2.data_ptr()
+
+
+def test_plan_cache_is_bounded_and_weights_are_shared(dev):
+    """Many input shapes (--keep_res / multi-scale): plans are an LRU, packed weights are packed
+    once per module and shared by every plan."""
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    m = _model("resdcn_18", heads, 317, dev)
+    m.max_plans = 3
+    with torch.no_grad():
+        first = m(synth.images(1, 64, 64, seed=1).to(dev))[-1]["hm"].clone()
+        n_w = len(m.__dict__["_wcache"])
+        for hw in (96, 128, 160, 192):
+            m(synth.images(1, hw, hw, seed=1).to(dev))
+        assert len(m.__dict__["_plans"]) == 3
+        assert len(m.__dict__["_wcache"]) == n_w            # nothing re-packed
+        again = m(synth.images(1, 64, 64, seed=1).to(dev))[-1]["hm"]   # evicted shape: rebuilt
+        assert torch.equal(first, again)
 
 
 def test_batch_independence_and_graph_replay(dev):

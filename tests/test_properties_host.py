@@ -1,5 +1,5 @@
 """Property tests (hypothesis) of the host-side restatements against the scalar oracles:
-random sizes / matrices / detections, bit-exact agreement.  CPU only, a few seconds."""
+random sizes / matrices / detections, bit-exact agreement (1e-4 px on mapped coordinates).  CPU only, a few seconds."""
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
@@ -42,4 +42,10 @@ def test_batched_tail_equals_reference_loop(K, ncls, seed, cx, cy, s):
     for i in range(2):
         ref = post_oracle.ctdet_results(dets[i:i + 1].copy(), meta, ncls, scale=1, max_per_image=100)
         for j in range(1, ncls + 1):
-            assert np.array_equal(got[i][j], ref[j])
+            # same rows, same order, same scores; coordinates within 1e-4 px: the product writes
+            # the similarity in closed form, the oracle solves the reference's three-point
+            # system, whose float32 construction points make it a similarity only up to their
+            # rounding (exact for the half-integer centres real frames have; <= 3e-5 px here)
+            assert got[i][j].shape == ref[j].shape and got[i][j].dtype == ref[j].dtype
+            assert np.array_equal(got[i][j][:, 4], ref[j][:, 4])
+            assert np.abs(got[i][j][:, :4] - ref[j][:, :4]).max(initial=0) <= 1e-4

@@ -84,3 +84,47 @@ def test_weight_broadcast_world2_gloo():
     assert res[0][1] == res[1][1] > 50e6            # ~63 MB for res_18
     assert res[0][3] == (0, 3) and res[1][3] == (3, 5)
     assert res[0][4] == (6, 4, 6) and res[0][5] == 1.0
+
+
+def test_launch_ranks_spawns_world(tmp_path):
+    """bench.py --gpus N without a launcher starts N ranks itself through
+    sharding.launch_ranks: here a 2-rank gloo job whose rank 0 reports the world it saw."""
+    import subprocess
+    import sys
+    import textwrap
+    script = tmp_path / "probe.py"
+    out = tmp_path / "seen.txt"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import torch, torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(dist.get_rank() + 1)])
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            open(sys.argv[1], "w").write("%d %d %s" % (dist.get_world_size(), int(t.item()), sys.argv[2]))
+        dist.destroy_process_group()
+    """))
+    cmd = sharding.launch_command(str(script), [str(out), "--flag"], 2)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "127.0.0.1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    rc = sharding.launch_ranks(str(script), [str(out), "--flag"], 2)
+    assert rc == 0
+    assert out.read_text() == "2 3 --flag"
+
+
+def test_bench_refuses_world_mismatch():
+    """bench.py under a launcher whose world size differs from --gpus must fail loudly (the
+    round-1 defect: --gpus was parsed and ignored)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "launch_ranks" in src and "world != a.gpus" in src
+    sys.path.insert(0, root)
+    import bench
+    a = bench.parse(["--gpus", "8", "--config", "3"])
+    assert (a.gpus, a.task, a.arch, a.batch, a.fp16) == (8, "multi_pose", "dla_34", 32, False)
+    a = bench.parse(["--config", "4"])
+    assert (a.arch, a.batch, a.fp16) == ("hourglass", 8, True)
+    a = bench.parse([])
+    assert (a.gpus, a.task, a.arch, a.batch, a.fp16, a.res) == (1, "ctdet", "resdcn_18", 32, False, 512)
