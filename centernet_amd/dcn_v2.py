@@ -31,10 +31,11 @@ def dcn_v2_forward(input, offset, mask, weight, bias, stride=1, padding=1, dilat
     """input (B,Cin,H,W), offset (B,2*9*dg,Ho,Wo), mask (B,9*dg,Ho,Wo) -> (B,Cout,Ho,Wo)."""
     if not input.is_cuda:
         raise NotImplementedError  # same as the reference (dcn_v2_func.py:23-24)
-    native.require_f32(input, offset, mask, weight, bias)
     lib = native.lib()
     input, offset, mask = input.contiguous(), offset.contiguous(), mask.contiguous()
-    weight, bias = weight.detach().contiguous(), bias.detach().contiguous()
+    native.require_f32(input, offset, mask, weight, bias)
+    weight = weight.detach().to(input.device).contiguous()   # a module left on the host still runs
+    bias = bias.detach().to(input.device).contiguous()
     B, Cin, H, W = input.shape
     Cout, Cin_w, kh, kw = weight.shape
     if Cin_w != Cin:

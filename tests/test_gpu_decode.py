@@ -55,12 +55,11 @@ def test_fused_sigmoid_matches_oracle(dev):
                               apply_sigmoid=True, return_inds=True)
     dets, inds = dets.cpu().numpy(), inds.cpu().numpy()
     assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-6
-    gap = np.minimum(np.abs(np.diff(ref[..., 4], axis=1, prepend=np.inf)),
-                     np.abs(np.diff(ref[..., 4], axis=1, append=-np.inf)))
-    safe = gap > 1e-6
-    assert safe.mean() >= 0.99, safe.mean()
-    assert np.array_equal(inds[safe], ref_inds[safe])
-    assert np.abs(dets[safe] - ref[safe]).max() < 1e-4
+    from oracle.parity import compare_topk
+    ids = np.stack([inds, dets[..., 5].astype(np.int64)], -1)
+    rids = np.stack([ref_inds, ref[..., 5].astype(np.int64)], -1)
+    r = compare_topk(dets, ref, tie=1e-6, got_ids=ids, ref_ids=rids)
+    assert r["paired"] >= 0.99 and r["in_place"] >= 0.9, r
 
 
 def test_ties_and_degenerate_maps(dev):

@@ -154,11 +154,12 @@ def test_multi_pose_detector_matches_oracle(dev):
                                   hm_hp, out["hp_offset"].numpy(), K=opt.K)
     ref = np.array(post_oracle.multi_pose_results(dets, meta)[1], np.float32)
     assert np.abs(got[:, 4] - ref[:, 4]).max() < 1e-4            # scores
-    same = np.abs(got[:, 4] - ref[:, 4]) < 1e-6
+    from oracle.parity import compare_topk
+    r = compare_topk(got[None], ref[None], box_tol=1e-5)         # 1e-5 x 512 px = 5e-3 px
+    print("multi_pose detector: paired %.3f, same rank %.3f" % (r["paired"], r["in_place"]))
+    assert r["paired"] >= 0.99
     gap = np.minimum(np.abs(np.diff(ref[:, 4], prepend=np.inf)), np.abs(np.diff(ref[:, 4], append=-np.inf)))
     safe = gap > 2e-6
-    print("multi_pose detector: safe fraction %.3f" % safe.mean())
-    assert safe.mean() >= 0.95
     assert np.abs(got[safe, :4] - ref[safe, :4]).max() < 5e-3    # boxes, image pixels
     # keypoints: regression branch within 5e-3 px; the heat-map-snapped ones are discrete
     # choices, so allow a few to differ where the reject rule sits on its threshold
@@ -185,7 +186,9 @@ def test_multi_pose_flip_test_matches_oracle_pipeline(dev):
     assert np.abs(got[:, 4] - ref[:, 4]).max() < 1e-4
     gap = np.minimum(np.abs(np.diff(ref[:, 4], prepend=np.inf)), np.abs(np.diff(ref[:, 4], append=-np.inf)))
     safe = gap > 2e-6
-    assert safe.mean() >= 0.9
+    from oracle.parity import compare_topk
+    r = compare_topk(got[None], ref[None], box_tol=2e-5)
+    assert r["paired"] >= 0.99, r
     assert np.abs(got[safe, :4] - ref[safe, :4]).max() < 5e-3
     assert (np.abs(got[safe, 5:] - ref[safe, 5:]) < 5e-3).mean() > 0.97
 

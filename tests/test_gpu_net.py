@@ -7,6 +7,7 @@ import torch
 
 from centernet_amd import synth
 from oracle import cref, net_oracle
+from oracle.parity import compare_topk
 
 pytestmark = pytest.mark.gpu
 
@@ -63,17 +64,14 @@ def test_end_to_end_boxes_512(dev, arch, B):
     ref_hm = ref_out["hm"].numpy()
     ref_inds = cref.ctdet_decode(ref_hm, ref_out["wh"].numpy(), ref_out["reg"].numpy(), K=100,
                                  return_inds=True)[1]
-    # scores within 1e-4 everywhere
+    # scores within 1e-4 everywhere; every detection paired with its oracle row (near-ties may
+    # trade ranks): flat index and class IDENTICAL, boxes within 1e-4 of the grid scale
     assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-4
-    # indices / classes identical wherever the oracle's neighbouring scores differ by > 2e-6
-    s = ref[..., 4]
-    gap = np.minimum(np.abs(np.diff(s, axis=1, prepend=np.inf)), np.abs(np.diff(s, axis=1, append=-np.inf)))
-    safe = gap > 2e-6
-    print("%s B=%d: safe fraction %.4f" % (arch, B, safe.mean()))
-    assert safe.mean() >= 0.99
-    assert np.array_equal(inds[safe], ref_inds[safe])
-    assert np.array_equal(dets[..., 5][safe], ref[..., 5][safe])
-    assert np.abs(dets[safe] - ref[safe]).max() < 1e-4 * max(1.0, np.abs(ref[safe][:, :4]).max())
+    ids = np.stack([inds, dets[..., 5].astype(np.int64)], -1)
+    rids = np.stack([ref_inds, ref[..., 5].astype(np.int64)], -1)
+    r = compare_topk(dets, ref, got_ids=ids, ref_ids=rids)
+    print("%s B=%d: paired %.4f, same rank %.4f" % (arch, B, r["paired"], r["in_place"]))
+    assert r["paired"] >= 0.99 and r["in_place"] >= 0.95
 
 
 def _safe_positions(scores, gap_min=2e-6):
@@ -113,13 +111,12 @@ def test_end_to_end_boxes_at_benchmark_batch(dev, arch, B):
         hm_err = max(hm_err, float(np.abs(hm_dev[b0:b0 + 8] - ro["hm"].numpy()).max()))
     assert hm_err < 1e-4, hm_err
     assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-4
-    safe = _safe_positions(ref[..., 4])
-    print("%s B=%d: safe fraction %.4f, heat-map max err %.2e, score max err %.2e" % (
-        arch, B, safe.mean(), hm_err, np.abs(dets[..., 4] - ref[..., 4]).max()))
-    assert safe.mean() >= 0.99
-    assert np.array_equal(inds[safe], ref_inds[safe])
-    assert np.array_equal(dets[..., 5][safe], ref[..., 5][safe])
-    assert np.abs(dets[safe] - ref[safe]).max() < 1e-4 * max(1.0, np.abs(ref[safe][:, :4]).max())
+    ids = np.stack([inds, dets[..., 5].astype(np.int64)], -1)
+    rids = np.stack([ref_inds, ref[..., 5].astype(np.int64)], -1)
+    r = compare_topk(dets, ref, got_ids=ids, ref_ids=rids)
+    print("%s B=%d: paired %.4f, same rank %.4f, heat-map max err %.2e, score max err %.2e" % (
+        arch, B, r["paired"], r["in_place"], hm_err, np.abs(dets[..., 4] - ref[..., 4]).max()))
+    assert r["paired"] >= 0.99 and r["in_place"] >= 0.95
 
 
 @pytest.mark.slow
@@ -139,11 +136,10 @@ def test_end_to_end_pose_at_benchmark_batch(dev):
         ref[b0:b0 + 8] = net_oracle.multi_pose_process("dla_34", m.state_dict(), x[b0:b0 + 8],
                                                        list(heads), K=100)[1]
     assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-4
+    r = compare_topk(dets, ref, box_tol=1e-4)
+    print("dla_34 multi_pose B=32: paired %.4f, same rank %.4f" % (r["paired"], r["in_place"]))
+    assert r["paired"] >= 0.99 and r["in_place"] >= 0.9   # one class: scores crowd more
     safe = _safe_positions(ref[..., 4])
-    print("dla_34 multi_pose B=32: safe fraction %.4f" % safe.mean())
-    assert safe.mean() >= 0.97      # one class: scores crowd more than in the 80-class case
-    assert np.abs(dets[safe][:, :4] - ref[safe][:, :4]).max() < 1e-3
-    assert np.array_equal(dets[..., 39][safe], ref[..., 39][safe])
     # keypoints: regression branch to 1e-3 grid cells; the heat-map-snapped ones are discrete
     # choices that may flip where the reject rule sits on its threshold
     kd = np.abs(dets[safe][:, 5:39] - ref[safe][:, 5:39])
@@ -172,11 +168,11 @@ def test_end_to_end_hourglass_512_batch8(dev):
         ref_inds[b0:b0 + 2] = cref.ctdet_decode(ro["hm"].numpy(), ro["wh"].numpy(), ro["reg"].numpy(),
                                                 K=100, return_inds=True)[1]
     assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-4
-    safe = _safe_positions(ref[..., 4])
-    print("hourglass fp32 B=8 512^2: safe fraction %.4f" % safe.mean())
-    assert safe.mean() >= 0.99
-    assert np.array_equal(inds[safe], ref_inds[safe])
-    assert np.abs(dets[safe] - ref[safe]).max() < 1e-4 * max(1.0, np.abs(ref[safe][:, :4]).max())
+    ids = np.stack([inds, dets[..., 5].astype(np.int64)], -1)
+    rids = np.stack([ref_inds, ref[..., 5].astype(np.int64)], -1)
+    r = compare_topk(dets, ref, got_ids=ids, ref_ids=rids)
+    print("hourglass fp32 B=8 512^2: paired %.4f, same rank %.4f" % (r["paired"], r["in_place"]))
+    assert r["paired"] >= 0.99 and r["in_place"] >= 0.95
     m.half_compute()
     with torch.no_grad():
         o16 = m(x.to(dev))[-1]
