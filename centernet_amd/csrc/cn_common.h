@@ -31,3 +31,65 @@ static inline size_t cn_align_up(size_t v, size_t a) { return (v + a - 1) / a * 
 typedef float cn_f32x4 __attribute__((ext_vector_type(4)));
 typedef int cn_i32x4 __attribute__((ext_vector_type(4)));
 typedef float cn_f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- "f32s": fp32 values stored as a pair of fp16 (CN_DTYPE_F32S) ------------------------
+// gfx950's fp32 matrix instruction runs at 1/16 of the fp16 rate, so the dense layers compute
+//     a*b  ~=  ah*bh + ah*bl + al*bh          (a = ah + al, b = bh + bl; fp32 accumulate)
+// with three v_mfma_f32_32x32x16_f16 per product instead of one v_mfma_f32_32x32x2_f32: 5.3x
+// the matrix throughput at fp32-level accuracy (ah = fp16(a) keeps 11 bits, al = fp16(a - ah)
+// the next 11: |a - ah - al| <= 2^-22 |a| and the dropped al*bl term is <= 2^-22 |ab|, the
+// size of fp32's own rounding error in a K-long accumulation).
+// Storage: a group of 32 channels occupies the same 128 bytes as 32 floats -- 32 fp16 high
+// parts, then 32 fp16 low parts -- so tensors keep their fp32 byte size, pitch and addressing
+// per (pixel, 32-channel group); pitches of f32s tensors are multiples of 32 channels.
+// A 128-byte group IS the LDS row the MFMA loop reads: bytes [32*kk + 16*h, +16) of a row are
+// k = 16*kk + 8h .. +7 of the high parts (kk = 0, 1) or of the low parts (kk = 2, 3).
+struct cn_f32s { float raw; };   // element tag of f32s tensors in kernel templates (4 bytes)
+typedef _Float16 cn_f16x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 cn_f16x8v __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void cn_split4(cn_f32x4 v, cn_f16x4v &hi, cn_f16x4v &lo)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // clamp to the fp16 range: an overflow would make the low part NaN (inf - inf)
+        const float c = __builtin_fminf(__builtin_fmaxf(v[e], -65504.0f), 65504.0f);
+        hi[e] = (_Float16)c;
+        lo[e] = (_Float16)(c - (float)hi[e]);
+    }
+}
+__device__ __forceinline__ cn_f32x4 cn_join4(cn_f16x4v hi, cn_f16x4v lo)
+{
+    cn_f32x4 r = {(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1],
+                  (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]};
+    return r;
+}
+// 4 consecutive channels n..n+3 (n % 4 == 0) of pixel `pix` of an f32s tensor
+__device__ __forceinline__ void cn_store4_f32s(void *base, size_t pix, int pitch, int n, cn_f32x4 v)
+{
+    char *g = reinterpret_cast<char *>(base) + (pix * (size_t)pitch + (size_t)(n & ~31)) * 4;
+    cn_f16x4v hi, lo;
+    cn_split4(v, hi, lo);
+    *reinterpret_cast<cn_f16x4v *>(g + (n & 31) * 2) = hi;
+    *reinterpret_cast<cn_f16x4v *>(g + 64 + (n & 31) * 2) = lo;
+}
+__device__ __forceinline__ cn_f32x4 cn_load4_f32s(const void *base, size_t pix, int pitch, int n)
+{
+    const char *g = reinterpret_cast<const char *>(base) + (pix * (size_t)pitch + (size_t)(n & ~31)) * 4;
+    return cn_join4(*reinterpret_cast<const cn_f16x4v *>(g + (n & 31) * 2),
+                    *reinterpret_cast<const cn_f16x4v *>(g + 64 + (n & 31) * 2));
+}
+__device__ __forceinline__ void cn_store1_f32s(void *base, size_t pix, int pitch, int n, float v)
+{
+    char *g = reinterpret_cast<char *>(base) + (pix * (size_t)pitch + (size_t)(n & ~31)) * 4;
+    const float c = __builtin_fminf(__builtin_fmaxf(v, -65504.0f), 65504.0f);
+    const _Float16 hi = (_Float16)c;
+    *reinterpret_cast<_Float16 *>(g + (n & 31) * 2) = hi;
+    *reinterpret_cast<_Float16 *>(g + 64 + (n & 31) * 2) = (_Float16)(c - (float)hi);
+}
+__device__ __forceinline__ float cn_load1_f32s(const void *base, size_t pix, int pitch, int n)
+{
+    const char *g = reinterpret_cast<const char *>(base) + (pix * (size_t)pitch + (size_t)(n & ~31)) * 4;
+    return (float)*reinterpret_cast<const _Float16 *>(g + (n & 31) * 2) +
+           (float)*reinterpret_cast<const _Float16 *>(g + 64 + (n & 31) * 2);
+}

@@ -78,6 +78,7 @@ typedef _Float16 cn_f16x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> { static constexpr int EPV = 4; };
 template <> struct ElemTraits<_Float16> { static constexpr int EPV = 8; };
+template <> struct ElemTraits<cn_f32s> { static constexpr int EPV = 4; };   // 128-byte groups, as fp32
 
 __device__ __forceinline__ cn_f32x4 load4_as_f32(const float *p) { return *reinterpret_cast<const cn_f32x4 *>(p); }
 __device__ __forceinline__ cn_f32x4 load4_as_f32(const _Float16 *p)
@@ -650,6 +651,25 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, T *__restrict__ 
         wp[i] = (T)v;
     }
 }
+// f32s form of the same layout: every 32-channel group of a row is 32 fp16 high parts followed
+// by 32 fp16 low parts (cn_common.h); `wp` is addressed in fp16 units (2 per packed float)
+__global__ void pack_weight_f32s_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp,
+                                        int Cout, int Cin, int taps, int cout_pad, int cin_pad)
+{
+    const size_t total = (size_t)taps * cout_pad * cin_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cin_pad);
+        const int n = (int)((i / cin_pad) % cout_pad);
+        const int t = (int)(i / ((size_t)cin_pad * cout_pad));
+        float v = 0.f;
+        if (c < Cin && n < Cout) v = w[((size_t)n * Cin + c) * taps + t];
+        const _Float16 hi = (_Float16)v;
+        const size_t g = (i - (size_t)(c & 31)) * 2;   // first fp16 of the 32-channel group
+        wp[g + (c & 31)] = hi;
+        wp[g + 32 + (c & 31)] = (_Float16)(v - (float)hi);
+    }
+}
 // stem: (Cout,3,KH,KW) -> [cout_pad][kpad], k = tap*3 + rgb
 template <typename T>
 __global__ void pack_stem_weight_kernel(const float *__restrict__ w, T *__restrict__ wp,
@@ -758,6 +778,7 @@ extern "C" size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW
 
 extern "C" size_t cn_packed_conv_weight_elems(int Cout, int Cin, int KH, int KW, int dtype)
 {
+    // f32s: counted in 4-byte units like fp32 (the stem keeps plain fp32 weights)
     return packed_elems(Cout, Cin, KH, KW, dtype == CN_DTYPE_F16 ? 64 : 32);
 }
 
@@ -791,7 +812,17 @@ extern "C" int cn_pack_conv_weight(const float *w_oihw, void *w_packed, int Cout
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return CN_ERR_SHAPE;
     if (dtype == CN_DTYPE_F16)
         return pack_conv_weight_t<_Float16>(w_oihw, w_packed, Cout, Cin, KH, KW, 64, (hipStream_t)stream);
-    if (dtype != CN_DTYPE_F32) return CN_ERR_UNSUPPORTED;
+    if (dtype == CN_DTYPE_F32S && Cin != 3) {
+        const int taps = KH * KW, cout_pad = round_up(Cout, 32), cin_pad = round_up(Cin, 32);
+        const size_t total = (size_t)taps * cout_pad * cin_pad;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_weight_f32s_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           w_oihw, (_Float16 *)w_packed, Cout, Cin, taps, cout_pad, cin_pad);
+        CN_CHECK_LAUNCH();
+        return CN_OK;
+    }
+    if (dtype != CN_DTYPE_F32 && dtype != CN_DTYPE_F32S) return CN_ERR_UNSUPPORTED;
     return pack_conv_weight_t<float>(w_oihw, w_packed, Cout, Cin, KH, KW, 32, (hipStream_t)stream);
 }
 
@@ -827,7 +858,13 @@ static int conv_fill_args(const cn_conv_desc *d, IgemmArgs *a)
     a->M = d->B * d->Ho * d->Wo;
     a->cout_pad = round_up(d->Cout, 32);
     const int f16 = (d->dtype == CN_DTYPE_F16);
-    if (d->dtype != CN_DTYPE_F32 && !f16) return CN_ERR_UNSUPPORTED;
+    const int f32s = (d->dtype == CN_DTYPE_F32S);
+    if (d->dtype != CN_DTYPE_F32 && !f16 && !f32s) return CN_ERR_UNSUPPORTED;
+    // f32s tensors are addressed in 128-byte groups of 32 channels
+    if (f32s && d->in_layout == CN_LAYOUT_NHWC && !(d->flags & CN_CONV_X_PLAIN) && (d->in_pitch & 31))
+        return CN_ERR_UNSUPPORTED;
+    if (f32s && d->out_layout == CN_LAYOUT_NHWC && !(d->flags & CN_CONV_Y_PLAIN) && (d->out_pitch & 31))
+        return CN_ERR_UNSUPPORTED;
     const int bke = f16 ? 64 : 32, epv = f16 ? 8 : 4;
     if (is_stem(d->Cin, d->in_layout)) {
         a->cin_pad = round_up(d->KH * d->KW * 3, bke);
@@ -897,12 +934,13 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
                  (!residual || (((uintptr_t)residual) % valign) == 0)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool stem = is_stem(d->Cin, d->in_layout);
+    const bool f32s = (d->dtype == CN_DTYPE_F32S);
     int cls;
     bool bm64;
     dense_tile_class(d, a, &cls, &bm64);
     // split-K for under-filled grids (needs the caller's workspace; skipped without it)
     a.ksplit = 1;
-    const int want = dense_ksplit(d, a);
+    const int want = f32s ? 1 : dense_ksplit(d, a);
     if (want > 1 && workspace && cn_aligned16(workspace) &&
         workspace_bytes >= (size_t)want * a.M * a.cout_pad * sizeof(float)) {
         a.ksplit = want;
@@ -939,7 +977,7 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         return launch_igemm<128, 32, 4, 1, A_STEM, false>(a, st);
     }
     // 16-channel input, <= 32 output channels (DLA level0 / level1): cn_conv16.hip
-    if (!g_tune_nohalo && !f16 && !residual && a.ksplit == 1 && d->Cin == 16 && d->Cout <= 32 &&
+    if (!g_tune_nohalo && !f16 && !f32s && !residual && a.ksplit == 1 && d->Cin == 16 && d->Cout <= 32 &&
         d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->dil == 1 &&
         d->oy_mul == 1 && d->ox_mul == 1 && d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho &&
         d->OW == d->Wo && d->in_layout == CN_LAYOUT_NHWC) {
@@ -955,7 +993,8 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         return cn_conv3x3s1(x, w_packed, scale, shift, residual, y, d->B, d->H, d->W, d->Cin,
                             d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
                             g_tune_setprio | (g_tune_bm256 << 1) | (g_tune_waves8 << 2) | (g_tune_occ4 << 7) |
-                                (g_tune_dbgskip << 4), cls, f16 ? 1 : 0, st);
+                                (g_tune_dbgskip << 4), cls, d->dtype | (d->flags << 8), st);
+    if (f32s) return CN_ERR_UNSUPPORTED;   // (generic f32s forms follow below as they are built)
     if (f16) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_h<64, 128, 2, 2, A_DENSE, false>(a, st)

@@ -19,6 +19,7 @@
 // Same numerics as the generic kernel: v_mfma_f32_32x32x2_f32, fp32 accumulate, K consumed
 // chunk-major then tap, epilogue y = relu?(acc*scale + shift + residual).
 #include "cn_common.h"
+#include <type_traits>
 
 // cn_set_tuning key 18: phase shift of co-resident workgroups, percent of one tile's MFMA time
 // (0 = off); see the kernel prologue
@@ -33,6 +34,7 @@ typedef _Float16 c3_f16x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct C3Elem;
 template <> struct C3Elem<float> { static constexpr int EPV = 4; };
 template <> struct C3Elem<_Float16> { static constexpr int EPV = 8; };
+template <> struct C3Elem<cn_f32s> { static constexpr int EPV = 4; };   // 128-byte groups, as fp32
 __device__ __forceinline__ cn_f32x4 c3_load4(const float *p) { return *reinterpret_cast<const cn_f32x4 *>(p); }
 __device__ __forceinline__ cn_f32x4 c3_load4(const _Float16 *p)
 {
@@ -53,11 +55,13 @@ struct C3Args {
     const void *residual;        // element type T
     void *y;                     // element type T
     int B, H, W, Cin, Cout, in_pitch, out_pitch, relu;
+    int res_pitch;               // pixel pitch of the residual (= out_pitch unless stated)
     int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, vec_out, setprio;
     int bm256, waves8, occ4;     // tile-shape knobs (cn_set_tuning keys 14, 15, 19)
     int nkk_last;                // KSKIP: 8-channel K groups of the last chunk that hold data
     int dbg;                     // ablation switches (cn_set_tuning key 9)
     int stagger, stagger_slots;  // phase shift of co-resident workgroups (cycles per slot, slots)
+    int in_plain, out_plain, res_plain;  // f32s kernels: x / y / residual are plain fp32 tensors
 };
 
 // Fused detection heads (HEADS = true): blockIdx.y selects the head; its 64 hidden channels
@@ -94,6 +98,8 @@ constexpr size_t c3_union_floats()
 
 // T = float: v_mfma_f32_32x32x2_f32, 32 channels per chunk; T = fp16: v_mfma_f32_32x32x16_f16
 // (fp32 accumulate), 64 channels per chunk -- same 128-byte LDS rows and read addresses.
+// T = cn_f32s: fp32 values as (high, low) fp16 pairs, 32 channels per 128-byte row; every
+// 16-deep K step is three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi), see cn_common.h.
 // NBUFB: LDS buffers of the per-tap weight tile (2: one barrier per tap; 1: two barriers per tap
 // but 9 KB less LDS -- the 4-workgroups-per-CU variant below)
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
@@ -105,13 +111,15 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     // neighbourhood) with its own weights, writing out[2y+py][2x+px] (resnet_dcn.py:228-235)
     constexpr int NTAPS = DECONV ? 4 : 9;
     constexpr int TAPW = DECONV ? 2 : 3;
-    static_assert(!DECONV || (!HEADS && !KSKIP && sizeof(T) == 4), "deconv variant: plain fp32");
+    constexpr bool SPLIT = std::is_same<T, cn_f32s>::value;
+    static_assert(!DECONV || (!HEADS && !KSKIP && sizeof(T) == 4), "deconv variant: fp32 / f32s");
+    static_assert(!SPLIT || !KSKIP, "f32s multiplies the zero-padded channels");
     const int par_y = DECONV ? (int)(blockIdx.z >> 1) : 0, par_x = DECONV ? (int)(blockIdx.z & 1) : 0;
     constexpr int NT = WM * WN * 64;  // 4 waves (256 threads) or 8 waves (512 threads)
     constexpr int RPP = NT / 8;       // LDS rows staged per pass of the block
     static_assert(!HEADS || NT == 256, "fused heads are built for 4 waves");
     static_assert(!HEADS || BM == 128, "fused heads are built for 128-pixel tiles");
-    static_assert(!HEADS || (BN == HEAD_CONV && sizeof(T) == 4), "fused heads: fp32, 64 hidden channels");
+    static_assert(!HEADS || (BN == HEAD_CONV && sizeof(T) == 4), "fused heads: fp32 / f32s, 64 hidden channels");
     constexpr int EPV = C3Elem<T>::EPV;
     constexpr int BKE = 8 * EPV;
     constexpr bool F16 = (EPV == 8);
@@ -204,6 +212,22 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         }
     };
     auto store_A = [&]() {
+        if constexpr (SPLIT) {
+            if (a.in_plain) {  // plain fp32 input: channels 4q..4q+3 split while staging
+#pragma unroll
+                for (int p = 0; p < NPA; ++p) {
+                    const int hr = p * RPP + lrow;
+                    cn_f16x4v hi, lo;
+                    cn_split4(ra[p], hi, lo);
+                    if (hr < HR) {
+                        char *row = reinterpret_cast<char *>(As + hr * LDT);
+                        *reinterpret_cast<cn_f16x4v *>(row + 8 * q) = hi;
+                        *reinterpret_cast<cn_f16x4v *>(row + 64 + 8 * q) = lo;
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {
             const int hr = p * RPP + lrow;
@@ -240,6 +264,35 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         const int toff = (ky * HW_ + kx) * LDT;
         const float *Bb = Bs + buf * BN * LDT + (wn * TN + l31) * LDT + 4 * lh;
         if (a.setprio) __builtin_amdgcn_s_setprio(1);
+        if constexpr (SPLIT) {
+            // the row's four 32-byte quarters: high parts k 0-15, 16-31, low parts k 0-15, 16-31
+            c3_f16x8 af[4][MB], bf[4][NB];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    af[kk][i] = *reinterpret_cast<const c3_f16x8 *>(As + abase[i] + toff + kk * 8);
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    bf[kk][j] = *reinterpret_cast<const c3_f16x8 *>(Bb + j * 32 * LDT + kk * 8);
+            }
+            // smallest terms first (lo*hi, hi*lo, then hi*hi); independent accumulators interleaved
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            const int ka = (term == 0) ? 2 + s : s;
+                            const int kb = (term == 1) ? 2 + s : s;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ka][i], bf[kb][j],
+                                                                               acc[i][j], 0, 0, 0);
+                        }
+            if (a.setprio) __builtin_amdgcn_s_setprio(0);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if (KSKIP && kk >= nkk) break;
@@ -451,9 +504,17 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
             for (int k = 0; k < ITERS; ++k) {
                 const int lr = k * RPI + r0;
                 offs[k] = (lr < EP) ? rowoff[rbase + lr] : -1;
-                if (a.residual)
-                    res[k] = c3_load4(reinterpret_cast<const T *>(a.residual) +
-                                      (size_t)(offs[k] >= 0 ? offs[k] : 0) * a.out_pitch + n);
+                if (a.residual) {
+                    if constexpr (SPLIT)
+                        res[k] = a.res_plain
+                                     ? c3_load4(reinterpret_cast<const float *>(a.residual) +
+                                                (size_t)(offs[k] >= 0 ? offs[k] : 0) * a.res_pitch + n)
+                                     : cn_load4_f32s(a.residual, (size_t)(offs[k] >= 0 ? offs[k] : 0),
+                                                     a.res_pitch, n);
+                    else
+                        res[k] = c3_load4(reinterpret_cast<const T *>(a.residual) +
+                                          (size_t)(offs[k] >= 0 ? offs[k] : 0) * a.out_pitch + n);
+                }
             }
         }
         if (pass) __syncthreads();  // previous pass fully read
@@ -480,7 +541,14 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                     if (a.residual) t += res[k][e];
                     v[e] = a.relu ? fmaxf(t, 0.f) : t;
                 }
-                c3_store4(reinterpret_cast<T *>(a.y) + (size_t)offs[k] * a.out_pitch + n, v);
+                if constexpr (SPLIT) {
+                    if (a.out_plain)
+                        c3_store4(reinterpret_cast<float *>(a.y) + (size_t)offs[k] * a.out_pitch + n, v);
+                    else
+                        cn_store4_f32s(a.y, (size_t)offs[k], a.out_pitch, n, v);
+                } else {
+                    c3_store4(reinterpret_cast<T *>(a.y) + (size_t)offs[k] * a.out_pitch + n, v);
+                }
             }
         } else if (n < a.Cout) {
             for (int k = 0; k < ITERS; ++k) {
@@ -491,8 +559,19 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                 for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
                     const size_t o = (size_t)off * a.out_pitch + n + e;
                     float t = Cs[lr * LDC + c4 * 4 + e] * sc[e] + sf[e];
-                    if (a.residual) t += (float)reinterpret_cast<const T *>(a.residual)[o];
-                    reinterpret_cast<T *>(a.y)[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
+                    if constexpr (SPLIT) {
+                        if (a.residual)
+                            t += a.res_plain ? reinterpret_cast<const float *>(a.residual)[(size_t)off * a.res_pitch + n + e]
+                                             : cn_load1_f32s(a.residual, (size_t)off, a.res_pitch, n + e);
+                        t = a.relu ? fmaxf(t, 0.f) : t;
+                        if (a.out_plain)
+                            reinterpret_cast<float *>(a.y)[o] = t;
+                        else
+                            cn_store1_f32s(a.y, (size_t)off, a.out_pitch, n + e, t);
+                    } else {
+                        if (a.residual) t += (float)reinterpret_cast<const T *>(a.residual)[o];
+                        reinterpret_cast<T *>(a.y)[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
+                    }
                 }
             }
         }
@@ -554,7 +633,11 @@ int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
         // resident workgroups per CU of this variant (registers / LDS), MFMA cycles one tile
         // needs per SIMD, and the number of dispatch rounds of this launch
         constexpr int slots = (BN >= 128 || HEADS || BM > 128) ? 2 : (BN == 64 ? 3 : 4);
-        constexpr long cyc_iter = sizeof(T) == 4 ? (long)BM * BN / 4 : (long)BM * BN / 32;
+        // MFMA cycles per SIMD of one (tap, chunk): fp32 16 x 64-cycle, f32s 6 x 32-cycle, fp16
+        // 4 x 32-cycle (64 channels) instructions per 32 x 32 block, four blocks' worth per SIMD
+        constexpr long cyc_iter = std::is_same<T, float>::value ? (long)BM * BN / 4
+                                  : std::is_same<T, cn_f32s>::value ? (long)BM * BN * 3 / 64
+                                                                    : (long)BM * BN / 32;
         const long total = (long)grid.x * grid.y * grid.z;
         const long rounds = total / (256L * slots);
         const long tile_cycles = (long)b.nchunk * (DECONV ? 4 : 9) * cyc_iter;
@@ -581,7 +664,7 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
 {
     const bool wide = a.W >= 32;  // 4 x 32 tiles keep an MFMA block on one halo row
     // fp32 layers whose last 32-channel chunk is less than 3/4 full skip its empty K groups
-    const bool kskip = sizeof(T) == 4 && a.nkk_last < 4;
+    const bool kskip = std::is_same<T, float>::value && a.nkk_last < 4;
     if (bn_class == 2) {
         // fewer than two 128-wide workgroups per CU: nothing overlaps a workgroup's halo / weight
         // staging and epilogue (ablation: 113 -> 133 TFLOP/s without them at 512->512@16^2), so
@@ -609,7 +692,7 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
         if (kskip)
             return wide ? launch_c3<float, 32, 64, 2, 2, false, 128, true>(a, st)
                         : launch_c3<float, 16, 64, 2, 2, false, 128, true>(a, st);
-        if (sizeof(T) == 4 && a.occ4 != 2) {
+        if (std::is_same<T, float>::value && a.occ4 != 2) {
             // four workgroups per CU when that needs fewer (work-normalised) dispatch rounds than
             // three: 4096 tiles = 5.33 rounds of 768 but exactly 4 of 1024 (resdcn_18 -1.0 %,
             // tools/bench_knob.py 19); cn_set_tuning key 19: 0 = this rule, 1 = always, 2 = never
@@ -642,12 +725,19 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_pitch = in_pitch;
     a.out_pitch = out_pitch; a.relu = relu; a.vec_out = vec_out; a.setprio = setprio;
-    const int bke = f16 ? 64 : 32;
+    a.res_pitch = out_pitch;
+    // f16: the dtype code CN_DTYPE_F32 / F16 / F32S in the low byte, cn_conv_desc.flags above it
+    a.in_plain = (f16 >> 8) & CN_CONV_X_PLAIN ? 1 : 0;
+    a.out_plain = (f16 >> 8) & CN_CONV_Y_PLAIN ? 1 : 0;
+    a.res_plain = (f16 >> 8) & CN_CONV_R_PLAIN ? 1 : 0;
+    f16 &= 255;
+    const int bke = f16 == CN_DTYPE_F16 ? 64 : 32;
     a.cin_pad = (Cin + bke - 1) / bke * bke;
     a.cout_pad = (Cout + 31) / 32 * 32;
     a.nchunk = a.cin_pad / bke;
-    a.nkk_last = f16 ? 4 : ((Cin - (a.nchunk - 1) * 32) + 7) / 8;
-    return f16 ? c3_dispatch<_Float16>(a, bn_class, st) : c3_dispatch<float>(a, bn_class, st);
+    a.nkk_last = f16 != CN_DTYPE_F32 ? 4 : ((Cin - (a.nchunk - 1) * 32) + 7) / 8;
+    if (f16 == CN_DTYPE_F32S) return c3_dispatch<cn_f32s>(a, bn_class, st);
+    return f16 == CN_DTYPE_F16 ? c3_dispatch<_Float16>(a, bn_class, st) : c3_dispatch<float>(a, bn_class, st);
 }
 
 // Fused CenterNet heads: for every head h, y_h = conv1x1(relu(conv3x3(x) + bias1_h)) + bias2_h,

@@ -254,6 +254,75 @@ extern "C" int cn_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, 
     return cn_maxpool_nhwc_f32(x, y, B, H, W, C, 3, 2, 1, stream);
 }
 
+// ---- plain fp32 <-> f32s (fp16 high/low pairs, 32-channel groups; cn_common.h) -------------
+namespace {
+__global__ void f32_to_f32s_kernel(const float *__restrict__ x, void *__restrict__ y, size_t npix,
+                                   int C, int in_pitch, int out_pitch)
+{
+    const int c4n = (C + 3) >> 2;
+    const size_t total = npix * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / c4n;
+        const int n = (int)(i - p * c4n) * 4;
+        cn_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n + 4 <= C && (in_pitch & 3) == 0) {
+            v = *reinterpret_cast<const cn_f32x4 *>(x + p * in_pitch + n);
+        } else {
+            for (int e = 0; e < 4 && n + e < C; ++e) v[e] = x[p * in_pitch + n + e];
+        }
+        cn_store4_f32s(y, p, out_pitch, n, v);   // channels past C inside the group: zeros
+    }
+}
+__global__ void f32s_to_f32_kernel(const void *__restrict__ x, float *__restrict__ y, size_t npix,
+                                   int C, int in_pitch, int out_pitch)
+{
+    const int c4n = (C + 3) >> 2;
+    const size_t total = npix * c4n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / c4n;
+        const int n = (int)(i - p * c4n) * 4;
+        const cn_f32x4 v = cn_load4_f32s(x, p, in_pitch, n);
+        if (n + 4 <= C && (out_pitch & 3) == 0) {
+            *reinterpret_cast<cn_f32x4 *>(y + p * out_pitch + n) = v;
+        } else {
+            for (int e = 0; e < 4 && n + e < C; ++e) y[p * out_pitch + n + e] = v[e];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int cn_f32_to_f32s(const float *x, void *y, size_t npix, int C, int in_pitch,
+                              int out_pitch, void *stream)
+{
+    if (!x || !y) return CN_ERR_NULL;
+    if (C <= 0 || in_pitch < C || out_pitch < C) return CN_ERR_SHAPE;
+    if ((out_pitch & 31) || !cn_aligned16(y)) return CN_ERR_ALIGN;
+    if ((in_pitch & 3) == 0 && !cn_aligned16(x)) return CN_ERR_ALIGN;
+    const size_t total = npix * ((C + 3) >> 2);
+    if (!total) return CN_OK;
+    hipLaunchKernelGGL(f32_to_f32s_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, npix, C, in_pitch, out_pitch);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_f32s_to_f32(const void *x, float *y, size_t npix, int C, int in_pitch,
+                              int out_pitch, void *stream)
+{
+    if (!x || !y) return CN_ERR_NULL;
+    if (C <= 0 || in_pitch < C || out_pitch < C) return CN_ERR_SHAPE;
+    if ((in_pitch & 31) || !cn_aligned16(x)) return CN_ERR_ALIGN;
+    if ((out_pitch & 3) == 0 && !cn_aligned16(y)) return CN_ERR_ALIGN;
+    const size_t total = npix * ((C + 3) >> 2);
+    if (!total) return CN_OK;
+    hipLaunchKernelGGL(f32s_to_f32_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, npix, C, in_pitch, out_pitch);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
 // ---- reference-layout (NCHW) DCNv2 entry point --------------------------------
 namespace {
 struct DcnWs {

@@ -20,6 +20,8 @@ LAYOUT_NCHW = 0
 LAYOUT_NHWC = 1
 DTYPE_F32 = 0
 DTYPE_F16 = 1
+DTYPE_F32S = 2        # fp32 values as fp16 (high, low) pairs: three fp16 MFMAs per product
+CONV_X_PLAIN, CONV_Y_PLAIN = 1, 2
 
 _lib = None
 
@@ -33,7 +35,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad_h", "pad_w",
         "dil", "in_layout", "in_pitch", "out_layout", "out_pitch", "OH", "OW", "oy_mul",
-        "oy_add", "ox_mul", "ox_add", "relu", "dtype")]
+        "oy_add", "ox_mul", "ox_add", "relu", "dtype", "flags")]
 
 
 class HeadOut(ctypes.Structure):
@@ -70,6 +72,10 @@ def _declare(lib):
     lib.cn_dcn_v2_forward_nhwc_f32.argtypes = [vp, vp, vp, vp, i, vp, vp, vp] + [i] * 7 + [vp, sz, vp]
     lib.cn_dcn_v2_forward_nhwc_workspace_bytes.restype = sz
     lib.cn_dcn_v2_forward_nhwc_workspace_bytes.argtypes = [i] * 5
+    lib.cn_f32_to_f32s.restype = i
+    lib.cn_f32_to_f32s.argtypes = [vp, vp, sz, i, i, i, vp]
+    lib.cn_f32s_to_f32.restype = i
+    lib.cn_f32s_to_f32.argtypes = [vp, vp, sz, i, i, i, vp]
     lib.cn_packed_conv_weight_floats.restype = sz
     lib.cn_packed_conv_weight_floats.argtypes = [i] * 4
     lib.cn_pack_conv_weight_f32.restype = i

@@ -46,6 +46,9 @@ typedef enum cn_status {
  * a surface the reference does not have. */
 #define CN_DTYPE_F32 0
 #define CN_DTYPE_F16 1
+/* fp32 values stored as fp16 (high, low) pairs, 32-channel groups of 128 bytes; computed
+ * with three fp16 MFMAs per product at fp32-level accuracy (csrc/cn_common.h) */
+#define CN_DTYPE_F32S 2
 
 /* Library / ABI version (major*10000 + minor*100 + patch). */
 int cn_version(void);
@@ -153,6 +156,14 @@ int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_pack
                                int Cout, int mask_sigmoid, int relu, void *workspace,
                                size_t workspace_bytes, void *stream);
 
+/* Plain fp32 NHWC <-> f32s NHWC (CN_DTYPE_F32S: fp16 high / low pairs in 128-byte groups of 32
+ * channels).  Pitches in channels; f32s pitches are multiples of 32; channels of the last
+ * group beyond C are written as zeros.  New surface (the reference has one tensor format). */
+int cn_f32_to_f32s(const float *x, void *y, size_t npix, int C, int in_pitch, int out_pitch,
+                   void *stream);
+int cn_f32s_to_f32(const void *x, float *y, size_t npix, int C, int in_pitch, int out_pitch,
+                   void *stream);
+
 /* ------------------------------------------------------------------------
  * Dense convolution as an implicit GEMM on fp32 MFMA (no im2col buffer).
  *
@@ -179,8 +190,14 @@ typedef struct cn_conv_desc {
     int out_layout, out_pitch;
     int OH, OW, oy_mul, oy_add, ox_mul, ox_add;
     int relu;
-    int dtype;              /* CN_DTYPE_F32 / CN_DTYPE_F16 (x, w, residual, NHWC y) */
+    int dtype;              /* CN_DTYPE_F32 / CN_DTYPE_F16 / CN_DTYPE_F32S (x, w, residual, NHWC y) */
+    int flags;              /* CN_CONV_* bits, 0 by default */
 } cn_conv_desc;
+/* dtype = CN_DTYPE_F32S only: x (and the residual) / y are plain fp32 NHWC tensors; the kernel
+ * converts while staging / storing (e.g. the offset maps the deformable kernel reads). */
+#define CN_CONV_X_PLAIN 1
+#define CN_CONV_Y_PLAIN 2
+#define CN_CONV_R_PLAIN 4
 
 /* Number of floats of the packed weight for (Cout,Cin,KH,KW). */
 size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
