@@ -27,6 +27,7 @@
 // consumed in the order {k, k+4}: lane half h holds k = 4h..4h+3 of each 8-group
 // for both operands (any fixed K permutation is a valid dot-product order).
 #include "cn_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -68,6 +69,7 @@ struct IgemmArgs {
     int dbgskip;     // ablation: skip A (bit 0) / B (bit 1) staging after the first chunk (WRONG results)
     int ksplit;    // split-K: blockIdx.z owns chunks [z*KT/ksplit, (z+1)*KT/ksplit)
     float *partial; // split-K: raw fp32 partial sums [ksplit][M][cout_pad]
+    int in_plain, out_plain, res_plain;  // f32s kernels: x / y / residual are plain fp32 tensors
 };
 
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -105,8 +107,14 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     constexpr int EPV = ElemTraits<T>::EPV;  // elements per 16-byte vector
     constexpr int BKE = 8 * EPV;             // channels per chunk (one 128-byte LDS row)
     constexpr bool F16 = (EPV == 8);
+    // T = cn_f32s: fp32 values as fp16 (high, low) pairs in the same 128-byte rows; three
+    // v_mfma_f32_32x32x16_f16 per 16-deep K step (cn_common.h).  The deformable form reads a
+    // PLAIN fp32 input (one 16-byte gather per corner), blends in fp32 and splits the blended
+    // value when it writes the A tile.
+    constexpr bool SPLIT = std::is_same<T, cn_f32s>::value;
     constexpr bool DCN = (AMODE == A_DCN || AMODE == A_DCN_PAD);
-    static_assert(!(F16 && DCN), "the deformable kernel is fp32 only");
+    static_assert(!(F16 && DCN), "the deformable kernel is fp32 / f32s only");
+    static_assert(!(SPLIT && AMODE == A_STEM), "the stem reads the fp32 image: fp32 kernel");
     static_assert(NBUF == 1 || NBUF == 2, "LDS tile buffers");
     static_assert(WM * WN == NT / CN_WAVE, "4 waves");
     constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         }
         // ---- A
         if (a.dbgskip & 1) return;
-        if (AMODE == A_DENSE) {
+        if constexpr (AMODE == A_DENSE) {
             const int ky = tap / a.KW, kx = tap - ky * a.KW;
             const int c = c0 + EPV * q;
 #pragma unroll
@@ -304,13 +312,13 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 const int iy = a_iy0[p] + ky * a.dil;
                 const int ix = a_ix0[p] + kx * a.dil;
                 const bool ok = a_pix[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W &&
-                                c < a.Cin;
+                                ((SPLIT && !a.in_plain) ? (c0 < a.Cin) : (c < a.Cin));
                 // always load from a valid address, then select: no exec-mask branches
                 const size_t off = ok ? ((size_t)(a_pix[p] + iy * a.W + ix) * a.in_pitch + c) : 0;
                 const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(xT + off);
                 ra[p][0] = ok ? v : zero4;
             }
-        } else if (AMODE == A_STEM) {
+        } else if constexpr (AMODE == A_STEM) {
             // K is packed densely as k = tap*3 + rgb (147 -> 160 for 7x7, not 196 -> 224);
             // the image is fp32 NCHW; (offset, ky, kx) of every k come from the LDS table
             const float *xin = reinterpret_cast<const float *>(a.x);
@@ -374,9 +382,30 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   (dcn_v2_im2col_cuda.cu:43-45,174)
                 v = ra[p][0] * w1 + ra[p][1] * w2 + ra[p][2] * w3 + ra[p][3] * w4;
                 v = v * mk;
-                *reinterpret_cast<cn_f32x4 *>(Ad + r * LDT + 4 * q) = v;
+                if constexpr (SPLIT) {
+                    cn_f16x4v hi, lo;
+                    cn_split4(v, hi, lo);
+                    char *row = reinterpret_cast<char *>(Ad + r * LDT);
+                    *reinterpret_cast<cn_f16x4v *>(row + 8 * q) = hi;
+                    *reinterpret_cast<cn_f16x4v *>(row + 64 + 8 * q) = lo;
+                } else {
+                    *reinterpret_cast<cn_f32x4 *>(Ad + r * LDT + 4 * q) = v;
+                }
             }
         } else {
+            if constexpr (SPLIT) {
+                if (a.in_plain) {  // plain fp32 input: channels 4q..4q+3 split while staging
+#pragma unroll
+                    for (int p = 0; p < PA; ++p) {
+                        cn_f16x4v hi, lo;
+                        cn_split4(ra[p][0], hi, lo);
+                        char *row = reinterpret_cast<char *>(Ad + (p * 32 + lrow) * LDT);
+                        *reinterpret_cast<cn_f16x4v *>(row + 8 * q) = hi;
+                        *reinterpret_cast<cn_f16x4v *>(row + 64 + 8 * q) = lo;
+                    }
+                    return;
+                }
+            }
 #pragma unroll
             for (int p = 0; p < PA; ++p)
                 *reinterpret_cast<cn_f32x4 *>(Ad + (p * 32 + lrow) * LDT + 4 * q) = ra[p][0];
@@ -388,6 +417,45 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         const float *Ab = As + buf * BM * LDT + (wm * TM + l31) * LDT + 4 * lh;
         const float *Bb = Bs + buf * BN * LDT + (wn * TN + l31) * LDT + 4 * lh;
         if (a.setprio) __builtin_amdgcn_s_setprio(1);
+        if constexpr (SPLIT) {
+            // row quarters: high parts k 0-15, 16-31, low parts k 0-15, 16-31
+            cn_f16x8 af[4][MB], bf[4][NB];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    af[kk][i] = *reinterpret_cast<const cn_f16x8 *>(Ab + i * 32 * LDT + kk * 8);
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    bf[kk][j] = *reinterpret_cast<const cn_f16x8 *>(Bb + j * 32 * LDT + kk * 8);
+            }
+            // All twelve fragments are in registers BEFORE the first MFMA issues, and the compiler
+            // may not sink a read back into the MFMA stream: an MFMA that waits in the matrix pipe
+            // for its accumulator (dependent chain, pipe shared with co-resident waves) reads its
+            // A/B registers late, and a ds_read issued right behind it into the same registers
+            // (hipcc re-used them to save VGPRs) overwrote the operand first -- rare wrong rows
+            // that came and went with occupancy (measured: tools/dbg_determinism.py).
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int term = 0; term < 3; ++term)   // lo*hi, hi*lo, hi*hi
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            const int ka = (term == 0) ? 2 + s2 : s2;
+                            const int kb = (term == 1) ? 2 + s2 : s2;
+                            if (OUT_NCHW)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    bf[kb][j], af[ka][i], acc[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    af[ka][i], bf[kb][j], acc[i][j], 0, 0, 0);
+                        }
+            if (a.setprio) __builtin_amdgcn_s_setprio(0);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             cn_f32x4 af[MB], bf[NB];
@@ -507,8 +575,14 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                     const int lr = it * RPI + r0;
                     offs[it] = (lr < TM) ? rowoff[rbase + lr] : -1;
                     if (a.residual) {
-                        const size_t o = (size_t)(offs[it] >= 0 ? offs[it] : 0) * a.out_pitch + n;
-                        res[it] = load4_as_f32(reinterpret_cast<const T *>(a.residual) + o);
+                        const size_t po = (size_t)(offs[it] >= 0 ? offs[it] : 0);
+                        const size_t o = po * a.out_pitch + n;
+                        if constexpr (SPLIT)
+                            res[it] = a.res_plain
+                                          ? load4_as_f32(reinterpret_cast<const float *>(a.residual) + o)
+                                          : cn_load4_f32s(a.residual, po, a.out_pitch, n);
+                        else
+                            res[it] = load4_as_f32(reinterpret_cast<const T *>(a.residual) + o);
                     }
                 }
 #pragma unroll
@@ -522,7 +596,15 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                         if (a.residual) t += res[it][e];
                         v[e] = a.relu ? fmaxf(t, 0.f) : t;
                     }
-                    store4_from_f32(reinterpret_cast<T *>(a.y) + (size_t)offs[it] * a.out_pitch + n, v);
+                    if constexpr (SPLIT) {
+                        if (a.out_plain)
+                            store4_from_f32(reinterpret_cast<float *>(a.y) +
+                                            (size_t)offs[it] * a.out_pitch + n, v);
+                        else
+                            cn_store4_f32s(a.y, (size_t)offs[it], a.out_pitch, n, v);
+                    } else {
+                        store4_from_f32(reinterpret_cast<T *>(a.y) + (size_t)offs[it] * a.out_pitch + n, v);
+                    }
                 }
             } else if (n < a.Cout) {
                 for (int it = 0; it < ITERS; ++it) {
@@ -533,8 +615,19 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                     for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
                         const size_t o = (size_t)off * a.out_pitch + n + e;
                         float t = (Cs[lr * LDC + c4 * 4 + e] + bs[e]) * sc[e] + sf[e];
-                        if (a.residual) t += (float)reinterpret_cast<const T *>(a.residual)[o];
-                        reinterpret_cast<T *>(a.y)[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
+                        if constexpr (SPLIT) {
+                            if (a.residual)
+                                t += a.res_plain ? reinterpret_cast<const float *>(a.residual)[o]
+                                                 : cn_load1_f32s(a.residual, (size_t)off, a.out_pitch, n + e);
+                            t = a.relu ? fmaxf(t, 0.f) : t;
+                            if (a.out_plain)
+                                reinterpret_cast<float *>(a.y)[o] = t;
+                            else
+                                cn_store1_f32s(a.y, (size_t)off, a.out_pitch, n + e, t);
+                        } else {
+                            if (a.residual) t += (float)reinterpret_cast<const T *>(a.residual)[o];
+                            reinterpret_cast<T *>(a.y)[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
+                        }
                     }
                 }
             }
@@ -621,6 +714,16 @@ int launch_igemm_h(const IgemmArgs &a, hipStream_t st)
     return launch_igemm_n<_Float16, BM, BN, WM, WN, AMODE, OUT_NCHW, 2>(a, st);
 }
 
+// f32s (fp16 high/low pairs, fp32 accumulate): dense and deformable forms
+template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW>
+int launch_igemm_s(const IgemmArgs &a, hipStream_t st)
+{
+    static_assert(AMODE != A_STEM, "the stem stays on the fp32 kernel");
+    if (!OUT_NCHW && a.stride == 1 && g_tune_nbuf != 2)
+        return launch_igemm_n<cn_f32s, BM, BN, WM, WN, AMODE, OUT_NCHW, 1>(a, st);
+    return launch_igemm_n<cn_f32s, BM, BN, WM, WN, AMODE, OUT_NCHW, 2>(a, st);
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE, bool OUT_NCHW>
 int launch_igemm(const IgemmArgs &a, hipStream_t st)
 {
@@ -704,9 +807,9 @@ int cn_conv3x3_c16(const float *x, const float *w_packed, const float *scale, co
                    float *y, int B, int H, int W, int Ho, int Wo, int Cin, int Cout, int stride,
                    int in_pitch, int out_pitch, int relu, hipStream_t st);
 extern int cn_tune_stagger_pct;  // cn_conv3x3.hip
-int cn_deconv4x4s2_halo(const float *x, const float *w_packed, const float *scale, const float *shift,
-                        float *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
-                        int relu, int vec_out, int setprio, hipStream_t st);
+int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale, const float *shift,
+                        void *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
+                        int relu, int vec_out, int setprio, int dtype_flags, hipStream_t st);
 namespace {
 
 // split-K second stage: sum the partial tiles, then the usual epilogue
@@ -732,16 +835,34 @@ __global__ void splitk_reduce_kernel(const IgemmArgs a)
         const int oy = rr / a.Wo;
         const int ox = rr - oy * a.Wo;
         const size_t off = (size_t)((b * a.OH + oy * a.oy_mul + a.oy_add) * a.OW + ox * a.ox_mul + a.ox_add);
-        const T *res = reinterpret_cast<const T *>(a.residual);
-        T *y = reinterpret_cast<T *>(a.y);
-        for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
-            const float bs = a.bias ? a.bias[n + e] : 0.f;
-            const float sc = a.scale ? a.scale[n + e] : 1.f;
-            const float sf = a.shift ? a.shift[n + e] : 0.f;
-            float t = (v[e] + bs) * sc + sf;
-            const size_t o = off * a.out_pitch + n + e;
-            if (res) t += (float)res[o];
-            y[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
+        if constexpr (std::is_same<T, cn_f32s>::value) {
+            for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
+                const float bs = a.bias ? a.bias[n + e] : 0.f;
+                const float sc = a.scale ? a.scale[n + e] : 1.f;
+                const float sf = a.shift ? a.shift[n + e] : 0.f;
+                float t = (v[e] + bs) * sc + sf;
+                const size_t o = off * a.out_pitch + n + e;
+                if (a.residual)
+                    t += a.res_plain ? reinterpret_cast<const float *>(a.residual)[o]
+                                     : cn_load1_f32s(a.residual, off, a.out_pitch, n + e);
+                t = a.relu ? fmaxf(t, 0.f) : t;
+                if (a.out_plain)
+                    reinterpret_cast<float *>(a.y)[o] = t;
+                else
+                    cn_store1_f32s(a.y, off, a.out_pitch, n + e, t);
+            }
+        } else {
+            const T *res = reinterpret_cast<const T *>(a.residual);
+            T *y = reinterpret_cast<T *>(a.y);
+            for (int e = 0; e < 4 && (n + e) < a.Cout; ++e) {
+                const float bs = a.bias ? a.bias[n + e] : 0.f;
+                const float sc = a.scale ? a.scale[n + e] : 1.f;
+                const float sf = a.shift ? a.shift[n + e] : 0.f;
+                float t = (v[e] + bs) * sc + sf;
+                const size_t o = off * a.out_pitch + n + e;
+                if (res) t += (float)res[o];
+                y[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
+            }
         }
     }
 }
@@ -940,14 +1061,23 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
     dense_tile_class(d, a, &cls, &bm64);
     // split-K for under-filled grids (needs the caller's workspace; skipped without it)
     a.ksplit = 1;
-    const int want = f32s ? 1 : dense_ksplit(d, a);
+    a.in_plain = (d->flags & CN_CONV_X_PLAIN) ? 1 : 0;
+    a.out_plain = (d->flags & CN_CONV_Y_PLAIN) ? 1 : 0;
+    a.res_plain = (d->flags & CN_CONV_R_PLAIN) ? 1 : 0;
+    const int want = dense_ksplit(d, a);
     if (want > 1 && workspace && cn_aligned16(workspace) &&
         workspace_bytes >= (size_t)want * a.M * a.cout_pad * sizeof(float)) {
         a.ksplit = want;
         a.partial = (float *)workspace;
     }
+    if (f32s && stem) return CN_ERR_UNSUPPORTED;   // the fp32 image goes through the fp32 stem kernels
     if (d->out_layout == CN_LAYOUT_NCHW) {
         if (residual || stem) return CN_ERR_UNSUPPORTED;
+        if (f32s) {
+            if (cls == 2) return launch_igemm_s<128, 128, 2, 2, A_DENSE, true>(a, st);
+            if (cls == 1) return launch_igemm_s<128, 64, 2, 2, A_DENSE, true>(a, st);
+            return launch_igemm_s<128, 32, 4, 1, A_DENSE, true>(a, st);
+        }
         if (f16) {
             if (cls == 2) return launch_igemm_h<128, 128, 2, 2, A_DENSE, true>(a, st);
             if (cls == 1) return launch_igemm_h<128, 64, 2, 2, A_DENSE, true>(a, st);
@@ -994,8 +1124,15 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
                             d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
                             g_tune_setprio | (g_tune_bm256 << 1) | (g_tune_waves8 << 2) | (g_tune_occ4 << 7) |
                                 (g_tune_dbgskip << 4), cls, d->dtype | (d->flags << 8), st);
-    if (f32s) return CN_ERR_UNSUPPORTED;   // (generic f32s forms follow below as they are built)
-    if (f16) {
+    if (f32s) {
+        if (cls == 2)
+            rc = bm64 ? launch_igemm_s<64, 128, 2, 2, A_DENSE, false>(a, st)
+                      : launch_igemm_s<128, 128, 2, 2, A_DENSE, false>(a, st);
+        else if (cls == 1)
+            rc = launch_igemm_s<128, 64, 2, 2, A_DENSE, false>(a, st);
+        else
+            rc = launch_igemm_s<128, 32, 4, 1, A_DENSE, false>(a, st);
+    } else if (f16) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_h<64, 128, 2, 2, A_DENSE, false>(a, st)
                       : launch_igemm_h<128, 128, 2, 2, A_DENSE, false>(a, st);
@@ -1016,7 +1153,9 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
     const size_t total = (size_t)a.M * (a.cout_pad >> 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    if (f16)
+    if (f32s)
+        hipLaunchKernelGGL(splitk_reduce_kernel<cn_f32s>, dim3(blocks), dim3(256), 0, st, a);
+    else if (f16)
         hipLaunchKernelGGL(splitk_reduce_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
@@ -1058,17 +1197,34 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
                                           int Cout, int mask_sigmoid, int relu, void *workspace,
                                           size_t workspace_bytes, void *stream)
 {
+    return cn_dcn_v2_forward_nhwc(input_nhwc, weight_packed, bias, offset_mask_nhwc, om_pitch, scale,
+                                  shift, output_nhwc, Cout, B, Cin, H, W, Cout, mask_sigmoid, relu,
+                                  CN_DTYPE_F32, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weight_packed,
+                                      const float *bias, const float *offset_mask_nhwc,
+                                      int om_pitch, const float *scale, const float *shift,
+                                      void *output_nhwc, int out_pitch, int B, int Cin, int H,
+                                      int W, int Cout, int mask_sigmoid, int relu, int dtype,
+                                      int flags, void *workspace, size_t workspace_bytes,
+                                      void *stream)
+{
     if (!input_nhwc || !weight_packed || !offset_mask_nhwc || !output_nhwc) return CN_ERR_NULL;
-    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return CN_ERR_SHAPE;
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || out_pitch < Cout) return CN_ERR_SHAPE;
     if (om_pitch < 27) return CN_ERR_SHAPE;
     if ((Cin & 3) != 0) return CN_ERR_UNSUPPORTED;
+    const bool f32s = (dtype == CN_DTYPE_F32S);
+    if (dtype != CN_DTYPE_F32 && !f32s) return CN_ERR_UNSUPPORTED;
+    if (f32s && !(flags & CN_CONV_Y_PLAIN) && (out_pitch & 31)) return CN_ERR_UNSUPPORTED;
     if (!cn_aligned16(input_nhwc) || !cn_aligned16(weight_packed)) return CN_ERR_ALIGN;
-    if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1L << 30)) return CN_ERR_UNSUPPORTED;  // 32-bit byte offsets
+    if ((long)B * H * W * (long)(Cin > out_pitch ? Cin : out_pitch) >= (1L << 30)) return CN_ERR_UNSUPPORTED;  // 32-bit byte offsets
     // LDS-staged input window (cn_dcn.hip): measured 20-30 % SLOWER than the L1/L2-served
     // gather below on every CenterNet shape (tools/bench_dcn.py), so it is opt-in only
-    if (g_tune_dcn_window && Cout > 32) {
-        const int rc = cn_dcn_window_f32(input_nhwc, weight_packed, bias, offset_mask_nhwc, om_pitch,
-                                         scale, shift, output_nhwc, B, Cin, H, W, Cout,
+    if (!f32s && out_pitch == Cout && g_tune_dcn_window && Cout > 32) {
+        const int rc = cn_dcn_window_f32(input_nhwc, (const float *)weight_packed, bias,
+                                         offset_mask_nhwc, om_pitch, scale, shift,
+                                         (float *)output_nhwc, B, Cin, H, W, Cout,
                                          mask_sigmoid, relu, g_tune_setprio, (hipStream_t)stream);
         if (rc != CN_ERR_UNSUPPORTED) return rc;
     }
@@ -1078,7 +1234,9 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
     a.mask_sigmoid = mask_sigmoid;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = H; a.Wo = W; a.Cout = Cout;
     a.KH = 3; a.KW = 3; a.stride = 1; a.pad_h = 1; a.pad_w = 1; a.dil = 1;
-    a.in_pitch = Cin; a.out_pitch = Cout;
+    a.in_pitch = Cin; a.out_pitch = out_pitch;
+    a.in_plain = 1;                                   // the gather reads plain fp32 in every mode
+    a.out_plain = (flags & CN_CONV_Y_PLAIN) ? 1 : 0;
     a.OH = H; a.OW = W; a.oy_mul = 1; a.oy_add = 0; a.ox_mul = 1; a.ox_add = 0;
     a.relu = relu;
     a.M = B * H * W;
@@ -1086,7 +1244,7 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
     a.cout_pad = round_up(Cout, 32);
     a.nchunk = a.cin_pad / 32;
     a.KT = 9 * a.nchunk;
-    a.vec_out = ((Cout & 3) == 0 && cn_aligned16(output_nhwc)) ? 1 : 0;
+    a.vec_out = ((Cout & 3) == 0 && (out_pitch & 3) == 0 && cn_aligned16(output_nhwc)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     // 64-pixel tiles: 128-pixel tiles were measured slower at every CenterNet shape
     // (tools/bench_dcn.py) and are no longer built
@@ -1102,6 +1260,23 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
     }
     int rc;
     const bool padk = (Cin & 31) != 0;
+    if (f32s) {
+        if (Cout > 64)
+            rc = padk ? launch_igemm_s<64, 128, 2, 2, A_DCN_PAD, false>(a, st)
+                      : launch_igemm_s<64, 128, 2, 2, A_DCN, false>(a, st);
+        else if (Cout > 32)
+            rc = padk ? launch_igemm_s<64, 64, 2, 2, A_DCN_PAD, false>(a, st)
+                      : launch_igemm_s<64, 64, 2, 2, A_DCN, false>(a, st);
+        else
+            rc = padk ? launch_igemm_s<128, 32, 4, 1, A_DCN_PAD, false>(a, st)
+                      : launch_igemm_s<128, 32, 4, 1, A_DCN, false>(a, st);
+        if (rc != CN_OK || a.ksplit == 1) return rc;
+        const size_t tot = (size_t)a.M * (a.cout_pad >> 2);
+        const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel<cn_f32s>, dim3(nb), dim3(256), 0, st, a);
+        CN_CHECK_LAUNCH();
+        return CN_OK;
+    }
     if (Cout > 64)
         rc = padk ? launch_igemm<64, 128, 2, 2, A_DCN_PAD, false>(a, st)
                   : launch_igemm<64, 128, 2, 2, A_DCN, false>(a, st);
@@ -1124,7 +1299,7 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
 // with ky(0,.) = {3,1}, ky(1,.) = {2,0}: four 2x2 convolutions, one launch (blockIdx.z).
 namespace {
 __global__ void pack_deconv_weight_kernel(const float *__restrict__ w, float *__restrict__ wp,
-                                          int Cin, int Cout, int cout_pad, int cin_pad)
+                                          int Cin, int Cout, int cout_pad, int cin_pad, int f32s)
 {
     const size_t total = (size_t)16 * cout_pad * cin_pad;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -1138,7 +1313,15 @@ __global__ void pack_deconv_weight_kernel(const float *__restrict__ w, float *__
         const int kx = px ? (tx ? 0 : 2) : (tx ? 1 : 3);
         float v = 0.f;
         if (c < Cin && n < Cout) v = w[(((size_t)c * Cout + n) * 4 + ky) * 4 + kx];
-        wp[i] = v;
+        if (f32s) {   // fp16 (high, low) pairs per 32-channel group, see pack_weight_f32s_kernel
+            _Float16 *wh = reinterpret_cast<_Float16 *>(wp);
+            const _Float16 hi = (_Float16)v;
+            const size_t g = (i - (size_t)(c & 31)) * 2;
+            wh[g + (c & 31)] = hi;
+            wh[g + 32 + (c & 31)] = (_Float16)(v - (float)hi);
+        } else {
+            wp[i] = v;
+        }
     }
 }
 }  // namespace
@@ -1152,13 +1335,21 @@ extern "C" size_t cn_packed_deconv4x4s2_weight_floats(int Cin, int Cout)
 extern "C" int cn_pack_deconv4x4s2_weight_f32(const float *w_iohw, float *w_packed, int Cin,
                                               int Cout, void *stream)
 {
+    return cn_pack_deconv4x4s2_weight(w_iohw, w_packed, Cin, Cout, CN_DTYPE_F32, stream);
+}
+
+extern "C" int cn_pack_deconv4x4s2_weight(const float *w_iohw, void *w_packed, int Cin, int Cout,
+                                          int dtype, void *stream)
+{
     if (!w_iohw || !w_packed) return CN_ERR_NULL;
     if (Cin <= 0 || Cout <= 0) return CN_ERR_SHAPE;
+    if (dtype != CN_DTYPE_F32 && dtype != CN_DTYPE_F32S) return CN_ERR_UNSUPPORTED;
     const size_t total = cn_packed_deconv4x4s2_weight_floats(Cin, Cout);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_deconv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       w_iohw, w_packed, Cin, Cout, round_up(Cout, 32), round_up(Cin, 32));
+                       w_iohw, (float *)w_packed, Cin, Cout, round_up(Cout, 32), round_up(Cin, 32),
+                       dtype == CN_DTYPE_F32S ? 1 : 0);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -1168,9 +1359,22 @@ extern "C" int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_pa
                                           int B, int H, int W, int Cin, int Cout, int in_pitch,
                                           int out_pitch, int relu, void *stream)
 {
+    return cn_conv_transpose4x4s2(x_nhwc, w_packed, scale, shift, y_nhwc, B, H, W, Cin, Cout,
+                                  in_pitch, out_pitch, relu, CN_DTYPE_F32, 0, stream);
+}
+
+extern "C" int cn_conv_transpose4x4s2(const void *x_nhwc, const void *w_packed, const float *scale,
+                                      const float *shift, void *y_nhwc, int B, int H, int W,
+                                      int Cin, int Cout, int in_pitch, int out_pitch, int relu,
+                                      int dtype, int flags, void *stream)
+{
     if (!x_nhwc || !w_packed || !y_nhwc) return CN_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CN_ERR_SHAPE;
     if ((Cin & 3) || (in_pitch & 3) || in_pitch < Cin || out_pitch < Cout) return CN_ERR_UNSUPPORTED;
+    const bool f32s = (dtype == CN_DTYPE_F32S);
+    if (dtype != CN_DTYPE_F32 && !f32s) return CN_ERR_UNSUPPORTED;
+    if (f32s && !(flags & CN_CONV_X_PLAIN) && (in_pitch & 31)) return CN_ERR_UNSUPPORTED;
+    if (f32s && !(flags & CN_CONV_Y_PLAIN) && (out_pitch & 31)) return CN_ERR_UNSUPPORTED;
     if (!cn_aligned16(x_nhwc) || !cn_aligned16(w_packed)) return CN_ERR_ALIGN;
     if ((long)B * H * W * 4 * (long)out_pitch >= (1L << 31) || (long)B * H * W * (long)in_pitch >= (1L << 31))
         return CN_ERR_UNSUPPORTED;
@@ -1189,13 +1393,20 @@ extern "C" int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_pa
     a.zparity = 1;
     a.w_zstride = 4 * a.cout_pad * a.cin_pad;
     a.vec_out = ((out_pitch & 3) == 0 && cn_aligned16(y_nhwc)) ? 1 : 0;
+    a.in_plain = (flags & CN_CONV_X_PLAIN) ? 1 : 0;
+    a.out_plain = (flags & CN_CONV_Y_PLAIN) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     // LDS-halo form (cn_conv3x3.hip) unless disabled (cn_set_tuning key 10) or the tile would be
     // mostly padding (Cout <= 32)
     if (!g_tune_nohalo && Cout > 32 && a.vec_out && (in_pitch & 3) == 0)
         return cn_deconv4x4s2_halo(x_nhwc, w_packed, scale, shift, y_nhwc, B, H, W, Cin, Cout,
                                    in_pitch, out_pitch, relu, a.vec_out,
-                                   g_tune_setprio | (g_tune_occ4 << 7), st);
+                                   g_tune_setprio | (g_tune_occ4 << 7), dtype | (flags << 8), st);
+    if (f32s) {
+        if (Cout > 64) return launch_igemm_s<128, 128, 2, 2, A_DENSE, false>(a, st);
+        if (Cout > 32) return launch_igemm_s<128, 64, 2, 2, A_DENSE, false>(a, st);
+        return launch_igemm_s<128, 32, 4, 1, A_DENSE, false>(a, st);
+    }
     if (Cout > 64) return launch_igemm<128, 128, 2, 2, A_DENSE, false>(a, st);
     if (Cout > 32) return launch_igemm<128, 64, 2, 2, A_DENSE, false>(a, st);
     return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);

@@ -203,9 +203,12 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     cn_f32x4 ra[NPA], rb[PB];
     auto load_A = [&](int chunk) {
         const int c = chunk * BKE + EPV * q;
+        // f32s input: a 128-byte group holds 32 channels as high / low halves, so a 16-byte slot
+        // is not "4 channels": the whole group is taken (channels past Cin are stored as zeros)
+        const bool cok = (SPLIT && !a.in_plain) ? (chunk * BKE < a.Cin) : (c < a.Cin);
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {
-            const bool ok = hoff[p] >= 0 && c < a.Cin;
+            const bool ok = hoff[p] >= 0 && cok;
             const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
                 xT + (ok ? ((size_t)hoff[p] * a.in_pitch + c) : 0));
             ra[p] = ok ? v : zero4;
@@ -276,6 +279,10 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                 for (int j = 0; j < NB; ++j)
                     bf[kk][j] = *reinterpret_cast<const c3_f16x8 *>(Bb + j * 32 * LDT + kk * 8);
             }
+            // every fragment read is issued before the first MFMA and stays there (cn_conv.hip:
+            // a ds_read sunk behind an MFMA into that MFMA's operand registers can overwrite them
+            // before a queued MFMA has read them)
+            __builtin_amdgcn_sched_barrier(0);
             // smallest terms first (lo*hi, hi*lo, then hi*hi); independent accumulators interleaved
 #pragma unroll
             for (int term = 0; term < 3; ++term)
@@ -774,9 +781,9 @@ extern "C" int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin,
 // ConvTranspose2d(kernel 4, stride 2, padding 1) through the LDS-halo kernel: the four output
 // parities are 2x2 convolutions over the 3x3 neighbourhood the halo already holds.
 // w_packed: cn_pack_deconv4x4s2_weight_f32 layout [parity 4][tap 4][cout_pad][cin_pad].
-int cn_deconv4x4s2_halo(const float *x, const float *w_packed, const float *scale, const float *shift,
-                        float *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
-                        int relu, int vec_out, int setprio, hipStream_t st)
+int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale, const float *shift,
+                        void *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
+                        int relu, int vec_out, int setprio, int dtype_flags, hipStream_t st)
 {
     C3Args a = {};
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = nullptr; a.y = y;
@@ -786,7 +793,17 @@ int cn_deconv4x4s2_halo(const float *x, const float *w_packed, const float *scal
     a.cout_pad = (Cout + 31) / 32 * 32;
     a.nchunk = a.cin_pad / 32;
     a.nkk_last = 4;
+    a.res_pitch = out_pitch;
+    a.in_plain = (dtype_flags >> 8) & CN_CONV_X_PLAIN ? 1 : 0;
+    a.out_plain = (dtype_flags >> 8) & CN_CONV_Y_PLAIN ? 1 : 0;
     const bool wide = W >= 32;
+    if ((dtype_flags & 255) == CN_DTYPE_F32S) {
+        if (Cout > 64)
+            return wide ? launch_c3<cn_f32s, 32, 128, 4, 2, false, 128, false, true>(a, st)
+                        : launch_c3<cn_f32s, 16, 128, 4, 2, false, 128, false, true>(a, st);
+        return wide ? launch_c3<cn_f32s, 32, 64, 2, 2, false, 128, false, true>(a, st)
+                    : launch_c3<cn_f32s, 16, 64, 2, 2, false, 128, false, true>(a, st);
+    }
     if (Cout > 64)
         return wide ? launch_c3<float, 32, 128, 4, 2, false, 128, false, true>(a, st)
                     : launch_c3<float, 16, 128, 4, 2, false, 128, false, true>(a, st);

@@ -117,7 +117,7 @@ class DCN(DCNv2):
         pb = PlanBuilder(input.device, B, H, W)
         if self._tuned(C):
             x_nhwc = input.permute(0, 2, 3, 1).contiguous()
-            y = pb.dcn(Act(x_nhwc, B, H, W, C), self)
+            y = pb.dcn(Act(x_nhwc, B, H, W, C), self, out_plain=True)
             for op in pb.ops:
                 op()
             return y.t.permute(0, 3, 1, 2).contiguous()

@@ -19,7 +19,8 @@ import os
 import torch
 
 from . import native
-from .native import ConvDesc, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTYPE_F32
+from .native import (ConvDesc, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTYPE_F32, DTYPE_F32S,
+                     CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN)
 
 
 def _out_size(n, k, s, p, d=1):
@@ -27,18 +28,45 @@ def _out_size(n, k, s, p, d=1):
 
 
 class Act:
-    """An activation: NHWC fp32 tensor ``t`` of shape (B,H,W,pitch) using channels
-    [c_off, c_off + C).  For NCHW tensors (network input, head outputs) ``nchw`` is set."""
-    __slots__ = ("t", "B", "H", "W", "C", "pitch", "c_off", "nchw")
+    """An activation: NHWC tensor ``t`` of shape (B,H,W,pitch) using channels
+    [c_off, c_off + C).  For NCHW tensors (network input, head outputs) ``nchw`` is set.
+    ``fmt``: "f32" plain floats, "f16" halves, or "f32s" -- fp32 values stored as fp16
+    (high, low) pairs in 128-byte groups of 32 channels (same bytes and pitch as fp32; the
+    tensor is typed float32 but opaque to torch), see csrc/cn_common.h."""
+    __slots__ = ("t", "B", "H", "W", "C", "pitch", "c_off", "nchw", "fmt")
 
-    def __init__(self, t, B, H, W, C, pitch=None, c_off=0, nchw=False):
+    def __init__(self, t, B, H, W, C, pitch=None, c_off=0, nchw=False, fmt="f32"):
         self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
         self.pitch = C if pitch is None else pitch
         self.c_off = c_off
         self.nchw = nchw
+        self.fmt = fmt
 
     def ptr(self):
         return ctypes.c_void_p(self.t.data_ptr() + self.t.element_size() * self.c_off)
+
+    def to_float(self):
+        """The activation's values as a plain (B, H, W, C) fp32 tensor (host-side decoding with
+        torch ops: for tests and debugging, not on the hot path)."""
+        t = self.t
+        if self.nchw:
+            return t.permute(0, 2, 3, 1).float()
+        if self.fmt == "f32s":
+            h = t.view(torch.float16).reshape(self.B, self.H, self.W, self.pitch // 32, 2, 32)
+            t = (h[..., 0, :].float() + h[..., 1, :].float()).reshape(self.B, self.H, self.W,
+                                                                      self.pitch)
+        return t[..., self.c_off:self.c_off + self.C].float()
+
+
+def prescale_rows(w):
+    """f32s weights: a per-output-channel power of two brings max|w| of every row into [0.5, 1)
+    so that the fp16 low parts stay normal numbers; exact, and undone by the returned factors in
+    the epilogue scale.  Returns (scaled weight, factor per row)."""
+    w = w.detach().float()
+    m = w.abs().flatten(1).amax(dim=1).clamp_min(1e-30)
+    e = torch.frexp(m)[1]                                   # m = mantissa * 2^e
+    shape = (-1,) + (1,) * (w.dim() - 1)
+    return torch.ldexp(w, (-e).view(shape).expand_as(w)), torch.ldexp(torch.ones_like(m), e)
 
 
 def fold_bn(conv_bias, bn, cout, device):
@@ -65,9 +93,15 @@ def fold_bn(conv_bias, bn, cout, device):
 class PlanBuilder:
     """Records launches for one (B, H, W) input shape."""
 
-    def __init__(self, device, B, H, W, dtype=torch.float32, wcache=None):
+    def __init__(self, device, B, H, W, dtype=torch.float32, wcache=None, split=None):
         assert dtype in (torch.float32, torch.float16)
         self.device = device
+        # fp32 networks compute in f32s (three fp16 MFMAs per product, fp32-level accuracy, 5.3x
+        # the matrix rate of v_mfma_f32_32x32x2_f32) unless split=False / CN_F32S=0 asks for the
+        # plain fp32 matrix instruction
+        if split is None:
+            split = os.environ.get("CN_F32S", "1") != "0"
+        self.split = bool(split) and dtype == torch.float32
         # packed weights shared by every plan of one module (keyed by source storage, packing
         # and dtype): a new input shape re-uses them instead of re-packing the whole network
         self.wcache = wcache if wcache is not None else {}
@@ -86,38 +120,91 @@ class PlanBuilder:
         self.ws_bytes = 0
 
     # ---- helpers -------------------------------------------------------------
-    def _new(self, B, H, W, C, pitch=None):
+    def _new(self, B, H, W, C, pitch=None, fmt=None):
+        if fmt is None:
+            fmt = "f16" if self.dtype == torch.float16 else "f32"
         pitch = C if pitch is None else pitch
-        t = torch.empty((B, H, W, pitch), device=self.device, dtype=self.dtype)
-        return Act(t, B, H, W, C, pitch)
+        if fmt == "f32s":
+            pitch = (pitch + 31) // 32 * 32
+            # zero-filled once: the pad channels of the last group are read as K by the next layer
+            t = torch.zeros((B, H, W, pitch), device=self.device, dtype=torch.float32)
+        else:
+            t = torch.empty((B, H, W, pitch), device=self.device, dtype=self.dtype)
+        return Act(t, B, H, W, C, pitch, fmt=fmt)
+
+    def plain(self, x):
+        """``x`` as a plain fp32 activation (a converter launch when it is f32s)."""
+        if x is None or x.fmt != "f32s":
+            return x
+        assert x.c_off % 32 == 0      # a slice starts on a 32-channel group
+        out = self._new(x.B, x.H, x.W, x.C, fmt="f32")
+        lib, npix = self.lib, x.B * x.H * x.W
+
+        def run():
+            rc = lib.cn_f32s_to_f32(x.ptr(), out.ptr(), npix, x.C, x.pitch, out.pitch,
+                                    native.stream_ptr())
+            if rc:
+                native.check(rc, "cn_f32s_to_f32")
+        self._emit_simple(run, "convert", out, 8 * npix * x.C)
+        return out
+
+    def packed(self, x):
+        """``x`` as an f32s activation (a converter launch when it is plain fp32)."""
+        if x is None or x.fmt == "f32s":
+            return x
+        assert x.fmt == "f32" and not x.nchw
+        out = self._new(x.B, x.H, x.W, x.C, fmt="f32s")
+        lib, npix = self.lib, x.B * x.H * x.W
+        src = Act(x.t, x.B, x.H, x.W, x.C, x.pitch, x.c_off)
+
+        def run():
+            rc = lib.cn_f32_to_f32s(src.ptr(), out.ptr(), npix, x.C, x.pitch, out.pitch,
+                                    native.stream_ptr())
+            if rc:
+                native.check(rc, "cn_f32_to_f32s")
+        self._emit_simple(run, "convert", out, 8 * npix * x.C)
+        return out
 
     def _wkey(self, kind, sources):
         return (kind, self.cdtype, str(self.device)) + tuple(
             (t.data_ptr(), tuple(t.shape)) for t in sources)
 
-    def _pack(self, w_oihw, sources=None):
+    def _pack(self, w_oihw, sources=None, f32s=False):
         """Packed copy of a (Cout,Cin,KH,KW) weight.  ``sources``: the parameter tensors the
         weight was assembled from (defaults to the weight itself) -- the cache key.  The pack
         kernel runs on the current stream, which also orders the temporary's release: no
-        host synchronisation."""
+        host synchronisation.  ``f32s``: high/low fp16 form of the row-prescaled weight; returns
+        (packed, per-row factor to fold into the epilogue scale)."""
         if sources is None:
             sources = [w_oihw]
         # only module parameters have storage that outlives the plan: temporaries are not cached
         cacheable = all(isinstance(t, torch.nn.Parameter) for t in sources)
-        key = self._wkey("conv", sources) if cacheable else None
-        wp = self.wcache.get(key) if cacheable else None
-        if wp is None:
+        key = self._wkey("conv_f32s" if f32s else "conv", sources) if cacheable else None
+        hit = self.wcache.get(key) if cacheable else None
+        if hit is None:
             w = w_oihw.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            factor = None
+            if f32s:
+                w, factor = prescale_rows(w)
+                w = w.contiguous()
+            cd = DTYPE_F32S if f32s else self.cdtype
             co, ci, kh, kw = w.shape
-            n = self.lib.cn_packed_conv_weight_elems(co, ci, kh, kw, self.cdtype)
-            wp = torch.empty(n, device=self.device, dtype=self.dtype)
+            n = self.lib.cn_packed_conv_weight_elems(co, ci, kh, kw, cd)
+            wp = torch.empty(n, device=self.device, dtype=torch.float32 if f32s else self.dtype)
             native.check(self.lib.cn_pack_conv_weight(native.ptr(w), native.ptr(wp), co, ci, kh,
-                                                      kw, self.cdtype, native.stream_ptr()),
+                                                      kw, cd, native.stream_ptr()),
                          "cn_pack_conv_weight")
+            hit = (wp, factor)
             if cacheable:
-                self.wcache[key] = wp
-        self.keep.append(wp)
-        return wp
+                self.wcache[key] = hit
+        self.keep += [hit[0], hit[1]]
+        return hit if f32s else hit[0]
+
+    @staticmethod
+    def _f32s_conv_form(kh, kw, stride, padding, dilation, out_nchw):
+        """Convolution forms that have an f32s kernel: every NHWC-input form (the 3-channel stem
+        reads the fp32 image on the fp32 kernels)."""
+        return True
 
     def _grow_ws(self, need):
         # split-K scratch shared by every launch (stream-ordered; ops read self.ws at run time)
@@ -132,27 +219,53 @@ class PlanBuilder:
 
     # ---- ops -------------------------------------------------------------------
     def conv(self, x, weight, bias=None, bn=None, relu=False, residual=None, stride=1,
-             padding=0, dilation=1, out_nchw=False, out=None, wsources=None):
-        """conv2d (+bias) (+BN eval) (+residual) (+ReLU) as one implicit-GEMM launch."""
+             padding=0, dilation=1, out_nchw=False, out=None, wsources=None, out_plain=False):
+        """conv2d (+bias) (+BN eval) (+residual) (+ReLU) as one implicit-GEMM launch.
+        ``out_plain``: in an f32s plan, write the result as plain fp32 (for consumers that read
+        floats, e.g. the offset maps of the deformable kernel)."""
         co, ci, kh, kw = weight.shape
         assert ci == x.C, (ci, x.C)
         Ho = _out_size(x.H, kh, stride, padding, dilation)
         Wo = _out_size(x.W, kw, stride, padding, dilation)
-        wp = self._pack(weight, wsources)
+        use_s = self.split and not x.nchw and self._f32s_conv_form(kh, kw, stride, padding,
+                                                                  dilation, out_nchw)
         scale, shift = fold_bn(bias, bn, co, self.device)
+        flags = 0
+        if use_s:
+            wp, factor = self._pack(weight, wsources, f32s=True)
+            scale = factor if scale is None else scale * factor     # undo the row prescale
+            scale = scale.contiguous()
+            if x.fmt == "f32":
+                flags |= CONV_X_PLAIN
+            if residual is not None and residual.fmt == "f32":
+                flags |= CONV_R_PLAIN
+            cd = DTYPE_F32S
+        else:
+            x, residual = self.plain(x), self.plain(residual)
+            wp = self._pack(weight, wsources)
+            cd = self.cdtype
         self.keep += [scale, shift]
         if out is None:
             if out_nchw:
                 t = torch.empty((x.B, co, Ho, Wo), device=self.device, dtype=torch.float32)
                 out = Act(t, x.B, Ho, Wo, co, nchw=True)
             else:
-                out = self._new(x.B, Ho, Wo, co)
+                out = self._new(x.B, Ho, Wo, co,
+                                fmt="f32s" if (use_s and not out_plain) else None)
+        if use_s and out.fmt != "f32s":
+            flags |= CONV_Y_PLAIN
+        assert use_s or out.fmt != "f32s"
+        if residual is not None and residual.pitch != out.pitch:
+            assert use_s            # e.g. a plain 40-channel residual next to a pitch-64 f32s output
+            residual = self.packed(residual)
+            flags &= ~CONV_R_PLAIN
+            assert residual.pitch == out.pitch
         d = ConvDesc(B=x.B, H=x.H, W=x.W, Cin=ci, Ho=Ho, Wo=Wo, Cout=co, KH=kh, KW=kw,
                      stride=stride, pad_h=padding, pad_w=padding, dil=dilation,
                      in_layout=LAYOUT_NCHW if x.nchw else LAYOUT_NHWC, in_pitch=x.pitch,
                      out_layout=LAYOUT_NCHW if out.nchw else LAYOUT_NHWC, out_pitch=out.pitch,
                      OH=Ho, OW=Wo, oy_mul=1, oy_add=0, ox_mul=1, ox_add=0, relu=int(relu),
-                     dtype=self.cdtype)
+                     dtype=cd, flags=flags)
         fl = 2 * x.B * Ho * Wo * co * ci * kh * kw
         by = 4 * (x.B * x.H * x.W * ci + x.B * Ho * Wo * co * (2 if residual is not None else 1)
                   + co * ci * kh * kw)
@@ -181,36 +294,53 @@ class PlanBuilder:
         self.meta.append(meta)
         self.trace.append((meta["kind"], out))
 
-    def conv_transpose4x4s2(self, x, weight, bn=None, relu=False):
+    def conv_transpose4x4s2(self, x, weight, bn=None, relu=False, out_plain=False):
         """ConvTranspose2d(k=4, s=2, p=1, bias=False) [+BN+ReLU]: the four output-parity
         2x2 convolutions in one launch (reference: resnet_dcn.py:228-235)."""
         ci, co, kh, kw = weight.shape
         assert (kh, kw) == (4, 4) and ci == x.C
         assert self.dtype == torch.float32, "ConvTranspose is built for fp32 only"
-        out = self._new(x.B, 2 * x.H, 2 * x.W, co)
-        scale, shift = fold_bn(None, bn, co, self.device)
         lib = self.lib
+        use_s = self.split
+        scale, shift = fold_bn(None, bn, co, self.device)
         cacheable = isinstance(weight, torch.nn.Parameter)
-        key = self._wkey("deconv4x4s2", [weight])
-        wp = self.wcache.get(key) if cacheable else None
-        if wp is None:
-            w = weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        key = self._wkey("deconv4x4s2_f32s" if use_s else "deconv4x4s2", [weight])
+        hit = self.wcache.get(key) if cacheable else None
+        if hit is None:
+            w = weight.detach().to(device=self.device, dtype=torch.float32)
+            factor = None
+            if use_s:   # prescale per OUTPUT channel (dim 1 of torch's (Cin, Cout, 4, 4) layout)
+                wt, factor = prescale_rows(w.transpose(0, 1).contiguous())
+                w = wt.transpose(0, 1)
+            w = w.contiguous()
             wp = torch.empty(lib.cn_packed_deconv4x4s2_weight_floats(ci, co), device=self.device,
                              dtype=torch.float32)
-            native.check(lib.cn_pack_deconv4x4s2_weight_f32(native.ptr(w), native.ptr(wp), ci, co,
-                                                            native.stream_ptr()),
-                         "cn_pack_deconv4x4s2_weight_f32")
+            native.check(lib.cn_pack_deconv4x4s2_weight(native.ptr(w), native.ptr(wp), ci, co,
+                                                        DTYPE_F32S if use_s else DTYPE_F32,
+                                                        native.stream_ptr()),
+                         "cn_pack_deconv4x4s2_weight")
+            hit = (wp, factor)
             if cacheable:
-                self.wcache[key] = wp
-        self.keep += [scale, shift, wp]
+                self.wcache[key] = hit
+        wp, factor = hit
+        flags = 0
+        if use_s:
+            scale = (factor if scale is None else scale * factor).contiguous()
+            if x.fmt == "f32":
+                flags |= CONV_X_PLAIN
+            if out_plain:
+                flags |= CONV_Y_PLAIN
+        out = self._new(x.B, 2 * x.H, 2 * x.W, co, fmt="f32s" if (use_s and not out_plain) else None)
+        self.keep += [scale, shift, wp, factor]
         sp, hp, wpp = native.ptr(scale), native.ptr(shift), native.ptr(wp)
+        cd = DTYPE_F32S if use_s else DTYPE_F32
 
         def run():
-            rc = lib.cn_conv_transpose4x4s2_f32(x.ptr(), wpp, sp, hp, out.ptr(), x.B, x.H, x.W, ci,
-                                                co, x.pitch, out.pitch, int(relu),
-                                                native.stream_ptr())
+            rc = lib.cn_conv_transpose4x4s2(x.ptr(), wpp, sp, hp, out.ptr(), x.B, x.H, x.W, ci, co,
+                                            x.pitch, out.pitch, int(relu), cd, flags,
+                                            native.stream_ptr())
             if rc:
-                native.check(rc, "cn_conv_transpose4x4s2_f32")
+                native.check(rc, "cn_conv_transpose4x4s2")
         self.ops.append(run)
         fl = 2 * x.B * (2 * x.H) * (2 * x.W) * co * ci * 4
         by = 4 * (x.B * x.H * x.W * (ci + 4 * co) + co * ci * 16)
@@ -221,6 +351,7 @@ class PlanBuilder:
 
     def maxpool(self, x, k, s, pad):
         assert self.dtype == torch.float32, "max-pool is built for fp32 only"
+        x = self.plain(x)
         Ho, Wo = _out_size(x.H, k, s, pad), _out_size(x.W, k, s, pad)
         out = self._new(x.B, Ho, Wo, x.C)
         lib = self.lib
@@ -245,6 +376,7 @@ class PlanBuilder:
     def concat(self, acts):
         """torch.cat(acts, 1) (Root.forward, pose_dla_dcn.py:159): channel-slice copies into
         one NHWC buffer."""
+        acts = [self.plain(a) for a in acts]
         a0 = acts[0]
         C = sum(a.C for a in acts)
         out = self._new(a0.B, a0.H, a0.W, C)
@@ -267,6 +399,7 @@ class PlanBuilder:
     def dw_deconv(self, x, weight, f, add=None):
         """Depthwise ConvTranspose2d(C, C, 2f, stride f, padding f//2, groups=C) + add
         (IDAUp, pose_dla_dcn.py:370-373, 381-386)."""
+        x, add = self.plain(x), self.plain(add)
         C = x.C
         assert tuple(weight.shape) == (C, 1, 2 * f, 2 * f) and x.pitch == C and x.c_off == 0
         wt = weight.detach().to(device=self.device, dtype=torch.float32)
@@ -289,6 +422,7 @@ class PlanBuilder:
 
     def upsample2x_add(self, x, add=None):
         """nn.Upsample(scale_factor=2) (nearest) + skip add (large_hourglass.py:102-109)."""
+        x, add = self.plain(x), self.plain(add)
         assert x.pitch == x.C and x.c_off == 0
         out = self._new(x.B, 2 * x.H, 2 * x.W, x.C)
         lib = self.lib
@@ -303,7 +437,7 @@ class PlanBuilder:
         self._emit_simple(run, "upsample", out, 4 * x.B * x.C * x.H * x.W * (1 + 4 + (4 if add is not None else 0)))
         return out
 
-    def dcn(self, x, dcn_mod, bn=None, relu=False):
+    def dcn(self, x, dcn_mod, bn=None, relu=False, out_plain=False):
         """DCN (DCNv2/dcn_v2.py:44-70) [+ BatchNorm + ReLU]: conv_offset_mask as an
         implicit-GEMM launch writing 27 channels at pitch 32, then the fused deformable
         kernel (gather + MFMA contraction + bias/BN/ReLU epilogue)."""
@@ -312,27 +446,37 @@ class PlanBuilder:
             "only the 3x3/s1/p1/d1/dg1 DCN that CenterNet instantiates is supported"
         assert self.dtype == torch.float32, "the deformable kernel is fp32 only"
         com = dcn_mod.conv_offset_mask
-        om = self._new(x.B, x.H, x.W, 27, pitch=32)
+        om = self._new(x.B, x.H, x.W, 27, pitch=32)        # plain fp32: read as floats below
+        x = self.plain(x)
         self.conv(x, com.weight, bias=com.bias, stride=1, padding=1, out=om)
         co, ci = dcn_mod.weight.shape[0], dcn_mod.weight.shape[1]
-        wp = self._pack(dcn_mod.weight)
+        use_s = self.split
         bias = dcn_mod.bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
         scale, shift = fold_bn(None, bn, co, self.device)
+        if use_s:
+            wp, factor = self._pack(dcn_mod.weight, f32s=True)
+            bias = (bias / factor).contiguous()          # (acc' + bias') * (scale * factor)
+            scale = (factor if scale is None else scale * factor).contiguous()
+        else:
+            wp = self._pack(dcn_mod.weight)
         self.keep += [bias, scale, shift]
-        out = self._new(x.B, x.H, x.W, co)
+        out = self._new(x.B, x.H, x.W, co, fmt="f32s" if (use_s and not out_plain) else None)
         lib = self.lib
-        assert x.pitch == x.C and x.c_off == 0
+        assert x.pitch == x.C and x.c_off == 0 and x.fmt == "f32"
         bp, sp, hp, wpp = native.ptr(bias), native.ptr(scale), native.ptr(shift), native.ptr(wp)
+        cd = DTYPE_F32S if use_s else DTYPE_F32
+        flags = CONV_Y_PLAIN if (use_s and out_plain) else 0
 
         self._grow_ws(lib.cn_dcn_v2_forward_nhwc_workspace_bytes(x.B, ci, x.H, x.W, co))
 
         def run():
             wsp = ctypes.c_void_p(self.ws.data_ptr()) if self.ws is not None else None
-            rc = lib.cn_dcn_v2_forward_nhwc_f32(x.ptr(), wpp, bp, om.ptr(), om.pitch, sp, hp,
-                                                out.ptr(), x.B, ci, x.H, x.W, co, 1, int(relu),
-                                                wsp, self.ws_bytes, native.stream_ptr())
+            rc = lib.cn_dcn_v2_forward_nhwc(x.ptr(), wpp, bp, om.ptr(), om.pitch, sp, hp,
+                                            out.ptr(), out.pitch, x.B, ci, x.H, x.W, co, 1,
+                                            int(relu), cd, flags, wsp, self.ws_bytes,
+                                            native.stream_ptr())
             if rc:
-                native.check(rc, "cn_dcn_v2_forward_nhwc_f32")
+                native.check(rc, "cn_dcn_v2_forward_nhwc")
         self.ops.append(run)
         fl = 2 * x.B * x.H * x.W * co * ci * 9
         # activations 4*(Cin + 27 + Cout)*HW per image + weights once per launch
@@ -369,7 +513,7 @@ class PlanBuilder:
                 all(c.weight.shape[0] == 64 and c.padding[0] == 1 and c.stride[0] == 1
                     for c in firsts) and
                 all(tuple(pairs[n][1].kernel_size) == (1, 1) for n in names)):
-            return self._heads_fused(x, names, pairs, w, b)
+            return self._heads_fused(self.plain(x), names, pairs, w, b)
         mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2,
                         wsources=[c.weight for c in firsts])
         outs = {}
@@ -377,7 +521,7 @@ class PlanBuilder:
         for n in names:
             first, last = pairs[n]
             hc = first.weight.shape[0]
-            sl = Act(mid.t, mid.B, mid.H, mid.W, hc, pitch=mid.pitch, c_off=off)
+            sl = Act(mid.t, mid.B, mid.H, mid.W, hc, pitch=mid.pitch, c_off=off, fmt=mid.fmt)
             outs[n] = self.conv(sl, last.weight, bias=last.bias, stride=1,
                                 padding=last.kernel_size[0] // 2, out_nchw=True)
             off += hc
@@ -504,6 +648,14 @@ class PlannedModule(torch.nn.Module):
         raise NotImplementedError
 
     compute_dtype = torch.float32   # set to torch.float16 with .half_compute() (hourglass)
+    f32s = None                     # None: default (on unless CN_F32S=0); see .fp32_mfma()
+
+    def fp32_mfma(self, enable=True):
+        """Compute on the plain fp32 matrix instruction (v_mfma_f32_32x32x2_f32, the round-1
+        kernels) instead of f32s (three fp16 MFMAs per product): the A/B reference mode."""
+        self.f32s = (not enable) if enable is not None else None
+        self.invalidate_plans()
+        return self
 
     def half_compute(self, enable=True):
         """fp16 activations/weights with fp32 accumulation (BASELINE configs[4]); parameters
@@ -519,13 +671,13 @@ class PlannedModule(torch.nn.Module):
         ``max_plans`` shapes -- --keep_res / multi-scale evaluation sees many (H, W) -- while the
         packed weights live in one per-module cache shared by all of them."""
         cache = self.__dict__.setdefault("_plans", {})
-        key = (B, H, W, str(device), self.compute_dtype)
+        key = (B, H, W, str(device), self.compute_dtype, self.f32s)
         plan = cache.pop(key, None)
         if plan is None:
             native.lib()  # raises if the HIP library is missing
             with torch.no_grad():
                 pb = PlanBuilder(device, B, H, W, dtype=self.compute_dtype,
-                                 wcache=self.__dict__.setdefault("_wcache", {}))
+                                 wcache=self.__dict__.setdefault("_wcache", {}), split=self.f32s)
                 x = pb.set_input(3)
                 outs = self.describe(pb, x)
             plan = Plan(pb, outs)

@@ -21,7 +21,7 @@ LAYOUT_NHWC = 1
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 DTYPE_F32S = 2        # fp32 values as fp16 (high, low) pairs: three fp16 MFMAs per product
-CONV_X_PLAIN, CONV_Y_PLAIN = 1, 2
+CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN = 1, 2, 4
 
 _lib = None
 
@@ -76,6 +76,12 @@ def _declare(lib):
     lib.cn_f32_to_f32s.argtypes = [vp, vp, sz, i, i, i, vp]
     lib.cn_f32s_to_f32.restype = i
     lib.cn_f32s_to_f32.argtypes = [vp, vp, sz, i, i, i, vp]
+    lib.cn_dcn_v2_forward_nhwc.restype = i
+    lib.cn_dcn_v2_forward_nhwc.argtypes = [vp, vp, vp, vp, i, vp, vp, vp] + [i] * 10 + [vp, sz, vp]
+    lib.cn_pack_deconv4x4s2_weight.restype = i
+    lib.cn_pack_deconv4x4s2_weight.argtypes = [vp, vp, i, i, i, vp]
+    lib.cn_conv_transpose4x4s2.restype = i
+    lib.cn_conv_transpose4x4s2.argtypes = [vp, vp, vp, vp, vp] + [i] * 10 + [vp]
     lib.cn_packed_conv_weight_floats.restype = sz
     lib.cn_packed_conv_weight_floats.argtypes = [i] * 4
     lib.cn_pack_conv_weight_f32.restype = i

@@ -117,7 +117,9 @@ class PoseResNet(PlannedModule):
                 x = pb.dcn(x, m, bn=mods[i + 1], relu=True)
                 i += 3
             elif isinstance(m, nn.ConvTranspose2d):
-                x = pb.conv_transpose4x4s2(x, m.weight, bn=mods[i + 1], relu=True)
+                # a deformable layer gathers plain floats: its producer writes them directly
+                to_dcn = i + 3 < len(mods) and isinstance(mods[i + 3], DCN)
+                x = pb.conv_transpose4x4s2(x, m.weight, bn=mods[i + 1], relu=True, out_plain=to_dcn)
                 i += 3
             else:
                 raise RuntimeError("unexpected module in deconv_layers: %r" % m)

@@ -149,6 +149,15 @@ int cn_dcn_v2_forward_f32(const float *input, const float *weight, const float *
  * too small workspace the layer runs unsplit (same result up to fp32 summation order).
  */
 size_t cn_dcn_v2_forward_nhwc_workspace_bytes(int B, int Cin, int H, int W, int Cout);
+/* dtype-generic form: the input stays a PLAIN fp32 NHWC tensor in every mode (one 16-byte gather
+ * per bilinear corner); dtype = CN_DTYPE_F32S takes an f32s-packed weight, contracts on the
+ * fp16 matrix instruction (the blended sample is split as it enters the LDS A tile) and writes
+ * y as f32s (pitch % 32 == 0) or, with CN_CONV_Y_PLAIN, as plain fp32. */
+int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weight_packed, const float *bias,
+                           const float *offset_mask_nhwc, int om_pitch, const float *scale,
+                           const float *shift, void *output_nhwc, int out_pitch, int B, int Cin,
+                           int H, int W, int Cout, int mask_sigmoid, int relu, int dtype, int flags,
+                           void *workspace, size_t workspace_bytes, void *stream);
 int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_packed,
                                const float *bias, const float *offset_mask_nhwc,
                                int om_pitch, const float *scale, const float *shift,
@@ -229,6 +238,12 @@ int cn_conv2d(const cn_conv_desc *desc, const void *x, const void *w_packed, con
  * x (B,H,W,in_pitch) NHWC -> y (B,2H,2W,out_pitch) NHWC.
  * ------------------------------------------------------------------------ */
 size_t cn_packed_deconv4x4s2_weight_floats(int Cin, int Cout);
+/* dtype-generic forms (CN_DTYPE_F32 / CN_DTYPE_F32S; `flags`: CN_CONV_X_PLAIN / CN_CONV_Y_PLAIN) */
+int cn_pack_deconv4x4s2_weight(const float *w_iohw, void *w_packed, int Cin, int Cout, int dtype,
+                               void *stream);
+int cn_conv_transpose4x4s2(const void *x_nhwc, const void *w_packed, const float *scale,
+                           const float *shift, void *y_nhwc, int B, int H, int W, int Cin, int Cout,
+                           int in_pitch, int out_pitch, int relu, int dtype, int flags, void *stream);
 int cn_pack_deconv4x4s2_weight_f32(const float *w_iohw, float *w_packed, int Cin, int Cout,
                                    void *stream);
 int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_packed, const float *scale,

@@ -61,8 +61,9 @@ def _bn(C, seed):
     (3, 16, 9, 256, 9, 3, 2, 1, True, False, True, False),      # one N block, stride 2
     (5, 16, 130, 128, 16, 3, 1, 1, False, True, True, False),   # 650 tiles > 512 workgroups
 ])
-def test_conv_bn_relu_residual(dev, cfg):
-    _conv_case(dev, cfg)
+@pytest.mark.parametrize("split", [True, False], ids=["f32s", "fp32mfma"])
+def test_conv_bn_relu_residual(dev, cfg, split):
+    _conv_case(dev, cfg, split)
 
 
 def test_conv_256_pixel_tiles(dev):
@@ -103,7 +104,9 @@ def test_conv_8_wave_tiles(dev):
         lib.cn_set_tuning(15, 1)
 
 
-def _conv_case(dev, cfg):
+def _conv_case(dev, cfg, split=False):
+    """``split``: f32s (three fp16 MFMAs per product) or the plain fp32 matrix instruction;
+    the knob tests below exercise the fp32-MFMA tile variants."""
     from centernet_amd.engine import PlanBuilder
     B, Cin, H, W, Cout, k, s, p, use_bias, use_bn, relu, use_res = cfg
     x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1))
@@ -119,11 +122,23 @@ def _conv_case(dev, cfg):
         ref = ref + res
     if relu:
         ref = F.relu(ref)
-    pb = PlanBuilder(dev, B, H, W)
+    pb = PlanBuilder(dev, B, H, W, split=split)
     y = pb.conv(_nhwc_act(x, dev), w, bias=bias, bn=bn, relu=relu,
                 residual=_nhwc_act(res, dev) if use_res else None, stride=s, padding=p)
+    assert y.fmt == ("f32s" if split else "f32")
+    y = pb.plain(y)
     _run(pb)
-    _check(y.t.permute(0, 3, 1, 2).cpu(), ref.detach())
+    _check(y.t[..., :Cout].permute(0, 3, 1, 2).cpu(), ref.detach())
+    if split:
+        # f32s activations in, f32s residual, plain out: the other format combinations
+        pb = PlanBuilder(dev, B, H, W, split=True)
+        xs = pb.packed(_nhwc_act(x, dev))
+        rs = pb.packed(_nhwc_act(res, dev)) if use_res else None
+        y = pb.conv(xs, w, bias=bias, bn=bn, relu=relu, residual=rs, stride=s, padding=p,
+                    out_plain=True)
+        assert y.fmt == "f32"
+        _run(pb)
+        _check(y.t[..., :Cout].permute(0, 3, 1, 2).cpu(), ref.detach())
 
 
 def test_stem_conv_nchw_input(dev):
@@ -180,30 +195,37 @@ def test_stem_kernels_vs_torch(dev, cfg):
         lib.cn_set_tuning(12, 1)
 
 
+@pytest.mark.parametrize("split", [True, False], ids=["f32s", "fp32mfma"])
 @pytest.mark.parametrize("halo", [True, False])
 @pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 64), (1, 256, 16, 16, 256), (1, 128, 9, 7, 64),
                                  (2, 128, 37, 45, 96), (1, 64, 8, 40, 24)])
-def test_conv_transpose_4x4_s2(dev, cfg, halo):
+def test_conv_transpose_4x4_s2(dev, cfg, halo, split):
     """Both forms: LDS-halo parity kernel (default) and the generic implicit GEMM (key 10)."""
     from centernet_amd import native
     native.lib().cn_set_tuning(10, 0 if halo else 1)
     try:
-        _deconv_case(dev, cfg)
+        _deconv_case(dev, cfg, split)
     finally:
         native.lib().cn_set_tuning(10, 0)
 
 
-def _deconv_case(dev, cfg):
+def _deconv_case(dev, cfg, split=False):
     from centernet_amd.engine import PlanBuilder
     B, Cin, H, W, Cout = cfg
     x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1))
     w = torch.from_numpy(synth.normal((Cin, Cout, 4, 4), (2.0 / (Cin * 4)) ** 0.5, 2))
     bn = _bn(Cout, 3)
     ref = F.relu(bn(F.conv_transpose2d(x, w, None, 2, 1, 0))).detach()
-    pb = PlanBuilder(dev, B, H, W)
-    y = pb.conv_transpose4x4s2(_nhwc_act(x, dev), w, bn=bn, relu=True)
+    pb = PlanBuilder(dev, B, H, W, split=split)
+    y = pb.plain(pb.conv_transpose4x4s2(_nhwc_act(x, dev), w, bn=bn, relu=True))
     _run(pb)
-    _check(y.t.permute(0, 3, 1, 2).cpu(), ref)
+    _check(y.t[..., :Cout].permute(0, 3, 1, 2).cpu(), ref)
+    if split:    # f32s input, plain output (the producer of a deformable layer's input)
+        pb = PlanBuilder(dev, B, H, W, split=True)
+        y = pb.conv_transpose4x4s2(pb.packed(_nhwc_act(x, dev)), w, bn=bn, relu=True, out_plain=True)
+        assert y.fmt == "f32"
+        _run(pb)
+        _check(y.t[..., :Cout].permute(0, 3, 1, 2).cpu(), ref)
 
 
 def test_heads_fused_nchw_outputs(dev):
@@ -312,3 +334,33 @@ def test_fused_heads(dev, cfg):
     for name in heads:
         assert outs[name].nchw and tuple(outs[name].t.shape) == tuple(ref[name].shape)
         _check(outs[name].t.cpu(), ref[name])
+
+
+def test_f32s_kernels_are_run_to_run_deterministic(dev):
+    """Repeated launches at the benchmark batch (several workgroups per CU) give bit-identical
+    results.  Guards the operand hazard found in round 2: a fragment read scheduled behind an
+    MFMA into that MFMA's source registers can overwrite them before a queued MFMA reads them
+    (csrc/cn_conv.hip, SPLIT compute)."""
+    from centernet_amd.dcn_v2 import DCN
+    from centernet_amd.engine import PlanBuilder, Act
+    B = 32
+    cases = []
+    x64 = Act(torch.randn((B, 64, 64, 64), device=dev).relu_(), B, 64, 64, 64)
+    pb = PlanBuilder(dev, B, 64, 64, split=True)
+    cases.append((pb, pb.conv(x64, torch.randn((64, 64, 3, 3)) * 0.05, relu=True, stride=1, padding=1)))
+    pb = PlanBuilder(dev, B, 64, 64, split=True)
+    cases.append((pb, pb.conv(x64, torch.randn((128, 64, 3, 3)) * 0.05, relu=True, stride=2, padding=1)))
+    for (C, H, Co) in [(256, 32, 128), (128, 64, 64)]:
+        m = DCN(C, Co, (3, 3), 1, 1)
+        synth.fill_state_dict_(m, 5)
+        pb = PlanBuilder(dev, B, H, H, split=True)
+        xa = Act(torch.randn((B, H, H, C), device=dev).relu_(), B, H, H, C)
+        cases.append((pb, pb.dcn(xa, m, out_plain=True)))
+    for pb, y in cases:
+        first = None
+        for _ in range(12):
+            _run(pb)
+            cur = y.t.clone().view(torch.int32)
+            if first is None:
+                first = cur
+            assert torch.equal(cur, first)

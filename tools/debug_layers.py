@@ -26,7 +26,7 @@ tr = net_oracle.TRACE
 # GPU trace: drop the offset-mask convs (27 channels, pitch 32), and group 4 deconv launches
 gtr = []
 for kind, act in plan.b.trace:
-    if act.C == 27 and act.pitch == 32:
+    if kind == "convert" or (act.C == 27 and act.pitch == 32):
         continue
     if act.nchw:
         continue
@@ -35,7 +35,7 @@ for kind, act in plan.b.trace:
     gtr.append((kind, act))
 print(len(tr), len(gtr))
 for (name, r), (kind, act) in zip(tr, gtr):
-    g = act.t[..., :act.C].permute(0, 3, 1, 2).cpu()
+    g = act.to_float().permute(0, 3, 1, 2).cpu()
     if g.shape != r.shape:
         print("SHAPE", name, kind, tuple(g.shape), tuple(r.shape)); continue
     d = (g - r).abs()
