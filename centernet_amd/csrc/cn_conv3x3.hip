@@ -120,6 +120,7 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     static_assert(!HEADS || NT == 256, "fused heads are built for 4 waves");
     static_assert(!HEADS || BM == 128, "fused heads are built for 128-pixel tiles");
     static_assert(!HEADS || (BN == HEAD_CONV && sizeof(T) == 4), "fused heads: fp32 / f32s, 64 hidden channels");
+    static_assert(LDS2 * 4 >= 2 * 128 + 16, "a hidden row holds two 128-byte f32s groups + the bias column");
     constexpr int EPV = C3Elem<T>::EPV;
     constexpr int BKE = 8 * EPV;
     constexpr bool F16 = (EPV == 8);
@@ -343,8 +344,16 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         for (int idx = tid; idx < rows * (HEAD_CONV / 4); idx += NT) {
             const int row = idx / (HEAD_CONV / 4), k4 = idx - row * (HEAD_CONV / 4);
             const int src = min(row, cout2 - 1);  // padded rows: computed, never stored
-            *reinterpret_cast<cn_f32x4 *>(W2 + row * LDS2 + k4 * 4) =
-                *reinterpret_cast<const cn_f32x4 *>(w2 + (size_t)src * HEAD_CONV + k4 * 4);
+            const cn_f32x4 wv = *reinterpret_cast<const cn_f32x4 *>(w2 + (size_t)src * HEAD_CONV + k4 * 4);
+            if constexpr (SPLIT) {  // rows of two 128-byte groups [32 high | 32 low] (k = 4*k4 ..)
+                cn_f16x4v hi, lo;
+                cn_split4(wv, hi, lo);
+                char *g = reinterpret_cast<char *>(W2 + row * LDS2) + (k4 >> 3) * 128 + (k4 & 7) * 8;
+                *reinterpret_cast<cn_f16x4v *>(g) = hi;
+                *reinterpret_cast<cn_f16x4v *>(g + 64) = lo;
+            } else {
+                *reinterpret_cast<cn_f32x4 *>(W2 + row * LDS2 + k4 * 4) = wv;
+            }
         }
         for (int row = tid; row < rows; row += NT)
             W2[row * LDS2 + HEAD_CONV] = (b2 && row < cout2) ? b2[row] : 0.f;
@@ -404,8 +413,18 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float t = acc[i][j][r] * s1 + b1;
-                        S[row * LDS2 + n + j * 32] = a.relu ? fmaxf(t, 0.f) : t;
+                        float t = acc[i][j][r] * s1 + b1;
+                        t = a.relu ? fmaxf(t, 0.f) : t;
+                        if constexpr (SPLIT) {   // hidden channel nn of the row, as (high, low)
+                            const int nn = n + j * 32;
+                            const float c = fminf(t, 65504.0f);
+                            const _Float16 hi = (_Float16)c;
+                            char *g = reinterpret_cast<char *>(S + row * LDS2) + (nn >> 5) * 128 + (nn & 31) * 2;
+                            *reinterpret_cast<_Float16 *>(g) = hi;
+                            *reinterpret_cast<_Float16 *>(g + 64) = (_Float16)(c - (float)hi);
+                        } else {
+                            S[row * LDS2 + n + j * 32] = t;
+                        }
                     }
         }
         const int HWp = a.H * a.W;
@@ -422,8 +441,16 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                 for (int idx = tid; idx < rows * (HEAD_CONV / 4); idx += NT) {
                     const int row = idx / (HEAD_CONV / 4), k4 = idx - row * (HEAD_CONV / 4);
                     const int src = min(g0 + row, cout2 - 1);
-                    *reinterpret_cast<cn_f32x4 *>(W2 + row * LDS2 + k4 * 4) =
-                        *reinterpret_cast<const cn_f32x4 *>(w2 + (size_t)src * HEAD_CONV + k4 * 4);
+                    const cn_f32x4 wv = *reinterpret_cast<const cn_f32x4 *>(w2 + (size_t)src * HEAD_CONV + k4 * 4);
+                    if constexpr (SPLIT) {
+                        cn_f16x4v hi, lo;
+                        cn_split4(wv, hi, lo);
+                        char *g = reinterpret_cast<char *>(W2 + row * LDS2) + (k4 >> 3) * 128 + (k4 & 7) * 8;
+                        *reinterpret_cast<cn_f16x4v *>(g) = hi;
+                        *reinterpret_cast<cn_f16x4v *>(g + 64) = lo;
+                    } else {
+                        *reinterpret_cast<cn_f32x4 *>(W2 + row * LDS2 + k4 * 4) = wv;
+                    }
                 }
                 for (int row = tid; row < rows; row += NT)
                     W2[row * LDS2 + HEAD_CONV] = (b2 && g0 + row < cout2) ? b2[g0 + row] : 0.f;
@@ -436,6 +463,35 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[jb][r] = 0.f;
             const float *Wb = W2 + l31 * LDS2 + 4 * lh;
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int g = 0; g < HEAD_CONV / 32; ++g) {
+                    c3_f16x8 sf[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        sf[kk] = *reinterpret_cast<const c3_f16x8 *>(Sa + g * 32 + kk * 8);
+#pragma unroll
+                    for (int jb = 0; jb < W2_ROWS / 32; ++jb) {
+                        if (jb < nblk) {  // uniform
+                            c3_f16x8 wf[4];
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk)
+                                wf[kk] = *reinterpret_cast<const c3_f16x8 *>(Wb + jb * 32 * LDS2 + g * 32 + kk * 8);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                                for (int s2 = 0; s2 < 2; ++s2) {
+                                    const int kw = (term == 0) ? 2 + s2 : s2;   // weight part
+                                    const int ks = (term == 1) ? 2 + s2 : s2;   // activation part
+                                    acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kw], sf[ks],
+                                                                                      acc2[jb], 0, 0, 0);
+                                }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int kk = 0; kk < HEAD_CONV / 8; ++kk) {
                 const cn_f32x4 af = *reinterpret_cast<const cn_f32x4 *>(Sa + kk * 8);
@@ -754,11 +810,26 @@ extern "C" int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin,
                                    const float *w1_packed, const float *bias1, int head_conv,
                                    int n_heads, const cn_head_out *heads, void *stream)
 {
+    return cn_heads3x3_1x1(x, B, H, W, Cin, in_pitch, w1_packed, nullptr, bias1, head_conv, n_heads,
+                           heads, CN_DTYPE_F32, 0, stream);
+}
+
+// dtype-generic form: CN_DTYPE_F32S takes f32s activations (or plain ones with CN_CONV_X_PLAIN)
+// and an f32s-packed 3x3 weight with its per-row prescale factors in `scale1`; the hidden tile
+// and the 1x1 weights are split inside the kernel, outputs stay fp32 NCHW.
+extern "C" int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int in_pitch,
+                               const void *w1_packed, const float *scale1, const float *bias1,
+                               int head_conv, int n_heads, const cn_head_out *heads, int dtype,
+                               int flags, void *stream)
+{
     hipStream_t st = (hipStream_t)stream;
     if (!x || !w1_packed || !heads) return CN_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || n_heads <= 0) return CN_ERR_SHAPE;
     if (head_conv != HEAD_CONV || n_heads > MAX_HEADS) return CN_ERR_UNSUPPORTED;
+    const bool f32s = (dtype == CN_DTYPE_F32S);
+    if (dtype != CN_DTYPE_F32 && !f32s) return CN_ERR_UNSUPPORTED;
     if ((in_pitch & 3) || !cn_aligned16(x) || !cn_aligned16(w1_packed)) return CN_ERR_ALIGN;
+    if (f32s && !(flags & CN_CONV_X_PLAIN) && (in_pitch & 31)) return CN_ERR_UNSUPPORTED;
     C3Heads hd = {};
     for (int h = 0; h < n_heads; ++h) {
         if (!heads[h].w || !heads[h].y) return CN_ERR_NULL;
@@ -768,12 +839,16 @@ extern "C" int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin,
         hd.cout[h] = heads[h].cout;
     }
     C3Args a = {};
-    a.x = x; a.w = w1_packed; a.scale = nullptr; a.shift = bias1; a.residual = nullptr; a.y = nullptr;
+    a.x = x; a.w = w1_packed; a.scale = scale1; a.shift = bias1; a.residual = nullptr; a.y = nullptr;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = n_heads * HEAD_CONV; a.in_pitch = in_pitch;
     a.out_pitch = 0; a.relu = 1; a.vec_out = 0; a.setprio = 1;
+    a.in_plain = (flags & CN_CONV_X_PLAIN) ? 1 : 0;
     a.cin_pad = (Cin + 31) / 32 * 32;
     a.cout_pad = a.Cout;
     a.nchunk = a.cin_pad / 32;
+    if (f32s)
+        return (W >= 32) ? launch_c3<cn_f32s, 32, 64, 2, 2, true>(a, st, &hd)
+                         : launch_c3<cn_f32s, 16, 64, 2, 2, true>(a, st, &hd);
     return (W >= 32) ? launch_c3<float, 32, 64, 2, 2, true>(a, st, &hd)
                      : launch_c3<float, 16, 64, 2, 2, true>(a, st, &hd);
 }

@@ -256,9 +256,15 @@ class PlanBuilder:
             flags |= CONV_Y_PLAIN
         assert use_s or out.fmt != "f32s"
         if residual is not None and residual.pitch != out.pitch:
-            assert use_s            # e.g. a plain 40-channel residual next to a pitch-64 f32s output
-            residual = self.packed(residual)
-            flags &= ~CONV_R_PLAIN
+            # channel counts that are not a multiple of 32: an f32s tensor is padded to whole
+            # groups, a plain one is not -- bring the residual to the output's format
+            assert use_s
+            if out.fmt == "f32s":
+                residual = self.packed(residual)
+                flags &= ~CONV_R_PLAIN
+            else:
+                residual = self.plain(residual)
+                flags |= CONV_R_PLAIN
             assert residual.pitch == out.pitch
         d = ConvDesc(B=x.B, H=x.H, W=x.W, Cin=ci, Ho=Ho, Wo=Wo, Cout=co, KH=kh, KW=kw,
                      stride=stride, pad_h=padding, pad_w=padding, dil=dilation,
@@ -513,7 +519,7 @@ class PlanBuilder:
                 all(c.weight.shape[0] == 64 and c.padding[0] == 1 and c.stride[0] == 1
                     for c in firsts) and
                 all(tuple(pairs[n][1].kernel_size) == (1, 1) for n in names)):
-            return self._heads_fused(self.plain(x), names, pairs, w, b)
+            return self._heads_fused(x, names, pairs, w, b)
         mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2,
                         wsources=[c.weight for c in firsts])
         outs = {}
@@ -533,7 +539,14 @@ class PlanBuilder:
         stay in LDS between its 3x3 and its 1x1 convolution."""
         lib = self.lib
         nh = len(names)
-        wp = self._pack(w1, [pairs[n][0].weight for n in names])
+        use_s = self.split
+        scale1 = None
+        if use_s:
+            wp, scale1 = self._pack(w1, [pairs[n][0].weight for n in names], f32s=True)
+        else:
+            wp = self._pack(w1, [pairs[n][0].weight for n in names])
+        cd = DTYPE_F32S if use_s else DTYPE_F32
+        flags = CONV_X_PLAIN if (use_s and x.fmt == "f32") else 0
         b1 = b1.to(device=self.device, dtype=torch.float32).contiguous()
         arr = (native.HeadOut * nh)()
         outs = {}
@@ -555,15 +568,15 @@ class PlanBuilder:
             arr[i].cout = co
             fl += 2 * x.B * x.H * x.W * co * 64
             by += 4 * (x.B * x.H * x.W * co + co * 64)
-        self.keep += [b1, arr]
-        wpp, b1p = native.ptr(wp), native.ptr(b1)
+        self.keep += [b1, arr, scale1]
+        wpp, b1p, s1p = native.ptr(wp), native.ptr(b1), native.ptr(scale1)
         ci = x.C
 
         def run():
-            rc = lib.cn_heads3x3_1x1_f32(x.ptr(), x.B, x.H, x.W, ci, x.pitch, wpp, b1p, 64, nh,
-                                         arr, native.stream_ptr())
+            rc = lib.cn_heads3x3_1x1(x.ptr(), x.B, x.H, x.W, ci, x.pitch, wpp, s1p, b1p, 64, nh,
+                                     arr, cd, flags, native.stream_ptr())
             if rc:
-                native.check(rc, "cn_heads3x3_1x1_f32")
+                native.check(rc, "cn_heads3x3_1x1")
         self.ops.append(run)
         self.meta.append(dict(kind="conv", flops=fl, bytes=by))
         self.trace.append(("heads", outs[names[0]]))

@@ -82,6 +82,8 @@ def _declare(lib):
     lib.cn_pack_deconv4x4s2_weight.argtypes = [vp, vp, i, i, i, vp]
     lib.cn_conv_transpose4x4s2.restype = i
     lib.cn_conv_transpose4x4s2.argtypes = [vp, vp, vp, vp, vp] + [i] * 10 + [vp]
+    lib.cn_heads3x3_1x1.restype = i
+    lib.cn_heads3x3_1x1.argtypes = [vp, i, i, i, i, i, vp, vp, vp, i, i, vp, i, i, vp]
     lib.cn_packed_conv_weight_floats.restype = sz
     lib.cn_packed_conv_weight_floats.argtypes = [i] * 4
     lib.cn_pack_conv_weight_f32.restype = i

@@ -294,6 +294,12 @@ typedef struct cn_head_out {
 int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin, int in_pitch,
                         const float *w1_packed, const float *bias1, int head_conv, int n_heads,
                         const cn_head_out *heads, void *stream);
+/* dtype-generic form.  CN_DTYPE_F32S: x is an f32s tensor (or plain fp32 with CN_CONV_X_PLAIN),
+ * w1_packed an f32s-packed weight whose per-row prescale factors come in scale1 (NULL = 1);
+ * the hidden tile and the 1x1 weights are split inside the kernel; outputs are fp32 NCHW. */
+int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int in_pitch,
+                    const void *w1_packed, const float *scale1, const float *bias1, int head_conv,
+                    int n_heads, const cn_head_out *heads, int dtype, int flags, void *stream);
 
 /* ------------------------------------------------------------------------
  * Pre-process on the device: BaseDetector.pre_process

@@ -309,8 +309,9 @@ def test_fp16_stem_and_nchw_head(dev):
     (1, 256, 16, 16, {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}),
     (1, 64, 8, 40, {"big": 130, "wh": 2}),                           # > 96 channels: two passes
 ])
-def test_fused_heads(dev, cfg):
-    """cn_heads3x3_1x1_f32 (one launch for all heads, hidden channels kept in LDS) vs the
+@pytest.mark.parametrize("split", [True, False], ids=["f32s", "fp32mfma"])
+def test_fused_heads(dev, cfg, split):
+    """cn_heads3x3_1x1 (one launch for all heads, hidden channels kept in LDS) vs the
     per-head Sequential(conv3x3, ReLU, conv1x1) of resnet_dcn.py:155-177 on torch CPU."""
     from centernet_amd.engine import PlanBuilder
     B, Fc, H, W, heads = cfg
@@ -326,14 +327,19 @@ def test_fused_heads(dev, cfg):
             c2.bias.copy_(torch.from_numpy(synth.normal((classes,), 0.5, 50 + i)))
             ref[name] = c2(F.relu(c1(x)))
         pairs[name] = (c1, c2)
-    pb = PlanBuilder(dev, B, H, W)
-    assert pb.fuse_heads
-    outs = pb.heads_from_convs(_nhwc_act(x, dev), pairs)
-    assert len(pb.ops) == 1, "heads with 64 hidden channels must be a single fused launch"
-    _run(pb)
-    for name in heads:
-        assert outs[name].nchw and tuple(outs[name].t.shape) == tuple(ref[name].shape)
-        _check(outs[name].t.cpu(), ref[name])
+    for packed_in in ((False, True) if split else (False,)):
+        pb = PlanBuilder(dev, B, H, W, split=split)
+        assert pb.fuse_heads
+        xa = _nhwc_act(x, dev)
+        if packed_in:
+            xa = pb.packed(xa)
+        n0 = len(pb.ops)
+        outs = pb.heads_from_convs(xa, pairs)
+        assert len(pb.ops) == n0 + 1, "heads with 64 hidden channels must be a single fused launch"
+        _run(pb)
+        for name in heads:
+            assert outs[name].nchw and tuple(outs[name].t.shape) == tuple(ref[name].shape)
+            _check(outs[name].t.cpu(), ref[name])
 
 
 def test_f32s_kernels_are_run_to_run_deterministic(dev):
