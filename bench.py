@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md)
+# f32s: every fp32 product is three fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate), so the
+# matrix-pipe ceiling in ALGORITHMIC (fp32-equivalent) FLOPs is a third of the fp16 peak
+F32S_MFMA_PEAK_TF = F16_MFMA_PEAK_TF / 3.0
 
 DECODE_LAUNCHES = {"ctdet": 2, "multi_pose": 4}   # kernels per decode call (cn_decode.hip)
 
@@ -85,6 +88,8 @@ def parse(argv=None):
     p.add_argument("--res", type=int, default=512)
     p.add_argument("--fp16", action="store_true", default=None,
                    help="fp16 activations/weights, fp32 accumulate (configs[4], hourglass only)")
+    p.add_argument("--fp32-mfma", action="store_true",
+                   help="compute on v_mfma_f32_32x32x2_f32 (the round-1 kernels) instead of f32s")
     p.add_argument("--tune", action="append", default=[],
                    help="KEY=VALUE for cn_set_tuning (A/B experiments; not used by the driver)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,6 +102,31 @@ def parse(argv=None):
         if getattr(a, k) is None:
             setattr(a, k, v)
     return a
+
+
+def precision_check(dev):
+    """One dense layer (128 -> 128, 3x3, 2 x 64 x 64) on both compute modes against torch fp64:
+    max |error| relative to the output rms.  f32s (three fp16 MFMAs per fp32 product, fp32
+    accumulate) is held to the accuracy of the plain fp32 matrix instruction."""
+    import torch
+    import torch.nn.functional as F
+    from centernet_amd.engine import PlanBuilder, Act
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 128, 64, 64), generator=g).relu_()
+    w = torch.randn((128, 128, 3, 3), generator=g) * (2.0 / (128 * 9)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    rms = float(ref.pow(2).mean().sqrt())
+    out = {}
+    for name, split in (("f32s", True), ("fp32_mfma", False)):
+        pb = PlanBuilder(dev, 2, 64, 64, split=split)
+        y = pb.plain(pb.conv(Act(x.permute(0, 2, 3, 1).contiguous().to(dev), 2, 64, 64, 128), w,
+                             stride=1, padding=1))
+        for op in pb.ops:
+            op()
+        torch.cuda.synchronize()
+        out[name + "_max_err_over_rms"] = float((y.t.double().cpu() - ref).abs().max()) / rms
+    out["reference"] = "torch fp64 conv2d"
+    return out
 
 
 def _time_images(fn, make_input, seconds):
@@ -224,6 +254,8 @@ def main():
     det.model.invalidate_plans()
     if a.fp16:
         det.model.half_compute()
+    if a.fp32_mfma:
+        det.model.fp32_mfma()
     B = a.batch
     images = synth.images(B, a.res, a.res, seed=100 + rank).to(dev)
 
@@ -289,7 +321,7 @@ def main():
         kinds["decode"] = {"ms": dec_ms, "flops": 0, "bytes": dec_bytes * a.steps,
                            "launches": DECODE_LAUNCHES[a.task] * a.steps}
         dom = max(kinds, key=lambda k: kinds[k]["ms"])
-        standard = (a.res == 512 and not a.tune and
+        standard = (a.res == 512 and not a.tune and not a.fp32_mfma and
                     all(getattr(a, k) == v for k, v in CONFIGS[a.config].items()))
         pmc, pmc_file = pmc_traffic("cfg%d" % a.config) if standard else ({}, None)
 
@@ -306,7 +338,8 @@ def main():
             sec = s["ms"] * 1e-3
             if bound == "mfma":
                 ach = s["flops"] / sec / 1e12 if sec > 0 else 0.0
-                peak, unit = (F16_MFMA_PEAK_TF if a.fp16 else F32_MFMA_PEAK_TF), "TFLOP/s"
+                peak = F16_MFMA_PEAK_TF if a.fp16 else (F32_MFMA_PEAK_TF if a.fp32_mfma else F32S_MFMA_PEAK_TF)
+                unit = "TFLOP/s"
             else:
                 ach = s["bytes"] / sec / 1e9 if sec > 0 else 0.0
                 peak, unit = HBM_PEAK_GBS, "GB/s"
@@ -317,11 +350,19 @@ def main():
                     "launches_per_step": s["launches"] // a.steps}
 
         total_imgs = B * a.steps * world
+        if a.fp16:
+            compute_dtype = "f16"
+        elif a.fp32_mfma:
+            compute_dtype = "f32"
+        else:
+            # fp32 tensors and fp32 accumulation; products formed from fp16 (high, low) pairs on
+            # the fp16 matrix instruction -- fp32-level accuracy, see precision_check below
+            compute_dtype = "f32s"
         res = {
             "metric": "images/sec whole-node, 512x512 ctdet", "value": total_imgs / dt,
             "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if a.fp16 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": compute_dtype, "data": "synthetic",
             "config": {"workload": "%s %s %dx%d, batch %d per GPU (BASELINE configs[%d]%s), network "
                                    "+ fused sigmoid/peak-NMS/top-K decode, K=%d"
                                    % (a.task, a.arch, a.res, a.res, B, a.config,
@@ -336,6 +377,7 @@ def main():
             "roofline_dcn_hbm": roof("dcn", "hbm") if "dcn" in kinds else None,
             "roofline_decode_hbm": roof("decode", "hbm"),
             "pmc_profile": pmc_file,
+            "precision_check": precision_check(dev) if not a.fp16 else None,
             "time_share": {k: round(v["ms"] / (dt * 1e3), 4) for k, v in kinds.items()},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -773,6 +773,32 @@ __global__ void pack_weight_f32s_kernel(const float *__restrict__ w, _Float16 *_
         wp[g + 32 + (c & 31)] = (_Float16)(v - (float)hi);
     }
 }
+// Fragment-ordered f32s copy for the register-streamed form of the LDS-halo kernel
+// (cn_conv3x3.hip, NBUFB = 0): [tap][chunk][cout block of 32][lane 64][quarter 4][8 fp16].
+// Lane (l31 = lane & 31, h = lane >> 5) of a 32 x 32 x 16 MFMA holds, for quarter kk, the
+// channels 16 * (kk & 1) + 8 * h .. + 7 of output channel 32 * block + l31 -- high parts for
+// kk < 2, low parts for kk >= 2 -- i.e. exactly what it would ds_read_b128 from the row form.
+__global__ void pack_weight_f32s_frag_kernel(const float *__restrict__ w, _Float16 *__restrict__ wf,
+                                             int Cout, int Cin, int taps, int ncb, int nchunk)
+{
+    const size_t total = (size_t)taps * nchunk * ncb * 64 * 32;   // fp16 elements
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7);
+        const int kk = (int)((i >> 3) & 3);
+        const int lane = (int)((i >> 5) & 63);
+        size_t r = i >> 11;
+        const int nb = (int)(r % ncb); r /= ncb;
+        const int chunk = (int)(r % nchunk);
+        const int t = (int)(r / nchunk);
+        const int n = nb * 32 + (lane & 31);
+        const int c = chunk * 32 + 16 * (kk & 1) + 8 * (lane >> 5) + e;
+        float v = 0.f;
+        if (c < Cin && n < Cout) v = w[((size_t)n * Cin + c) * taps + t];
+        const _Float16 hi = (_Float16)v;
+        wf[i] = (kk < 2) ? hi : (_Float16)(v - (float)hi);
+    }
+}
 // stem: (Cout,3,KH,KW) -> [cout_pad][kpad], k = tap*3 + rgb
 template <typename T>
 __global__ void pack_stem_weight_kernel(const float *__restrict__ w, T *__restrict__ wp,
@@ -807,6 +833,7 @@ int cn_conv3x3_c16(const float *x, const float *w_packed, const float *scale, co
                    float *y, int B, int H, int W, int Ho, int Wo, int Cin, int Cout, int stride,
                    int in_pitch, int out_pitch, int relu, hipStream_t st);
 extern int cn_tune_stagger_pct;  // cn_conv3x3.hip
+extern int cn_tune_f32s_lds_weights;  // cn_conv3x3.hip
 int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale, const float *shift,
                         void *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
                         int relu, int vec_out, int setprio, int dtype_flags, hipStream_t st);
@@ -899,8 +926,10 @@ extern "C" size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW
 
 extern "C" size_t cn_packed_conv_weight_elems(int Cout, int Cin, int KH, int KW, int dtype)
 {
-    // f32s: counted in 4-byte units like fp32 (the stem keeps plain fp32 weights)
-    return packed_elems(Cout, Cin, KH, KW, dtype == CN_DTYPE_F16 ? 64 : 32);
+    // f32s: counted in 4-byte units like fp32 (the stem keeps plain fp32 weights); 3x3 kernels
+    // carry a second, fragment-ordered copy of the same size behind the row-ordered one
+    const size_t n = packed_elems(Cout, Cin, KH, KW, dtype == CN_DTYPE_F16 ? 64 : 32);
+    return (dtype == CN_DTYPE_F32S && KH == 3 && KW == 3 && Cin != 3) ? 2 * n : n;
 }
 
 template <typename T>
@@ -941,6 +970,12 @@ extern "C" int cn_pack_conv_weight(const float *w_oihw, void *w_packed, int Cout
         hipLaunchKernelGGL(pack_weight_f32s_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            w_oihw, (_Float16 *)w_packed, Cout, Cin, taps, cout_pad, cin_pad);
         CN_CHECK_LAUNCH();
+        if (KH == 3 && KW == 3) {
+            hipLaunchKernelGGL(pack_weight_f32s_frag_kernel, dim3(blocks), dim3(256), 0,
+                               (hipStream_t)stream, w_oihw, (_Float16 *)w_packed + 2 * total, Cout, Cin,
+                               taps, cout_pad / 32, cin_pad / 32);
+            CN_CHECK_LAUNCH();
+        }
         return CN_OK;
     }
     if (dtype != CN_DTYPE_F32 && dtype != CN_DTYPE_F32S) return CN_ERR_UNSUPPORTED;
@@ -1414,6 +1449,10 @@ extern "C" int cn_conv_transpose4x4s2(const void *x_nhwc, const void *w_packed, 
 
 extern "C" int cn_set_tuning(int key, int value)
 {
+    if (key == 20 && (value == 0 || value == 1)) {
+        cn_tune_f32s_lds_weights = value;
+        return CN_OK;
+    }
     if (key == 1 && value >= 0 && value <= 2) {
         g_tune_nbuf = value;
         return CN_OK;

@@ -62,6 +62,8 @@ struct C3Args {
     int dbg;                     // ablation switches (cn_set_tuning key 9)
     int stagger, stagger_slots;  // phase shift of co-resident workgroups (cycles per slot, slots)
     int in_plain, out_plain, res_plain;  // f32s kernels: x / y / residual are plain fp32 tensors
+    int ncb;                     // f32s: 32-channel output blocks in the packed weight (cout_pad / 32)
+    size_t wfrag_off;            // f32s: byte offset of the fragment-ordered weight copy behind the row-ordered one
 };
 
 // Fused detection heads (HEADS = true): blockIdx.y selects the head; its 64 hidden channels
@@ -101,7 +103,12 @@ constexpr size_t c3_union_floats()
 // T = cn_f32s: fp32 values as (high, low) fp16 pairs, 32 channels per 128-byte row; every
 // 16-deep K step is three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi), see cn_common.h.
 // NBUFB: LDS buffers of the per-tap weight tile (2: one barrier per tap; 1: two barriers per tap
-// but 9 KB less LDS -- the 4-workgroups-per-CU variant below)
+// but 9 KB less LDS -- the 4-workgroups-per-CU variant below; 0 (f32s only): NO weight tile in
+// LDS -- every wave streams its B fragments straight from the fragment-ordered copy of the packed
+// weight (L1/L2-resident, 4 KB contiguous per 32 output channels x 32 input channels) into a
+// double-buffered register set one tap ahead, so the only barriers left are the two around a
+// halo restage per 32-channel chunk.  With three fp16 MFMAs per product a tap is only ~400
+// cycles of matrix work: the per-tap weight staging + barrier of the LDS form cost more than that.
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
           bool KSKIP = false, bool DECONV = false, int NBUFB = 2>
 __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &hd)
@@ -112,6 +119,8 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     constexpr int NTAPS = DECONV ? 4 : 9;
     constexpr int TAPW = DECONV ? 2 : 3;
     constexpr bool SPLIT = std::is_same<T, cn_f32s>::value;
+    constexpr bool WREG = (NBUFB == 0);
+    static_assert(!WREG || SPLIT, "register-streamed weights are built for f32s");
     static_assert(!DECONV || (!HEADS && !KSKIP && sizeof(T) == 4), "deconv variant: fp32 / f32s");
     static_assert(!SPLIT || !KSKIP, "f32s multiplies the zero-padded channels");
     const int par_y = DECONV ? (int)(blockIdx.z >> 1) : 0, par_x = DECONV ? (int)(blockIdx.z & 1) : 0;
@@ -359,38 +368,125 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
             W2[row * LDS2 + HEAD_CONV] = (b2 && row < cout2) ? b2[row] : 0.f;
     }
 
-    // ---- main loop: chunk-major, taps inner; B double-buffered, A halo single-buffered
-    load_A(0);
-    load_B(0, 0);
-    store_A();
-    store_B(0);
-    __syncthreads();
-    const int total = a.nchunk * NTAPS;
-    int it = 0;
-    for (int c = 0; c < a.nchunk; ++c) {
-#pragma unroll 1
-        for (int t = 0; t < NTAPS; ++t, ++it) {
-            const bool more = (it + 1) < total;
-            const bool newA = (t == NTAPS - 1) && (c + 1 < a.nchunk);
-            if (more && !(a.dbg & 2)) load_B(t == NTAPS - 1 ? c + 1 : c, t == NTAPS - 1 ? 0 : t + 1);
-            if (newA && !(a.dbg & 4)) load_A(c + 1);
-            if constexpr (NBUFB == 1) {
-                compute(t, 0, (KSKIP && c == a.nchunk - 1) ? a.nkk_last : 4);
-                __syncthreads();  // every wave is done with the weight tile (and the old halo)
-                if (newA) store_A();
-                if (more) store_B(0);
-                __syncthreads();
-                continue;
+    if constexpr (WREG) {
+        // ---- register-streamed weights, software-pipelined one tap ahead.  A lane's four
+        // 16-byte quarter fragments of (tap, chunk, 32-channel output block) are 64 contiguous
+        // bytes of the fragment-ordered weight copy.  Both operand sets (A from the LDS halo, B
+        // from global) are double-buffered in registers and the set a load targets was last read
+        // by MFMAs issued a full term earlier -- never by the MFMA just issued (see the operand
+        // hazard note in cn_conv.hip).
+        const char *wf = reinterpret_cast<const char *>(a.w) + (size_t)a.wfrag_off +
+                         (DECONV ? (size_t)blockIdx.z * NTAPS * a.nchunk * a.ncb * 4096 : (size_t)0);
+        int nbk[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) nbk[j] = min((n0 + wn * TN) / 32 + j, a.ncb - 1);
+        c3_f16x8 afr[2][4][MB], bfr[2][4][NB];
+        auto load_Bf = [&](c3_f16x8 (*dst)[NB], int chunk, int tap) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const char *src = wf + ((((size_t)tap * a.nchunk + chunk) * a.ncb + nbk[j]) * 64 + lane) * 64;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    dst[kk][j] = *reinterpret_cast<const c3_f16x8 *>(src + kk * 16);
             }
-            compute(t, it & 1, (KSKIP && c == a.nchunk - 1) ? a.nkk_last : 4);
-            if (newA) {
+        };
+        auto load_Af = [&](c3_f16x8 (*dst)[MB], int tap) {
+            const int ky = tap / TAPW + par_y, kx = tap % TAPW + par_x;
+            const int toff = (ky * HW_ + kx) * LDT;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    dst[kk][i] = *reinterpret_cast<const c3_f16x8 *>(As + abase[i] + toff + kk * 8);
+        };
+        auto mfma_term = [&](int term, const c3_f16x8 (*af)[MB], const c3_f16x8 (*bf)[NB]) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int ka = (term == 0) ? 2 + s2 : s2;   // lo*hi, hi*lo, hi*hi
+                        const int kb = (term == 1) ? 2 + s2 : s2;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ka][i], bf[kb][j],
+                                                                           acc[i][j], 0, 0, 0);
+                    }
+        };
+        load_A(0);
+        load_Bf(bfr[0], 0, 0);
+        store_A();
+        __syncthreads();
+        load_Af(afr[0], 0);
+        // one chunk = NTAPS MFMA phases without a barrier; P = register set of its first tap
+        auto do_chunk = [&](auto P, int c) {
+            constexpr int p0 = decltype(P)::value;
+            const bool next_chunk = (c + 1) < a.nchunk;
+            if (next_chunk) load_A(c + 1);   // halo of the next chunk: in flight behind the MFMAs
+            if (a.setprio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const int cur = (p0 + t) & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_term(0, afr[cur], bfr[cur]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NTAPS) {
+                    load_Bf(bfr[cur ^ 1], c, t + 1);
+                    load_Af(afr[cur ^ 1], t + 1);
+                } else if (next_chunk) {
+                    load_Bf(bfr[cur ^ 1], c + 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_term(1, afr[cur], bfr[cur]);
+                mfma_term(2, afr[cur], bfr[cur]);
+            }
+            if (a.setprio) __builtin_amdgcn_s_setprio(0);
+            if (next_chunk) {
                 __syncthreads();  // every wave is done with the old halo
                 store_A();
+                __syncthreads();
+                load_Af(afr[(p0 + NTAPS) & 1], 0);
             }
-            if (more) store_B((it + 1) & 1);
-            __syncthreads();
+        };
+        for (int c = 0; c < a.nchunk; c += 2) {
+            do_chunk(std::integral_constant<int, 0>{}, c);
+            if (c + 1 < a.nchunk) do_chunk(std::integral_constant<int, NTAPS & 1>{}, c + 1);
         }
-    }
+        __syncthreads();  // all waves out of the main loop before the epilogue reuses the LDS
+    } else {
+    // ---- main loop: chunk-major, taps inner; B double-buffered, A halo single-buffered
+        load_A(0);
+        load_B(0, 0);
+        store_A();
+        store_B(0);
+        __syncthreads();
+        const int total = a.nchunk * NTAPS;
+        int it = 0;
+        for (int c = 0; c < a.nchunk; ++c) {
+    #pragma unroll 1
+            for (int t = 0; t < NTAPS; ++t, ++it) {
+                const bool more = (it + 1) < total;
+                const bool newA = (t == NTAPS - 1) && (c + 1 < a.nchunk);
+                if (more && !(a.dbg & 2)) load_B(t == NTAPS - 1 ? c + 1 : c, t == NTAPS - 1 ? 0 : t + 1);
+                if (newA && !(a.dbg & 4)) load_A(c + 1);
+                if constexpr (NBUFB == 1) {
+                    compute(t, 0, (KSKIP && c == a.nchunk - 1) ? a.nkk_last : 4);
+                    __syncthreads();  // every wave is done with the weight tile (and the old halo)
+                    if (newA) store_A();
+                    if (more) store_B(0);
+                    __syncthreads();
+                    continue;
+                }
+                compute(t, it & 1, (KSKIP && c == a.nchunk - 1) ? a.nkk_last : 4);
+                if (newA) {
+                    __syncthreads();  // every wave is done with the old halo
+                    store_A();
+                }
+                if (more) store_B((it + 1) & 1);
+                __syncthreads();
+            }
+        }
+    
+}
 
     if constexpr (HEADS) {
         // ---- fused head epilogue (resnet_dcn.py:155-177): hidden = relu(acc + bias1) stays in
@@ -642,10 +738,10 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
 }
 
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false, bool DECONV = false>
+          bool KSKIP = false, bool DECONV = false, int NBUFB = 2>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
 {
-    conv3x3s1_body<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, 2>(a, hd);
+    conv3x3s1_body<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB>(a, hd);
 }
 
 // 64-wide tiles at FOUR workgroups per CU (<= 128 registers, single-buffered weight tile ->
@@ -682,12 +778,12 @@ int launch_c3_occ4(const C3Args &a, hipStream_t st)
 }
 
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false, bool DECONV = false>
+          bool KSKIP = false, bool DECONV = false, int NBUFB = 2>
 int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 {
     constexpr int TH = BM / TW;
-    constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS, BM>() * 4 + BM * 4;
-    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV>), lds);
+    constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS, BM, NBUFB>() * 4 + BM * 4;
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
@@ -712,7 +808,7 @@ int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
         }
     }
     const C3Heads none = {};
-    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV>), grid,
+    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB>), grid,
                        dim3(WM * WN * 64), lds,
                        st, b,
                        hd ? *hd : none);
@@ -721,6 +817,21 @@ int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 }
 
 }  // namespace
+
+// f32s, 128-wide tiles: register-streamed weights (NBUFB = 0) unless cn_set_tuning key 20 = 1
+int cn_tune_f32s_lds_weights = 0;
+
+// Measured (tools/bench_f32s.py, B = 32): 128-wide tiles as four waves of 64 x 64 with
+// register-streamed weights beat the LDS-weight form by 5-20 % (128->128@64^2 0.148 -> 0.141 ms,
+// 256->256@32^2 0.144 -> 0.126, 512->512@16^2 0.142 -> 0.115); eight waves of 32 x 64 lose
+// (0.183 / 0.173 / 0.126), and for 64- / 32-wide tiles the LDS form is as fast or faster
+// (64->64@128^2 0.175 vs 0.173, 128->27@64^2 0.068 vs 0.057), so those keep it.
+static int c3_dispatch_f32s_wreg(C3Args &a, hipStream_t st)
+{
+    const bool wide = a.W >= 32;
+    return wide ? launch_c3<cn_f32s, 32, 128, 2, 2, false, 128, false, false, 0>(a, st)
+                : launch_c3<cn_f32s, 16, 128, 2, 2, false, 128, false, false, 0>(a, st);
+}
 
 template <typename T>
 static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
@@ -736,6 +847,9 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
                          cn_cdiv(a.Cout, 128);
         // (threshold measured: 512 -> resdcn_18 B=8 2.77 -> 2.57 ms, B=32 7.96 -> 7.92; 768 / 1024 lose)
         if (wgs < 512 && (a.Cout % 64) == 0) bn_class = 1;
+    }
+    if constexpr (std::is_same<T, cn_f32s>::value) {
+        if (bn_class == 2 && !cn_tune_f32s_lds_weights) return c3_dispatch_f32s_wreg(a, st);
     }
     if (bn_class == 2) {
         // 8 waves per 128 x 128 tile (wave tile 32 x 64): 4 waves/SIMD at 2 workgroups per CU
@@ -799,6 +913,8 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     a.cout_pad = (Cout + 31) / 32 * 32;
     a.nchunk = a.cin_pad / bke;
     a.nkk_last = f16 != CN_DTYPE_F32 ? 4 : ((Cin - (a.nchunk - 1) * 32) + 7) / 8;
+    a.ncb = a.cout_pad / 32;
+    a.wfrag_off = (size_t)9 * a.cout_pad * a.cin_pad * 4;   // behind the row-ordered copy
     if (f16 == CN_DTYPE_F32S) return c3_dispatch<cn_f32s>(a, bn_class, st);
     return f16 == CN_DTYPE_F16 ? c3_dispatch<_Float16>(a, bn_class, st) : c3_dispatch<float>(a, bn_class, st);
 }

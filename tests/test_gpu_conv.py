@@ -370,3 +370,20 @@ def test_f32s_kernels_are_run_to_run_deterministic(dev):
             if first is None:
                 first = cur
             assert torch.equal(cur, first)
+
+
+@pytest.mark.parametrize("lds_weights", [0, 1])
+def test_f32s_halo_weight_forms(dev, lds_weights):
+    """128-wide f32s tiles: weights streamed into registers from the fragment-ordered copy
+    (default) and the per-tap LDS weight tile (cn_set_tuning key 20) -- odd channel counts,
+    several chunks, narrow and wide maps, residual."""
+    from centernet_amd import native
+    lib = native.lib()
+    lib.cn_set_tuning(20, lds_weights)
+    try:
+        _conv_case(dev, (2, 256, 32, 32, 256, 3, 1, 1, False, True, True, True), split=True)
+        _conv_case(dev, (3, 160, 19, 27, 130, 3, 1, 1, True, False, True, False), split=True)
+        _conv_case(dev, (20, 96, 12, 20, 200, 3, 1, 1, True, True, False, False), split=True)
+        _conv_case(dev, (16, 64, 64, 64, 192, 3, 1, 1, True, False, True, False), split=True)
+    finally:
+        lib.cn_set_tuning(20, 0)
