@@ -61,7 +61,7 @@ def pmc_traffic(tag):
         if not isinstance(v, dict) or "hbm_bytes_per_launch" not in v:
             continue
         if k.startswith("igemm_kernel"):
-            c = "dcn" if k.rstrip(">").split(",")[5].strip() == "2" else "conv"
+            c = "dcn" if k.rstrip(">").split(",")[5].strip() in ("2", "3") else "conv"
         elif k.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_")):
             c = "conv"
         elif k.startswith(("nms_topk", "merge_topk", "peak_", "pose_match", "decode_")):
