@@ -818,8 +818,12 @@ int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 
 }  // namespace
 
-// f32s, 128-wide tiles: register-streamed weights (NBUFB = 0) unless cn_set_tuning key 20 = 1
-int cn_tune_f32s_lds_weights = 0;
+// f32s, 128-wide tiles: register-streamed weights (NBUFB = 0) when cn_set_tuning key 20 = 0.
+// Default 1 (per-tap LDS weight tile): the streamed form wins a back-to-back micro-benchmark by
+// 5-20 % (tools/bench_f32s.py) but not inside the network (resdcn_18 B=32: 4.425 vs 4.408 ms per
+// step, two runs each on one box), where its 1-wave-per-SIMD occupancy hides less of the
+// neighbouring launches' tails.
+int cn_tune_f32s_lds_weights = 1;
 
 // Measured (tools/bench_f32s.py, B = 32): 128-wide tiles as four waves of 64 x 64 with
 // register-streamed weights beat the LDS-weight form by 5-20 % (128->128@64^2 0.148 -> 0.141 ms,

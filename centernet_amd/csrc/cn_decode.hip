@@ -418,6 +418,253 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// Image-level top-K without a per-band select (ctdet / _topk: the K best peaks of ALL classes of
+// an image, decode.py:103-119).  Only ~K of the C*H*W cells matter, so the exact select runs on
+// a threshold-pruned candidate list instead of in every (class, band):
+//   phase 1  group_max_kernel: ONE streaming pass over the raw map (logits when the sigmoid is
+//            fused: the logistic is monotone, no transcendental per cell).  A GROUP is the set of
+//            cells a workgroup covers in one sweep of its 256 threads; per group it records the
+//            largest raw value of all cells and the largest raw value among the cells that pass
+//            the 3x3 peak test on RAW values (a raw peak is also a peak of the sigmoid values).
+//   phase 2  group_threshold_kernel: T_b = K-th largest group peak-maximum of image b (as a
+//            score).  At least K distinct peaks reach T_b, so every cell of the exact top-K has
+//            a peak value >= T_b -- ties at T_b included -- and nothing below can be in it.
+//   phase 3  peak_collect_kernel: only the groups whose all-cell maximum reaches T_b are
+//            looked at again (~10 % of them, L2 / Infinity-Cache resident); their cells above a
+//            conservative raw threshold get the EXACT treatment -- sigmoid, 3x3 equality test
+//            on sigmoid values (decode.py:9-15) -- and are appended to the image's candidate
+//            list as 64-bit keys (score, ~flat index).
+//   phase 4  merge_topk_kernel<MODE, true>: exact radix select + sort of the few hundred
+//            candidates, gather, box assembly.
+// Degenerate inputs (T_b <= 0: fewer than K groups with a positive peak; constant maps; more
+// than GCAP cells >= T_b) take an exact full-scan path inside phase 4, so every input is handled.
+// ---------------------------------------------------------------------------
+constexpr int GCAP = 4096;  // candidate keys per image
+
+// A GROUP = 8 rows x 128 columns of one (image, class) plane.  One half-wave owns a 16-row x
+// 128-column unit (two groups): lane l holds the 4-cell quad l of a row and walks down the
+// rows with the previous / current / next row in registers, so every cell is loaded from global
+// memory exactly once (18 row loads for 16 rows, all issued up front), horizontal neighbours come
+// from the adjacent lanes by shuffle, and nothing goes through LDS.
+constexpr int GROWS = 8;     // rows per group
+constexpr int GUNIT = 16;    // rows per half-wave unit
+
+__global__ __launch_bounds__(NT) void group_max_kernel(const float *__restrict__ heat, int H, int W,
+                                                       int nrg, int ncb, int flags,
+                                                       uint32_t *__restrict__ gpeak,
+                                                       uint32_t *__restrict__ gall)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & (CN_WAVE - 1);
+    const int hl = lane & 31;                 // lane inside the half-wave
+    const int hw = tid >> 5;                  // half-wave of the workgroup (0..7)
+    const int nunit_r = (nrg + 1) / 2;        // 16-row units per plane
+    const int units = nunit_r * ncb;          // units per plane
+    const int w4 = W >> 2;
+    const float NEG_INF = -__builtin_huge_valf();
+    const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;
+    const size_t plane_id = blockIdx.x;       // b * C + c
+    const float *plane = heat + plane_id * (size_t)H * W;
+    for (int u = hw; u < units; u += NT / 32) {   // uniform per half-wave
+        const int ur = u / ncb, cb = u - ur * ncb;
+        const int y0 = ur * GUNIT;
+        const int x4 = cb * 32 + hl;              // this lane's quad column
+        const bool col_ok = x4 < w4;
+        // rows y0-1 .. y0+16: all loads issued before the first use
+        cn_f32x4 rowv[GUNIT + 2];
+        float lft[GUNIT + 2], rgt[GUNIT + 2];     // cells just outside the 128-column block
+#pragma unroll
+        for (int r = 0; r < GUNIT + 2; ++r) {
+            const int y = y0 - 1 + r;
+            const bool ok = col_ok && y >= 0 && y < H;
+            rowv[r].x = rowv[r].y = rowv[r].z = rowv[r].w = NEG_INF;
+            lft[r] = rgt[r] = NEG_INF;
+            if (ok) {
+                const float *p = plane + (size_t)y * W + x4 * 4;
+                rowv[r] = *reinterpret_cast<const cn_f32x4 *>(p);
+                if (hl == 0 && x4 > 0) lft[r] = p[-1];
+                if (hl == 31 && x4 + 1 < w4) rgt[r] = p[4];
+            }
+        }
+        // horizontal 3-max of every row, then the vertical combination
+        cn_f32x4 hmax[GUNIT + 2];
+#pragma unroll
+        for (int r = 0; r < GUNIT + 2; ++r) {
+            float l = __shfl_up(rowv[r].w, 1, 32);
+            float rr = __shfl_down(rowv[r].x, 1, 32);
+            if (hl == 0) l = lft[r];
+            if (hl == 31) rr = rgt[r];
+            if (!col_ok) { l = NEG_INF; rr = NEG_INF; }
+            // a lane beyond the map's last quad hands -inf to its left neighbour
+            hmax[r].x = fmaxf(fmaxf(l, rowv[r].x), rowv[r].y);
+            hmax[r].y = fmaxf(fmaxf(rowv[r].x, rowv[r].y), rowv[r].z);
+            hmax[r].z = fmaxf(fmaxf(rowv[r].y, rowv[r].z), rowv[r].w);
+            hmax[r].w = fmaxf(fmaxf(rowv[r].z, rowv[r].w), rr);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t kp = 0u, ka = 0u;
+#pragma unroll
+            for (int r = 1 + half * GROWS; r < 1 + (half + 1) * GROWS; ++r) {
+                const int y = y0 - 1 + r;
+                if (!(col_ok && y < H)) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = rowv[r][e];
+                    const float m = fmaxf(fmaxf(hmax[r - 1][e], hmax[r][e]), hmax[r + 1][e]);
+                    const uint32_t k = f2key(v + 0.0f);
+                    ka = max(ka, k);
+                    if (nonms || m == v) kp = max(kp, k);
+                }
+            }
+            for (int o = 16; o > 0; o >>= 1) {
+                kp = max(kp, (uint32_t)__shfl_xor((int)kp, o, 32));
+                ka = max(ka, (uint32_t)__shfl_xor((int)ka, o, 32));
+            }
+            const int rg = ur * 2 + half;
+            if (hl == 0 && rg < nrg) {
+                const size_t gi = (plane_id * nrg + rg) * ncb + cb;
+                gpeak[gi] = kp;
+                gall[gi] = ka;
+            }
+        }
+    }
+}
+
+// phase 2: per image, the K-th largest group peak-maximum (exact).  thr[b] = its SCORE key (the
+// logistic applied when it is fused), rawthr[b] = a conservative lower bound, in raw units, of
+// every cell whose score can reach it; counts[b] = 0, or GCAP + 1 for a degenerate image (fewer
+// than K groups, or a non-positive threshold: zeros of suppressed cells would take part)
+__global__ __launch_bounds__(NT) void group_threshold_kernel(const uint32_t *__restrict__ gpeak, int ng,
+                                                             int K, int flags,
+                                                             uint32_t *__restrict__ thr,
+                                                             float *__restrict__ rawthr,
+                                                             int32_t *__restrict__ counts)
+{
+    __shared__ SelShared sh;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const uint32_t *g = gpeak + (size_t)b * ng;
+    if (ng < K) {
+        if (tid == 0) { thr[b] = 0; rawthr[b] = 0.f; counts[b] = GCAP + 1; }
+        return;
+    }
+    auto for_each = [&](auto &&f) {
+        for (int j = tid; j < ng; j += NT) f(((u64)g[j] << 32) | (u64)(0xFFFFFFFFu - (uint32_t)j), false);
+    };
+    u64 prefix, mask;
+    radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
+    collect_and_sort<NT>(for_each, prefix, mask, sh);
+    if (tid == 0) {
+        const uint32_t kraw = (uint32_t)(sh.sel[K - 1] >> 32);
+        if (kraw == 0u) {   // fewer than K groups hold a peak at all
+            thr[b] = 0; rawthr[b] = 0.f; counts[b] = GCAP + 1;
+            return;
+        }
+        const float raw = key2f(kraw);
+        const bool sig = (flags & 1) != 0;
+        const float score = sig ? sigmoidf_ref(raw) : raw;
+        const uint32_t t = f2key(score + 0.0f);
+        thr[b] = t;
+        // the device logistic is monotone only up to its last bit: admit a margin of raw values
+        // below the K-th one; the exact test in phase 3 sorts them out
+        rawthr[b] = sig ? raw - (1e-3f + 1e-3f * fabsf(raw)) : raw;
+        counts[b] = (t <= KEY_ZERO) ? GCAP + 1 : 0;
+    }
+}
+
+// phase 3: exact evaluation of the cells that can reach the threshold, group by group; one
+// workgroup per (image, class) plane walks the plane's group list
+__global__ __launch_bounds__(NT) void peak_collect_kernel(const float *__restrict__ heat, int C, int H,
+                                                          int W, int nrg, int ncb, int flags,
+                                                          const uint32_t *__restrict__ gall,
+                                                          const uint32_t *__restrict__ thr,
+                                                          const float *__restrict__ rawthr,
+                                                          u64 *__restrict__ keys,
+                                                          int32_t *__restrict__ counts)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & (CN_WAVE - 1);
+    const size_t plane_id = blockIdx.x;
+    const int b = (int)(plane_id / C), c = (int)(plane_id - (size_t)b * C);
+    const uint32_t tkey = thr[b];
+    if (tkey <= KEY_ZERO) return;   // degenerate image: phase 4 scans it exactly
+    const bool sig = (flags & 1) != 0;
+    const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;
+    const float rthr = rawthr[b];
+    const uint32_t rkey = f2key(rthr + 0.0f);   // group maxima are RAW keys
+    const float *plane = heat + plane_id * (size_t)H * W;
+    const uint32_t base = (uint32_t)c * (uint32_t)(H * W);
+    u64 *kimg = keys + (size_t)b * GCAP;
+    auto collect_group = [&](int g) {
+        const int rg = g / ncb, cb = g - rg * ncb;
+        // 8 rows x 128 columns = 1024 cells, four per thread
+#pragma unroll 1
+        for (int s = 0; s < (GROWS * 128) / NT; ++s) {
+            const int e = s * NT + tid;
+            const int y = rg * GROWS + (e >> 7), x = cb * 128 + (e & 127);
+            bool take = false;
+            uint32_t k = 0u;
+            const int cell = y * W + x;
+            if (y < H && x < W) {
+                const float raw = plane[cell];
+                if (raw >= rthr) {
+                    const float v = sig ? sigmoidf_ref(raw) : raw;
+                    float m = v;
+                    if (!nonms) {
+                        for (int dy = -1; dy <= 1; ++dy)
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                const int yy = y + dy, xx = x + dx;
+                                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                                const float n = plane[yy * W + xx];
+                                m = fmaxf(m, sig ? sigmoidf_ref(n) : n);
+                            }
+                    }
+                    k = f2key(((m == v) ? v : 0.0f) + 0.0f);
+                    take = k >= tkey;
+                }
+            }
+            const u64 bal = __ballot(take);
+            if (bal) {
+                const int leader = __ffsll((long long)bal) - 1;
+                int pos0 = 0;
+                if (lane == leader) pos0 = atomicAdd(&counts[b], __popcll(bal));
+                pos0 = __shfl(pos0, leader);
+                if (take) {
+                    const int pos = pos0 + (int)__builtin_amdgcn_mbcnt_hi(
+                                               (uint32_t)(bal >> 32),
+                                               __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (pos < GCAP)
+                        kimg[pos] = ((u64)k << 32) | (u64)(0xFFFFFFFFu - (base + (uint32_t)cell));
+                }
+            }
+        }
+    };
+    const int ng = nrg * ncb;
+    // which groups can hold a qualifying cell: all group maxima are fetched at once (a chain of
+    // dependent loads here cost more than the whole streaming pass)
+    __shared__ u64 live[4];
+    for (int g0 = 0; g0 < ng; g0 += NT) {
+        const int g = g0 + tid;
+        const bool q = g < ng && gall[plane_id * ng + g] >= rkey;
+        const u64 bal = __ballot(q);
+        if (lane == 0) live[tid >> 6] = bal;
+        __syncthreads();
+        u64 mine[4] = {live[0], live[1], live[2], live[3]};
+        __syncthreads();
+#pragma unroll 1
+        for (int w = 0; w < 4; ++w) {
+            u64 bits = mine[w];
+            while (bits) {
+                const int bit = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                collect_group(g0 + w * 64 + bit);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // kernel 2: merge candidate lists of one group into its K best, sorted.
 //   CTDET : group = image; N = C*per_class candidates, class = j / per_class;
 //           output = gathered boxes (decode.py:472-493)
@@ -427,15 +674,43 @@ enum { MODE_CTDET = 0, MODE_CHANNEL = 1, MODE_POSE = 2, MODE_TOPK = 3 };
 
 constexpr int NTM = 1024;  // the merge runs one workgroup per image: make it a big one
 
-template <int MODE>
+// image-level candidate keys (phase 3 above) and what the exact full-scan path needs
+struct KeySrc {
+    const u64 *keys;          // [B][GCAP]
+    const int32_t *counts;    // [B]; > GCAP: degenerate / overflowed image -> full scan
+    const float *heat;        // (B, C, H, W) as passed to the decode
+    int flags;                // bit 0 sigmoid, CN_DECODE_NO_PEAK_TEST
+};
+
+// peak value of cell (y, x) of a plane straight from global memory (full-scan path only)
+__device__ __forceinline__ float peak_value_global(const float *plane, int H, int W, int y, int x,
+                                                   bool sig, bool nonms)
+{
+    float v = plane[(size_t)y * W + x];
+    if (sig) v = sigmoidf_ref(v);
+    if (nonms) return v + 0.0f;
+    float m = v;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            float n = plane[(size_t)yy * W + xx];
+            if (sig) n = sigmoidf_ref(n);
+            m = fmaxf(m, n);
+        }
+    return ((m == v) ? v : 0.0f) + 0.0f;
+}
+
+template <int MODE, bool KEYS = false>
 __global__ __launch_bounds__(NTM) void merge_topk_kernel(
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int N,
     int per_class, int H, int W, int K, int C, const float *__restrict__ wh,
     const float *__restrict__ reg, int cat_spec_wh, float *__restrict__ dets, int det_dim,
     int32_t *__restrict__ inds_out, float *__restrict__ out_scores,
-    const float *__restrict__ kps_map, int J, int32_t *__restrict__ cls_out)
+    const float *__restrict__ kps_map, int J, int32_t *__restrict__ cls_out, const KeySrc ks)
 {
     constexpr bool CTDET = (MODE != MODE_CHANNEL);  // group = image, class from position
+    static_assert(!KEYS || CTDET, "candidate keys are image-level");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SelShared &sh = *reinterpret_cast<SelShared *>(smem);
     const int tid = threadIdx.x;
@@ -444,18 +719,45 @@ __global__ __launch_bounds__(NTM) void merge_topk_kernel(
     const float *cs = cand_score + (size_t)g * N;
     const int32_t *ci = cand_idx + (size_t)g * N;
 
-    auto for_each = [&](auto &&f) {
-        for (int j = tid; j < N; j += NTM) {
-            const int32_t idx = ci[j];
-            if (idx < 0) continue;
-            const uint32_t kk = f2key(cs[j] + 0.0f);
-            const uint32_t fid = CTDET ? (uint32_t)((j / per_class) * HW + idx) : (uint32_t)idx;
-            f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - fid), kk == KEY_ZERO);
-        }
-    };
     u64 prefix, mask;
-    radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
-    collect_and_sort<NTM>(for_each, prefix, mask, sh);
+    if constexpr (KEYS) {
+        const int cnt = ks.counts[g];
+        if (cnt <= GCAP && cnt >= K) {   // (fewer than K can only follow a non-monotone logistic)
+            const u64 *kg = ks.keys + (size_t)g * GCAP;
+            auto for_each = [&](auto &&f) {
+                for (int j = tid; j < cnt; j += NTM) f(kg[j], false);
+            };
+            radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
+            collect_and_sort<NTM>(for_each, prefix, mask, sh);
+        } else {
+            // exact full scan of the image (constant maps, tiny maps, fewer than K positive
+            // peaks): slow, never taken on ordinary heat-maps
+            const float *img = ks.heat + (size_t)g * C * HW;
+            const bool sig = (ks.flags & 1) != 0, nonms = (ks.flags & CN_DECODE_NO_PEAK_TEST) != 0;
+            auto for_each = [&](auto &&f) {
+                for (int fid = tid; fid < C * HW; fid += NTM) {
+                    const int c = fid / HW, e = fid - c * HW;
+                    const int y = e / W, x = e - y * W;
+                    const uint32_t kk = f2key(peak_value_global(img + (size_t)c * HW, H, W, y, x, sig, nonms));
+                    f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - (uint32_t)fid), kk == KEY_ZERO);
+                }
+            };
+            radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
+            collect_and_sort<NTM>(for_each, prefix, mask, sh);
+        }
+    } else {
+        auto for_each = [&](auto &&f) {
+            for (int j = tid; j < N; j += NTM) {
+                const int32_t idx = ci[j];
+                if (idx < 0) continue;
+                const uint32_t kk = f2key(cs[j] + 0.0f);
+                const uint32_t fid = CTDET ? (uint32_t)((j / per_class) * HW + idx) : (uint32_t)idx;
+                f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - fid), kk == KEY_ZERO);
+            }
+        };
+        radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
+        collect_and_sort<NTM>(for_each, prefix, mask, sh);
+    }
 
     if (tid < K) {
         const u64 k = sh.sel[tid];
@@ -544,12 +846,65 @@ int launch_nms_topk(const float *heat, int B, int C, int H, int W, int K, int ap
 
 }  // namespace
 
+namespace {
+// image-level (threshold-pruned) top-K: layout of its scratch behind the per-band candidate
+// arrays, and whether a shape takes it (enough groups per image for a meaningful threshold;
+// single-class maps such as the pose centre map keep the per-band select)
+struct ImgPlan {
+    bool use;
+    int nrg, ncb;                  // 8-row groups per plane, 128-column blocks per row
+    size_t gpeak, gall, thr, rawthr, counts, keys, total;   // byte offsets in the workspace
+};
+ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
+{
+    ImgPlan p = {};
+    const size_t n = (size_t)B * C * bp.nbands * K;
+    size_t o = cn_align_up(n * sizeof(float), 256) + cn_align_up(n * sizeof(int32_t), 256);
+    p.nrg = cn_cdiv(H, GROWS);
+    p.ncb = cn_cdiv(W, 128);
+    // enough groups per image for a meaningful threshold; rows of whole quads
+    p.use = (W & 3) == 0 && (long)C * p.nrg * p.ncb >= 4L * K;
+    const size_t ng = (size_t)B * C * p.nrg * p.ncb;
+    p.gpeak = o;  o += cn_align_up(ng * 4, 256);
+    p.gall = o;   o += cn_align_up(ng * 4, 256);
+    p.thr = o;    o += cn_align_up((size_t)B * 4, 256);
+    p.rawthr = o; o += cn_align_up((size_t)B * 4, 256);
+    p.counts = o; o += cn_align_up((size_t)B * 4, 256);
+    p.keys = o;   o += cn_align_up((size_t)B * GCAP * 8, 256);
+    p.total = o;
+    return p;
+}
+
+// phases 1-3 (the merge launch follows in the caller: its epilogue differs per entry point)
+int launch_image_candidates(const float *heat, int B, int C, int H, int W, int K, int flags,
+                            const BandPlan &bp, const ImgPlan &ip, char *ws, hipStream_t st)
+{
+    (void)bp;
+    uint32_t *gpeak = (uint32_t *)(ws + ip.gpeak);
+    uint32_t *gall = (uint32_t *)(ws + ip.gall);
+    uint32_t *thr = (uint32_t *)(ws + ip.thr);
+    float *rawthr = (float *)(ws + ip.rawthr);
+    int32_t *counts = (int32_t *)(ws + ip.counts);
+    u64 *keys = (u64 *)(ws + ip.keys);
+    dim3 grid((unsigned)(B * C)), block(NT);
+    hipLaunchKernelGGL(group_max_kernel, grid, block, 0, st, heat, H, W, ip.nrg, ip.ncb, flags, gpeak,
+                       gall);
+    CN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(group_threshold_kernel, dim3(B), dim3(NT), 0, st, gpeak, C * ip.nrg * ip.ncb, K,
+                       flags, thr, rawthr, counts);
+    CN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(peak_collect_kernel, grid, block, 0, st, heat, C, H, W, ip.nrg, ip.ncb, flags,
+                       gall, thr, rawthr, keys, counts);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+}  // namespace
+
 extern "C" size_t cn_ctdet_decode_workspace_bytes(int B, int C, int H, int W, int K)
 {
     BandPlan bp;
     if (B <= 0 || C <= 0 || K <= 0 || !make_band_plan(B, C, H, W, K, &bp)) return 0;
-    const size_t n = (size_t)B * C * bp.nbands * K;
-    return cn_align_up(n * sizeof(float), 256) + cn_align_up(n * sizeof(int32_t), 256);
+    return make_img_plan(B, C, H, W, K, bp).total;
 }
 
 static int decode_checks(const void *heat, int B, int C, int H, int W, int K, BandPlan *bp)
@@ -579,12 +934,26 @@ extern "C" int cn_ctdet_decode_f32(const float *heat, const float *wh, const flo
     const size_t n = (size_t)B * C * bp.nbands * K;
     float *cand_score = (float *)workspace;
     int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
+    const ImgPlan ip = make_img_plan(B, C, H, W, K, bp);
+    if (ip.use && !(apply_sigmoid & 2048)) {   // bit 11: force the per-band select (tests / A-B)
+        char *ws = (char *)workspace;
+        rc = launch_image_candidates(heat, B, C, H, W, K, apply_sigmoid, bp, ip, ws, st);
+        if (rc != CN_OK) return rc;
+        const KeySrc ks = {(const u64 *)(ws + ip.keys), (const int32_t *)(ws + ip.counts), heat,
+                           apply_sigmoid};
+        hipLaunchKernelGGL((merge_topk_kernel<MODE_CTDET, true>), dim3(B), dim3(NTM),
+                           sizeof(SelShared), st, cand_score, cand_idx, 0, 1, H, W, K, C, wh, reg,
+                           cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr, 0,
+                           (int32_t *)nullptr, ks);
+        CN_CHECK_LAUNCH();
+        return CN_OK;
+    }
     rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
     if (rc != CN_OK) return rc;
     hipLaunchKernelGGL(merge_topk_kernel<MODE_CTDET>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg,
                        cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr, 0,
-                       (int32_t *)nullptr);
+                       (int32_t *)nullptr, KeySrc{});
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -613,7 +982,7 @@ extern "C" int cn_nms_topk_channel_f32(const float *heat, int B, int C, int H, i
     hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * C), dim3(NTM), sizeof(SelShared),
                        st, cand_score, cand_idx, bp.nbands * K, bp.nbands * K, H, W, K, C,
                        (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0, inds,
-                       scores, (const float *)nullptr, 0, (int32_t *)nullptr);
+                       scores, (const float *)nullptr, 0, (int32_t *)nullptr, KeySrc{});
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -743,7 +1112,8 @@ extern "C" int cn_multi_pose_decode_f32(const float *heat, const float *wh, cons
     if (rc != CN_OK) return rc;
     hipLaunchKernelGGL(merge_topk_kernel<MODE_POSE>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_s, cand_i, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg, 0,
-                       dets, D, (int32_t *)nullptr, (float *)nullptr, kps, J, (int32_t *)nullptr);
+                       dets, D, (int32_t *)nullptr, (float *)nullptr, kps, J, (int32_t *)nullptr,
+                       KeySrc{});
     CN_CHECK_LAUNCH();
     if (!hm_hp) return CN_OK;
     // stage B: per-joint top-K of the keypoint heat-map
@@ -757,7 +1127,7 @@ extern "C" int cn_multi_pose_decode_f32(const float *heat, const float *wh, cons
                            sizeof(SelShared), st, cand_s, cand_i, bph.nbands * K, bph.nbands * K, H,
                            W, K, J, (const float *)nullptr, (const float *)nullptr, 0,
                            (float *)nullptr, 0, hp_i, hp_s, (const float *)nullptr, 0,
-                           (int32_t *)nullptr);
+                           (int32_t *)nullptr, KeySrc{});
         CN_CHECK_LAUNCH();
     }
     // stage C
@@ -840,12 +1210,26 @@ extern "C" int cn_topk_f32(const float *heat, int B, int C, int H, int W, int K,
     const size_t n = (size_t)B * C * bp.nbands * K;
     float *cand_score = (float *)workspace;
     int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
+    const ImgPlan ip = make_img_plan(B, C, H, W, K, bp);
+    if (ip.use && !(apply_sigmoid & 2048)) {
+        char *ws = (char *)workspace;
+        rc = launch_image_candidates(heat, B, C, H, W, K, apply_sigmoid, bp, ip, ws, st);
+        if (rc != CN_OK) return rc;
+        const KeySrc ks = {(const u64 *)(ws + ip.keys), (const int32_t *)(ws + ip.counts), heat,
+                           apply_sigmoid};
+        hipLaunchKernelGGL((merge_topk_kernel<MODE_TOPK, true>), dim3(B), dim3(NTM),
+                           sizeof(SelShared), st, cand_score, cand_idx, 0, 1, H, W, K, C,
+                           (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0,
+                           inds, scores, (const float *)nullptr, 0, clses, ks);
+        CN_CHECK_LAUNCH();
+        return CN_OK;
+    }
     rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
     if (rc != CN_OK) return rc;
     hipLaunchKernelGGL(merge_topk_kernel<MODE_TOPK>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C,
                        (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0, inds,
-                       scores, (const float *)nullptr, 0, clses);
+                       scores, (const float *)nullptr, 0, clses, KeySrc{});
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -83,8 +83,9 @@ const char *cn_arch(void);
  * key 14: 1 = 256-pixel tiles for 64-wide layers in the LDS-halo kernel (default 0: measured,
  *         no gain).
  * key 13: tap split of the deformable kernel, 0 = auto, 1 = never, 3 or 9 = force.
- * key 20: f32s LDS-halo kernel, 128-wide tiles: 0 = weights streamed into registers from the
- *         fragment-ordered copy (default, +5-20 %), 1 = per-tap weight tile in LDS.
+ * key 20: f32s LDS-halo kernel, 128-wide tiles: 1 = per-tap weight tile in LDS (default),
+ *         0 = weights streamed into registers from the fragment-ordered copy (+5-20 % in a
+ *         back-to-back micro-benchmark, no gain inside the network: measured).
  * key 12: 0 = one-tile-per-workgroup stem kernel instead of the persistent, prefetching one
  *         (default 1; both in cn_stem.hip). */
 int cn_set_tuning(int key, int value);

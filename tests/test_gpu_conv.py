@@ -386,4 +386,4 @@ def test_f32s_halo_weight_forms(dev, lds_weights):
         _conv_case(dev, (20, 96, 12, 20, 200, 3, 1, 1, True, True, False, False), split=True)
         _conv_case(dev, (16, 64, 64, 64, 192, 3, 1, 1, True, False, True, False), split=True)
     finally:
-        lib.cn_set_tuning(20, 0)
+        lib.cn_set_tuning(20, 1)

@@ -233,3 +233,48 @@ def test_mismatched_inputs_raise_instead_of_reading_out_of_bounds(dev):
         _transpose_and_gather_feat(feat, torch.tensor([[0, 256], [1, 2]], device=dev))
     with pytest.raises(RuntimeError):
         _transpose_and_gather_feat(feat, torch.tensor([[0, -1], [1, 2]], device=dev))
+
+
+@pytest.mark.parametrize("shape", [(4, 80, 128, 128, 100), (2, 100, 64, 64, 50), (3, 24, 96, 160, 40),
+                                   (2, 40, 50, 70, 20)])
+def test_image_level_select_equals_per_band_select(dev, shape):
+    """The threshold-pruned image-level top-K (group maxima -> K-th largest as threshold ->
+    candidate keys -> exact select) and the per-(class, band) select of round 1 (debug flag
+    2048) give bit-identical detections; both equal the oracle."""
+    from centernet_amd.decode import ctdet_decode
+    B, C, H, W, K = shape
+    heat = synth.heatmap((B, C, H, W), 31 + C)
+    wh = synth.uniform((B, 2, H, W), 0, 40, 5)
+    reg = synth.uniform((B, 2, H, W), 0, 1, 6)
+    a, ia = ctdet_decode(_gpu(heat, dev), _gpu(wh, dev), _gpu(reg, dev), K=K, return_inds=True)
+    b, ib = ctdet_decode(_gpu(heat, dev), _gpu(wh, dev), _gpu(reg, dev), K=K, return_inds=True,
+                         _debug_flags=2048)
+    assert torch.equal(ia, ib) and torch.equal(a, b)
+    ref, ref_inds = cref.ctdet_decode(heat, wh, reg, K=K, return_inds=True)
+    assert np.array_equal(ia.cpu().numpy(), ref_inds)
+    assert np.array_equal(a.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_image_level_select_degenerate_maps(dev):
+    """Inputs on which the threshold is useless -- constant maps (every cell ties), fewer than
+    K positive peaks, thousands of cells tying the K-th score -- take the exact full-scan path
+    of the merge kernel: still bit-exact vs the oracle (ties: class asc, index asc)."""
+    from centernet_amd.decode import ctdet_decode
+    B, C, H, W, K = 2, 100, 64, 64, 50
+    wh = synth.uniform((B, 2, H, W), 0, 40, 5)
+    cases = []
+    cases.append(np.full((B, C, H, W), 0.25, np.float32))                     # constant
+    few = np.zeros((B, C, H, W), np.float32)                                   # 7 positive peaks
+    for i in range(7):
+        few[0, 3 * i, 5 + 2 * i, 9 + 3 * i] = 0.9 - 0.1 * i
+    few[1, 99, 63, 63] = 0.5
+    cases.append(few)
+    plateau = synth.heatmap((B, C, H, W), 77)
+    plateau[:, :, ::2, ::2] = np.maximum(plateau[:, :, ::2, ::2], 0.97)        # 100k cells at 0.97+
+    plateau[:, :, ::2, ::2] = 0.97
+    cases.append(plateau.astype(np.float32))
+    for heat in cases:
+        ref, ref_inds = cref.ctdet_decode(heat, wh, None, K=K, return_inds=True)
+        d, i = ctdet_decode(_gpu(heat, dev), _gpu(wh, dev), None, K=K, return_inds=True)
+        assert np.array_equal(i.cpu().numpy(), ref_inds)
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))

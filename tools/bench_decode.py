@@ -35,7 +35,7 @@ def run(flags, iters=30):
     return s.elapsed_time(e) / iters
 
 
-for name, flags in (("full (sigmoid+nms+select)", 1), ("no sigmoid", 0), ("no select/sort", 1 | 256),
-                    ("no nms compare", 1 | 512), ("load+sigmoid only", 1 | 256 | 512), ("load only", 256 | 512), ("forced full-scan fallback", 1 | 1024)):
+for name, flags in (("image-level select, logits in (default)", 1), ("image-level select, post-sigmoid in", 0),
+                    ("per-band select of round 1 (flag 2048)", 1 | 2048)):
     ms = run(flags)
-    print("%-28s %7.3f ms  %7.1f GB/s" % (name, ms, alg / ms / 1e6))
+    print("%-44s %7.3f ms  %7.1f GB/s" % (name, ms, alg / ms / 1e6))

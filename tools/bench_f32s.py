@@ -71,17 +71,14 @@ for (ci, H, W, co) in SHAPES:
     w = torch.randn((co, ci, 3, 3), generator=g) * (2.0 / (ci * 9)) ** 0.5
     fl = 2.0 * B * H * W * co * ci * 9
     ms0, y0 = run(ci, H, W, co, DTYPE_F32, x, w)
-    lib.cn_set_tuning(20, 1)
-    ms2, _ = run(ci, H, W, co, DTYPE_F32S, x, w)
     lib.cn_set_tuning(20, 0)
-    lib.cn_set_tuning(15, 0)
-    ms3, _ = run(ci, H, W, co, DTYPE_F32S, x, w)
-    lib.cn_set_tuning(15, 1)
+    ms2, _ = run(ci, H, W, co, DTYPE_F32S, x, w)
+    lib.cn_set_tuning(20, 1)
     ms1, y1 = run(ci, H, W, co, DTYPE_F32S, x, w)
     nb = min(B, 2)
     ref = torch.nn.functional.conv2d(x[:nb].permute(0, 3, 1, 2).double().cpu(), w.double(), padding=1).permute(0, 2, 3, 1)
     rms = float(ref.pow(2).mean().sqrt())
     e0 = float((y0[:nb].double().cpu() - ref).abs().max()) / rms
     e1 = float((y1[:nb].double().cpu() - ref).abs().max()) / rms
-    print("%-26s %7.3f ms %7.1f TF   %7.3f ms %7.1f TF   %.2e  %.2e | LDS-weights form %7.3f ms %6.1f TF | 4-wave 128-wide %7.3f ms" % (
-        str((ci, H, W, co)), ms0, fl / ms0 / 1e9, ms1, fl / ms1 / 1e9, e1, e0, ms2, fl / ms2 / 1e9, ms3))
+    print("%-26s %7.3f ms %7.1f TF   %7.3f ms %7.1f TF   %.2e  %.2e | register-streamed weights (key 20=0) %7.3f ms %6.1f TF" % (
+        str((ci, H, W, co)), ms0, fl / ms0 / 1e9, ms1, fl / ms1 / 1e9, e1, e0, ms2, fl / ms2 / 1e9))
