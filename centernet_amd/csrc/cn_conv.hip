@@ -1105,7 +1105,9 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         a.ksplit = want;
         a.partial = (float *)workspace;
     }
-    if (f32s && stem) return CN_ERR_UNSUPPORTED;   // the fp32 image goes through the fp32 stem kernels
+    // the stem reads the fp32 image and keeps fp32 packed weights; CN_CONV_STEM_F32S asks the
+    // persistent stem kernel for f32s arithmetic (split inside the kernel), output plain fp32
+    if (f32s && stem) return CN_ERR_UNSUPPORTED;
     if (d->out_layout == CN_LAYOUT_NCHW) {
         if (residual || stem) return CN_ERR_UNSUPPORTED;
         if (f32s) {
@@ -1134,7 +1136,7 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
             rc = cn_stem_conv_f32((const float *)x, (const float *)w_packed, scale, shift,
                                   (float *)y, d->B, d->H, d->W, d->Ho, d->Wo, d->Cout, d->KH,
                                   d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad,
-                                  g_tune_stem_persist, st);
+                                  g_tune_stem_persist | ((d->flags & CN_CONV_STEM_F32S) ? 2 : 0), st);
             if (rc != CN_ERR_UNSUPPORTED) return rc;
         }
         if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_STEM, false>(a, st);

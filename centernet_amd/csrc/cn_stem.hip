@@ -391,6 +391,207 @@ __global__ __launch_bounds__(NT) void stem_persist_f32_kernel(const StemArgs a, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// f32s form of the persistent stem (7x7 / stride 2, 32 or 64 output channels per tile): the
+// same tile walk and register prefetch, but the window lives in LDS as two fp16 planes (high
+// and low parts of the fp32 pixels, split while it is staged) and K is consumed 16 at a time
+// by v_mfma_f32_32x32x16_f16 -- three per step (hi*hi + hi*lo + lo*hi), 33 per 32 x 32 block
+// instead of 84 fp32 matrix instructions of twice the latency.  K order: step s, lane half h,
+// element j  <->  window row r = 2s + h (= c*7 + ky), kx = j; j = 7 and r = 21 carry zero
+// weights (and read the next pixel / the zeroed spare row).  A lane's eight kx of a row are
+// eight consecutive fp16 of the window -- 4-byte aligned at stride 2 -- fetched as four
+// ds_read_b32 with immediate offsets.  Output stays plain fp32 (the max-pool reads it).
+constexpr int SKS = 11;            // 16-deep K steps (22 window rows incl. the zero row)
+constexpr int SKP = 16 * SKS;      // 176 K values per part
+constexpr int SLDW = SKP + 8;      // fp16 per LDS weight row (368 bytes: conflict-free b128 reads)
+typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t st_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BN>
+__global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a, int total_tiles)
+{
+    constexpr int S = 2;
+    constexpr int WN = BN / 32;
+    constexpr int WM = 4 / WN;
+    constexpr int TM = BM / WM;
+    constexpr int MB = TM / 32;
+    constexpr int WX = (BM - 1) * S + PKW;           // 261 columns carry data
+    constexpr int WXH = 262;                          // fp16 per window row: even, = 2 mod 4
+    static_assert(WXH >= WX + 1 && (WXH & 3) == 2, "window pitch");
+    constexpr int PLANE = (PROWS + 1) * WXH;          // + the zero row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 *winH = reinterpret_cast<_Float16 *>(smem);            // [22][WXH]
+    _Float16 *winL = winH + PLANE;
+    _Float16 *WsH = winL + PLANE + 8;                                // [BN][SLDW], 16-byte aligned
+    _Float16 *WsL = WsH + BN * SLDW;
+    static_assert(((2 * PLANE + 8) * 2) % 16 == 0, "weight tile alignment");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.y * BN;
+    const int tpr = a.Wo / BM;
+
+    // ---- once per workgroup: zero both planes (the spare row and column 261 stay zero), and
+    // the weights of this N tile, split and permuted into the (step, half, kx) K order
+    for (int i = tid; i < 2 * PLANE; i += NT) winH[i] = (_Float16)0.f;
+    for (int i = tid; i < BN * SKP; i += NT) {
+        const int nrow = i / SKP, k = i - nrow * SKP;
+        const int st = k >> 4, h = (k >> 3) & 1, j = k & 7;
+        const int r = 2 * st + h;
+        const int c = r / PKH, ky = r - c * PKH;
+        const int nn = min(n0 + nrow, a.cout_pad - 1);
+        float w = 0.f;
+        if (r < PROWS && j < PKW) w = a.w[(size_t)nn * a.KP + (ky * PKW + j) * 3 + c];
+        const _Float16 hi = (_Float16)w;
+        WsH[nrow * SLDW + k] = hi;
+        WsL[nrow * SLDW + k] = (_Float16)(w - (float)hi);
+    }
+    __syncthreads();
+
+    const int trow = tid >> 3, tcol = NT + (tid & 7);
+    const bool tail_ok = trow < PROWS && tcol < WX;
+    const bool col_ok = tid < WX;
+    const int tc = trow / PKH, twy = trow - tc * PKH;
+
+    float v[PROWS], vt;
+    unsigned vmask = 0;
+    auto prefetch = [&](int tile) {
+        const int xt = tile % tpr;
+        const int rowid = tile / tpr;  // b*Ho + oy
+        const int b = rowid / a.Ho, oy = rowid - b * a.Ho;
+        const int iy_min = oy * S - a.pad, ix_min = xt * BM * S - a.pad;
+        const float *xb = a.x + (size_t)b * 3 * a.H * a.W;
+        const int ix = ix_min + tid;
+        const bool cok = col_ok && ix >= 0 && ix < a.W;
+        unsigned mk = 0;
+#pragma unroll
+        for (int u = 0; u < PROWS; ++u) {
+            const int c = u / PKH, wy = u % PKH;
+            const int iy = iy_min + wy;
+            const bool ok = cok && iy >= 0 && iy < a.H;
+            v[u] = xb[ok ? ((size_t)(c * a.H + iy) * a.W + ix) : 0];
+            mk |= ok ? (1u << u) : 0u;
+        }
+        {
+            const int iy = iy_min + twy, jx = ix_min + tcol;
+            const bool ok = tail_ok && iy >= 0 && iy < a.H && jx >= 0 && jx < a.W;
+            vt = xb[ok ? ((size_t)(tc * a.H + iy) * a.W + jx) : 0];
+            mk |= ok ? (1u << PROWS) : 0u;
+        }
+        vmask = mk;
+    };
+    auto put = [&](int idx, float x) {
+        const _Float16 hi = (_Float16)x;
+        winH[idx] = hi;
+        winL[idx] = (_Float16)(x - (float)hi);
+    };
+    auto store_window = [&]() {
+        if (col_ok) {
+#pragma unroll
+            for (int u = 0; u < PROWS; ++u) put(u * WXH + tid, ((vmask >> u) & 1u) ? v[u] : 0.f);
+        }
+        if (tail_ok) put(trow * WXH + tcol, ((vmask >> PROWS) & 1u) ? vt : 0.f);
+    };
+
+    // 32-bit views: a lane's 8 kx of a window row are words (2*pixel + 0..3) of the row
+    const uint32_t *aH[MB], *aL[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int off = (wm * TM + i * 32 + l31) * S + lh * WXH;   // fp16 index: even
+        aH[i] = reinterpret_cast<const uint32_t *>(winH + off);
+        aL[i] = reinterpret_cast<const uint32_t *>(winL + off);
+    }
+    const _Float16 *wH = WsH + (wn * 32 + l31) * SLDW + 8 * lh;
+    const _Float16 *wL = WsL + (wn * 32 + l31) * SLDW + 8 * lh;
+    const int n = n0 + wn * 32 + l31;
+    float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+    float sf = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+    asm volatile("" : "+v"(sc), "+v"(sf));
+
+    int tile = blockIdx.x;
+    if (tile < total_tiles) prefetch(tile);
+    for (; tile < total_tiles; tile += gridDim.x) {
+        store_window();
+        __syncthreads();  // window visible
+        const int next = tile + gridDim.x;
+        if (next < total_tiles) prefetch(next);  // in flight during the MFMAs below
+
+        cn_f32x16 acc[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // operand sets alternate by step parity; the set a load targets was last read by MFMAs
+        // issued a whole step earlier (see the operand hazard note in cn_conv.hip)
+        st_u32x4 fa[2][2][MB];      // [set][hi / lo][block]
+        st_f16x8 fb[2][2];          // [set][hi / lo]
+        auto load_step = [&](int set, int st) {
+            constexpr int RW = WXH / 2;   // words per window row
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fa[set][0][i][j] = aH[i][2 * st * RW + j];
+                    fa[set][1][i][j] = aL[i][2 * st * RW + j];
+                }
+            fb[set][0] = *reinterpret_cast<const st_f16x8 *>(wH + 16 * st);
+            fb[set][1] = *reinterpret_cast<const st_f16x8 *>(wL + 16 * st);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < SKS; ++st) {
+            const int cur = st & 1;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)    // lo * hi
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(st_f16x8, fa[cur][1][i]), fb[cur][0], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < SKS) load_step(cur ^ 1, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)    // hi * lo
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(st_f16x8, fa[cur][0][i]), fb[cur][1], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)    // hi * hi
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(st_f16x8, fa[cur][0][i]), fb[cur][0], acc[i], 0, 0, 0);
+        }
+
+        // epilogue: BN (scale/shift) + ReLU, NHWC plain fp32; lanes run along Cout
+        if (n < a.Cout) {
+            const int xt = tile % tpr;
+            const int rowid = tile / tpr;
+            float *yb = a.y + ((size_t)rowid * a.Wo + (size_t)xt * BM) * a.out_pitch + n;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float t = acc[i][r] * sc + sf;
+                    if (a.relu) t = fmaxf(t, 0.f);
+                    yb[(size_t)m * a.out_pitch] = t;
+                }
+        }
+        __syncthreads();  // every wave is done reading the window
+    }
+}
+
+template <int BN>
+int launch_stem_persist_f32s(const StemArgs &a, int B, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)(2 * (PROWS + 1) * 262 + 8 + 2 * BN * SLDW) * 2;
+    const long total = (long)B * a.tiles_per_image;
+    const int wgs = (int)(total < 512 ? total : 512);  // two resident workgroups per CU
+    dim3 grid(wgs, cn_cdiv(a.Cout, BN));
+    CN_SET_MAX_LDS_ONCE((stem_persist_f32s_kernel<BN>), lds);
+    hipLaunchKernelGGL((stem_persist_f32s_kernel<BN>), grid, dim3(NT), lds, st, a, (int)total);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
 template <int BN, int S>
 int launch_stem_persist(const StemArgs &a, int B, hipStream_t st)
 {
@@ -423,6 +624,11 @@ int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, 
         a.stride = stride; a.pad = pad; a.relu = relu; a.out_pitch = out_pitch; a.KP = KP;
         a.tiles_per_image = Ho * (Wo / BM);
         a.cout_pad = (Cout + 31) / 32 * 32;
+        // bit 1 of `persistent`: f32s arithmetic (three fp16 MFMAs per product), stride-2 stems
+        // of more than 16 output channels
+        if ((persistent & 2) && stride == 2 && Cout > 16)
+            return Cout > 32 ? launch_stem_persist_f32s<64>(a, B, st)
+                             : launch_stem_persist_f32s<32>(a, B, st);
         if (Cout > 32)
             return stride == 2 ? launch_stem_persist<64, 2>(a, B, st)
                                : launch_stem_persist<64, 1>(a, B, st);

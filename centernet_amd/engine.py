@@ -20,7 +20,7 @@ import torch
 
 from . import native
 from .native import (ConvDesc, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTYPE_F32, DTYPE_F32S,
-                     CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN)
+                     CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN, CONV_STEM_F32S)
 
 
 def _out_size(n, k, s, p, d=1):
@@ -244,6 +244,8 @@ class PlanBuilder:
             x, residual = self.plain(x), self.plain(residual)
             wp = self._pack(weight, wsources)
             cd = self.cdtype
+            if self.split and x.nchw:
+                flags |= CONV_STEM_F32S     # the stem kernel splits image and weights itself
         self.keep += [scale, shift]
         if out is None:
             if out_nchw:

@@ -21,7 +21,7 @@ LAYOUT_NHWC = 1
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 DTYPE_F32S = 2        # fp32 values as fp16 (high, low) pairs: three fp16 MFMAs per product
-CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN = 1, 2, 4
+CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN, CONV_STEM_F32S = 1, 2, 4, 8
 
 _lib = None
 

@@ -210,6 +210,9 @@ typedef struct cn_conv_desc {
 #define CN_CONV_X_PLAIN 1
 #define CN_CONV_Y_PLAIN 2
 #define CN_CONV_R_PLAIN 4
+/* dtype = CN_DTYPE_F32, 3-channel NCHW stem only: compute with three fp16 MFMAs per product
+ * (the image and the packed weight stay fp32 and are split inside the kernel) */
+#define CN_CONV_STEM_F32S 8
 
 /* Number of floats of the packed weight for (Cout,Cin,KH,KW). */
 size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
