@@ -207,6 +207,7 @@ __device__ __forceinline__ float sigmoidf_ref(float x)
 }
 
 constexpr int CAND_CAP = 4096;  // compacted positive peaks per band (uint16 tile offsets)
+constexpr int GATE_CAP = 4096;  // = GCAP below: candidate keys per image of the image-level mode
 
 // ---------------------------------------------------------------------------
 // kernel 1: per (image, class, row-band): sigmoid + 3x3 peak test + top-K
@@ -222,8 +223,15 @@ constexpr int CAND_CAP = 4096;  // compacted positive peaks per band (uint16 til
 __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ heat, int C, int H,
                                                       int W, int K, int R, int apply_sigmoid,
                                                       float *__restrict__ cand_score,
-                                                      int32_t *__restrict__ cand_idx)
+                                                      int32_t *__restrict__ cand_idx,
+                                                      const int32_t *__restrict__ gate)
 {
+    // gate (image-level mode): this per-band select only runs for the images whose candidate
+    // list was unusable (counts outside [K, GCAP]: plateaus of equal scores, degenerate maps)
+    if (gate) {
+        const int cnt = gate[blockIdx.z];
+        if (cnt >= K && cnt <= GATE_CAP) return;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SelShared &sh = *reinterpret_cast<SelShared *>(smem);
     float *tile = reinterpret_cast<float *>(smem + sizeof(SelShared));
@@ -436,10 +444,12 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
 //            list as 64-bit keys (score, ~flat index).
 //   phase 4  merge_topk_kernel<MODE, true>: exact radix select + sort of the few hundred
 //            candidates, gather, box assembly.
-// Degenerate inputs (T_b <= 0: fewer than K groups with a positive peak; constant maps; more
-// than GCAP cells >= T_b) take an exact full-scan path inside phase 4, so every input is handled.
+// Images whose list is unusable (T_b <= 0: fewer than K groups with a positive peak; constant
+// maps; plateaus of more than GCAP cells tying T_b) are served by the per-(class, band) select
+// of nms_topk_kernel, launched behind phase 4 and gated on the image's count: its workgroups
+// exit at once for every image the list did serve, so every input is handled exactly.
 // ---------------------------------------------------------------------------
-constexpr int GCAP = 4096;  // candidate keys per image
+constexpr int GCAP = GATE_CAP;  // candidate keys per image
 
 // A GROUP = 8 rows x 128 columns of one (image, class) plane.  One half-wave owns a 16-row x
 // 128-column unit (two groups): lane l holds the 4-cell quad l of a row and walks down the
@@ -677,29 +687,10 @@ constexpr int NTM = 1024;  // the merge runs one workgroup per image: make it a 
 // image-level candidate keys (phase 3 above) and what the exact full-scan path needs
 struct KeySrc {
     const u64 *keys;          // [B][GCAP]
-    const int32_t *counts;    // [B]; > GCAP: degenerate / overflowed image -> full scan
+    const int32_t *counts;    // [B]; outside [K, GCAP]: the gated per-band select serves the image
     const float *heat;        // (B, C, H, W) as passed to the decode
     int flags;                // bit 0 sigmoid, CN_DECODE_NO_PEAK_TEST
 };
-
-// peak value of cell (y, x) of a plane straight from global memory (full-scan path only)
-__device__ __forceinline__ float peak_value_global(const float *plane, int H, int W, int y, int x,
-                                                   bool sig, bool nonms)
-{
-    float v = plane[(size_t)y * W + x];
-    if (sig) v = sigmoidf_ref(v);
-    if (nonms) return v + 0.0f;
-    float m = v;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = y + dy, xx = x + dx;
-            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-            float n = plane[(size_t)yy * W + xx];
-            if (sig) n = sigmoidf_ref(n);
-            m = fmaxf(m, n);
-        }
-    return ((m == v) ? v : 0.0f) + 0.0f;
-}
 
 template <int MODE, bool KEYS = false>
 __global__ __launch_bounds__(NTM) void merge_topk_kernel(
@@ -721,31 +712,21 @@ __global__ __launch_bounds__(NTM) void merge_topk_kernel(
 
     u64 prefix, mask;
     if constexpr (KEYS) {
+        // usable candidate list: between K and GCAP keys; otherwise the gated per-band select
+        // (launched right behind this kernel) produces this image
         const int cnt = ks.counts[g];
-        if (cnt <= GCAP && cnt >= K) {   // (fewer than K can only follow a non-monotone logistic)
-            const u64 *kg = ks.keys + (size_t)g * GCAP;
-            auto for_each = [&](auto &&f) {
-                for (int j = tid; j < cnt; j += NTM) f(kg[j], false);
-            };
-            radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
-            collect_and_sort<NTM>(for_each, prefix, mask, sh);
-        } else {
-            // exact full scan of the image (constant maps, tiny maps, fewer than K positive
-            // peaks): slow, never taken on ordinary heat-maps
-            const float *img = ks.heat + (size_t)g * C * HW;
-            const bool sig = (ks.flags & 1) != 0, nonms = (ks.flags & CN_DECODE_NO_PEAK_TEST) != 0;
-            auto for_each = [&](auto &&f) {
-                for (int fid = tid; fid < C * HW; fid += NTM) {
-                    const int c = fid / HW, e = fid - c * HW;
-                    const int y = e / W, x = e - y * W;
-                    const uint32_t kk = f2key(peak_value_global(img + (size_t)c * HW, H, W, y, x, sig, nonms));
-                    f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - (uint32_t)fid), kk == KEY_ZERO);
-                }
-            };
-            radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
-            collect_and_sort<NTM>(for_each, prefix, mask, sh);
-        }
+        if (cnt < K || cnt > GCAP) return;
+        const u64 *kg = ks.keys + (size_t)g * GCAP;
+        auto for_each = [&](auto &&f) {
+            for (int j = tid; j < cnt; j += NTM) f(kg[j], false);
+        };
+        radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
+        collect_and_sort<NTM>(for_each, prefix, mask, sh);
     } else {
+        if (CTDET && ks.counts) {   // gated: only the images the candidate list could not serve
+            const int cnt = ks.counts[g];
+            if (cnt >= K && cnt <= GCAP) return;
+        }
         auto for_each = [&](auto &&f) {
             for (int j = tid; j < N; j += NTM) {
                 const int32_t idx = ci[j];
@@ -834,12 +815,13 @@ bool make_band_plan(int B, int C, int H, int W, int K, BandPlan *bp)
 }
 
 int launch_nms_topk(const float *heat, int B, int C, int H, int W, int K, int apply_sigmoid,
-                    const BandPlan &bp, float *cand_score, int32_t *cand_idx, hipStream_t st)
+                    const BandPlan &bp, float *cand_score, int32_t *cand_idx, hipStream_t st,
+                    const int32_t *gate = nullptr)
 {
     dim3 grid(bp.nbands, C, B), block(NT);
     CN_SET_MAX_LDS_ONCE(nms_topk_kernel, 160 * 1024);
     hipLaunchKernelGGL(nms_topk_kernel, grid, block, bp.lds, st, heat, C, H, W, K, bp.R,
-                       apply_sigmoid, cand_score, cand_idx);
+                       apply_sigmoid, cand_score, cand_idx, gate);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -945,6 +927,14 @@ extern "C" int cn_ctdet_decode_f32(const float *heat, const float *wh, const flo
                            sizeof(SelShared), st, cand_score, cand_idx, 0, 1, H, W, K, C, wh, reg,
                            cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr, 0,
                            (int32_t *)nullptr, ks);
+        CN_CHECK_LAUNCH();
+        // images whose candidate list was unusable (every workgroup of the others exits at once)
+        rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st, ks.counts);
+        if (rc != CN_OK) return rc;
+        hipLaunchKernelGGL(merge_topk_kernel<MODE_CTDET>, dim3(B), dim3(NTM), sizeof(SelShared), st,
+                           cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh,
+                           reg, cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr,
+                           0, (int32_t *)nullptr, ks);
         CN_CHECK_LAUNCH();
         return CN_OK;
     }
@@ -1219,6 +1209,13 @@ extern "C" int cn_topk_f32(const float *heat, int B, int C, int H, int W, int K,
                            apply_sigmoid};
         hipLaunchKernelGGL((merge_topk_kernel<MODE_TOPK, true>), dim3(B), dim3(NTM),
                            sizeof(SelShared), st, cand_score, cand_idx, 0, 1, H, W, K, C,
+                           (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0,
+                           inds, scores, (const float *)nullptr, 0, clses, ks);
+        CN_CHECK_LAUNCH();
+        rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st, ks.counts);
+        if (rc != CN_OK) return rc;
+        hipLaunchKernelGGL(merge_topk_kernel<MODE_TOPK>, dim3(B), dim3(NTM), sizeof(SelShared), st,
+                           cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C,
                            (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0,
                            inds, scores, (const float *)nullptr, 0, clses, ks);
         CN_CHECK_LAUNCH();
