@@ -201,10 +201,12 @@ class PlanBuilder:
         return hit if f32s else hit[0]
 
     @staticmethod
-    def _f32s_conv_form(kh, kw, stride, padding, dilation, out_nchw):
-        """Convolution forms that have an f32s kernel: every NHWC-input form (the 3-channel stem
-        reads the fp32 image on the fp32 kernels)."""
-        return True
+    def _f32s_conv_form(kh, kw, stride, padding, dilation, out_nchw, ci=0, co=0):
+        """Convolution forms that run in f32s: every NHWC-input form except DLA's 16-channel
+        3x3 layers (level0 / level1), which are HBM-bound at full resolution and keep their
+        dedicated 16x16x4 kernel (cn_conv16.hip: half the K padding of a 32-channel chunk)."""
+        return not (ci == 16 and co <= 32 and (kh, kw, padding, dilation) == (3, 3, 1, 1)
+                    and not out_nchw)
 
     def _grow_ws(self, need):
         # split-K scratch shared by every launch (stream-ordered; ops read self.ws at run time)
@@ -228,7 +230,7 @@ class PlanBuilder:
         Ho = _out_size(x.H, kh, stride, padding, dilation)
         Wo = _out_size(x.W, kw, stride, padding, dilation)
         use_s = self.split and not x.nchw and self._f32s_conv_form(kh, kw, stride, padding,
-                                                                  dilation, out_nchw)
+                                                                  dilation, out_nchw, ci, co)
         scale, shift = fold_bn(bias, bn, co, self.device)
         flags = 0
         if use_s:

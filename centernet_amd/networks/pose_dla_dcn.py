@@ -147,8 +147,10 @@ class DeformConv(nn.Module):
                         deformable_groups=1)
 
     def describe(self, pb, x):
-        # pose_dla_dcn.py:354-357: DCN -> BN -> ReLU, one fused launch (+ the offset conv)
-        return pb.dcn(x, self.conv, bn=self.actf[0], relu=True)
+        # pose_dla_dcn.py:354-357: DCN -> BN -> ReLU, one fused launch (+ the offset conv).
+        # Everything downstream in the up-sampling pyramid reads plain floats (the deformable
+        # gather, the depthwise transposed conv and its skip add), so the result is written plain.
+        return pb.dcn(x, self.conv, bn=self.actf[0], relu=True, out_plain=True)
 
 
 class IDAUp(nn.Module):
