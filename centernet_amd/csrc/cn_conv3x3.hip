@@ -24,6 +24,11 @@
 // cn_set_tuning key 18: phase shift of co-resident workgroups, percent of one tile's MFMA time
 // (0 = off); see the kernel prologue
 int cn_tune_stagger_pct = 100;
+// f32s: taps a weight tile is requested ahead of its use (1 = the fp32 schedule; build-time so that
+// the register allocation of each form is its own: -DCN_F32S_PREFETCH_TAPS=1 for A/B builds)
+#ifndef CN_F32S_PREFETCH_TAPS
+#define CN_F32S_PREFETCH_TAPS 3
+#endif
 
 namespace {
 
@@ -110,7 +115,7 @@ constexpr size_t c3_union_floats()
 // halo restage per 32-channel chunk.  With three fp16 MFMAs per product a tap is only ~400
 // cycles of matrix work: the per-tap weight staging + barrier of the LDS form cost more than that.
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false, bool DECONV = false, int NBUFB = 2>
+          bool KSKIP = false, bool DECONV = false, int NBUFB = 2, bool DEEP = true>
 __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &hd)
 {
     // DECONV: ConvTranspose2d(4, stride 2, pad 1) -- blockIdx.z = output parity (py, px); each
@@ -183,14 +188,18 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         }
     }
     // ---- per-thread halo rows: pixel offset in the input (or -1: outside image / halo)
-    int hoff[NPA];
+    // as BYTE offsets of the lane's 16-byte slot in chunk 0 (tensors < 4 GiB, checked by the
+    // caller): loads are SGPR base + 32-bit lane offset, no 64-bit address arithmetic in the loop
+    constexpr unsigned NOPIX = 0xffffffffu;
+    unsigned hoff[NPA];
 #pragma unroll
     for (int p = 0; p < NPA; ++p) {
         const int hr = p * RPP + lrow;
         const int hy = hr / HW_, hx = hr - hy * HW_;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
         hoff[p] = (hr < HR && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                      ? (b * a.H + iy) * a.W + ix : -1;
+                      ? (unsigned)(((b * a.H + iy) * a.W + ix) * a.in_pitch + EPV * q) * (unsigned)sizeof(T)
+                      : NOPIX;
     }
     for (int m = tid; m < BM; m += NT) {
         const int ty = m / TW, tx = m - ty * TW;
@@ -216,11 +225,12 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         // f32s input: a 128-byte group holds 32 channels as high / low halves, so a 16-byte slot
         // is not "4 channels": the whole group is taken (channels past Cin are stored as zeros)
         const bool cok = (SPLIT && !a.in_plain) ? (chunk * BKE < a.Cin) : (c < a.Cin);
+        const unsigned coff = (unsigned)(chunk * BKE) * (unsigned)sizeof(T);
+        const char *xb = reinterpret_cast<const char *>(xT);
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {
-            const bool ok = hoff[p] >= 0 && cok;
-            const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
-                xT + (ok ? ((size_t)hoff[p] * a.in_pitch + c) : 0));
+            const bool ok = hoff[p] != NOPIX && cok;
+            const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(xb + (ok ? hoff[p] + coff : 0u));
             ra[p] = ok ? v : zero4;
         }
     };
@@ -247,13 +257,19 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
             if (hr < HR) *reinterpret_cast<cn_f32x4 *>(As + hr * LDT + 4 * q) = ra[p];
         }
     };
-    auto load_B = [&](int chunk, int tap) {
+    // weight rows of this thread: byte offsets inside one tap's [cout_pad][cin_pad] matrix
+    unsigned boff[PB];
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int n = min(n0 + p * RPP + lrow, a.cout_pad - 1);
-            rb[p] = *reinterpret_cast<const cn_f32x4 *>(
-                wT + ((size_t)(tap * a.cout_pad + n) * a.cin_pad + chunk * BKE + EPV * q));
-        }
+    for (int p = 0; p < PB; ++p)
+        boff[p] = (unsigned)(min(n0 + p * RPP + lrow, a.cout_pad - 1) * a.cin_pad + EPV * q) * (unsigned)sizeof(T);
+    auto wtile = [&](int chunk, int tap) {   // uniform base of (tap, chunk)
+        return reinterpret_cast<const char *>(wT) +
+               ((size_t)tap * a.cout_pad * a.cin_pad + (size_t)chunk * BKE) * sizeof(T);
+    };
+    auto load_B = [&](int chunk, int tap) {
+        const char *wb = wtile(chunk, tap);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const cn_f32x4 *>(wb + boff[p]);
     };
     auto store_B = [&](int buf) {
         float *Bd = Bs + buf * BN * LDT;
@@ -453,6 +469,55 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         }
         __syncthreads();  // all waves out of the main loop before the epilogue reuses the LDS
     } else {
+        // ---- f32s: weight tiles prefetched PD taps ahead.  With three fp16 MFMAs per product a
+        // (tap, chunk) step is ~400 matrix cycles (0.17 us); a weight tile requested one step
+        // ahead (the fp32 schedule below) arrives after ~1-1.5 us under load, so every step ended
+        // up waiting for L2.  Here the request for step i + PD is issued when step i starts, into
+        // a rotating register queue (slots static: NTAPS % PD == 0, the tap loop is unrolled), and
+        // the next chunk's halo is requested AHEAD taps before it is needed.
+        constexpr int PD = (SPLIT && NBUFB == 2 && DEEP && CN_F32S_PREFETCH_TAPS > 1) ? (DECONV ? 2 : CN_F32S_PREFETCH_TAPS) : 1;
+        if constexpr (PD > 1) {
+            {
+                static_assert(NTAPS % PD == 0, "static queue slots");
+                constexpr int AHEAD = NTAPS > 4 ? NTAPS - 4 : 0;
+                cn_f32x4 rq[PD][PB];
+                auto issue_B = [&](cn_f32x4 *dst, int chunk, int tap) {
+                    const char *wb = wtile(chunk, tap);
+#pragma unroll
+                    for (int p = 0; p < PB; ++p) dst[p] = *reinterpret_cast<const cn_f32x4 *>(wb + boff[p]);
+                };
+                auto put_B = [&](const cn_f32x4 *src, int buf) {
+                    float *Bd = Bs + buf * BN * LDT;
+#pragma unroll
+                    for (int p = 0; p < PB; ++p)
+                        *reinterpret_cast<cn_f32x4 *>(Bd + (p * RPP + lrow) * LDT + 4 * q) = src[p];
+                };
+                load_A(0);
+#pragma unroll
+                for (int u = 0; u < PD; ++u) issue_B(rq[u], 0, u);
+                store_A();
+                put_B(rq[0], 0);
+                __syncthreads();
+                for (int c = 0; c < a.nchunk; ++c) {
+                    const bool nextc = (c + 1) < a.nchunk;
+#pragma unroll
+                    for (int t = 0; t < NTAPS; ++t) {
+                        const int it = c * NTAPS + t;
+                        const bool wrap = (t + PD) >= NTAPS;
+                        // step it + PD goes into the slot step `it` left when it was put into LDS
+                        if (!wrap || nextc) issue_B(rq[t % PD], wrap ? c + 1 : c, (t + PD) % NTAPS);
+                        if (t == AHEAD && nextc) load_A(c + 1);
+                        compute(t, it & 1, 4);
+                        if (t == NTAPS - 1 && nextc) {
+                            __syncthreads();  // every wave is done with the old halo
+                            store_A();
+                        }
+                        if (t + 1 < NTAPS || nextc) put_B(rq[(t + 1) % PD], (it + 1) & 1);
+                        __syncthreads();
+                    }
+                }
+            }
+        } else {
     // ---- main loop: chunk-major, taps inner; B double-buffered, A halo single-buffered
         load_A(0);
         load_B(0, 0);
@@ -485,8 +550,8 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                 __syncthreads();
             }
         }
-    
-}
+        }
+    }
 
     if constexpr (HEADS) {
         // ---- fused head epilogue (resnet_dcn.py:155-177): hidden = relu(acc + bias1) stays in
@@ -738,10 +803,10 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
 }
 
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false, bool DECONV = false, int NBUFB = 2>
+          bool KSKIP = false, bool DECONV = false, int NBUFB = 2, bool DEEP = true>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
 {
-    conv3x3s1_body<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB>(a, hd);
+    conv3x3s1_body<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, DEEP>(a, hd);
 }
 
 // 64-wide tiles at FOUR workgroups per CU (<= 128 registers, single-buffered weight tile ->
@@ -778,12 +843,12 @@ int launch_c3_occ4(const C3Args &a, hipStream_t st)
 }
 
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false, bool DECONV = false, int NBUFB = 2>
+          bool KSKIP = false, bool DECONV = false, int NBUFB = 2, bool DEEP = true>
 int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 {
     constexpr int TH = BM / TW;
     constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS, BM, NBUFB>() * 4 + BM * 4;
-    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB>), lds);
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, DEEP>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
@@ -808,7 +873,7 @@ int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
         }
     }
     const C3Heads none = {};
-    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB>), grid,
+    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, DEEP>), grid,
                        dim3(WM * WN * 64), lds,
                        st, b,
                        hd ? *hd : none);
@@ -881,6 +946,14 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
                              cn_cdiv(a.Cout, 64);
             if (a.occ4 == 1 || c3_occ4_pays(wgs))
                 return wide ? launch_c3_occ4<float, 32>(a, st) : launch_c3_occ4<float, 16>(a, st);
+        }
+        if constexpr (std::is_same<T, cn_f32s>::value) {
+            // deep weight prefetch costs the 64-wide tile one of its three workgroups per CU
+            // (174 vs 132 registers): it pays on long K loops (512->512@16^2: 0.135 -> 0.117 ms)
+            // and loses on the two-chunk 64->64 layers (0.149 -> 0.158), measured at B = 32
+            if (a.nchunk < 4)
+                return wide ? launch_c3<T, 32, 64, 2, 2, false, 128, false, false, 2, false>(a, st)
+                            : launch_c3<T, 16, 64, 2, 2, false, 128, false, false, 2, false>(a, st);
         }
         return wide ? launch_c3<T, 32, 64, 2, 2>(a, st) : launch_c3<T, 16, 64, 2, 2>(a, st);
     }
@@ -996,8 +1069,9 @@ int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale,
         if (Cout > 64)
             return wide ? launch_c3<cn_f32s, 32, 128, 4, 2, false, 128, false, true>(a, st)
                         : launch_c3<cn_f32s, 16, 128, 4, 2, false, 128, false, true>(a, st);
-        return wide ? launch_c3<cn_f32s, 32, 64, 2, 2, false, 128, false, true>(a, st)
-                    : launch_c3<cn_f32s, 16, 64, 2, 2, false, 128, false, true>(a, st);
+        // (64-wide: the one-tap-ahead schedule keeps three workgroups per CU, 0.092 vs 0.105 ms)
+        return wide ? launch_c3<cn_f32s, 32, 64, 2, 2, false, 128, false, true, 2, false>(a, st)
+                    : launch_c3<cn_f32s, 16, 64, 2, 2, false, 128, false, true, 2, false>(a, st);
     }
     if (Cout > 64)
         return wide ? launch_c3<float, 32, 128, 4, 2, false, 128, false, true>(a, st)

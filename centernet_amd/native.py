@@ -12,7 +12,8 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcenternet_amd.so")
+# CENTERNET_AMD_LIB: another build of the same library (A/B measurements, tools/build_variant.sh)
+LIB_PATH = os.environ.get("CENTERNET_AMD_LIB") or os.path.join(_HERE, "libcenternet_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CN_OK = 0

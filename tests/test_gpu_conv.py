@@ -125,7 +125,8 @@ def _conv_case(dev, cfg, split=False):
     pb = PlanBuilder(dev, B, H, W, split=split)
     y = pb.conv(_nhwc_act(x, dev), w, bias=bias, bn=bn, relu=relu,
                 residual=_nhwc_act(res, dev) if use_res else None, stride=s, padding=p)
-    assert y.fmt == ("f32s" if split else "f32")
+    want_s = split and PlanBuilder._f32s_conv_form(k, k, s, p, 1, False, Cin, Cout)
+    assert y.fmt == ("f32s" if want_s else "f32")
     y = pb.plain(y)
     _run(pb)
     _check(y.t[..., :Cout].permute(0, 3, 1, 2).cpu(), ref.detach())

@@ -7,14 +7,23 @@ import torch
 from centernet_amd import native
 from centernet_amd.engine import PlanBuilder, Act
 dev = torch.device("cuda:0"); lib = native.lib(); B = 32
-SHAPES = [(64, 128, 128, 64), (128, 64, 64, 128), (256, 32, 32, 256), (512, 16, 16, 512)]
+SHAPES = [(64, 128, 128, 64), (64, 128, 128, 192), (128, 64, 64, 128), (256, 32, 32, 256), (512, 16, 16, 512)]
+ONLY = [int(v) for v in os.environ.get("ONLY", "").split(",") if v]
+MODES = [int(v) for v in os.environ.get("MODES", "0,1,2,4,7").split(",")]
+if ONLY:
+    SHAPES = [SHAPES[i] for i in ONLY]
 STAG = [int(v) for v in os.environ.get("STAG", "").split(",") if v]
 print("%-22s" % "Cin,H,W,Cout", "  ".join("%-12s" % n for n in (["stag%d" % v for v in STAG] if STAG else ("full", "-epilogue", "-B stage", "-A stage", "-all three"))))
 for ci, H, W, co in SHAPES:
     x = Act(torch.randn((B, H, W, ci), device=dev), B, H, W, ci)
+    if os.environ.get("CN_F32S", "1") != "0":       # f32s activations, as inside the network
+        pb0 = PlanBuilder(dev, B, H, W)
+        x = pb0.packed(x)
+        for op in pb0.ops: op()
+        torch.cuda.synchronize()
     w = torch.randn((co, ci, 3, 3)) * 0.05
     row = []
-    for dbg in (STAG if STAG else (0, 1, 2, 4, 7)):
+    for dbg in (STAG if STAG else MODES):
         lib.cn_set_tuning(18 if STAG else 9, dbg)
         pb = PlanBuilder(dev, B, H, W)
         pb.conv(x, w, relu=True, stride=1, padding=1)
