@@ -1159,7 +1159,7 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho && d->OW == d->Wo)
         return cn_conv3x3s1(x, w_packed, scale, shift, residual, y, d->B, d->H, d->W, d->Cin,
                             d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
-                            g_tune_setprio | (g_tune_bm256 << 1) | (g_tune_waves8 << 2) | (g_tune_occ4 << 7) |
+                            g_tune_setprio | ((g_tune_bm256 & 1) << 1) | ((g_tune_bm256 >> 1) << 3) | (g_tune_waves8 << 2) | (g_tune_occ4 << 7) |
                                 (g_tune_dbgskip << 4), cls, d->dtype | (d->flags << 8), st);
     if (f32s) {
         if (cls == 2)
@@ -1500,7 +1500,7 @@ extern "C" int cn_set_tuning(int key, int value)
         g_tune_dcn_split = value;
         return CN_OK;
     }
-    if (key == 14 && (value == 0 || value == 1)) {
+    if (key == 14 && value >= 0 && value <= 3) {
         g_tune_bm256 = value;
         return CN_OK;
     }

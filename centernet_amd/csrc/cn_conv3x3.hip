@@ -804,7 +804,8 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
 
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
           bool KSKIP = false, bool DECONV = false, int NBUFB = 2, bool DEEP = true>
-__global__ __launch_bounds__(WM * WN * 64) void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
+__global__ __launch_bounds__(WM * WN * 64, (std::is_same<T, cn_f32s>::value && BM == 256 && WM * WN == 8) ? 4 : 1)
+void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
 {
     conv3x3s1_body<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, DEEP>(a, hd);
 }
@@ -933,8 +934,15 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
         // per barrier.  Measured on MI355X (tools/bench_knob.py 14): no gain (resdcn_18 8.21 vs
         // 8.23 ms, dla_34 24.36 vs 24.39 ms per 32 images), so opt-in only (cn_set_tuning 14).
         const long wgs256 = (long)a.B * cn_cdiv(a.H, 8) * cn_cdiv(a.W, 32) * cn_cdiv(a.Cout, 64);
-        if (wide && a.H >= 8 && a.bm256 && wgs256 >= 1024)
+        if (wide && a.H >= 8 && a.bm256 == 1 && wgs256 >= 1024)
             return launch_c3<T, 32, 64, 4, 1, false, 256>(a, st);
+        if constexpr (std::is_same<T, cn_f32s>::value) {
+            // 256-pixel tiles as EIGHT waves of 64 x 32 (two workgroups = 16 waves per CU)
+            if (wide && a.H >= 8 && a.bm256 == 2 && wgs256 >= 1024)
+                return launch_c3<T, 32, 64, 4, 2, false, 256, false, false, 2, false>(a, st);
+            if (wide && a.H >= 8 && a.bm256 == 3 && wgs256 >= 1024)
+                return launch_c3<T, 32, 64, 4, 2, false, 256, false, false, 2, true>(a, st);
+        }
         if (kskip)
             return wide ? launch_c3<float, 32, 64, 2, 2, false, 128, true>(a, st)
                         : launch_c3<float, 16, 64, 2, 2, false, 128, true>(a, st);
@@ -971,7 +979,7 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
                  int f16, hipStream_t st)
 {
     C3Args a = {};
-    a.bm256 = (setprio >> 1) & 1;  // bit 1 of the knob word: cn_set_tuning key 14
+    a.bm256 = ((setprio >> 1) & 1) | ((setprio >> 2) & 2);  // bits 1 and 3 of the knob word: cn_set_tuning key 14
     a.waves8 = (setprio >> 2) & 1; // bit 2: cn_set_tuning key 15
     a.dbg = (setprio >> 4) & 7;    // bits 4-6: ablation switches (cn_set_tuning key 9)
     a.occ4 = (setprio >> 7) & 3;   // bits 7-8: cn_set_tuning key 19

@@ -583,8 +583,15 @@ __global__ __launch_bounds__(NT) void group_threshold_kernel(const uint32_t *__r
     }
 }
 
-// phase 3: exact evaluation of the cells that can reach the threshold, group by group; one
-// workgroup per (image, class) plane walks the plane's group list
+// phase 3: exact evaluation of the cells that can reach the threshold.  One workgroup per (image,
+// class) plane; its eight half-waves share the plane's live groups (all-cell maximum >= the raw
+// threshold).  A half-wave re-reads its 8 x 128 group with the same rolling register window as
+// phase 1 (10 row loads, neighbours by shuffle), applies the logistic to the whole window and
+// runs the reference's test on the SCORES -- 3x3 maximum, exact equality (decode.py:9-15) -- in
+// registers; qualifying cells are counted per lane, placed by a half-wave prefix sum and ONE
+// atomic per group.  The threshold often falls INTO the noise floor of a real heat-map (a few
+// confident objects, K = 100): then most groups are live and this pass costs about what phase 1
+// does plus the logistics -- not nine dependent loads per cell over the threshold.
 __global__ __launch_bounds__(NT) void peak_collect_kernel(const float *__restrict__ heat, int C, int H,
                                                           int W, int nrg, int ncb, int flags,
                                                           const uint32_t *__restrict__ gall,
@@ -595,10 +602,11 @@ __global__ __launch_bounds__(NT) void peak_collect_kernel(const float *__restric
 {
     const int tid = threadIdx.x;
     const int lane = tid & (CN_WAVE - 1);
+    const int hl = lane & 31, hw = tid >> 5;
     const size_t plane_id = blockIdx.x;
     const int b = (int)(plane_id / C), c = (int)(plane_id - (size_t)b * C);
     const uint32_t tkey = thr[b];
-    if (tkey <= KEY_ZERO) return;   // degenerate image: phase 4 scans it exactly
+    if (tkey <= KEY_ZERO) return;   // degenerate image: served by the gated per-band select
     const bool sig = (flags & 1) != 0;
     const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;
     const float rthr = rawthr[b];
@@ -606,46 +614,91 @@ __global__ __launch_bounds__(NT) void peak_collect_kernel(const float *__restric
     const float *plane = heat + plane_id * (size_t)H * W;
     const uint32_t base = (uint32_t)c * (uint32_t)(H * W);
     u64 *kimg = keys + (size_t)b * GCAP;
+    const int w4 = W >> 2;
+    const float NEG_INF = -__builtin_huge_valf();
+
     auto collect_group = [&](int g) {
         const int rg = g / ncb, cb = g - rg * ncb;
-        // 8 rows x 128 columns = 1024 cells, four per thread
-#pragma unroll 1
-        for (int s = 0; s < (GROWS * 128) / NT; ++s) {
-            const int e = s * NT + tid;
-            const int y = rg * GROWS + (e >> 7), x = cb * 128 + (e & 127);
-            bool take = false;
-            uint32_t k = 0u;
-            const int cell = y * W + x;
-            if (y < H && x < W) {
-                const float raw = plane[cell];
-                if (raw >= rthr) {
-                    const float v = sig ? sigmoidf_ref(raw) : raw;
-                    float m = v;
-                    if (!nonms) {
-                        for (int dy = -1; dy <= 1; ++dy)
-                            for (int dx = -1; dx <= 1; ++dx) {
-                                const int yy = y + dy, xx = x + dx;
-                                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-                                const float n = plane[yy * W + xx];
-                                m = fmaxf(m, sig ? sigmoidf_ref(n) : n);
-                            }
-                    }
-                    k = f2key(((m == v) ? v : 0.0f) + 0.0f);
-                    take = k >= tkey;
-                }
+        const int y0 = rg * GROWS;
+        const int x4 = cb * 32 + hl;
+        const bool col_ok = x4 < w4;
+        cn_f32x4 rowv[GROWS + 2];
+        float lft[GROWS + 2], rgt[GROWS + 2];
+#pragma unroll
+        for (int r = 0; r < GROWS + 2; ++r) {
+            const int y = y0 - 1 + r;
+            const bool ok = col_ok && y >= 0 && y < H;
+            rowv[r].x = rowv[r].y = rowv[r].z = rowv[r].w = NEG_INF;
+            lft[r] = rgt[r] = NEG_INF;
+            if (ok) {
+                const float *p = plane + (size_t)y * W + x4 * 4;
+                rowv[r] = *reinterpret_cast<const cn_f32x4 *>(p);
+                if (hl == 0 && x4 > 0) lft[r] = p[-1];
+                if (hl == 31 && x4 + 1 < w4) rgt[r] = p[4];
             }
-            const u64 bal = __ballot(take);
-            if (bal) {
-                const int leader = __ffsll((long long)bal) - 1;
-                int pos0 = 0;
-                if (lane == leader) pos0 = atomicAdd(&counts[b], __popcll(bal));
-                pos0 = __shfl(pos0, leader);
-                if (take) {
-                    const int pos = pos0 + (int)__builtin_amdgcn_mbcnt_hi(
-                                               (uint32_t)(bal >> 32),
-                                               __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        }
+        if (sig) {   // scores of the whole window (cells outside the map stay -inf)
+#pragma unroll
+            for (int r = 0; r < GROWS + 2; ++r) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rowv[r][e] != NEG_INF) rowv[r][e] = sigmoidf_ref(rowv[r][e]);
+                if (lft[r] != NEG_INF) lft[r] = sigmoidf_ref(lft[r]);
+                if (rgt[r] != NEG_INF) rgt[r] = sigmoidf_ref(rgt[r]);
+            }
+        }
+        cn_f32x4 hmax[GROWS + 2];
+#pragma unroll
+        for (int r = 0; r < GROWS + 2; ++r) {
+            float l = __shfl_up(rowv[r].w, 1, 32);
+            float rr = __shfl_down(rowv[r].x, 1, 32);
+            if (hl == 0) l = lft[r];
+            if (hl == 31) rr = rgt[r];
+            if (!col_ok) { l = NEG_INF; rr = NEG_INF; }
+            hmax[r].x = fmaxf(fmaxf(l, rowv[r].x), rowv[r].y);
+            hmax[r].y = fmaxf(fmaxf(rowv[r].x, rowv[r].y), rowv[r].z);
+            hmax[r].z = fmaxf(fmaxf(rowv[r].y, rowv[r].z), rowv[r].w);
+            hmax[r].w = fmaxf(fmaxf(rowv[r].z, rowv[r].w), rr);
+        }
+        // this lane's 32 cells: bit (r-1)*4+e set when the cell's key reaches the threshold
+        auto cell_key = [&](int r, int e) -> uint32_t {
+            const float v = rowv[r][e];
+            const float m = fmaxf(fmaxf(hmax[r - 1][e], hmax[r][e]), hmax[r + 1][e]);
+            return f2key(((nonms || m == v) ? v : 0.0f) + 0.0f);
+        };
+        uint32_t tmask = 0u;
+#pragma unroll
+        for (int r = 1; r <= GROWS; ++r) {
+            const int y = y0 - 1 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool take = col_ok && y < H && cell_key(r, e) >= tkey;
+                tmask |= take ? (1u << ((r - 1) * 4 + e)) : 0u;
+            }
+        }
+        // half-wave inclusive prefix sum of the per-lane counts, one atomic for the group
+        const int mine = __popc(tmask);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int t = __shfl_up(incl, o, 32);
+            if (hl >= o) incl += t;
+        }
+        const int total = __shfl(incl, 31, 32);
+        if (total == 0) return;
+        int pos0 = 0;
+        if (hl == 31) pos0 = atomicAdd(&counts[b], total);
+        int pos = __shfl(pos0, 31, 32) + incl - mine;
+#pragma unroll
+        for (int r = 1; r <= GROWS; ++r) {
+            const int y = y0 - 1 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (tmask & (1u << ((r - 1) * 4 + e))) {
+                    const uint32_t cell = (uint32_t)(y * W + x4 * 4 + e);
                     if (pos < GCAP)
-                        kimg[pos] = ((u64)k << 32) | (u64)(0xFFFFFFFFu - (base + (uint32_t)cell));
+                        kimg[pos] = ((u64)cell_key(r, e) << 32) | (u64)(0xFFFFFFFFu - (base + cell));
+                    ++pos;
                 }
             }
         }
@@ -653,24 +706,27 @@ __global__ __launch_bounds__(NT) void peak_collect_kernel(const float *__restric
     const int ng = nrg * ncb;
     // which groups can hold a qualifying cell: all group maxima are fetched at once (a chain of
     // dependent loads here cost more than the whole streaming pass)
-    __shared__ u64 live[4];
+    // and the live ones compacted into a list, so that the two halves of a wave always work on
+    // two groups at the same time
+    __shared__ u64 live[NT / 64];
+    __shared__ int glist[NT];
     for (int g0 = 0; g0 < ng; g0 += NT) {
         const int g = g0 + tid;
         const bool q = g < ng && gall[plane_id * ng + g] >= rkey;
         const u64 bal = __ballot(q);
         if (lane == 0) live[tid >> 6] = bal;
         __syncthreads();
-        u64 mine[4] = {live[0], live[1], live[2], live[3]};
-        __syncthreads();
-#pragma unroll 1
-        for (int w = 0; w < 4; ++w) {
-            u64 bits = mine[w];
-            while (bits) {
-                const int bit = __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                collect_group(g0 + w * 64 + bit);
-            }
+        int before = 0, nlive = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) {
+            const int n = __popcll(live[w]);
+            if (w < (tid >> 6)) before += n;
+            nlive += n;
         }
+        if (q) glist[before + __popcll(bal & ((1ull << lane) - 1ull))] = g;
+        __syncthreads();
+        for (int i = hw; i < nlive; i += NT / 32) collect_group(glist[i]);
+        __syncthreads();
     }
 }
 

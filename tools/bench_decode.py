@@ -7,9 +7,38 @@ lib = native.lib()
 dev = torch.device("cuda:0")
 B, C, H, W, K = int(os.environ.get("B", 32)), 80, 128, 128, 100
 g = torch.Generator().manual_seed(0)
-logits = (2 * torch.randn((B, C, H, W), generator=g) - 2.19).to(dev)
 wh = (40 * torch.rand((B, 2, H, W), generator=g)).to(dev)
 reg = torch.rand((B, 2, H, W), generator=g).to(dev)
+
+
+def heat_map(kind):
+    """iid: independent Gaussian logits; net: the hm head of resdcn_18 on synthetic images
+    (spatially smooth); floor: what a trained detector emits -- a smooth noise floor near
+    sigmoid = 1e-3 with a few confident blobs, so the K-th peak lies INSIDE the floor."""
+    if kind == "iid":
+        return (2 * torch.randn((B, C, H, W), generator=g) - 2.19).to(dev)
+    if kind == "net":
+        from centernet_amd import synth
+        from centernet_amd.model import create_model
+        m = create_model("resdcn_18", {"hm": C, "wh": 2, "reg": 2}, 64)
+        synth.fill_state_dict_(m, 317)
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            return m(synth.images(B, 4 * H, 4 * W, seed=0).to(dev))[-1]["hm"].clone()
+    lo = torch.nn.functional.interpolate(torch.randn((B, C, H // 4, W // 4), generator=g), scale_factor=4,
+                                         mode="bilinear", align_corners=False)
+    x = -6.9 + 0.4 * lo + 0.05 * torch.randn((B, C, H, W), generator=g)
+    for b in range(B):
+        for _ in range(12):
+            c, y, xx = (int(torch.randint(0, n_, (1,), generator=g)) for n_ in (C, H - 8, W - 8))
+            yy, xg = torch.meshgrid(torch.arange(8.0), torch.arange(8.0), indexing="ij")
+            x[b, c, y:y + 8, xx:xx + 8] += 8.0 * torch.exp(-((yy - 3.5) ** 2 + (xg - 3.5) ** 2) / 6.0)
+    return x.to(dev)
+
+
+KIND = os.environ.get("HEAT", "iid")
+logits = heat_map(KIND).contiguous()
+print("heat map:", KIND)
 dets = torch.empty((B, K, 6), device=dev)
 inds = torch.empty((B, K), device=dev, dtype=torch.int32)
 n = lib.cn_ctdet_decode_workspace_bytes(B, C, H, W, K)
