@@ -822,6 +822,10 @@ int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, 
                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
                      int stride, int pad, int relu, int out_pitch, int KP, int persistent,
                      hipStream_t st);
+int cn_stem_pool_rows(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int KP);
+int cn_stem_pool_f32s(const float *x, const float *w_packed, const float *scale, const float *shift,
+                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
+                      int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st);
 int cn_dcn_window_f32(const float *x, const float *w_packed, const float *bias, const float *om,
                       int om_pitch, const float *scale, const float *shift, float *y, int B, int Cin,
                       int H, int W, int Cout, int mask_sigmoid, int relu, int setprio, hipStream_t st);
@@ -1131,6 +1135,14 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
             return launch_igemm_h<128, 32, 4, 1, A_STEM, false>(a, st);
         }
         // LDS-window kernel (cn_stem.hip) when the tile's input window fits; else generic
+        if (d->flags & CN_CONV_STEM_MAXPOOL) {
+            // y is the max-pooled map (B, Ho/2, Wo/2): only the fused f32s kernel produces it
+            if (!(d->flags & CN_CONV_STEM_F32S) || residual || d->pad_h != d->pad_w || d->dil != 1)
+                return CN_ERR_UNSUPPORTED;
+            return cn_stem_pool_f32s((const float *)x, (const float *)w_packed, scale, shift,
+                                     (float *)y, d->B, d->H, d->W, d->Ho, d->Wo, d->Cout, d->KH,
+                                     d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad, st);
+        }
         if (!g_tune_nostem && d->pad_h == d->pad_w && d->dil == 1 && d->oy_mul == 1 &&
             d->ox_mul == 1 && d->OH == d->Ho && d->OW == d->Wo) {
             rc = cn_stem_conv_f32((const float *)x, (const float *)w_packed, scale, shift,
@@ -1160,7 +1172,7 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         return cn_conv3x3s1(x, w_packed, scale, shift, residual, y, d->B, d->H, d->W, d->Cin,
                             d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
                             g_tune_setprio | ((g_tune_bm256 & 1) << 1) | ((g_tune_bm256 >> 1) << 3) | (g_tune_waves8 << 2) | (g_tune_occ4 << 7) |
-                                (g_tune_dbgskip << 4), cls, d->dtype | (d->flags << 8), st);
+                                ((g_tune_dbgskip & 7) << 4) | ((g_tune_dbgskip >> 3) << 9), cls, d->dtype | (d->flags << 8), st);
     if (f32s) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_s<64, 128, 2, 2, A_DENSE, false>(a, st)
@@ -1449,6 +1461,15 @@ extern "C" int cn_conv_transpose4x4s2(const void *x_nhwc, const void *w_packed, 
     return launch_igemm<128, 32, 4, 1, A_DENSE, false>(a, st);
 }
 
+extern "C" int cn_stem_maxpool_supported(const cn_conv_desc *d)
+{
+    if (!d || !is_stem(d->Cin, d->in_layout) || d->out_layout != CN_LAYOUT_NHWC) return 0;
+    if (d->dtype != CN_DTYPE_F32 || d->pad_h != d->pad_w || d->dil != 1) return 0;
+    if (round_up(d->KH * d->KW * 3, 32) > STEM_KMAX) return 0;
+    return cn_stem_pool_rows(d->B, d->Ho, d->Wo, d->Cout, d->KH, d->KW, d->stride,
+                             round_up(d->KH * d->KW * 3, 32)) > 0;
+}
+
 extern "C" int cn_set_tuning(int key, int value)
 {
     if (key == 20 && (value == 0 || value == 1)) {
@@ -1480,7 +1501,7 @@ extern "C" int cn_set_tuning(int key, int value)
         g_tune_setprio = value;
         return CN_OK;
     }
-    if (key == 9 && value >= 0 && value <= 7) {
+    if (key == 9 && value >= 0 && value <= 31) {
         g_tune_dbgskip = value;
         return CN_OK;
     }

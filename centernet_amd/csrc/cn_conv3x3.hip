@@ -288,6 +288,10 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     }
     // KSKIP (Cin % 32 != 0, e.g. DLA level0's 16 channels): the last chunk's all-zero 8-channel
     // K groups are not multiplied at all
+#ifdef CN_ABLATE
+    c3_f16x8 abl_af[4][MB], abl_bf[4][NB];
+    bool abl_loaded = false;
+#endif
     auto compute = [&](int tap, int buf, int nkk) {
         const int ky = tap / TAPW + par_y, kx = tap % TAPW + par_x;
         const int toff = (ky * HW_ + kx) * LDT;
@@ -295,7 +299,12 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         if (a.setprio) __builtin_amdgcn_s_setprio(1);
         if constexpr (SPLIT) {
             // the row's four 32-byte quarters: high parts k 0-15, 16-31, low parts k 0-15, 16-31
+#ifdef CN_ABLATE   // variant builds only (tools/build_variant.sh): fragments outlive the call
+            c3_f16x8 (&af)[4][MB] = abl_af; c3_f16x8 (&bf)[4][NB] = abl_bf;
+            if (!(a.dbg & 16) || !abl_loaded)
+#else
             c3_f16x8 af[4][MB], bf[4][NB];
+#endif
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -305,6 +314,9 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                 for (int j = 0; j < NB; ++j)
                     bf[kk][j] = *reinterpret_cast<const c3_f16x8 *>(Bb + j * 32 * LDT + kk * 8);
             }
+#ifdef CN_ABLATE
+            abl_loaded = true;
+#endif
             // every fragment read is issued before the first MFMA and stays there (cn_conv.hip:
             // a ds_read sunk behind an MFMA into that MFMA's operand registers can overwrite them
             // before a queued MFMA has read them)
@@ -546,6 +558,9 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                     __syncthreads();  // every wave is done with the old halo
                     store_A();
                 }
+#ifdef CN_ABLATE
+                if (a.dbg & 8) continue;   // no weight-tile store, no per-tap barrier
+#endif
                 if (more) store_B((it + 1) & 1);
                 __syncthreads();
             }
@@ -981,7 +996,7 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     C3Args a = {};
     a.bm256 = ((setprio >> 1) & 1) | ((setprio >> 2) & 2);  // bits 1 and 3 of the knob word: cn_set_tuning key 14
     a.waves8 = (setprio >> 2) & 1; // bit 2: cn_set_tuning key 15
-    a.dbg = (setprio >> 4) & 7;    // bits 4-6: ablation switches (cn_set_tuning key 9)
+    a.dbg = ((setprio >> 4) & 7) | (((setprio >> 9) & 3) << 3);  // bits 4-6, 9-10: ablation switches (cn_set_tuning key 9)
     a.occ4 = (setprio >> 7) & 3;   // bits 7-8: cn_set_tuning key 19
     setprio &= 1;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;

@@ -579,6 +579,260 @@ __global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// f32s stem + MaxPool2d(3, stride 2, padding 1) in one kernel (resnet_dcn.py:138-141,
+// msra_resnet.py: conv1 -> bn1 -> relu -> maxpool): the 7x7 output (537 MB at B = 32, 512^2) is
+// never written.  A workgroup owns a STRIP of the image -- full rows, R pooled rows high -- and
+// walks its stem rows top to bottom, the TPR 128-pixel tiles of a row left to right.  Per tile:
+//   * BN + ReLU on the accumulators; a lane holds, for one channel, pixel groups {4g .. 4g+3};
+//   * horizontal 3-max at stride 2: pooled column 2g+1 = max(4g+1, 4g+2, 4g+3) is lane-local,
+//     pooled column 2g = max(4g-1, 4g, 4g+1) takes pixel 4g-1 from the partner lane (other half
+//     of the wave), from the other wave pair (pixel 63) or from the previous tile (pixel 127 of
+//     the tile to the left) through a 1 KB LDS line;
+//   * vertical 3-max as a running maximum in registers (16 per tile column): an even stem row
+//     joins it, an odd row 2p+1 completes pooled row p -- which is stored -- and starts p+1.
+// The strip's first row (2*p0 - 1) is computed only to start the running maximum: one extra row
+// per 2R (6 % at R = 8).  max() is exact, so the result equals stem -> max-pool bit for bit.
+template <int TPR>
+__global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, int nstrips, int R)
+{
+    constexpr int BN = 64;
+    constexpr int S = 2;
+    constexpr int WN = 2, WM = 2, TM = BM / WM, MB = TM / 32;
+    constexpr int WX = (BM - 1) * S + PKW;
+    constexpr int WXH = 262;
+    constexpr int PLANE = (PROWS + 1) * WXH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 *winH = reinterpret_cast<_Float16 *>(smem);
+    _Float16 *winL = winH + PLANE;
+    _Float16 *WsH = winL + PLANE + 8;
+    _Float16 *WsL = WsH + BN * SLDW;
+    float *bnd = reinterpret_cast<float *>(WsL + BN * SLDW);   // [2 parity][2 wm][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int PH = a.Ho / 2, PW = a.Wo / 2;
+    const int spi = PH / R;                  // strips per image
+    const float NEG_INF = -__builtin_huge_valf();
+
+    for (int i = tid; i < 2 * PLANE; i += NT) winH[i] = (_Float16)0.f;
+    for (int i = tid; i < BN * SKP; i += NT) {
+        const int nrow = i / SKP, k = i - nrow * SKP;
+        const int st = k >> 4, h = (k >> 3) & 1, j = k & 7;
+        const int r = 2 * st + h;
+        const int c = r / PKH, ky = r - c * PKH;
+        const int nn = min(nrow, a.cout_pad - 1);
+        float w = 0.f;
+        if (r < PROWS && j < PKW) w = a.w[(size_t)nn * a.KP + (ky * PKW + j) * 3 + c];
+        const _Float16 hi = (_Float16)w;
+        WsH[nrow * SLDW + k] = hi;
+        WsL[nrow * SLDW + k] = (_Float16)(w - (float)hi);
+    }
+    __syncthreads();
+
+    const int trow = tid >> 3, tcol = NT + (tid & 7);
+    const bool tail_ok = trow < PROWS && tcol < WX;
+    const bool col_ok = tid < WX;
+    const int tc = trow / PKH, twy = trow - tc * PKH;
+
+    float v[PROWS], vt;
+    unsigned vmask = 0;
+    auto prefetch = [&](int b, int oy, int xt) {
+        const int iy_min = oy * S - a.pad, ix_min = xt * BM * S - a.pad;
+        const float *xb = a.x + (size_t)b * 3 * a.H * a.W;
+        const int ix = ix_min + tid;
+        const bool cok = col_ok && ix >= 0 && ix < a.W;
+        unsigned mk = 0;
+#pragma unroll
+        for (int u = 0; u < PROWS; ++u) {
+            const int c = u / PKH, wy = u % PKH;
+            const int iy = iy_min + wy;
+            const bool ok = cok && iy >= 0 && iy < a.H;
+            v[u] = xb[ok ? ((size_t)(c * a.H + iy) * a.W + ix) : 0];
+            mk |= ok ? (1u << u) : 0u;
+        }
+        {
+            const int iy = iy_min + twy, jx = ix_min + tcol;
+            const bool ok = tail_ok && iy >= 0 && iy < a.H && jx >= 0 && jx < a.W;
+            vt = xb[ok ? ((size_t)(tc * a.H + iy) * a.W + jx) : 0];
+            mk |= ok ? (1u << PROWS) : 0u;
+        }
+        vmask = mk;
+    };
+    auto put = [&](int idx, float x) {
+        const _Float16 hi = (_Float16)x;
+        winH[idx] = hi;
+        winL[idx] = (_Float16)(x - (float)hi);
+    };
+    auto store_window = [&]() {
+        if (col_ok) {
+#pragma unroll
+            for (int u = 0; u < PROWS; ++u) put(u * WXH + tid, ((vmask >> u) & 1u) ? v[u] : 0.f);
+        }
+        if (tail_ok) put(trow * WXH + tcol, ((vmask >> PROWS) & 1u) ? vt : 0.f);
+    };
+
+    const uint32_t *aH[MB], *aL[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int off = (wm * TM + i * 32 + l31) * S + lh * WXH;
+        aH[i] = reinterpret_cast<const uint32_t *>(winH + off);
+        aL[i] = reinterpret_cast<const uint32_t *>(winL + off);
+    }
+    const _Float16 *wH = WsH + (wn * 32 + l31) * SLDW + 8 * lh;
+    const _Float16 *wL = WsL + (wn * 32 + l31) * SLDW + 8 * lh;
+    const int n = wn * 32 + l31;
+    float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+    float sf = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+    asm volatile("" : "+v"(sc), "+v"(sf));
+
+    // strip s: image b = s / spi, pooled rows p0 .. p0 + R - 1, stem rows 2*p0 - 1 .. 2*(p0+R) - 1
+    // (row -1 of the first strip does not exist: the running maximum starts at -inf)
+    auto first_row = [&](int s) { const int p0 = (s % spi) * R; return p0 == 0 ? 0 : 2 * p0 - 1; };
+    int s = blockIdx.x;
+    if (s >= nstrips) return;
+    int y = first_row(s), cb = 0, par = 0;
+    prefetch(s / spi, y, 0);
+    float cur[TPR][8 * MB];
+    while (true) {
+        const int b = s / spi, p0 = (s % spi) * R;
+        const int ylast = 2 * (p0 + R) - 1;
+        if (cb == 0 && y == first_row(s)) {
+#pragma unroll
+            for (int t = 0; t < TPR; ++t)
+#pragma unroll
+                for (int e = 0; e < 8 * MB; ++e) cur[t][e] = NEG_INF;
+        }
+        store_window();
+        __syncthreads();  // window visible
+        // the tile after this one (possibly the first of the next strip): in flight during the MFMAs
+        int ns = s, ny = y, ncb = cb + 1;
+        if (ncb == TPR) { ncb = 0; ny = y + 1; }
+        if (ny > ylast) { ns = s + gridDim.x; ny = ns < nstrips ? first_row(ns) : 0; }
+        const bool more = ns < nstrips;
+        if (more) prefetch(ns / spi, ny, ncb);
+
+        cn_f32x16 acc[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        st_u32x4 fa[2][2][MB];
+        st_f16x8 fb[2][2];
+        auto load_step = [&](int set, int st) {
+            constexpr int RW = WXH / 2;
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fa[set][0][i][j] = aH[i][2 * st * RW + j];
+                    fa[set][1][i][j] = aL[i][2 * st * RW + j];
+                }
+            fb[set][0] = *reinterpret_cast<const st_f16x8 *>(wH + 16 * st);
+            fb[set][1] = *reinterpret_cast<const st_f16x8 *>(wL + 16 * st);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < SKS; ++st) {
+            const int cs = st & 1;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(st_f16x8, fa[cs][1][i]), fb[cs][0], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < SKS) load_step(cs ^ 1, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(st_f16x8, fa[cs][0][i]), fb[cs][1], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(st_f16x8, fa[cs][0][i]), fb[cs][0], acc[i], 0, 0, 0);
+        }
+
+        // ---- BN + ReLU, then the pooling; acc[i][4q + j] = pixel wm*64 + i*32 + 8q + 4lh + j
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = acc[i][r] * sc + sf;
+                acc[i][r] = a.relu ? fmaxf(t, 0.f) : t;
+            }
+        // this wave pair's last pixel (63 / 127) goes to the LDS line of this tile's parity
+        if (lh == 1) bnd[(par * 2 + wm) * BN + n] = acc[MB - 1][15];
+        __syncthreads();   // also: every wave is done reading the window
+        float lastp[MB][4];   // the partner lane's pixel 4g' + 3 of every group it holds
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lastp[i][q] = __shfl_xor(acc[i][4 * q + 3], 32);
+        // pixel -1 of this wave pair's 64 pixels
+        float edge = NEG_INF;
+        if (wm == 1) edge = bnd[(par * 2 + 0) * BN + n];
+        else if (cb > 0) edge = bnd[((par ^ 1) * 2 + 1) * BN + n];
+        float hp[MB][4][2];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // group g = 2q + lh (+ 8i): pixel 4g - 1 is the last pixel of group g - 1
+                float left;
+                if (lh == 1) left = lastp[i][q];
+                else left = q > 0 ? lastp[i][q - 1] : (i > 0 ? lastp[i - 1][3] : edge);
+                hp[i][q][0] = fmaxf(fmaxf(left, acc[i][4 * q]), acc[i][4 * q + 1]);
+                hp[i][q][1] = fmaxf(fmaxf(acc[i][4 * q + 1], acc[i][4 * q + 2]), acc[i][4 * q + 3]);
+            }
+        const bool odd = (y & 1) != 0;
+#pragma unroll
+        for (int t = 0; t < TPR; ++t) {
+            if (t != cb) continue;
+            if (odd && y > first_row(s)) {
+                // completes pooled row (y - 1) / 2
+                const int pr = (y - 1) >> 1;
+                float *yb = a.y + ((size_t)(b * PH + pr) * PW + (size_t)cb * (BM / 2)) * a.out_pitch + n;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int pc = 2 * (2 * q + lh + 8 * i + 16 * wm) + h2;
+                            if (n < a.Cout)
+                                yb[(size_t)pc * a.out_pitch] = fmaxf(cur[t][(i * 4 + q) * 2 + h2], hp[i][q][h2]);
+                        }
+            }
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int e = (i * 4 + q) * 2 + h2;
+                        cur[t][e] = odd ? hp[i][q][h2] : fmaxf(cur[t][e], hp[i][q][h2]);
+                    }
+        }
+        if (!more) break;
+        par ^= 1;
+        s = ns; y = ny; cb = ncb;
+    }
+}
+
+template <int TPR>
+int launch_stem_pool_f32s(const StemArgs &a, int B, int R, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)(2 * (PROWS + 1) * 262 + 8 + 2 * 64 * SLDW) * 2 + 2 * 2 * 64 * 4;
+    const int nstrips = B * (a.Ho / 2 / R);
+    const int wgs = nstrips < 512 ? nstrips : 512;  // two resident workgroups per CU
+    CN_SET_MAX_LDS_ONCE((stem_pool_f32s_kernel<TPR>), lds);
+    hipLaunchKernelGGL((stem_pool_f32s_kernel<TPR>), dim3(wgs), dim3(NT), lds, st, a, nstrips, R);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
 template <int BN>
 int launch_stem_persist_f32s(const StemArgs &a, int B, hipStream_t st)
 {
@@ -607,6 +861,40 @@ int launch_stem_persist(const StemArgs &a, int B, hipStream_t st)
 }
 
 }  // namespace
+
+// Pooled rows per strip of the fused stem + max-pool kernel, or 0 when the shape is outside it:
+// 7x7 / stride 2, 33..64 output channels, rows of 1..4 whole 128-pixel tiles, an even number of
+// rows, and enough strips to fill the chip (shorter strips recompute more rows: 1 in 2R).
+int cn_stem_pool_rows(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int KP)
+{
+    if (KH != PKH || KW != PKW || stride != 2 || Cout <= 32 || Cout > 64) return 0;
+    if ((KP & 7) || KP < PKH * PKW * 3) return 0;
+    if (Wo % BM || Wo / BM > 4 || (Ho & 1)) return 0;
+    const int PH = Ho / 2;
+    if (PH % 8 == 0 && (long)B * (PH / 8) >= 384) return 8;
+    if (PH % 4 == 0 && (long)B * (PH / 4) >= 192) return 4;
+    return 0;
+}
+
+int cn_stem_pool_f32s(const float *x, const float *w_packed, const float *scale, const float *shift,
+                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
+                      int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st)
+{
+    const int R = cn_stem_pool_rows(B, Ho, Wo, Cout, KH, KW, stride, KP);
+    if (!R) return CN_ERR_UNSUPPORTED;
+    StemArgs a;
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y;
+    a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = KH; a.KW = KW;
+    a.stride = stride; a.pad = pad; a.relu = relu; a.out_pitch = out_pitch; a.KP = KP;
+    a.tiles_per_image = Ho * (Wo / BM);
+    a.cout_pad = (Cout + 31) / 32 * 32;
+    switch (Wo / BM) {
+    case 1: return launch_stem_pool_f32s<1>(a, B, R, st);
+    case 2: return launch_stem_pool_f32s<2>(a, B, R, st);
+    case 3: return launch_stem_pool_f32s<3>(a, B, R, st);
+    default: return launch_stem_pool_f32s<4>(a, B, R, st);
+    }
+}
 
 // Returns CN_ERR_UNSUPPORTED when the shape does not fit this kernel (the caller then uses
 // the generic implicit-GEMM stem).

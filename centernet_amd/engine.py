@@ -20,7 +20,8 @@ import torch
 
 from . import native
 from .native import (ConvDesc, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTYPE_F32, DTYPE_F32S,
-                     CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN, CONV_STEM_F32S)
+                     CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN, CONV_STEM_F32S,
+                     CONV_STEM_MAXPOOL)
 
 
 def _out_size(n, k, s, p, d=1):
@@ -221,7 +222,8 @@ class PlanBuilder:
 
     # ---- ops -------------------------------------------------------------------
     def conv(self, x, weight, bias=None, bn=None, relu=False, residual=None, stride=1,
-             padding=0, dilation=1, out_nchw=False, out=None, wsources=None, out_plain=False):
+             padding=0, dilation=1, out_nchw=False, out=None, wsources=None, out_plain=False,
+             pool=None):
         """conv2d (+bias) (+BN eval) (+residual) (+ReLU) as one implicit-GEMM launch.
         ``out_plain``: in an f32s plan, write the result as plain fp32 (for consumers that read
         floats, e.g. the offset maps of the deformable kernel)."""
@@ -231,6 +233,15 @@ class PlanBuilder:
         Wo = _out_size(x.W, kw, stride, padding, dilation)
         use_s = self.split and not x.nchw and self._f32s_conv_form(kh, kw, stride, padding,
                                                                   dilation, out_nchw, ci, co)
+        # ``pool`` = (kernel, stride, padding) of a MaxPool2d behind the layer (the ResNet stem,
+        # resnet_dcn.py:138-141): inside the stem kernel when it takes the shape, else a second launch
+        fuse_pool = False
+        if pool is not None and tuple(pool) == (3, 2, 1) and self.split and x.nchw and out is None \
+                and not out_nchw and residual is None and os.environ.get("CN_FUSE_STEM_POOL", "1") != "0":
+            probe = ConvDesc(B=x.B, H=x.H, W=x.W, Cin=ci, Ho=Ho, Wo=Wo, Cout=co, KH=kh, KW=kw,
+                             stride=stride, pad_h=padding, pad_w=padding, dil=dilation,
+                             in_layout=LAYOUT_NCHW, out_layout=LAYOUT_NHWC, dtype=self.cdtype)
+            fuse_pool = bool(self.lib.cn_stem_maxpool_supported(ctypes.byref(probe)))
         scale, shift = fold_bn(bias, bn, co, self.device)
         flags = 0
         if use_s:
@@ -248,11 +259,15 @@ class PlanBuilder:
             cd = self.cdtype
             if self.split and x.nchw:
                 flags |= CONV_STEM_F32S     # the stem kernel splits image and weights itself
+            if fuse_pool:
+                flags |= CONV_STEM_MAXPOOL
         self.keep += [scale, shift]
         if out is None:
             if out_nchw:
                 t = torch.empty((x.B, co, Ho, Wo), device=self.device, dtype=torch.float32)
                 out = Act(t, x.B, Ho, Wo, co, nchw=True)
+            elif fuse_pool:
+                out = self._new(x.B, Ho // 2, Wo // 2, co)
             else:
                 out = self._new(x.B, Ho, Wo, co,
                                 fmt="f32s" if (use_s and not out_plain) else None)
@@ -277,10 +292,12 @@ class PlanBuilder:
                      OH=Ho, OW=Wo, oy_mul=1, oy_add=0, ox_mul=1, ox_add=0, relu=int(relu),
                      dtype=cd, flags=flags)
         fl = 2 * x.B * Ho * Wo * co * ci * kh * kw
-        by = 4 * (x.B * x.H * x.W * ci + x.B * Ho * Wo * co * (2 if residual is not None else 1)
+        by = 4 * (x.B * x.H * x.W * ci + x.B * out.H * out.W * co * (2 if residual is not None else 1)
                   + co * ci * kh * kw)
         self._emit_conv(d, x, wp, scale, shift, residual, out, dict(kind="conv", flops=fl, bytes=by))
         self.flops += fl
+        if pool is not None and not fuse_pool:
+            return self.maxpool(out, *pool)
         return out
 
     def _emit_conv(self, d, x, wp, scale, shift, residual, out, meta):

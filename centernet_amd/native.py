@@ -22,7 +22,7 @@ LAYOUT_NHWC = 1
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 DTYPE_F32S = 2        # fp32 values as fp16 (high, low) pairs: three fp16 MFMAs per product
-CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN, CONV_STEM_F32S = 1, 2, 4, 8
+CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN, CONV_STEM_F32S, CONV_STEM_MAXPOOL = 1, 2, 4, 8, 16
 
 _lib = None
 
@@ -89,6 +89,8 @@ def _declare(lib):
     lib.cn_packed_conv_weight_floats.argtypes = [i] * 4
     lib.cn_pack_conv_weight_f32.restype = i
     lib.cn_pack_conv_weight_f32.argtypes = [vp, vp, i, i, i, i, vp]
+    lib.cn_stem_maxpool_supported.restype = i
+    lib.cn_stem_maxpool_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.cn_conv2d_f32.restype = i
     lib.cn_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     lib.cn_packed_conv_weight_elems.restype = sz

@@ -104,8 +104,8 @@ class PoseResNet(PlannedModule):
 
     def describe(self, pb, x):
         # resnet_dcn.py:248-263 / msra_resnet.py forward
-        x = pb.conv(x, self.conv1.weight, bn=self.bn1, relu=True, stride=2, padding=3)
-        x = pb.maxpool(x, 3, 2, 1)
+        x = pb.conv(x, self.conv1.weight, bn=self.bn1, relu=True, stride=2, padding=3,
+                    pool=(self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding))
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 x = blk.describe(pb, x)

@@ -213,6 +213,16 @@ typedef struct cn_conv_desc {
 /* dtype = CN_DTYPE_F32, 3-channel NCHW stem only: compute with three fp16 MFMAs per product
  * (the image and the packed weight stay fp32 and are split inside the kernel) */
 #define CN_CONV_STEM_F32S 8
+/* with CN_CONV_STEM_F32S: the MaxPool2d(kernel 3, stride 2, padding 1) that follows the stem in the
+ * ResNet backbones (resnet_dcn.py:138-141, msra_resnet.py:116-119) is applied inside the kernel;
+ * Ho / Wo stay the convolution's output size, y is the pooled (B, Ho/2, Wo/2, out_pitch) tensor.
+ * Only for shapes cn_stem_maxpool_supported() accepts, CN_ERR_UNSUPPORTED otherwise. */
+#define CN_CONV_STEM_MAXPOOL 16
+
+/* 1 when cn_conv2d accepts CN_CONV_STEM_MAXPOOL for this stem descriptor (7x7 / stride 2, 33..64
+ * output channels, rows of 1..4 whole 128-pixel tiles, even Ho, batch * Ho large enough to fill
+ * the chip with row strips), else 0.  Host-only, no GPU needed. */
+int cn_stem_maxpool_supported(const cn_conv_desc *d);
 
 /* Number of floats of the packed weight for (Cout,Cin,KH,KW). */
 size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);

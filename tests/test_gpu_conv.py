@@ -142,6 +142,44 @@ def _conv_case(dev, cfg, split=False):
         _check(y.t[..., :Cout].permute(0, 3, 1, 2).cpu(), ref.detach())
 
 
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cout, one launch?
+    (48, 64, 256, 64, True),      # one tile per row, strips of 4 pooled rows
+    (12, 256, 512, 64, True),     # two tiles per row: the column that crosses the tile edge
+    (24, 512, 256, 48, True),     # strips of 8 pooled rows, ragged Cout
+    (24, 128, 768, 64, True),     # three tiles per row
+    (24, 128, 1024, 64, True),    # four tiles per row
+    (2, 64, 256, 64, False),      # too few strips to fill the chip: stem + pooling kernel
+    (4, 64, 192, 64, False),      # rows that are not whole 128-pixel tiles
+])
+def test_stem_with_fused_maxpool_equals_two_launches(dev, cfg, monkeypatch):
+    """conv1 -> bn1 -> relu -> maxpool (resnet_dcn.py:138-141,247-250) in ONE kernel: max() is
+    exact, so the fused result is bit-identical to the f32s stem followed by the pooling kernel;
+    shapes the fused kernel does not take fall back to the two launches."""
+    from centernet_amd.engine import PlanBuilder
+    B, H, W, Cout, expect_fused = cfg
+    x = synth.images(B, H, W, 3)
+    w = torch.from_numpy(synth.normal((Cout, 3, 7, 7), (2.0 / 147) ** 0.5, 2))
+    bn = _bn(Cout, 4)
+
+    def build(fuse):
+        monkeypatch.setenv("CN_FUSE_STEM_POOL", "1" if fuse else "0")
+        pb = PlanBuilder(dev, B, H, W, split=True)
+        y = pb.conv(pb.set_input(3), w, bn=bn, relu=True, stride=2, padding=3, pool=(3, 2, 1))
+        pb.input.t = x.to(dev)
+        _run(pb)
+        return y.t.clone(), len(pb.ops)
+    two, n2 = build(False)
+    one, n1 = build(True)
+    assert n2 == 2
+    assert n1 == (1 if expect_fused else 2), (n1, cfg)
+    assert one.shape == two.shape == (B, H // 4, W // 4, Cout)
+    assert torch.equal(one, two)
+    nb = min(B, 2)
+    ref = F.max_pool2d(F.relu(bn(F.conv2d(x[:nb], w, None, 2, 3))), 3, 2, 1).detach()
+    _check(one[:nb].permute(0, 3, 1, 2).cpu(), ref)
+
+
 def test_stem_conv_nchw_input(dev):
     from centernet_amd.engine import PlanBuilder
     B, H, W = 2, 64, 96

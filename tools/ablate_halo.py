@@ -13,7 +13,7 @@ MODES = [int(v) for v in os.environ.get("MODES", "0,1,2,4,7").split(",")]
 if ONLY:
     SHAPES = [SHAPES[i] for i in ONLY]
 STAG = [int(v) for v in os.environ.get("STAG", "").split(",") if v]
-print("%-22s" % "Cin,H,W,Cout", "  ".join("%-12s" % n for n in (["stag%d" % v for v in STAG] if STAG else ("full", "-epilogue", "-B stage", "-A stage", "-all three"))))
+print("%-22s" % "Cin,H,W,Cout", "  ".join("%-12s" % n for n in (["stag%d" % v for v in STAG] if STAG else ["dbg%d" % m for m in MODES])))
 for ci, H, W, co in SHAPES:
     x = Act(torch.randn((B, H, W, ci), device=dev), B, H, W, ci)
     if os.environ.get("CN_F32S", "1") != "0":       # f32s activations, as inside the network

@@ -1,5 +1,6 @@
 """Layer-by-layer divergence of the HIP plan vs the CPU oracle (debugging aid, GPU box)."""
 import sys, os
+os.environ.setdefault("CN_FUSE_STEM_POOL", "0")   # the oracle traces the stem and the pool separately
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
