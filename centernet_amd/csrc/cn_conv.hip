@@ -838,6 +838,7 @@ int cn_conv3x3_c16(const float *x, const float *w_packed, const float *scale, co
                    int in_pitch, int out_pitch, int relu, hipStream_t st);
 extern int cn_tune_stagger_pct;  // cn_conv3x3.hip
 extern int cn_tune_f32s_lds_weights;  // cn_conv3x3.hip
+extern int cn_tune_f32s_policy;       // cn_conv3x3.hip
 int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale, const float *shift,
                         void *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
                         int relu, int vec_out, int setprio, int dtype_flags, hipStream_t st);
@@ -1474,6 +1475,10 @@ extern "C" int cn_set_tuning(int key, int value)
 {
     if (key == 20 && (value == 0 || value == 1)) {
         cn_tune_f32s_lds_weights = value;
+        return CN_OK;
+    }
+    if (key == 21 && value >= 0 && value <= 7) {
+        cn_tune_f32s_policy = value;
         return CN_OK;
     }
     if (key == 1 && value >= 0 && value <= 2) {

@@ -24,6 +24,7 @@
 // cn_set_tuning key 18: phase shift of co-resident workgroups, percent of one tile's MFMA time
 // (0 = off); see the kernel prologue
 int cn_tune_stagger_pct = 100;
+int cn_tune_f32s_policy = 0;   // cn_set_tuning key 21 (A/B): bit 0 = 128-wide tiles as eight waves three taps ahead, bit 1 = 64-wide tiles two taps ahead
 // f32s: taps a weight tile is requested ahead of its use (1 = the fp32 schedule; build-time so that
 // the register allocation of each form is its own: -DCN_F32S_PREFETCH_TAPS=1 for A/B builds)
 #ifndef CN_F32S_PREFETCH_TAPS
@@ -115,7 +116,7 @@ constexpr size_t c3_union_floats()
 // halo restage per 32-channel chunk.  With three fp16 MFMAs per product a tap is only ~400
 // cycles of matrix work: the per-tap weight staging + barrier of the LDS form cost more than that.
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false, bool DECONV = false, int NBUFB = 2, bool DEEP = true>
+          bool KSKIP = false, bool DECONV = false, int NBUFB = 2, int PDQ = CN_F32S_PREFETCH_TAPS>
 __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &hd)
 {
     // DECONV: ConvTranspose2d(4, stride 2, pad 1) -- blockIdx.z = output parity (py, px); each
@@ -487,10 +488,13 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         // up waiting for L2.  Here the request for step i + PD is issued when step i starts, into
         // a rotating register queue (slots static: NTAPS % PD == 0, the tap loop is unrolled), and
         // the next chunk's halo is requested AHEAD taps before it is needed.
-        constexpr int PD = (SPLIT && NBUFB == 2 && DEEP && CN_F32S_PREFETCH_TAPS > 1) ? (DECONV ? 2 : CN_F32S_PREFETCH_TAPS) : 1;
+        constexpr int PD = (SPLIT && NBUFB == 2 && PDQ > 1) ? (DECONV ? 2 : PDQ) : 1;
         if constexpr (PD > 1) {
             {
-                static_assert(NTAPS % PD == 0, "static queue slots");
+                // queue slot of step (chunk, tap) = (chunk * NTAPS + tap) % PD: static inside one
+                // unrolled pass over the taps once the chunk's phase is a template constant
+                constexpr int CP = (NTAPS % PD == 0) ? 1 : PD;   // chunks per slot period
+                static_assert(CP == 1 || PD == 2, "slot phases");
                 constexpr int AHEAD = NTAPS > 4 ? NTAPS - 4 : 0;
                 cn_f32x4 rq[PD][PB];
                 auto issue_B = [&](cn_f32x4 *dst, int chunk, int tap) {
@@ -510,22 +514,53 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                 store_A();
                 put_B(rq[0], 0);
                 __syncthreads();
-                for (int c = 0; c < a.nchunk; ++c) {
+                auto taps_of_chunk = [&](auto P, int c) {
+                    constexpr int p0 = decltype(P)::value;   // (c * NTAPS) % PD
                     const bool nextc = (c + 1) < a.nchunk;
 #pragma unroll
                     for (int t = 0; t < NTAPS; ++t) {
                         const int it = c * NTAPS + t;
                         const bool wrap = (t + PD) >= NTAPS;
                         // step it + PD goes into the slot step `it` left when it was put into LDS
-                        if (!wrap || nextc) issue_B(rq[t % PD], wrap ? c + 1 : c, (t + PD) % NTAPS);
+                        if (!wrap || nextc) issue_B(rq[(p0 + t) % PD], wrap ? c + 1 : c, (t + PD) % NTAPS);
                         if (t == AHEAD && nextc) load_A(c + 1);
                         compute(t, it & 1, 4);
                         if (t == NTAPS - 1 && nextc) {
                             __syncthreads();  // every wave is done with the old halo
                             store_A();
                         }
-                        if (t + 1 < NTAPS || nextc) put_B(rq[(t + 1) % PD], (it + 1) & 1);
+                        if (t + 1 < NTAPS || nextc) put_B(rq[(p0 + t + 1) % PD], (it + 1) & 1);
                         __syncthreads();
+                    }
+                };
+                if constexpr (CP == 1) {
+                    for (int c = 0; c < a.nchunk; ++c) taps_of_chunk(std::integral_constant<int, 0>{}, c);
+                } else {
+                    // PD = 2 over an odd number of taps: walk the steps in pairs instead (slot
+                    // and LDS buffer of a step = its parity, static; tap and chunk by counters)
+                    const int total = a.nchunk * NTAPS;
+                    int c = 0, t = 0;
+                    auto step = [&](auto SL, int it) {
+                        constexpr int sl = decltype(SL)::value;
+                        const bool nextc = (c + 1) < a.nchunk;
+                        if (it + 2 < total) {
+                            const bool wrap = (t + 2) >= NTAPS;
+                            issue_B(rq[sl], wrap ? c + 1 : c, wrap ? t + 2 - NTAPS : t + 2);
+                        }
+                        if (t == AHEAD && nextc) load_A(c + 1);
+                        compute(t, sl, 4);
+                        if (t == NTAPS - 1 && nextc) {
+                            __syncthreads();  // every wave is done with the old halo
+                            store_A();
+                        }
+                        if (it + 1 < total) put_B(rq[sl ^ 1], sl ^ 1);
+                        __syncthreads();
+                        if (++t == NTAPS) { t = 0; ++c; }
+                    };
+#pragma unroll 1
+                    for (int it = 0; it < total; it += 2) {
+                        step(std::integral_constant<int, 0>{}, it);
+                        if (it + 1 < total) step(std::integral_constant<int, 1>{}, it + 1);
                     }
                 }
             }
@@ -818,11 +853,13 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
 }
 
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false, bool DECONV = false, int NBUFB = 2, bool DEEP = true>
-__global__ __launch_bounds__(WM * WN * 64, (std::is_same<T, cn_f32s>::value && BM == 256 && WM * WN == 8) ? 4 : 1)
+          bool KSKIP = false, bool DECONV = false, int NBUFB = 2, int PDQ = CN_F32S_PREFETCH_TAPS>
+__global__ __launch_bounds__(WM * WN * 64, (std::is_same<T, cn_f32s>::value && BM == 256 && WM * WN == 8) ? 4
+                                           : (std::is_same<T, cn_f32s>::value && BN == 128 && WM * WN == 4 && NBUFB == 2 && PDQ == 2) ? 2
+                                           : (std::is_same<T, cn_f32s>::value && BN == 64 && BM == 128 && WM * WN == 4 && !HEADS && !DECONV && NBUFB == 2 && PDQ == 2) ? 3 : 1)
 void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
 {
-    conv3x3s1_body<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, DEEP>(a, hd);
+    conv3x3s1_body<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, PDQ>(a, hd);
 }
 
 // 64-wide tiles at FOUR workgroups per CU (<= 128 registers, single-buffered weight tile ->
@@ -859,12 +896,12 @@ int launch_c3_occ4(const C3Args &a, hipStream_t st)
 }
 
 template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM = 128,
-          bool KSKIP = false, bool DECONV = false, int NBUFB = 2, bool DEEP = true>
+          bool KSKIP = false, bool DECONV = false, int NBUFB = 2, int PDQ = CN_F32S_PREFETCH_TAPS>
 int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 {
     constexpr int TH = BM / TW;
     constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS, BM, NBUFB>() * 4 + BM * 4;
-    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, DEEP>), lds);
+    CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, PDQ>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
@@ -889,7 +926,7 @@ int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
         }
     }
     const C3Heads none = {};
-    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, DEEP>), grid,
+    hipLaunchKernelGGL((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, PDQ>), grid,
                        dim3(WM * WN * 64), lds,
                        st, b,
                        hd ? *hd : none);
@@ -940,6 +977,16 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
         // 8 waves per 128 x 128 tile (wave tile 32 x 64): 4 waves/SIMD at 2 workgroups per CU
         // hide the barrier / LDS latency better than 4-wave workgroups: +1 % on resdcn_18 and
         // dla_34 (tools/bench_knob.py 15).  The same change on 64-wide tiles measured no gain.
+        if constexpr (std::is_same<T, cn_f32s>::value) {
+            // f32s: four waves of 64 x 64 (2/3 of the fragment reads per MFMA) with the weight
+            // tiles two taps ahead -- 220 registers, two workgroups per CU.  Measured against
+            // eight waves of 32 x 64 three taps ahead (cn_set_tuning key 21 bit 0): 128->128@64^2
+            // 0.122 -> 0.115 ms, 256->256@32^2 0.117 -> 0.106, resdcn_18 B=32 +1.1 %
+            if (!(cn_tune_f32s_policy & 1))
+                return wide ? launch_c3<T, 32, 128, 2, 2, false, 128, false, false, 2, 2>(a, st)
+                            : launch_c3<T, 16, 128, 2, 2, false, 128, false, false, 2, 2>(a, st);
+            return wide ? launch_c3<T, 32, 128, 4, 2>(a, st) : launch_c3<T, 16, 128, 4, 2>(a, st);
+        }
         if (a.waves8 & 1)
             return wide ? launch_c3<T, 32, 128, 4, 2>(a, st) : launch_c3<T, 16, 128, 4, 2>(a, st);
         return wide ? launch_c3<T, 32, 128, 2, 2>(a, st) : launch_c3<T, 16, 128, 2, 2>(a, st);
@@ -954,9 +1001,9 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
         if constexpr (std::is_same<T, cn_f32s>::value) {
             // 256-pixel tiles as EIGHT waves of 64 x 32 (two workgroups = 16 waves per CU)
             if (wide && a.H >= 8 && a.bm256 == 2 && wgs256 >= 1024)
-                return launch_c3<T, 32, 64, 4, 2, false, 256, false, false, 2, false>(a, st);
+                return launch_c3<T, 32, 64, 4, 2, false, 256, false, false, 2, 1>(a, st);
             if (wide && a.H >= 8 && a.bm256 == 3 && wgs256 >= 1024)
-                return launch_c3<T, 32, 64, 4, 2, false, 256, false, false, 2, true>(a, st);
+                return launch_c3<T, 32, 64, 4, 2, false, 256, false, false, 2, 3>(a, st);
         }
         if (kskip)
             return wide ? launch_c3<float, 32, 64, 2, 2, false, 128, true>(a, st)
@@ -974,9 +1021,12 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
             // deep weight prefetch costs the 64-wide tile one of its three workgroups per CU
             // (174 vs 132 registers): it pays on long K loops (512->512@16^2: 0.135 -> 0.117 ms)
             // and loses on the two-chunk 64->64 layers (0.149 -> 0.158), measured at B = 32
+            if (cn_tune_f32s_policy & 2)   // experiment: two taps ahead for every 64-wide layer
+                return wide ? launch_c3<T, 32, 64, 2, 2, false, 128, false, false, 2, 2>(a, st)
+                            : launch_c3<T, 16, 64, 2, 2, false, 128, false, false, 2, 2>(a, st);
             if (a.nchunk < 4)
-                return wide ? launch_c3<T, 32, 64, 2, 2, false, 128, false, false, 2, false>(a, st)
-                            : launch_c3<T, 16, 64, 2, 2, false, 128, false, false, 2, false>(a, st);
+                return wide ? launch_c3<T, 32, 64, 2, 2, false, 128, false, false, 2, 1>(a, st)
+                            : launch_c3<T, 16, 64, 2, 2, false, 128, false, false, 2, 1>(a, st);
         }
         return wide ? launch_c3<T, 32, 64, 2, 2>(a, st) : launch_c3<T, 16, 64, 2, 2>(a, st);
     }
@@ -1093,8 +1143,8 @@ int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale,
             return wide ? launch_c3<cn_f32s, 32, 128, 4, 2, false, 128, false, true>(a, st)
                         : launch_c3<cn_f32s, 16, 128, 4, 2, false, 128, false, true>(a, st);
         // (64-wide: the one-tap-ahead schedule keeps three workgroups per CU, 0.092 vs 0.105 ms)
-        return wide ? launch_c3<cn_f32s, 32, 64, 2, 2, false, 128, false, true, 2, false>(a, st)
-                    : launch_c3<cn_f32s, 16, 64, 2, 2, false, 128, false, true, 2, false>(a, st);
+        return wide ? launch_c3<cn_f32s, 32, 64, 2, 2, false, 128, false, true, 2, 1>(a, st)
+                    : launch_c3<cn_f32s, 16, 64, 2, 2, false, 128, false, true, 2, 1>(a, st);
     }
     if (Cout > 64)
         return wide ? launch_c3<float, 32, 128, 4, 2, false, 128, false, true>(a, st)

@@ -78,10 +78,14 @@ const char *cn_arch(void);
  * key 18: phase shift of the workgroups that share a CU in the LDS-halo kernel, in percent of
  *         one tile's MFMA time (default 100, 0 = off); applied to launches of >= 4 dispatch rounds.
  * key 16 / 17: split-K: least K chunks per slice (default 8) / most slices (default 16).
- * key 15: 0 = 4-wave instead of 8-wave workgroups for the 128-wide tiles of the LDS-halo kernel
- *         (default 1: +1 %, measured).
- * key 14: 1 = 256-pixel tiles for 64-wide layers in the LDS-halo kernel (default 0: measured,
- *         no gain).
+ * key 15: fp32 / fp16 kernels: 0 = 4-wave instead of 8-wave workgroups for the 128-wide tiles of
+ *         the LDS-halo kernel (default 1: +1 %, measured).
+ * key 14: 64-wide layers in the LDS-halo kernel as 256-pixel tiles: 1 = four waves, 2 / 3 = eight
+ *         waves (f32s; one / three taps of weight prefetch); default 0 (measured, no gain).
+ * key 21: f32s LDS-halo kernel (A/B switches): bit 0 = 128-wide tiles as eight waves of 32 x 64
+ *         with weights three taps ahead instead of four waves of 64 x 64 two taps ahead
+ *         (default 0: +1 % on resdcn_18); bit 1 = every 64-wide layer two taps ahead (default:
+ *         one tap for two-chunk layers, three for longer K; measured).
  * key 13: tap split of the deformable kernel, 0 = auto, 1 = never, 3 or 9 = force.
  * key 20: f32s LDS-halo kernel, 128-wide tiles: 1 = per-tap weight tile in LDS (default),
  *         0 = weights streamed into registers from the fragment-ordered copy (+5-20 % in a

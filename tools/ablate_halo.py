@@ -12,6 +12,8 @@ ONLY = [int(v) for v in os.environ.get("ONLY", "").split(",") if v]
 MODES = [int(v) for v in os.environ.get("MODES", "0,1,2,4,7").split(",")]
 if ONLY:
     SHAPES = [SHAPES[i] for i in ONLY]
+for kv in [t for t in os.environ.get("TUNE", "").split(",") if t]:
+    lib.cn_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 STAG = [int(v) for v in os.environ.get("STAG", "").split(",") if v]
 print("%-22s" % "Cin,H,W,Cout", "  ".join("%-12s" % n for n in (["stag%d" % v for v in STAG] if STAG else ["dbg%d" % m for m in MODES])))
 for ci, H, W, co in SHAPES:
