@@ -29,6 +29,14 @@
 #include "cn_common.h"
 #include <type_traits>
 
+// f32s implicit GEMM: register sets of the tile prefetch.  2 = tiles requested two chunks ahead:
+// measured SLOWER on every layer that uses this kernel (3x3/s2 0.109 -> 0.179 ms, deformable
+// 0.135 -> 0.202 ms, resdcn_18 B=32 7929 -> 7399 img/s): the second set costs 50-90 registers, i.e.
+// one resident workgroup per CU, and these layers live on occupancy.  Kept for A/B builds only.
+#ifndef CN_IGEMM_F32S_SETS
+#define CN_IGEMM_F32S_SETS 1
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -286,11 +294,16 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     constexpr int NCORN = DCN ? 4 : 1;
-    cn_f32x4 ra[PA][NCORN];
-    cn_f32x4 rb[PB];
+    // NSET = 2 (A/B builds, see CN_IGEMM_F32S_SETS): the tiles of chunk k + 2 are requested while
+    // chunk k is multiplied
+    constexpr int NSET = SPLIT ? CN_IGEMM_F32S_SETS : 1;
+    cn_f32x4 ra_[NSET][PA][NCORN];
+    cn_f32x4 rb_[NSET][PB];
     const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    auto load_tiles = [&](int kt) {
+    auto load_tiles = [&](int kt, auto SET) {
+        auto &ra = ra_[decltype(SET)::value];
+        auto &rb = rb_[decltype(SET)::value];
         const int tap = kt / a.nchunk;
         const int c0 = (kt - tap * a.nchunk) * BKE;
         // ---- B: packed weight [tap][cout_pad][cin_pad]
@@ -362,7 +375,9 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         }
     };
 
-    auto store_tiles = [&](int buf, int kt) {
+    auto store_tiles = [&](int buf, int kt, auto SET) {
+        auto &ra = ra_[decltype(SET)::value];
+        auto &rb = rb_[decltype(SET)::value];
         float *Ad = As + buf * BM * LDT;
         float *Bd = Bs + buf * BN * LDT;
         if (!(a.dbgskip & 2))
@@ -499,23 +514,55 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     // ---- main loop: register prefetch of chunk k+1 during the MFMAs of chunk k.
     // NBUF=2: LDS double buffer, one barrier per chunk.  NBUF=1: half the LDS (more
     // workgroups per CU hide the second barrier), two barriers per chunk.
-    load_tiles(kt0);
-    store_tiles(0, kt0);
+    if constexpr (NSET == 2) {
+        constexpr std::integral_constant<int, 0> S0{};
+        constexpr std::integral_constant<int, 1> S1{};
+        load_tiles(kt0, S0);
+        if (kt0 + 1 < kt1) load_tiles(kt0 + 1, S1);
+        store_tiles(0, kt0, S0);
+        __syncthreads();
+        // chunk kt lives in register set / LDS buffer (kt - kt0) & 1: static inside a pair
+        auto step = [&](int kt, auto SET) {
+            constexpr int sv = decltype(SET)::value;
+            constexpr std::integral_constant<int, sv ^ 1> OTHER{};
+            if (kt + 2 < kt1) load_tiles(kt + 2, SET);   // this set's chunk went to LDS a step ago
+            const bool more = (kt + 1) < kt1;
+            if (NBUF == 2) {
+                compute(sv);
+                if (more) store_tiles(sv ^ 1, kt + 1, OTHER);
+                __syncthreads();
+            } else {
+                compute(0);
+                __syncthreads();
+                if (more) store_tiles(0, kt + 1, OTHER);
+                __syncthreads();
+            }
+        };
+#pragma unroll 1
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            step(kt, S0);
+            if (kt + 1 < kt1) step(kt + 1, S1);
+        }
+    } else {
+    constexpr std::integral_constant<int, 0> SZ{};
+    load_tiles(kt0, SZ);
+    store_tiles(0, kt0, SZ);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
         const bool more = (kt + 1) < kt1 && !(a.dbgskip == 3);
-        if (more) load_tiles(kt + 1);
+        if (more) load_tiles(kt + 1, SZ);
         if (NBUF == 2) {
             const int buf = (kt - kt0) & 1;
             compute(buf);
-            if (more) store_tiles(buf ^ 1, kt + 1);
+            if (more) store_tiles(buf ^ 1, kt + 1, SZ);
             __syncthreads();
         } else {
             compute(0);
             __syncthreads();
-            if (more) store_tiles(0, kt + 1);
+            if (more) store_tiles(0, kt + 1, SZ);
             __syncthreads();
         }
+    }
     }
 
     // ---- epilogue: y = relu?((acc + bias) * scale + shift + residual)
