@@ -46,6 +46,9 @@ __global__ void nhwc_to_nchw_kernel(const float *__restrict__ x, float *__restri
 }
 
 // max pooling, NHWC, -inf padding (torch.nn.MaxPool2d semantics), 4 channels/thread
+// IN_S: the input is an f32s tensor (fp16 high / low pairs, cn_common.h; C % 32 == 0); the output
+// is plain fp32 either way
+template <bool IN_S>
 __global__ void maxpool_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int H,
                                     int W, int C, int Ho, int Wo, int k, int s, int pad)
 {
@@ -67,8 +70,9 @@ __global__ void maxpool_nhwc_kernel(const float *__restrict__ x, float *__restri
             for (int dx = 0; dx < k; ++dx) {
                 const int ix = ox * s - pad + dx;
                 if (ix < 0 || ix >= W) continue;
-                const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(
-                    x + (((size_t)b * H + iy) * W + ix) * C + c4 * 4);
+                const size_t pix = ((size_t)b * H + iy) * W + ix;
+                const cn_f32x4 v = IN_S ? cn_load4_f32s(x, pix, C, c4 * 4)
+                                        : *reinterpret_cast<const cn_f32x4 *>(x + pix * C + c4 * 4);
                 m.x = fmaxf(m.x, v.x);
                 m.y = fmaxf(m.y, v.y);
                 m.z = fmaxf(m.z, v.z);
@@ -242,8 +246,27 @@ extern "C" int cn_maxpool_nhwc_f32(const float *x, float *y, int B, int H, int W
     const int Ho = (H + 2 * pad - k) / s + 1, Wo = (W + 2 * pad - k) / s + 1;
     if (Ho <= 0 || Wo <= 0) return CN_ERR_SHAPE;
     const size_t total = (size_t)B * Ho * Wo * (C >> 2);
-    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+    hipLaunchKernelGGL(maxpool_nhwc_kernel<false>, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
                        (hipStream_t)stream, x, y, B, H, W, C, Ho, Wo, k, s, pad);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_maxpool_nhwc(const void *x, float *y, int B, int H, int W, int C, int k, int s,
+                               int pad, int in_dtype, void *stream)
+{
+    if (in_dtype == CN_DTYPE_F32)
+        return cn_maxpool_nhwc_f32((const float *)x, y, B, H, W, C, k, s, pad, stream);
+    if (in_dtype != CN_DTYPE_F32S) return CN_ERR_UNSUPPORTED;
+    if (!x || !y) return CN_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || pad < 0) return CN_ERR_SHAPE;
+    if (C & 31) return CN_ERR_UNSUPPORTED;   // f32s tensors are whole 32-channel groups
+    if (!cn_aligned16(x) || !cn_aligned16(y)) return CN_ERR_ALIGN;
+    const int Ho = (H + 2 * pad - k) / s + 1, Wo = (W + 2 * pad - k) / s + 1;
+    if (Ho <= 0 || Wo <= 0) return CN_ERR_SHAPE;
+    const size_t total = (size_t)B * Ho * Wo * (C >> 2);
+    hipLaunchKernelGGL(maxpool_nhwc_kernel<true>, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, (const float *)x, y, B, H, W, C, Ho, Wo, k, s, pad);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -378,17 +378,19 @@ class PlanBuilder:
 
     def maxpool(self, x, k, s, pad):
         assert self.dtype == torch.float32, "max-pool is built for fp32 only"
-        x = self.plain(x)
+        from_s = x.fmt == "f32s" and x.C % 32 == 0     # read (high, low) pairs, write plain floats
+        if not from_s:
+            x = self.plain(x)
         Ho, Wo = _out_size(x.H, k, s, pad), _out_size(x.W, k, s, pad)
         out = self._new(x.B, Ho, Wo, x.C)
         lib = self.lib
         assert x.pitch == x.C and x.c_off == 0
 
         def run():
-            rc = lib.cn_maxpool_nhwc_f32(x.ptr(), out.ptr(), x.B, x.H, x.W, x.C, k, s, pad,
-                                         native.stream_ptr())
+            rc = lib.cn_maxpool_nhwc(x.ptr(), out.ptr(), x.B, x.H, x.W, x.C, k, s, pad,
+                                     DTYPE_F32S if from_s else DTYPE_F32, native.stream_ptr())
             if rc:
-                native.check(rc, "cn_maxpool_nhwc_f32")
+                native.check(rc, "cn_maxpool_nhwc")
         self.ops.append(run)
         self.meta.append(dict(kind="maxpool", flops=0,
                               bytes=4 * x.B * x.C * (x.H * x.W + Ho * Wo)))
@@ -403,16 +405,20 @@ class PlanBuilder:
     def concat(self, acts):
         """torch.cat(acts, 1) (Root.forward, pose_dla_dcn.py:159): channel-slice copies into
         one NHWC buffer."""
-        acts = [self.plain(a) for a in acts]
+        # f32s tensors of whole 32-channel groups concatenate as they are: a group is 128 bytes
+        # whatever the format, so the slice copy moves (high, low) groups unchanged
+        keep_s = all(a.fmt == "f32s" and a.C % 32 == 0 and a.pitch == a.C for a in acts)
+        if not keep_s:
+            acts = [self.plain(a) for a in acts]
         a0 = acts[0]
         C = sum(a.C for a in acts)
-        out = self._new(a0.B, a0.H, a0.W, C)
+        out = self._new(a0.B, a0.H, a0.W, C, fmt="f32s" if keep_s else None)
         lib = self.lib
         npix = a0.B * a0.H * a0.W
         off = 0
         for a in acts:
             assert (a.B, a.H, a.W) == (a0.B, a0.H, a0.W) and not a.nchw
-            dst = Act(out.t, out.B, out.H, out.W, a.C, pitch=C, c_off=off)
+            dst = Act(out.t, out.B, out.H, out.W, a.C, pitch=C, c_off=off, fmt=out.fmt)
 
             def run(a=a, dst=dst):
                 rc = lib.cn_copy_channels_f32(a.ptr(), a.pitch, dst.ptr(), C, npix, a.C,

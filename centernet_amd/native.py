@@ -113,6 +113,8 @@ def _declare(lib):
     lib.cn_maxpool3x3s2_nhwc_f32.argtypes = [vp, vp, i, i, i, i, vp]
     lib.cn_maxpool_nhwc_f32.restype = i
     lib.cn_maxpool_nhwc_f32.argtypes = [vp, vp, i, i, i, i, i, i, i, vp]
+    lib.cn_maxpool_nhwc.restype = i
+    lib.cn_maxpool_nhwc.argtypes = [vp, vp, i, i, i, i, i, i, i, i, vp]
     lib.cn_dw_conv_transpose_f32.restype = i
     lib.cn_dw_conv_transpose_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp]
     lib.cn_copy_channels_f32.restype = i

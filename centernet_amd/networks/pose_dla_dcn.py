@@ -38,12 +38,12 @@ class Root(nn.Module):
         self.conv = conv(in_channels, out_channels, 1, pad=(kernel_size - 1) // 2)
         self.bn = bn(out_channels)
 
-    def describe(self, pb, *children):
+    def describe(self, pb, *children, out_plain=False):
         # pose_dla_dcn.py:157-165: conv1x1(cat(children)) + BN (+ children[0]) + ReLU
         x = pb.concat(list(children))
         return pb.conv(x, self.conv.weight, bn=self.bn, relu=True,
                        residual=children[0] if self.residual else None,
-                       padding=self.conv.padding[0])
+                       padding=self.conv.padding[0], out_plain=out_plain)
 
 
 class Tree(nn.Module):
@@ -74,8 +74,9 @@ class Tree(nn.Module):
         if in_channels != out_channels:
             self.project = nn.Sequential(conv(in_channels, out_channels, 1), bn(out_channels))
 
-    def describe(self, pb, x, residual=None, children=None):
-        # pose_dla_dcn.py:206-221
+    def describe(self, pb, x, residual=None, children=None, out_plain=False):
+        # pose_dla_dcn.py:206-221.  ``out_plain``: the stage's result is written as plain floats
+        # (it feeds the deformable layers and skip adds of the up-sampling pyramid)
         children = [] if children is None else children
         bottom = pb.maxpool(x, self.stride, self.stride, 0) if self.downsample is not None else x
         residual = pb.conv(bottom, self.project[0].weight, bn=self.project[1]) \
@@ -85,9 +86,9 @@ class Tree(nn.Module):
         x1 = self.tree1.describe(pb, x, residual)
         if self.levels == 1:
             x2 = self.tree2.describe(pb, x1)
-            return self.root.describe(pb, x2, x1, *children)
+            return self.root.describe(pb, x2, x1, *children, out_plain=out_plain)
         children.append(x1)
-        return self.tree2.describe(pb, x1, children=children)
+        return self.tree2.describe(pb, x1, children=children, out_plain=out_plain)
 
 
 class DLA(nn.Module):
@@ -130,7 +131,9 @@ class DLA(nn.Module):
                     x = pb.conv(x, c.weight, bn=mods[j + 1], relu=True, stride=c.stride[0],
                                 padding=c.padding[0], dilation=c.dilation[0])
             else:
-                x = level.describe(pb, x)
+                # stage outputs feed the deformable layers / skip adds of the pyramid: plain floats
+                # (+1 % on dla_34 against converting them afterwards, same box)
+                x = level.describe(pb, x, out_plain=True)
             y.append(x)
         return y
 

@@ -276,6 +276,10 @@ int cn_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int 
 /* generic k x k / stride s max pooling NHWC (pose_dla_dcn.py:200 uses 2x2 s2) */
 int cn_maxpool_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, int k,
                         int s, int pad, void *stream);
+/* the same with an f32s input tensor (in_dtype = CN_DTYPE_F32S, C % 32 == 0; CN_DTYPE_F32: as
+ * above); the output is plain fp32 */
+int cn_maxpool_nhwc(const void *x_nhwc, float *y_nhwc, int B, int H, int W, int C, int k, int s,
+                    int pad, int in_dtype, void *stream);
 
 /* Depthwise ConvTranspose2d(C, C, kernel 2f, stride f, padding f/2, groups=C, bias=False)
  * -- the up-sampling of IDAUp (pose_dla_dcn.py:370-373) -- fused with the element-wise
