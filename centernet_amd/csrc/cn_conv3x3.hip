@@ -30,6 +30,9 @@ int cn_tune_f32s_policy = 0;   // cn_set_tuning key 21 (A/B): bit 0 = 128-wide t
 #ifndef CN_F32S_PREFETCH_TAPS
 #define CN_F32S_PREFETCH_TAPS 3
 #endif
+#ifndef CN_F16_PREFETCH_TAPS
+#define CN_F16_PREFETCH_TAPS 2
+#endif
 
 namespace {
 
@@ -488,7 +491,10 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         // up waiting for L2.  Here the request for step i + PD is issued when step i starts, into
         // a rotating register queue (slots static: NTAPS % PD == 0, the tap loop is unrolled), and
         // the next chunk's halo is requested AHEAD taps before it is needed.
-        constexpr int PD = (SPLIT && NBUFB == 2 && PDQ > 1) ? (DECONV ? 2 : PDQ) : 1;
+        // (fp16 tensors: CN_F16_PREFETCH_TAPS, a chunk of 64 channels is 4 MFMAs per block)
+        constexpr bool DEEP_T = SPLIT || (F16 && !HEADS && !DECONV && !KSKIP && CN_F16_PREFETCH_TAPS > 1);
+        constexpr int PDR = SPLIT ? PDQ : CN_F16_PREFETCH_TAPS;
+        constexpr int PD = (DEEP_T && NBUFB == 2 && PDR > 1) ? (DECONV ? 2 : PDR) : 1;
         if constexpr (PD > 1) {
             {
                 // queue slot of step (chunk, tap) = (chunk * NTAPS + tap) % PD: static inside one
