@@ -22,14 +22,15 @@ class BasicBlock(nn.Module):
         self.conv1, self.bn1 = conv(inplanes, planes, 3, stride), bn(planes)
         self.conv2, self.bn2 = conv(planes, planes, 3), bn(planes)
 
-    def describe(self, pb, x):
+    def describe(self, pb, x, out_plain=False):
         # resnet_dcn.py:49-67
         res = x
         if self.downsample is not None:
             ds = self.downsample
             res = pb.conv(x, ds[0].weight, bn=ds[1], stride=ds[0].stride[0])
         out = pb.conv(x, self.conv1.weight, bn=self.bn1, relu=True, stride=self.stride, padding=1)
-        return pb.conv(out, self.conv2.weight, bn=self.bn2, relu=True, residual=res, padding=1)
+        return pb.conv(out, self.conv2.weight, bn=self.bn2, relu=True, residual=res, padding=1,
+                       out_plain=out_plain)
 
 
 class Bottleneck(nn.Module):
@@ -43,7 +44,7 @@ class Bottleneck(nn.Module):
         self.conv2, self.bn2 = conv(planes, planes, 3, stride), bn(planes)
         self.conv3, self.bn3 = conv(planes, wide, 1), bn(wide)
 
-    def describe(self, pb, x):
+    def describe(self, pb, x, out_plain=False):
         # resnet_dcn.py:88-108
         res = x
         if self.downsample is not None:
@@ -51,7 +52,8 @@ class Bottleneck(nn.Module):
             res = pb.conv(x, ds[0].weight, bn=ds[1], stride=ds[0].stride[0])
         out = pb.conv(x, self.conv1.weight, bn=self.bn1, relu=True)
         out = pb.conv(out, self.conv2.weight, bn=self.bn2, relu=True, stride=self.stride, padding=1)
-        return pb.conv(out, self.conv3.weight, bn=self.bn3, relu=True, residual=res)
+        return pb.conv(out, self.conv3.weight, bn=self.bn3, relu=True, residual=res,
+                       out_plain=out_plain)
 
 
 class PoseResNet(PlannedModule):
@@ -106,10 +108,11 @@ class PoseResNet(PlannedModule):
         # resnet_dcn.py:248-263 / msra_resnet.py forward
         x = pb.conv(x, self.conv1.weight, bn=self.bn1, relu=True, stride=2, padding=3,
                     pool=(self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding))
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            for blk in layer:
-                x = blk.describe(pb, x)
         mods = list(self.deconv_layers)
+        blocks = [blk for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for blk in layer]
+        for blk in blocks:
+            # the trunk's last layer feeds a deformable layer (plain floats) in the DCN variants
+            x = blk.describe(pb, x, out_plain=blk is blocks[-1] and bool(mods) and isinstance(mods[0], DCN))
         i = 0
         while i < len(mods):
             m = mods[i]

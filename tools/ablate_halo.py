@@ -28,7 +28,7 @@ for ci, H, W, co in SHAPES:
     for dbg in (STAG if STAG else MODES):
         lib.cn_set_tuning(18 if STAG else 9, dbg)
         pb = PlanBuilder(dev, B, H, W)
-        pb.conv(x, w, relu=True, stride=1, padding=1)
+        pb.conv(x, w, relu=True, stride=1, padding=1, out_plain=os.environ.get("OUT_PLAIN", "0") == "1")
         for _ in range(3): pb.ops[0]()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
