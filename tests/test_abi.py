@@ -53,6 +53,30 @@ def test_shape_queries_without_gpu():
     assert lib.cn_dcn_v2_forward_workspace_bytes(2, 64, 16, 16, 64, 3, 3, 0) > 0
 
 
+def test_stem_maxpool_support_rule():
+    """cn_stem_maxpool_supported: the shapes whose stem runs with the max-pool inside the kernel."""
+    import ctypes
+    from centernet_amd import native
+    from centernet_amd.native import ConvDesc, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F32
+    lib = native.lib()
+
+    def ok(B, H, W, Cout, k=7, s=2, cin=3, layout=LAYOUT_NCHW):
+        d = ConvDesc(B=B, H=H, W=W, Cin=cin, Ho=(H + 6 - k) // s + 1, Wo=(W + 6 - k) // s + 1, Cout=Cout,
+                     KH=k, KW=k, stride=s, pad_h=3, pad_w=3, dil=1, in_layout=layout,
+                     out_layout=LAYOUT_NHWC, dtype=DTYPE_F32)
+        return lib.cn_stem_maxpool_supported(ctypes.byref(d))
+    assert ok(32, 512, 512, 64) == 1          # the headline configuration
+    assert ok(8, 512, 512, 64) == 1           # strips of 4 pooled rows
+    assert ok(1, 512, 512, 64) == 0           # too few strips to fill the chip: two launches
+    assert ok(32, 512, 384, 64) == 0          # rows that are not whole 128-pixel tiles
+    assert ok(32, 512, 512, 16) == 0          # DLA's 16-channel stem is a different kernel
+    assert ok(32, 512, 512, 128) == 0
+    assert ok(32, 512, 512, 64, s=1) == 0
+    assert ok(32, 512, 512, 64, k=3) == 0
+    assert ok(32, 512, 512, 64, cin=64, layout=LAYOUT_NHWC) == 0
+    assert lib.cn_stem_maxpool_supported(None) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     from centernet_amd import native
