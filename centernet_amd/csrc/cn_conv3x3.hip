@@ -86,6 +86,7 @@ struct C3Heads {
     const float *bias[MAX_HEADS];  // (cout) or null
     float *y[MAX_HEADS];           // (B, cout, H, W)
     int cout[MAX_HEADS];
+    int slices;                    // hidden width / 64: 64-channel slices of the hidden layer (1..4)
 };
 
 // LDS floats of the kernel: the main loop's tiles, unioned with the epilogue staging
@@ -170,7 +171,7 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     const int b = blockIdx.x / tiles;
     const int tr = blockIdx.x - b * tiles;
     const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;
-    const int n0 = blockIdx.y * BN;
+    int n0 = blockIdx.y * BN;   // fused heads: first hidden channel of the current slice (set per slice)
     const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     if (a.stagger) {
@@ -263,9 +264,12 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     };
     // weight rows of this thread: byte offsets inside one tap's [cout_pad][cin_pad] matrix
     unsigned boff[PB];
+    auto set_weight_rows = [&]() {
 #pragma unroll
-    for (int p = 0; p < PB; ++p)
-        boff[p] = (unsigned)(min(n0 + p * RPP + lrow, a.cout_pad - 1) * a.cin_pad + EPV * q) * (unsigned)sizeof(T);
+        for (int p = 0; p < PB; ++p)
+            boff[p] = (unsigned)(min(n0 + p * RPP + lrow, a.cout_pad - 1) * a.cin_pad + EPV * q) * (unsigned)sizeof(T);
+    };
+    set_weight_rows();
     auto wtile = [&](int chunk, int tap) {   // uniform base of (tap, chunk)
         return reinterpret_cast<const char *>(wT) +
                ((size_t)tap * a.cout_pad * a.cin_pad + (size_t)chunk * BKE) * sizeof(T);
@@ -374,18 +378,22 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         if (a.setprio) __builtin_amdgcn_s_setprio(0);
     };
 
-    if constexpr (HEADS) {
-        // 1x1 weights of this head (first W2_ROWS output channels) + their bias in pad column
-        // 64, staged now so the epilogue GEMM starts without a global round trip
+    // fused heads: rows [g0, g0 + W2_ROWS) of the head's 1x1 weight, hidden channels of slice sl,
+    // + their bias in pad column 64 -- staged at the START of a slice so that the second GEMM
+    // begins without a global round trip (the W2 region lies behind the main loop's tiles)
+    auto stage_W2 = [&](int g0, int sl) {
         float *W2 = As + UNION - W2_ROWS * LDS2;
-        const int cout2 = hd.cout[blockIdx.y];
-        const float *w2 = hd.w[blockIdx.y];
-        const float *b2 = hd.bias[blockIdx.y];
-        const int rows = min(W2_ROWS, (cout2 + 31) / 32 * 32);
+        const int head = blockIdx.y;
+        const int cout2 = hd.cout[head];
+        const float *w2 = hd.w[head];
+        const float *b2 = hd.bias[head];
+        const int hidden = hd.slices * HEAD_CONV;
+        const int rows = min(W2_ROWS, (cout2 - g0 + 31) / 32 * 32);
         for (int idx = tid; idx < rows * (HEAD_CONV / 4); idx += NT) {
             const int row = idx / (HEAD_CONV / 4), k4 = idx - row * (HEAD_CONV / 4);
-            const int src = min(row, cout2 - 1);  // padded rows: computed, never stored
-            const cn_f32x4 wv = *reinterpret_cast<const cn_f32x4 *>(w2 + (size_t)src * HEAD_CONV + k4 * 4);
+            const int src = min(g0 + row, cout2 - 1);  // padded rows: computed, never stored
+            const cn_f32x4 wv = *reinterpret_cast<const cn_f32x4 *>(
+                w2 + (size_t)src * hidden + sl * HEAD_CONV + k4 * 4);
             if constexpr (SPLIT) {  // rows of two 128-byte groups [32 high | 32 low] (k = 4*k4 ..)
                 cn_f16x4v hi, lo;
                 cn_split4(wv, hi, lo);
@@ -397,9 +405,10 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
             }
         }
         for (int row = tid; row < rows; row += NT)
-            W2[row * LDS2 + HEAD_CONV] = (b2 && row < cout2) ? b2[row] : 0.f;
-    }
+            W2[row * LDS2 + HEAD_CONV] = (b2 && g0 + row < cout2) ? b2[g0 + row] : 0.f;
+    };
 
+    auto main_loop = [&]() {
     if constexpr (WREG) {
         // ---- register-streamed weights, software-pipelined one tap ahead.  A lane's four
         // 16-byte quarter fragments of (tap, chunk, 32-channel output block) are 64 contiguous
@@ -609,138 +618,151 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         }
     }
 
+    };   // main_loop
+
     if constexpr (HEADS) {
-        // ---- fused head epilogue (resnet_dcn.py:155-177): hidden = relu(acc + bias1) stays in
-        // LDS as S[128 pixels][64]; the head's 1x1 convolution is a second MFMA GEMM
-        // out[cout][pixel] = W2[cout][64] . S^T with D rows = cout, cols = pixel, so that a
-        // wave's stores run along x of the NCHW map the decode consumes.
+        // ---- fused heads (resnet_dcn.py:155-177, pose_dla_dcn.py:456-468, large_hourglass.py:
+        // make_kp_layer): per 64-channel slice of the head's hidden layer, hidden =
+        // relu(conv3x3 + bias1) stays in LDS as S[128 pixels][64] and the 1x1 convolution
+        // accumulates out[cout][pixel] += W2[cout][slice] . S^T (D rows = cout, cols = pixel, so
+        // that a wave's stores run along x of the NCHW map the decode consumes).  head_conv = 64
+        // is one slice; 256 (dla_34, hourglass) four: the 256-channel hidden tensor never exists.
         const int head = blockIdx.y;
         const int cout2 = hd.cout[head];
+        // the multi-slice form keeps the 1x1 accumulators (48 registers) live across the main loop:
+        // it is the PDQ = 1 instantiation (one tap of weight prefetch, 232 registers, two workgroups
+        // per CU); head_conv = 64 keeps the deep-prefetch build with the short-lived accumulators
+        const int slices = (PDQ == 1) ? hd.slices : 1;
         float *y2 = hd.y[head];
         float *S = reinterpret_cast<float *>(smem);      // [BM][LDS2] (main-loop tiles are dead)
         float *W2 = As + UNION - W2_ROWS * LDS2;         // [W2_ROWS][LDS2], column 64 = bias
-        {
-            const int n = wn * TN + l31;  // NB == 1 for the 64-wide tile
-            const float s1 = a.scale ? a.scale[n0 + n] : 1.f;
-            const float b1 = a.shift ? a.shift[n0 + n] : 0.f;
+        const int HWp = a.H * a.W;
+        const int mpix = wave * 32 + l31;            // this lane's pixel (column of D)
+        const float *Sa = S + mpix * LDS2 + 4 * lh;
+        const float *Wb = W2 + l31 * LDS2 + 4 * lh;
+        cn_f32x16 acc2[W2_ROWS / 32];
+#pragma unroll
+        for (int jb = 0; jb < W2_ROWS / 32; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[jb][r] = 0.f;
+        for (int sl = 0; sl < slices; ++sl) {
+            n0 = (head * slices + sl) * BN;
+            set_weight_rows();
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        float t = acc[i][j][r] * s1 + b1;
-                        t = a.relu ? fmaxf(t, 0.f) : t;
-                        if constexpr (SPLIT) {   // hidden channel nn of the row, as (high, low)
-                            const int nn = n + j * 32;
-                            const float c = fminf(t, 65504.0f);
-                            const _Float16 hi = (_Float16)c;
-                            char *g = reinterpret_cast<char *>(S + row * LDS2) + (nn >> 5) * 128 + (nn & 31) * 2;
-                            *reinterpret_cast<_Float16 *>(g) = hi;
-                            *reinterpret_cast<_Float16 *>(g + 64) = (_Float16)(c - (float)hi);
-                        } else {
-                            S[row * LDS2 + n + j * 32] = t;
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            stage_W2(0, sl);
+            main_loop();
+            {
+                const int n = wn * TN + l31;  // NB == 1 for the 64-wide tile
+                const float s1 = a.scale ? a.scale[n0 + n] : 1.f;
+                const float b1 = a.shift ? a.shift[n0 + n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            float t = acc[i][j][r] * s1 + b1;
+                            t = a.relu ? fmaxf(t, 0.f) : t;
+                            if constexpr (SPLIT) {   // hidden channel nn of the row, as (high, low)
+                                const int nn = n + j * 32;
+                                const float c = fminf(t, 65504.0f);
+                                const _Float16 hi = (_Float16)c;
+                                char *g = reinterpret_cast<char *>(S + row * LDS2) + (nn >> 5) * 128 + (nn & 31) * 2;
+                                *reinterpret_cast<_Float16 *>(g) = hi;
+                                *reinterpret_cast<_Float16 *>(g + 64) = (_Float16)(c - (float)hi);
+                            } else {
+                                S[row * LDS2 + n + j * 32] = t;
+                            }
+                        }
+            }
+            // heads wider than W2_ROWS (only with one slice): one group of 1x1 rows after the other
+            for (int g0 = 0; g0 < cout2; g0 += W2_ROWS) {
+                const int rows = min(W2_ROWS, (cout2 - g0 + 31) / 32 * 32);
+                if (g0) {
+                    __syncthreads();  // previous group's W2 fully read
+                    stage_W2(g0, sl);
+#pragma unroll
+                    for (int jb = 0; jb < W2_ROWS / 32; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[jb][r] = 0.f;
+                }
+                __syncthreads();  // S (and a restaged W2) visible
+                const int nblk = rows / 32;
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int g = 0; g < HEAD_CONV / 32; ++g) {
+                        c3_f16x8 sf[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            sf[kk] = *reinterpret_cast<const c3_f16x8 *>(Sa + g * 32 + kk * 8);
+#pragma unroll
+                        for (int jb = 0; jb < W2_ROWS / 32; ++jb) {
+                            if (jb < nblk) {  // uniform
+                                c3_f16x8 wf[4];
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk)
+                                    wf[kk] = *reinterpret_cast<const c3_f16x8 *>(Wb + jb * 32 * LDS2 + g * 32 + kk * 8);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                                    for (int s2 = 0; s2 < 2; ++s2) {
+                                        const int kw = (term == 0) ? 2 + s2 : s2;   // weight part
+                                        const int ks = (term == 1) ? 2 + s2 : s2;   // activation part
+                                        acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kw], sf[ks],
+                                                                                          acc2[jb], 0, 0, 0);
+                                    }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
-        }
-        const int HWp = a.H * a.W;
-        const int mpix = wave * 32 + l31;            // this lane's pixel (column of D)
-        const int off = rowoff[mpix];                // (b*H + oy)*W + ox, or -1
-        const int pix = off - b * HWp;
-        const float *Sa = S + mpix * LDS2 + 4 * lh;
-        for (int g0 = 0; g0 < cout2; g0 += W2_ROWS) {
-            const int rows = min(W2_ROWS, (cout2 - g0 + 31) / 32 * 32);
-            if (g0) {  // heads wider than W2_ROWS: restage the next group of 1x1 rows
-                const float *w2 = hd.w[head];
-                const float *b2 = hd.bias[head];
-                __syncthreads();  // previous group's W2 fully read
-                for (int idx = tid; idx < rows * (HEAD_CONV / 4); idx += NT) {
-                    const int row = idx / (HEAD_CONV / 4), k4 = idx - row * (HEAD_CONV / 4);
-                    const int src = min(g0 + row, cout2 - 1);
-                    const cn_f32x4 wv = *reinterpret_cast<const cn_f32x4 *>(w2 + (size_t)src * HEAD_CONV + k4 * 4);
-                    if constexpr (SPLIT) {
-                        cn_f16x4v hi, lo;
-                        cn_split4(wv, hi, lo);
-                        char *g = reinterpret_cast<char *>(W2 + row * LDS2) + (k4 >> 3) * 128 + (k4 & 7) * 8;
-                        *reinterpret_cast<cn_f16x4v *>(g) = hi;
-                        *reinterpret_cast<cn_f16x4v *>(g + 64) = lo;
-                    } else {
-                        *reinterpret_cast<cn_f32x4 *>(W2 + row * LDS2 + k4 * 4) = wv;
-                    }
-                }
-                for (int row = tid; row < rows; row += NT)
-                    W2[row * LDS2 + HEAD_CONV] = (b2 && g0 + row < cout2) ? b2[g0 + row] : 0.f;
-            }
-            __syncthreads();  // S (and a restaged W2) visible
-            const int nblk = rows / 32;
-            cn_f32x16 acc2[W2_ROWS / 32];
+                } else
 #pragma unroll
-            for (int jb = 0; jb < W2_ROWS / 32; ++jb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[jb][r] = 0.f;
-            const float *Wb = W2 + l31 * LDS2 + 4 * lh;
-            if constexpr (SPLIT) {
-#pragma unroll
-                for (int g = 0; g < HEAD_CONV / 32; ++g) {
-                    c3_f16x8 sf[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        sf[kk] = *reinterpret_cast<const c3_f16x8 *>(Sa + g * 32 + kk * 8);
+                for (int kk = 0; kk < HEAD_CONV / 8; ++kk) {
+                    const cn_f32x4 af = *reinterpret_cast<const cn_f32x4 *>(Sa + kk * 8);
 #pragma unroll
                     for (int jb = 0; jb < W2_ROWS / 32; ++jb) {
                         if (jb < nblk) {  // uniform
-                            c3_f16x8 wf[4];
+                            const cn_f32x4 bf =
+                                *reinterpret_cast<const cn_f32x4 *>(Wb + jb * 32 * LDS2 + kk * 8);
 #pragma unroll
-                            for (int kk = 0; kk < 4; ++kk)
-                                wf[kk] = *reinterpret_cast<const c3_f16x8 *>(Wb + jb * 32 * LDS2 + g * 32 + kk * 8);
-                            __builtin_amdgcn_sched_barrier(0);
+                            for (int s = 0; s < 4; ++s)
+                                acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc2[jb],
+                                                                                0, 0, 0);
+                        }
+                    }
+                }
+                if (sl == slices - 1) {
+                    const int off = rowoff[mpix];                // (b*H + oy)*W + ox, or -1
+                    const int pix = off - b * HWp;
+                    if (off >= 0) {
 #pragma unroll
-                            for (int term = 0; term < 3; ++term)
+                        for (int jb = 0; jb < W2_ROWS / 32; ++jb) {
+                            if (jb < nblk) {
 #pragma unroll
-                                for (int s2 = 0; s2 < 2; ++s2) {
-                                    const int kw = (term == 0) ? 2 + s2 : s2;   // weight part
-                                    const int ks = (term == 1) ? 2 + s2 : s2;   // activation part
-                                    acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kw], sf[ks],
-                                                                                      acc2[jb], 0, 0, 0);
+                                for (int r = 0; r < 16; ++r) {
+                                    const int rr = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                    const int co = g0 + rr;
+                                    if (co < cout2)
+                                        y2[((size_t)b * cout2 + co) * HWp + pix] =
+                                            acc2[jb][r] + W2[rr * LDS2 + HEAD_CONV];
                                 }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-            } else
-#pragma unroll
-            for (int kk = 0; kk < HEAD_CONV / 8; ++kk) {
-                const cn_f32x4 af = *reinterpret_cast<const cn_f32x4 *>(Sa + kk * 8);
-#pragma unroll
-                for (int jb = 0; jb < W2_ROWS / 32; ++jb) {
-                    if (jb < nblk) {  // uniform
-                        const cn_f32x4 bf =
-                            *reinterpret_cast<const cn_f32x4 *>(Wb + jb * 32 * LDS2 + kk * 8);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc2[jb],
-                                                                            0, 0, 0);
-                    }
-                }
-            }
-            if (off >= 0) {
-#pragma unroll
-                for (int jb = 0; jb < W2_ROWS / 32; ++jb) {
-                    if (jb < nblk) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rr = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            const int co = g0 + rr;
-                            if (co < cout2)
-                                y2[((size_t)b * cout2 + co) * HWp + pix] =
-                                    acc2[jb][r] + W2[rr * LDS2 + HEAD_CONV];
+                            }
                         }
                     }
                 }
             }
+            __syncthreads();   // S and W2 fully read before the next slice restages them
         }
         return;
+    } else {
+        main_loop();
     }
 
     if (a.dbg & 1) {  // ablation (cn_set_tuning key 9): no epilogue, one store keeps acc live
@@ -862,7 +884,8 @@ template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM
           bool KSKIP = false, bool DECONV = false, int NBUFB = 2, int PDQ = CN_F32S_PREFETCH_TAPS>
 __global__ __launch_bounds__(WM * WN * 64, (std::is_same<T, cn_f32s>::value && BM == 256 && WM * WN == 8) ? 4
                                            : (std::is_same<T, cn_f32s>::value && BN == 128 && WM * WN == 4 && NBUFB == 2 && PDQ == 2) ? 2
-                                           : (std::is_same<T, cn_f32s>::value && BN == 64 && BM == 128 && WM * WN == 4 && !HEADS && !DECONV && NBUFB == 2 && PDQ == 2) ? 3 : 1)
+                                           : (std::is_same<T, cn_f32s>::value && BN == 64 && BM == 128 && WM * WN == 4 && !HEADS && !DECONV && NBUFB == 2 && PDQ == 2) ? 3
+                                           : (HEADS && PDQ == 1) ? 2 : 1)
 void conv3x3s1_kernel(const C3Args a, const C3Heads hd)
 {
     conv3x3s1_body<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, PDQ>(a, hd);
@@ -911,7 +934,9 @@ int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
     b.tiles_y = cn_cdiv(a.H, TH);
-    dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), cn_cdiv(a.Cout, BN), DECONV ? 4 : 1);
+    // fused heads: one workgroup row per HEAD (its hidden slices run inside the workgroup)
+    const int ny = (HEADS && hd) ? cn_cdiv(a.Cout, BN * (hd->slices > 0 ? hd->slices : 1)) : cn_cdiv(a.Cout, BN);
+    dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), ny, DECONV ? 4 : 1);
     {
         // resident workgroups per CU of this variant (registers / LDS), MFMA cycles one tile
         // needs per SIMD, and the number of dispatch rounds of this launch
@@ -1097,7 +1122,9 @@ extern "C" int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int 
     hipStream_t st = (hipStream_t)stream;
     if (!x || !w1_packed || !heads) return CN_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || n_heads <= 0) return CN_ERR_SHAPE;
-    if (head_conv != HEAD_CONV || n_heads > MAX_HEADS) return CN_ERR_UNSUPPORTED;
+    // hidden width: 64-channel slices handled one after the other inside the workgroup
+    if (head_conv <= 0 || head_conv % HEAD_CONV || head_conv > 4 * HEAD_CONV || n_heads > MAX_HEADS)
+        return CN_ERR_UNSUPPORTED;
     const bool f32s = (dtype == CN_DTYPE_F32S);
     if (dtype != CN_DTYPE_F32 && !f32s) return CN_ERR_UNSUPPORTED;
     if ((in_pitch & 3) || !cn_aligned16(x) || !cn_aligned16(w1_packed)) return CN_ERR_ALIGN;
@@ -1109,15 +1136,25 @@ extern "C" int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int 
         if (!cn_aligned16(heads[h].w)) return CN_ERR_ALIGN;
         hd.w[h] = heads[h].w; hd.bias[h] = heads[h].bias; hd.y[h] = heads[h].y;
         hd.cout[h] = heads[h].cout;
+        // several slices accumulate into ONE register tile of 1x1 outputs
+        if (head_conv > HEAD_CONV && heads[h].cout > W2_ROWS) return CN_ERR_UNSUPPORTED;
     }
+    hd.slices = head_conv / HEAD_CONV;
     C3Args a = {};
     a.x = x; a.w = w1_packed; a.scale = scale1; a.shift = bias1; a.residual = nullptr; a.y = nullptr;
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = n_heads * HEAD_CONV; a.in_pitch = in_pitch;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = n_heads * head_conv; a.in_pitch = in_pitch;
     a.out_pitch = 0; a.relu = 1; a.vec_out = 0; a.setprio = 1;
     a.in_plain = (flags & CN_CONV_X_PLAIN) ? 1 : 0;
     a.cin_pad = (Cin + 31) / 32 * 32;
     a.cout_pad = a.Cout;
     a.nchunk = a.cin_pad / 32;
+    if (hd.slices > 1) {
+        if (f32s)
+            return (W >= 32) ? launch_c3<cn_f32s, 32, 64, 2, 2, true, 128, false, false, 2, 1>(a, st, &hd)
+                             : launch_c3<cn_f32s, 16, 64, 2, 2, true, 128, false, false, 2, 1>(a, st, &hd);
+        return (W >= 32) ? launch_c3<float, 32, 64, 2, 2, true, 128, false, false, 2, 1>(a, st, &hd)
+                         : launch_c3<float, 16, 64, 2, 2, true, 128, false, false, 2, 1>(a, st, &hd);
+    }
     if (f32s)
         return (W >= 32) ? launch_c3<cn_f32s, 32, 64, 2, 2, true>(a, st, &hd)
                          : launch_c3<cn_f32s, 16, 64, 2, 2, true>(a, st, &hd);

@@ -543,8 +543,9 @@ class PlanBuilder:
         k = firsts[0].kernel_size[0]
         if (self.fuse_heads and self.dtype == torch.float32 and k == 3 and len(names) <= 8 and
                 not x.nchw and x.c_off == 0 and
-                all(c.weight.shape[0] == 64 and c.padding[0] == 1 and c.stride[0] == 1
-                    for c in firsts) and
+                self._fusable_hidden([c.weight.shape[0] for c in firsts],
+                                     [pairs[n][1].weight.shape[0] for n in names]) and
+                all(c.padding[0] == 1 and c.stride[0] == 1 for c in firsts) and
                 all(tuple(pairs[n][1].kernel_size) == (1, 1) for n in names)):
             return self._heads_fused(x, names, pairs, w, b)
         mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2,
@@ -561,11 +562,23 @@ class PlanBuilder:
         return outs
 
 
+    @staticmethod
+    def _fusable_hidden(hidden, couts):
+        """Hidden widths the fused head kernel takes: 64 (one slice) or 128 / 192 / 256 (64-channel
+        slices one after the other; their 1x1 outputs accumulate in one 96-row register tile)."""
+        hc = hidden[0]
+        if any(h != hc for h in hidden) or hc % 64 or not 64 <= hc <= 256:
+            return False
+        if hc > 64 and (max(couts) > 96 or os.environ.get("CN_FUSE_HEADS_WIDE", "1") == "0"):
+            return False
+        return True
+
     def _heads_fused(self, x, names, pairs, w1, b1):
-        """All heads as ONE launch (cn_heads3x3_1x1_f32): the 64 hidden channels of a head
-        stay in LDS between its 3x3 and its 1x1 convolution."""
+        """All heads as ONE launch (cn_heads3x3_1x1): the hidden channels of a head stay in LDS
+        between its 3x3 and its 1x1 convolution, 64 at a time."""
         lib = self.lib
         nh = len(names)
+        hc = pairs[names[0]][0].weight.shape[0]
         use_s = self.split
         scale1 = None
         if use_s:
@@ -583,7 +596,7 @@ class PlanBuilder:
             last = pairs[n][1]
             co = last.weight.shape[0]
             w2 = last.weight.detach().to(device=self.device, dtype=torch.float32)
-            w2 = w2.reshape(co, 64).contiguous()
+            w2 = w2.reshape(co, hc).contiguous()
             b2 = None if last.bias is None else \
                 last.bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
             t = torch.empty((x.B, co, x.H, x.W), device=self.device, dtype=torch.float32)
@@ -593,14 +606,14 @@ class PlanBuilder:
             arr[i].bias = b2.data_ptr() if b2 is not None else None
             arr[i].y = t.data_ptr()
             arr[i].cout = co
-            fl += 2 * x.B * x.H * x.W * co * 64
-            by += 4 * (x.B * x.H * x.W * co + co * 64)
+            fl += 2 * x.B * x.H * x.W * co * hc
+            by += 4 * (x.B * x.H * x.W * co + co * hc)
         self.keep += [b1, arr, scale1]
         wpp, b1p, s1p = native.ptr(wp), native.ptr(b1), native.ptr(scale1)
         ci = x.C
 
         def run():
-            rc = lib.cn_heads3x3_1x1(x.ptr(), x.B, x.H, x.W, ci, x.pitch, wpp, s1p, b1p, 64, nh,
+            rc = lib.cn_heads3x3_1x1(x.ptr(), x.B, x.H, x.W, ci, x.pitch, wpp, s1p, b1p, hc, nh,
                                      arr, cd, flags, native.stream_ptr())
             if rc:
                 native.check(rc, "cn_heads3x3_1x1")

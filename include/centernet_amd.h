@@ -306,8 +306,10 @@ int cn_upsample2x_add_f16(const void *x, const void *add, void *y, int B, int H,
  * concatenated biases; the hidden activations stay in LDS and each head's 1x1 convolution
  * runs as a second matrix-core GEMM in the same workgroup, writing the NCHW maps
  * (B, cout, H, W) that cn_ctdet_decode_f32 / cn_multi_pose_decode_f32 consume.
- * x is NHWC with row pitch in_pitch.  Built for head_conv == 64 and n_heads <= 8; anything
- * else returns CN_ERR_UNSUPPORTED (the caller then issues cn_conv2d per convolution). */
+ * x is NHWC with row pitch in_pitch.  Built for n_heads <= 8 and head_conv = 64 (resnet_dcn.py),
+ * or 128 / 192 / 256 (pose_dla_dcn.py:456-468, large_hourglass.py) with every cout <= 96: the
+ * hidden layer is then processed in 64-channel slices whose 1x1 products accumulate in registers.
+ * Anything else returns CN_ERR_UNSUPPORTED (the caller then issues cn_conv2d per convolution). */
 typedef struct cn_head_out {
     const float *w;    /* (cout, head_conv) row-major == Conv2d(head_conv, cout, 1).weight */
     const float *bias; /* (cout) or NULL */

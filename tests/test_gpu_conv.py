@@ -347,21 +347,28 @@ def test_fp16_stem_and_nchw_head(dev):
     (2, 64, 12, 20, {"hm": 3, "dep": 1}),                            # W < 32: 8x16 tiles
     (1, 256, 16, 16, {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}),
     (1, 64, 8, 40, {"big": 130, "wh": 2}),                           # > 96 channels: two passes
+    # head_conv = 256 (pose_dla_dcn.py:456-468, large_hourglass.py): four 64-channel slices of the
+    # hidden layer, their 1x1 products accumulated in registers
+    (2, 64, 32, 32, {"hm": 80, "wh": 2, "reg": 2}, 256),
+    (1, 64, 19, 33, {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}, 256),
+    (1, 256, 12, 20, {"hm": 80, "wh": 2, "reg": 2}, 256),            # hourglass: 256-channel features
+    (1, 96, 16, 16, {"hm": 5, "wh": 2}, 128),
 ])
 @pytest.mark.parametrize("split", [True, False], ids=["f32s", "fp32mfma"])
 def test_fused_heads(dev, cfg, split):
     """cn_heads3x3_1x1 (one launch for all heads, hidden channels kept in LDS) vs the
     per-head Sequential(conv3x3, ReLU, conv1x1) of resnet_dcn.py:155-177 on torch CPU."""
     from centernet_amd.engine import PlanBuilder
-    B, Fc, H, W, heads = cfg
+    hidden = cfg[5] if len(cfg) > 5 else 64
+    B, Fc, H, W, heads = cfg[:5]
     x = torch.from_numpy(synth.normal((B, Fc, H, W), 1.0, 11))
     pairs, ref = {}, {}
     for i, (name, classes) in enumerate(heads.items()):
-        c1 = torch.nn.Conv2d(Fc, 64, 3, padding=1, bias=True)
-        c2 = torch.nn.Conv2d(64, classes, 1, bias=True)
+        c1 = torch.nn.Conv2d(Fc, hidden, 3, padding=1, bias=True)
+        c2 = torch.nn.Conv2d(hidden, classes, 1, bias=True)
         with torch.no_grad():
             c1.weight.copy_(torch.from_numpy(synth.normal(tuple(c1.weight.shape), (2.0 / (Fc * 9)) ** 0.5, 20 + i)))
-            c1.bias.copy_(torch.from_numpy(synth.normal((64,), 0.2, 30 + i)))
+            c1.bias.copy_(torch.from_numpy(synth.normal((hidden,), 0.2, 30 + i)))
             c2.weight.copy_(torch.from_numpy(synth.normal(tuple(c2.weight.shape), 0.15, 40 + i)))
             c2.bias.copy_(torch.from_numpy(synth.normal((classes,), 0.5, 50 + i)))
             ref[name] = c2(F.relu(c1(x)))
@@ -374,7 +381,7 @@ def test_fused_heads(dev, cfg, split):
             xa = pb.packed(xa)
         n0 = len(pb.ops)
         outs = pb.heads_from_convs(xa, pairs)
-        assert len(pb.ops) == n0 + 1, "heads with 64 hidden channels must be a single fused launch"
+        assert len(pb.ops) == n0 + 1, "heads with 64..256 hidden channels must be a single fused launch"
         _run(pb)
         for name in heads:
             assert outs[name].nchw and tuple(outs[name].t.shape) == tuple(ref[name].shape)
