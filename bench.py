@@ -56,17 +56,33 @@ def pmc_traffic(tag):
         raw = json.load(f)
     cls = {"conv": 0.0, "dcn": 0.0, "decode": 0.0, "maxpool": 0.0}
     n = {"conv": 0, "dcn": 0, "decode": 0, "maxpool": 0}
-    steps = max(1, raw.get("nms_topk_kernel", {}).get("launches", 1))
+    def short(name):
+        # kernel names with _Float16 template arguments stay mangled in the rocprofv3 tables:
+        # _ZN12_GLOBAL__N_112igemm_kernelIDF16_Li128E...Li0E... -> ("igemm_kernel", [128, ..., 0, ...])
+        if name.startswith("_ZN"):
+            import re
+            m = re.match(r"_ZN\d+_GLOBAL__N_\d+([a-z_0-9]+?)(?:I|E)(.*)", name)
+            if not m:
+                return name, []
+            return m.group(1), [int(x) for x in re.findall(r"L[ib](\d+)E", m.group(2))]
+        base = name.split("<")[0]
+        args = [a.strip() for a in name[len(base):].strip("<>").split(",")] if "<" in name else []
+        return base, [int(a) if a.lstrip("-").isdigit() else a for a in args[1:]]
+    # profiled forward steps = launches of the stem kernel (exactly one per step in every network)
+    steps = sum(v.get("launches", 0) for k, v in raw.items()
+                if isinstance(v, dict) and short(k)[0].startswith("stem_"))
+    steps = max(1, steps or raw.get("nms_topk_kernel", {}).get("launches", 1))
     for k, v in raw.items():
         if not isinstance(v, dict) or "hbm_bytes_per_launch" not in v:
             continue
-        if k.startswith("igemm_kernel"):
-            c = "dcn" if k.rstrip(">").split(",")[5].strip() in ("2", "3") else "conv"
-        elif k.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_")):
+        base, targs = short(k)
+        if base == "igemm_kernel":
+            c = "dcn" if len(targs) > 4 and targs[4] in (2, 3) else "conv"   # AMODE
+        elif base.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_")):
             c = "conv"
-        elif k.startswith(("nms_topk", "merge_topk", "peak_", "pose_match", "decode_")):
+        elif base.startswith(("nms_topk", "merge_topk", "peak_", "group_", "pose_match", "decode_")):
             c = "decode"
-        elif k.startswith("maxpool"):
+        elif base.startswith("maxpool"):
             c = "maxpool"
         else:
             continue
