@@ -989,7 +989,8 @@ static int c3_dispatch_f32s_wreg(C3Args &a, hipStream_t st)
 template <typename T>
 static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
 {
-    const bool wide = a.W >= 32;  // 4 x 32 tiles keep an MFMA block on one halo row
+    // 4 x 32 tiles keep an MFMA block on one halo row; key 21 bit 2 (A/B): 8 x 16 tiles everywhere
+    const bool wide = a.W >= 32 && !(std::is_same<T, cn_f32s>::value && (cn_tune_f32s_policy & 4));
     // fp32 layers whose last 32-channel chunk is less than 3/4 full skip its empty K groups
     const bool kskip = std::is_same<T, float>::value && a.nkk_last < 4;
     if (bn_class == 2) {

@@ -85,7 +85,8 @@ const char *cn_arch(void);
  * key 21: f32s LDS-halo kernel (A/B switches): bit 0 = 128-wide tiles as eight waves of 32 x 64
  *         with weights three taps ahead instead of four waves of 64 x 64 two taps ahead
  *         (default 0: +1 % on resdcn_18); bit 1 = every 64-wide layer two taps ahead (default:
- *         one tap for two-chunk layers, three for longer K; measured).
+ *         one tap for two-chunk layers, three for longer K; measured); bit 2 = 8 x 16 pixel tiles
+ *         on wide maps too (no difference, measured).
  * key 13: tap split of the deformable kernel, 0 = auto, 1 = never, 3 or 9 = force.
  * key 20: f32s LDS-halo kernel, 128-wide tiles: 1 = per-tap weight tile in LDS (default),
  *         0 = weights streamed into registers from the fragment-ordered copy (+5-20 % in a
