@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from ..decode import ctdet_decode
-from ..post_process import ctdet_post_process, ctdet_results_batch
+from ..post_process import ctdet_results_batch
 from ..utils import flip_tensor
 from .base_detector import BaseDetector
 
@@ -44,21 +44,22 @@ class CtdetDetector(BaseDetector):
         unscaled frame (ctdet.py:47-56)."""
         host = dets.detach().cpu().numpy()
         host = host.reshape(1, -1, host.shape[2])
-        per_class = ctdet_post_process(host.copy(), [meta['c']], [meta['s']], meta['out_height'],
-                                       meta['out_width'], self.opt.num_classes)[0]
-        for cls in range(1, self.num_classes + 1):
-            rows = np.array(per_class[cls], dtype=np.float32).reshape(-1, 5)
-            rows[:, :4] /= scale
-            per_class[cls] = rows
-        return per_class
+        # the batch tail with a batch of one and no cap: same rows, same order, same float32
+        # rounding as ctdet_post_process + the per-class np.array / "/= scale" loop, without
+        # the trip through Python lists
+        return ctdet_results_batch(host, [meta], self.opt.num_classes, scale,
+                                   max_per_image=host.shape[1])[0]
 
     def merge_outputs(self, detections):
         """Concatenate the test scales per class, soft-NMS when asked or when there are several,
         then keep the ``max_per_image`` best over all classes by score threshold -- ``>=``, so
         ties may exceed the cap, as in the reference (ctdet.py:58-73)."""
         classes = range(1, self.num_classes + 1)
-        results = {c: np.concatenate([d[c] for d in detections], axis=0).astype(np.float32)
-                   for c in classes}
+        if len(detections) == 1 and not (len(self.scales) > 1 or self.opt.nms):
+            results = {c: detections[0][c] for c in classes}     # nothing to merge, nothing edited
+        else:
+            results = {c: np.concatenate([d[c] for d in detections], axis=0).astype(np.float32)
+                       for c in classes}
         if len(self.scales) > 1 or self.opt.nms:
             from ..soft_nms import soft_nms
             for c in classes:

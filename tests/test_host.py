@@ -180,6 +180,39 @@ def test_ctdet_results_batch_equals_per_image_loop():
                 assert (np.abs(got[i][j] - ref[j]) <= np.spacing(np.abs(ref[j]))).all()
 
 
+def test_detector_post_process_and_merge_match_the_oracle_tail():
+    """CtdetDetector.post_process + merge_outputs (the single-image API, ctdet.py:47-73) against
+    the oracle's restatement: one scale, two scales with soft-NMS, and more detections than the
+    cap.  The detector object is built without a model: only the host tail is exercised."""
+    import types
+    import torch
+    from centernet_amd.detectors.ctdet import CtdetDetector
+    from oracle import post_oracle
+    rng = np.random.RandomState(11)
+    meta = {'c': np.array([250., 187.5], np.float32), 's': 500.0, 'out_height': 128, 'out_width': 128}
+
+    def dets_for(K):
+        d = np.zeros((1, K, 6), np.float32)
+        d[0, :, :4] = rng.uniform(0, 128, (K, 4))
+        d[0, :, 4] = np.sort(rng.uniform(0, 1, K))[::-1]
+        d[0, :, 5] = rng.randint(0, 80, K)
+        return d
+    for K, scales, nms in ((100, [1.0], False), (120, [1.0], False), (100, [1.0, 2.0], False), (100, [1.0], True)):
+        det = object.__new__(CtdetDetector)
+        det.num_classes, det.max_per_image, det.scales = 80, 100, scales
+        det.opt = types.SimpleNamespace(num_classes=80, nms=nms)
+        per_scale, ref_scale = [], []
+        for sc in scales:
+            d = dets_for(K)
+            per_scale.append(det.post_process(torch.from_numpy(d.copy()), meta, sc))
+            ref_scale.append(post_oracle.ctdet_post_process_scale(d.copy(), meta, 80, sc))
+        got = det.merge_outputs(per_scale)
+        ref = post_oracle.ctdet_merge_outputs(ref_scale, 80, len(scales), nms=nms, max_per_image=100)
+        for j in range(1, 81):
+            assert got[j].dtype == np.float32 and got[j].shape == ref[j].shape, (K, scales, nms, j)
+            assert (np.abs(got[j] - ref[j]) <= 2 * np.spacing(np.abs(ref[j]))).all()
+
+
 def test_load_model_tolerant_like_the_reference(tmp_path, capsys):
     """model.py:31-67 behaviour: DataParallel prefixes stripped, shape mismatches skipped with a
     message, unknown keys dropped, missing keys keep the model's value; save_model round trip."""
