@@ -51,9 +51,14 @@ def get_affine_transform(center, scale, rot, output_size, shift=(0.0, 0.0), inv=
 def apply_affine(points, trans):
     """(N, 2) points through a 2x3 matrix: float32 homogeneous coordinates, float64 product
     (the arithmetic of utils/image.py:63-66 for a whole array at once)."""
-    pts = np.concatenate([np.asarray(points, np.float32).reshape(-1, 2),
-                          np.ones((len(points), 1), np.float32)], axis=1)
-    return pts.astype(np.float64) @ np.asarray(trans, np.float64).T
+    p = np.asarray(points, np.float32).reshape(-1, 2).astype(np.float64)
+    t = np.asarray(trans, np.float64)
+    # the dot product of utils/image.py:65 written out term by term ((t0*x + t1*y) + t2*1): plain
+    # element-wise numpy, no BLAS call (and none of its worker threads) on the per-frame path
+    out = np.empty((p.shape[0], 2), np.float64)
+    out[:, 0] = p[:, 0] * t[0, 0] + p[:, 1] * t[0, 1] + t[0, 2]
+    out[:, 1] = p[:, 0] * t[1, 0] + p[:, 1] * t[1, 1] + t[1, 2]
+    return out
 
 
 def affine_transform(pt, t):
