@@ -172,6 +172,31 @@ class BaseDetector(object):
         images, meta = self.pre_process(image, scale, meta)
         return images.to(self.opt.device), meta
 
+    def results_batch(self, dets, metas, scale):
+        """Host tail of ``run_frames`` (task specific): host array of raw detections + the
+        frames' metas -> what ``run(frame)['results']`` returns, per image."""
+        raise NotImplementedError
+
+    def run_frames(self, frames):
+        """A list of (H, W, 3) uint8 BGR frames of one size -> list of per-image results, what
+        ``run(frame)['results']`` returns for each (single scale, no flip).  The reference's
+        test loop is batch_size = 1 (test.py:60-62); here the frames are uploaded as ONE uint8
+        copy, pre-processed on the device straight into one batch tensor, and the whole batch
+        goes through the network + decode once (``run_batch``); the host tail is vectorised."""
+        if len(self.scales) != 1 or self.opt.flip_test:
+            raise ValueError("run_frames is single-scale, no flip")
+        if len({tuple(f.shape) for f in frames}) != 1:
+            raise ValueError("run_frames needs frames of one size")
+        scale = self.scales[0]
+        uploaded = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).to(self.opt.device)
+        g = self.input_geometry(uploaded.shape[1], uploaded.shape[2], scale)
+        batch = torch.empty((len(frames), 3, g.inp_h, g.inp_w), device=self.opt.device,
+                            dtype=torch.float32)
+        metas = [self.pre_process_device(frame, scale, out=batch[i:i + 1])[1]
+                 for i, frame in enumerate(uploaded)]
+        dets = self.run_batch(batch).detach().cpu().numpy()
+        return self.results_batch(dets, metas, scale)
+
     def run(self, image_or_path_or_tensor, meta=None):
         """One image (array, path, or the prefetch dict) through every test scale
         (base_detector.py:82-143, debug == 0 path); returns the results and the time buckets."""

@@ -95,22 +95,6 @@ class CtdetDetector(BaseDetector):
             probe['dec_events'] = (e0, e1)
             return dets
 
-    def run_frames(self, frames):
-        """A list of (H, W, 3) uint8 BGR frames of one size -> list of per-image result dicts,
-        what ``run(frame)['results']`` returns for each (single scale, no flip).  The reference's
-        test loop is batch_size = 1 (test.py:60-62); here the frames are uploaded as ONE uint8
-        copy, pre-processed on the device straight into one batch tensor, and the whole batch
-        goes through the network + decode once; the host tail is vectorised."""
-        if len(self.scales) != 1 or self.opt.flip_test:
-            raise ValueError("run_frames is single-scale, no flip")
-        if len({tuple(f.shape) for f in frames}) != 1:
-            raise ValueError("run_frames needs frames of one size")
-        scale = self.scales[0]
-        uploaded = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).to(self.opt.device)
-        g = self.input_geometry(uploaded.shape[1], uploaded.shape[2], scale)
-        batch = torch.empty((len(frames), 3, g.inp_h, g.inp_w), device=self.opt.device,
-                            dtype=torch.float32)
-        metas = [self.pre_process_device(frame, scale, out=batch[i:i + 1])[1]
-                 for i, frame in enumerate(uploaded)]
-        dets = self.run_batch(batch).detach().cpu().numpy()
+    def results_batch(self, dets, metas, scale):
+        """Host tail of ``run_frames``: (B, K, 6) host array -> per-image ``{class: (n, 5)}``."""
         return ctdet_results_batch(dets, metas, self.opt.num_classes, scale, self.max_per_image)

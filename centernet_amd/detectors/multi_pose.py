@@ -85,6 +85,20 @@ class MultiPoseDetector(BaseDetector):
                 probe['dec_events'] = (e0, e1)
             return dets
 
+    def results_batch(self, dets, metas, scale):
+        """Host tail of ``run_frames``: (B, K, 40) host array -> per image ``{1: [[x1, y1, x2,
+        y2, score, 17 x (x, y)], ...]}``, i.e. merge_outputs([post_process(...)]) for one scale
+        without NMS (multi_pose.py:62-81)."""
+        per = multi_pose_post_process(dets.copy(), [m['c'] for m in metas], [m['s'] for m in metas],
+                                      metas[0]['out_height'], metas[0]['out_width'])
+        out = []
+        for d in per:
+            rows = np.array(d[1], dtype=np.float32).reshape(-1, ROW)
+            rows[:, :4] /= scale
+            rows[:, 5:] /= scale
+            out.append({1: rows.tolist()})
+        return out
+
     def post_process(self, dets, meta, scale=1):
         """Output-grid units -> image coordinates of the unscaled frame (multi_pose.py:62-72)."""
         host = dets.detach().cpu().numpy()

@@ -193,6 +193,28 @@ def test_multi_pose_flip_test_matches_oracle_pipeline(dev):
     assert (np.abs(got[safe, 5:] - ref[safe, 5:]) < 5e-3).mean() > 0.97
 
 
+def test_multi_pose_run_frames_equals_run(dev):
+    """The batched surface for the pose task: run_frames == run() per frame."""
+    import contextlib, sys
+    from centernet_amd.opts import opts
+    from centernet_amd.detectors.detector_factory import detector_factory
+    with contextlib.redirect_stdout(sys.stderr):
+        opt = opts().init(["multi_pose", "--arch", "dla_34", "--input_h", "128", "--input_w", "128"])
+        det = detector_factory[opt.task](opt)
+    synth.fill_state_dict_(det.model, 317)
+    det.model.invalidate_plans()
+    rng = np.random.RandomState(6)
+    frames = [rng.randint(0, 256, (96, 120, 3)).astype(np.uint8) for _ in range(3)]
+    batched = det.run_frames(frames)
+    assert len(batched) == 3
+    for f, rb in zip(frames, batched):
+        rs = det.run(f)['results']
+        a, b = np.array(rb[1], np.float32), np.array(rs[1], np.float32)
+        assert a.shape == b.shape == (opt.K, 39)
+        assert np.abs(a[:, 4] - b[:, 4]).max() < 1e-4          # scores
+        assert np.abs(a - b).max() < 5e-3                      # pixels
+
+
 def test_run_frames_equals_run(dev):
     """run_frames (batched, device pre-process) == run() per frame (same kernels per image up to
     the batch-size dependent split-K summation order)."""
