@@ -180,6 +180,29 @@ def test_ctdet_results_batch_equals_per_image_loop():
                 assert (np.abs(got[i][j] - ref[j]) <= np.spacing(np.abs(ref[j]))).all()
 
 
+def test_ctdet_results_batch_with_mixed_frame_geometries():
+    """Images of different geometry in one batch: every distinct (centre, extent, grid) gets its
+    own inverse map, images sharing one go through it together."""
+    from centernet_amd.post_process import ctdet_results_batch
+    from oracle import post_oracle
+    rng = np.random.RandomState(8)
+    B, K = 5, 100
+    dets = np.zeros((B, K, 6), np.float32)
+    dets[:, :, :4] = rng.uniform(0, 128, (B, K, 4))
+    dets[:, :, 4] = np.sort(rng.uniform(0, 1, (B, K)), axis=1)[:, ::-1]
+    dets[:, :, 5] = rng.randint(0, 80, (B, K))
+    a = {'c': np.array([250., 187.5], np.float32), 's': 500.0, 'out_height': 128, 'out_width': 128}
+    b = {'c': np.array([320., 240.], np.float32), 's': np.array([640., 480.], np.float32),
+         'out_height': 128, 'out_width': 128}
+    metas = [a, b, dict(a), b, a]
+    got = ctdet_results_batch(dets.copy(), metas, 80, scale=2.0, max_per_image=100)
+    for i in range(B):
+        ref = post_oracle.ctdet_results(dets[i:i + 1].copy(), metas[i], 80, scale=2.0, max_per_image=100)
+        for j in range(1, 81):
+            assert got[i][j].shape == ref[j].shape
+            assert (np.abs(got[i][j] - ref[j]) <= np.spacing(np.abs(ref[j]))).all()
+
+
 def test_detector_post_process_and_merge_match_the_oracle_tail():
     """CtdetDetector.post_process + merge_outputs (the single-image API, ctdet.py:47-73) against
     the oracle's restatement: one scale, two scales with soft-NMS, and more detections than the
