@@ -92,7 +92,29 @@ def resize_matrix(in_size, out_size):
 def warp_bilinear_u8(img, Mi, dsize, replicate=False):
     """The arithmetic contract shared with the device kernel (csrc/cn_pre.hip) and
     oracle/pre_oracle.py: float64 bilinear in a fixed operation order, taps outside the image
-    zero (or clamped when ``replicate``), round-half-even to uint8."""
+    zero (or clamped when ``replicate``), round-half-even to uint8.  Runs in the library's host
+    routine ``cn_warp_bilinear_u8_host`` (the same operations in C, ~2 ms per 512x512 frame);
+    ``warp_bilinear_u8_numpy`` below is the array-at-once statement of it (30 ms), kept as the
+    readable definition and checked against it bit for bit (tests/test_host.py)."""
+    import ctypes
+    from . import native
+    img = np.ascontiguousarray(img)
+    assert img.dtype == np.uint8 and img.ndim in (2, 3)
+    w_out, h_out = int(dsize[0]), int(dsize[1])
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    if ch > 4:
+        return warp_bilinear_u8_numpy(img, Mi, dsize, replicate)
+    out = np.empty((h_out, w_out) if img.ndim == 2 else (h_out, w_out, ch), np.uint8)
+    m = (ctypes.c_double * 6)(*np.asarray(Mi, np.float64).reshape(-1)[:6])
+    native.check(native.lib().cn_warp_bilinear_u8_host(
+        img.ctypes.data_as(ctypes.c_void_p), img.shape[0], img.shape[1], ch, m, h_out, w_out,
+        int(bool(replicate)), out.ctypes.data_as(ctypes.c_void_p)), "cn_warp_bilinear_u8_host")
+    return out
+
+
+def warp_bilinear_u8_numpy(img, Mi, dsize, replicate=False):
+    """``warp_bilinear_u8`` written with whole-array numpy operations (the definition the C
+    routine and the device kernels follow operation for operation)."""
     w_out, h_out = int(dsize[0]), int(dsize[1])
     h_in, w_in = img.shape[:2]
     Mi = np.asarray(Mi, np.float64)

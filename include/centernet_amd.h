@@ -351,6 +351,15 @@ int cn_warp_normalize_u8_f32(const uint8_t *image_hwc, int H, int W, int pitch_b
 int cn_resize_bilinear_u8(const uint8_t *image_hwc, int H, int W, int pitch_bytes, int out_h,
                           int out_w, uint8_t *out_hwc, void *stream);
 
+/* cv2.resize / cv2.warpAffine (INTER_LINEAR) of a uint8 HWC image on the HOST, for callers that keep
+ * BaseDetector.pre_process on host cores (base_detector.py:37-65).  Mi = dst -> src 2x3 matrix
+ * (6 doubles, row-major); taps outside the image are zero, or clamped when `replicate` (resize);
+ * float64 bilinear in the operation order of the device kernels above, round-half-even: results
+ * equal cn_warp_normalize_u8_f32 / cn_resize_bilinear_u8 bit for bit.  channels <= 4. */
+int cn_warp_bilinear_u8_host(const uint8_t *image_hwc, int h_in, int w_in, int channels,
+                             const double *Mi, int h_out, int w_out, int replicate,
+                             uint8_t *out_hwc);
+
 /* Soft-NMS on a HOST array, in place (rows of `stride` floats: x1,y1,x2,y2,score,...).
  * Replaces external.nms.soft_nms / soft_nms_39 (src/lib/external/nms.pyx:77-275), used by
  * merge_outputs when --nms or multi-scale testing is on (detectors/ctdet.py:63-64).
