@@ -527,6 +527,26 @@ extern "C" int cn_upsample2x_add_f16(const void *x, const void *add, void *y, in
     return CN_OK;
 }
 
+// ((image / 255. - mean) / std).astype(float32), HWC -> CHW on the HOST (base_detector.py:56-58): the
+// float64 arithmetic numpy performs for `uint8_array / 255.`, then one rounding to float32.
+extern "C" int cn_normalize_u8_chw_f32_host(const uint8_t *img, int h, int w, const float *mean,
+                                            const float *std, float *out)
+{
+#pragma clang fp contract(off)
+    if (!img || !mean || !std || !out) return CN_ERR_NULL;
+    if (h <= 0 || w <= 0) return CN_ERR_SHAPE;
+    const size_t hw = (size_t)h * w;
+    for (int c = 0; c < 3; ++c) {
+        const double m = (double)mean[c], sd = (double)std[c];
+        double lut[256];   // 256 possible inputs per channel: the division is done once each
+        for (int v = 0; v < 256; ++v) lut[v] = ((double)v / 255.0 - m) / sd;
+        float *o = out + (size_t)c * hw;
+        const uint8_t *p = img + c;
+        for (size_t i = 0; i < hw; ++i) o[i] = (float)lut[p[3 * i]];
+    }
+    return CN_OK;
+}
+
 // Bilinear warp / resize of a uint8 HWC image on the HOST (BaseDetector.pre_process when the
 // caller keeps the pre-process on host cores, e.g. DataLoader workers: base_detector.py:37-65 ->
 // cv2.resize / cv2.warpAffine).  The arithmetic contract of csrc/cn_pre.hip and

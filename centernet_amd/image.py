@@ -167,7 +167,26 @@ def resize_bilinear(img, dsize):
 
 
 def normalize_chw(inp_u8, mean, std):
-    """((inp / 255. - mean) / std).astype(float32) then HWC -> CHW (base_detector.py:56-58)."""
+    """((inp / 255. - mean) / std).astype(float32) then HWC -> CHW (base_detector.py:56-58), in the
+    library's host routine (numpy's float64 arithmetic through a 256-entry table per channel;
+    ``normalize_chw_numpy`` is the definition it is checked against)."""
+    import ctypes
+    from . import native
+    img = np.ascontiguousarray(inp_u8)
+    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
+        return normalize_chw_numpy(inp_u8, mean, std)
+    m = np.ascontiguousarray(np.asarray(mean, np.float32).reshape(3))
+    sd = np.ascontiguousarray(np.asarray(std, np.float32).reshape(3))
+    out = np.empty((3, img.shape[0], img.shape[1]), np.float32)
+    native.check(native.lib().cn_normalize_u8_chw_f32_host(
+        img.ctypes.data_as(ctypes.c_void_p), img.shape[0], img.shape[1],
+        m.ctypes.data_as(ctypes.c_void_p), sd.ctypes.data_as(ctypes.c_void_p),
+        out.ctypes.data_as(ctypes.c_void_p)), "cn_normalize_u8_chw_f32_host")
+    return out
+
+
+def normalize_chw_numpy(inp_u8, mean, std):
+    """``normalize_chw`` as the reference writes it (base_detector.py:56-58)."""
     mean = np.asarray(mean, np.float32).reshape(1, 1, 3)
     std = np.asarray(std, np.float32).reshape(1, 1, 3)
     inp = ((inp_u8 / 255. - mean) / std).astype(np.float32)

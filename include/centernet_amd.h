@@ -360,6 +360,11 @@ int cn_warp_bilinear_u8_host(const uint8_t *image_hwc, int h_in, int w_in, int c
                              const double *Mi, int h_out, int w_out, int replicate,
                              uint8_t *out_hwc);
 
+/* ((image / 255. - mean) / std).astype(float32) + HWC -> CHW of a 3-channel uint8 image on the HOST
+ * (base_detector.py:56-58), numpy's float64 arithmetic, one rounding to float32. */
+int cn_normalize_u8_chw_f32_host(const uint8_t *image_hwc, int h, int w, const float *mean3,
+                                 const float *std3, float *out_chw);
+
 /* Soft-NMS on a HOST array, in place (rows of `stride` floats: x1,y1,x2,y2,score,...).
  * Replaces external.nms.soft_nms / soft_nms_39 (src/lib/external/nms.pyx:77-275), used by
  * merge_outputs when --nms or multi-scale testing is on (detectors/ctdet.py:63-64).

@@ -211,6 +211,20 @@ def test_host_warp_routine_equals_the_numpy_definition():
     assert (t1 - t0) < (t2 - t1), "the C routine should be faster than the numpy definition"
 
 
+def test_host_normalise_routine_equals_the_numpy_definition():
+    """cn_normalize_u8_chw_f32_host == ((img / 255. - mean) / std).astype(float32) + CHW, bit for bit
+    (every uint8 level occurs in the larger images)."""
+    from centernet_amd.image import normalize_chw, normalize_chw_numpy
+    rng = np.random.RandomState(4)
+    mean = np.array([0.408, 0.447, 0.470], np.float32)
+    std = np.array([0.289, 0.274, 0.278], np.float32)
+    for shape in ((1, 1, 3), (37, 53, 3), (128, 96, 3)):
+        img = rng.randint(0, 256, shape).astype(np.uint8)
+        a, b = normalize_chw(img, mean.reshape(1, 1, 3), std.reshape(1, 1, 3)), normalize_chw_numpy(img, mean, std)
+        assert a.dtype == np.float32 and a.shape == (3,) + shape[:2]
+        assert np.array_equal(a, np.ascontiguousarray(b))
+
+
 def test_ctdet_results_batch_with_mixed_frame_geometries():
     """Images of different geometry in one batch: every distinct (centre, extent, grid) gets its
     own inverse map, images sharing one go through it together."""
