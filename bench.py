@@ -109,6 +109,8 @@ def parse(argv=None):
     p.add_argument("--tune", action="append", default=[],
                    help="KEY=VALUE for cn_set_tuning (A/B experiments; not used by the driver)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-fp32-leg", action="store_true",
+                   help="skip the short fp32-MFMA leg that is reported next to the f32s headline")
     p.add_argument("--cpu-seconds", type=float, default=15.0,
                    help="bound of the CPU-baseline sample (seconds of CPU work)")
     p.add_argument("--per-op", action="store_true", help="print per-launch timings to stderr")
@@ -121,26 +123,30 @@ def parse(argv=None):
 
 
 def precision_check(dev):
-    """One dense layer (128 -> 128, 3x3, 2 x 64 x 64) on both compute modes against torch fp64:
-    max |error| relative to the output rms.  f32s (three fp16 MFMAs per fp32 product, fp32
-    accumulate) is held to the accuracy of the plain fp32 matrix instruction."""
+    """One dense layer (128 -> 128, 3x3, 2 x 64 x 64) on both compute modes against torch fp64,
+    at three activation scales: max |error| relative to the output rms.  f32s (three fp16 MFMAs
+    per fp32 product, fp32 accumulate, tensors stored with a per-tensor power-of-two exponent) is
+    held to the accuracy of the plain fp32 matrix instruction at every scale."""
     import torch
     import torch.nn.functional as F
-    from centernet_amd.engine import PlanBuilder, Act
+    from centernet_amd.engine import PlanBuilder, Act, exponent_for
     g = torch.Generator().manual_seed(5)
-    x = torch.randn((2, 128, 64, 64), generator=g).relu_()
+    x0 = torch.randn((2, 128, 64, 64), generator=g).relu_()
     w = torch.randn((128, 128, 3, 3), generator=g) * (2.0 / (128 * 9)) ** 0.5
-    ref = F.conv2d(x.double(), w.double(), padding=1).permute(0, 2, 3, 1)
-    rms = float(ref.pow(2).mean().sqrt())
     out = {}
-    for name, split in (("f32s", True), ("fp32_mfma", False)):
-        pb = PlanBuilder(dev, 2, 64, 64, split=split)
-        y = pb.plain(pb.conv(Act(x.permute(0, 2, 3, 1).contiguous().to(dev), 2, 64, 64, 128), w,
-                             stride=1, padding=1))
-        for op in pb.ops:
-            op()
-        torch.cuda.synchronize()
-        out[name + "_max_err_over_rms"] = float((y.t.double().cpu() - ref).abs().max()) / rms
+    for sname, sc in (("", 1.0), ("_x1e-4", 1e-4), ("_x1e+4", 1e4)):
+        x = x0 * sc
+        ref = F.conv2d(x.double(), w.double(), padding=1).permute(0, 2, 3, 1)
+        rms = float(ref.pow(2).mean().sqrt())
+        exps = {"x": exponent_for(float(x.abs().max())), "t1": exponent_for(float(ref.abs().max()))}
+        for name, split in (("f32s", True), ("fp32_mfma", False)):
+            pb = PlanBuilder(dev, 2, 64, 64, split=split, exps=exps)
+            xa = Act(x.permute(0, 2, 3, 1).contiguous().to(dev), 2, 64, 64, 128, exp=pb._exp("x"), lid="x")
+            y = pb.plain(pb.conv(xa, w, stride=1, padding=1))
+            for op in pb.ops:
+                op()
+            torch.cuda.synchronize()
+            out[name + "_max_err_over_rms" + sname] = float((y.t.double().cpu() - ref).abs().max()) / rms
     out["reference"] = "torch fp64 conv2d"
     return out
 
@@ -278,6 +284,9 @@ def main():
     for _ in range(max(a.warmup, 1)):
         dets = det.run_batch(images)
     torch.cuda.synchronize()
+    # f32s: the first forward calibrated the per-tensor exponents on this batch; a clamped value
+    # here would mean the calibration is broken -- never time a run that is not range-clean
+    assert det.range_ok(images), "f32s range check failed during warm-up"
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -300,6 +309,8 @@ def main():
         probe = {"event_after": bset}
         dets = det.run_batch(images, probe=probe)    # same entry point as the warm-up
         probes.append(probe)
+    # inside the timed region: the (synchronising) look at the f32s range words of all K steps
+    range_clean = det.range_ok()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -310,6 +321,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if not range_clean:
+        raise SystemExit("bench.py: an f32s forward clamped a value inside the timed region")
+    fp32_leg = None
+    if rank == 0 and not a.fp16 and not a.fp32_mfma and not a.no_fp32_leg:
+        # the same step on the plain fp32 matrix instruction (v_mfma_f32_32x32x2_f32), a few
+        # steps, so that the headline is never ambiguous about what the f32s arithmetic buys
+        det.model.fp32_mfma(True)
+        for _ in range(2):
+            det.run_batch(images)
+        torch.cuda.synchronize()
+        n_leg = max(3, min(10, a.steps))
+        t1 = time.perf_counter()
+        for _ in range(n_leg):
+            det.run_batch(images)
+        torch.cuda.synchronize()
+        leg_dt = time.perf_counter() - t1
+        fp32_leg = {"value": B * n_leg / leg_dt, "unit": "img/s (this rank)", "steps": n_leg,
+                    "ms_per_step": leg_dt / n_leg * 1e3, "dtype": "f32"}
+        det.model.fp32_mfma(None)
     if rank == 0:
         # ---- per-kernel-class time from the HIP events recorded inside the timed region
         kinds = {}
@@ -325,6 +355,8 @@ def main():
             for i, m in enumerate(plan.b.meta):
                 ms = sum(pr["net_events"][i].elapsed_time(pr["net_events"][i + 1]) for pr in probes) / a.steps
                 kind, act = plan.b.trace[i]
+                if act is None:
+                    continue
                 print("op %2d %-7s out(B,H,W,C)=(%d,%d,%d,%d) %8.3f ms  %7.2f TF/s  %7.1f GB/s" % (
                     i, kind, act.B, act.H, act.W, act.C, ms, m["flops"] / ms / 1e9 if ms else 0,
                     m["bytes"] / ms / 1e6 if ms else 0), file=sys.stderr)
@@ -394,6 +426,12 @@ def main():
             "roofline_decode_hbm": roof("decode", "hbm"),
             "pmc_profile": pmc_file,
             "precision_check": precision_check(dev) if not a.fp16 else None,
+            "fp32_mfma_leg": fp32_leg,
+            "f32s_range": None if (a.fp16 or a.fp32_mfma) else {
+                "clean": bool(range_clean),
+                "calibrations": det.model.__dict__.get("_calibrations", 0),
+                "policy": "per-tensor power-of-two exponents from one fp32 calibration pass; every "
+                          "split site max-es |value| into range words, read inside the timed region"},
             "time_share": {k: round(v["ms"] / (dt * 1e3), 4) for k, v in kinds.items()},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -48,6 +48,20 @@ struct cn_f32s { float raw; };   // element tag of f32s tensors in kernel templa
 typedef _Float16 cn_f16x4v __attribute__((ext_vector_type(4)));
 typedef _Float16 cn_f16x8v __attribute__((ext_vector_type(8)));
 
+//
+// Range.  An fp16 pair carries 22 bits only while the high part is a normal fp16 number and
+// the low part has not gone subnormal, i.e. for 2^-3 <~ |a| <= 65504; below that the absolute
+// error floor is 2^-25 whatever the magnitude.  The library therefore never splits a raw value:
+// every f32s tensor holds   stored = real * 2^-e   with a per-tensor exponent e the caller picks
+// so that the tensor's largest magnitude sits near 2^9 (centernet_amd/engine.py: measured once
+// per network on a plain-fp32 calibration pass), weights are pre-scaled per output row to
+// [2^13, 2^14), and the factors are undone -- exactly, they are powers of two -- through the
+// per-channel epilogue scale the kernels apply anyway.  Kernels take the remaining multipliers
+// in cn_f32s_ctl (x_mul for a plain input that is split while it is staged, res_mul for the
+// residual).  Nothing saturates silently: every split site keeps the running max |value| it was
+// asked to split and the launch max-es it into the caller's `range` words (cn_rng_* below); a
+// value beyond 65504 is still clamped (its low part would be NaN) but the word then reads
+// > 65504 and the host re-calibrates and re-runs (engine.Plan.check_range).
 __device__ __forceinline__ void cn_split4(cn_f32x4 v, cn_f16x4v &hi, cn_f16x4v &lo)
 {
 #pragma unroll
@@ -56,6 +70,44 @@ __device__ __forceinline__ void cn_split4(cn_f32x4 v, cn_f16x4v &hi, cn_f16x4v &
         const float c = __builtin_fminf(__builtin_fmaxf(v[e], -65504.0f), 65504.0f);
         hi[e] = (_Float16)c;
         lo[e] = (_Float16)(c - (float)hi[e]);
+    }
+}
+// ---- range words: running max |v| of everything a launch split, as float bit patterns
+// (non-negative floats order like unsigned integers).  One conditional atomic per wave, spread
+// over CN_RANGE_SLOTS words in separate 64-byte lines per side: the waves of a launch finish in
+// bursts (a whole dispatch round at once), and thousands of atomics on ONE address serialise
+// at ~12 ns each (measured: +30 us on a 38 us launch); cn_range_fold reduces the slots.
+__device__ __forceinline__ void cn_rng_upd4(float &m, cn_f32x4 v)
+{
+    m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))),
+                        __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+}
+__device__ __forceinline__ void cn_rng_upd1(float &m, float v) { m = __builtin_fmaxf(m, __builtin_fabsf(v)); }
+// single-word form (cn_absmax_f32)
+__device__ __forceinline__ void cn_rng_commit1(uint32_t *word, float m)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t bits = __builtin_bit_cast(uint32_t, m);
+        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(word, bits);
+    }
+}
+// call with the whole wave active (no early-returned lanes); `range` may be null;
+// side 0 = output side, 1 = input side (cn_f32s_ctl.range)
+__device__ __forceinline__ void cn_rng_commit(uint32_t *range, int side, float m)
+{
+    if (!range) return;   // uniform
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) + blockIdx.y * 7u +
+                               blockIdx.z * 13u) & (CN_RANGE_SLOTS - 1);
+        uint32_t *word = range + ((size_t)side * CN_RANGE_SLOTS + slot) * CN_RANGE_STRIDE;
+        const uint32_t bits = __builtin_bit_cast(uint32_t, m);
+        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(word, bits);
     }
 }
 __device__ __forceinline__ cn_f32x4 cn_join4(cn_f16x4v hi, cn_f16x4v lo)

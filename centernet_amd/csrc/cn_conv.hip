@@ -78,6 +78,8 @@ struct IgemmArgs {
     int ksplit;    // split-K: blockIdx.z owns chunks [z*KT/ksplit, (z+1)*KT/ksplit)
     float *partial; // split-K: raw fp32 partial sums [ksplit][M][cout_pad]
     int in_plain, out_plain, res_plain;  // f32s kernels: x / y / residual are plain fp32 tensors
+    float x_mul, res_mul;                // f32s range control (cn_f32s_ctl)
+    uint32_t *range;                     // f32s: [0] max |stored output|, [1] max |split input|
 };
 
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -229,6 +231,9 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 const float off_w = om[2 * tap + 1];
                 mk = om[18 + tap];
                 if (a.mask_sigmoid) mk = sigmoidf_dev(mk);  // dcn_v2.py:67
+                // f32s: the plain input is brought to stored units (x * 2^-e, exact) through the
+                // modulation factor it is multiplied with anyway
+                if constexpr (SPLIT) mk *= a.x_mul;
                 const int ki = tap / 3, kj = tap - ki * 3;
                 const float h_im = (float)(oy - 1 + ki) + off_h;
                 const float w_im = (float)(ox - 1 + kj) + off_w;
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
     constexpr int NSET = SPLIT ? CN_IGEMM_F32S_SETS : 1;
     cn_f32x4 ra_[NSET][PA][NCORN];
     cn_f32x4 rb_[NSET][PB];
+    float rng_in = 0.f, rng_out = 0.f;   // largest |value| split on the input / output side
     const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     auto load_tiles = [&](int kt, auto SET) {
@@ -399,6 +405,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                 v = v * mk;
                 if constexpr (SPLIT) {
                     cn_f16x4v hi, lo;
+                    cn_rng_upd4(rng_in, v);
                     cn_split4(v, hi, lo);
                     char *row = reinterpret_cast<char *>(Ad + r * LDT);
                     *reinterpret_cast<cn_f16x4v *>(row + 8 * q) = hi;
@@ -413,7 +420,9 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
                     for (int p = 0; p < PA; ++p) {
                         cn_f16x4v hi, lo;
-                        cn_split4(ra[p][0], hi, lo);
+                        const cn_f32x4 xs = ra[p][0] * a.x_mul;   // real -> stored units
+                        cn_rng_upd4(rng_in, xs);
+                        cn_split4(xs, hi, lo);
                         char *row = reinterpret_cast<char *>(Ad + (p * 32 + lrow) * LDT);
                         *reinterpret_cast<cn_f16x4v *>(row + 8 * q) = hi;
                         *reinterpret_cast<cn_f16x4v *>(row + 64 + 8 * q) = lo;
@@ -640,15 +649,20 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = (v[e] + bs[e]) * sc[e] + sf[e];
-                        if (a.residual) t += res[it][e];
+                        if (a.residual) {
+                            if constexpr (SPLIT) t = fmaf(res[it][e], a.res_mul, t);
+                            else t += res[it][e];
+                        }
                         v[e] = a.relu ? fmaxf(t, 0.f) : t;
                     }
                     if constexpr (SPLIT) {
                         if (a.out_plain)
                             store4_from_f32(reinterpret_cast<float *>(a.y) +
                                             (size_t)offs[it] * a.out_pitch + n, v);
-                        else
+                        else {
+                            cn_rng_upd4(rng_out, v);
                             cn_store4_f32s(a.y, (size_t)offs[it], a.out_pitch, n, v);
+                        }
                     } else {
                         store4_from_f32(reinterpret_cast<T *>(a.y) + (size_t)offs[it] * a.out_pitch + n, v);
                     }
@@ -664,13 +678,16 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                         float t = (Cs[lr * LDC + c4 * 4 + e] + bs[e]) * sc[e] + sf[e];
                         if constexpr (SPLIT) {
                             if (a.residual)
-                                t += a.res_plain ? reinterpret_cast<const float *>(a.residual)[o]
-                                                 : cn_load1_f32s(a.residual, (size_t)off, a.out_pitch, n + e);
+                                t = fmaf(a.res_plain ? reinterpret_cast<const float *>(a.residual)[o]
+                                                     : cn_load1_f32s(a.residual, (size_t)off, a.out_pitch, n + e),
+                                         a.res_mul, t);
                             t = a.relu ? fmaxf(t, 0.f) : t;
                             if (a.out_plain)
                                 reinterpret_cast<float *>(a.y)[o] = t;
-                            else
+                            else {
+                                cn_rng_upd1(rng_out, t);
                                 cn_store1_f32s(a.y, (size_t)off, a.out_pitch, n + e, t);
+                            }
                         } else {
                             if (a.residual) t += (float)reinterpret_cast<const T *>(a.residual)[o];
                             reinterpret_cast<T *>(a.y)[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
@@ -701,6 +718,12 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
                     }
                 }
             }
+        }
+    }
+    if constexpr (SPLIT) {
+        if (a.range) {   // uniform; the whole workgroup reaches this point
+            if (!OUT_NCHW && !a.out_plain && a.ksplit <= 1) cn_rng_commit(a.range, 0, rng_out);
+            if (DCN || a.in_plain) cn_rng_commit(a.range, 1, rng_in);
         }
     }
 }
@@ -868,18 +891,19 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
                      int stride, int pad, int relu, int out_pitch, int KP, int persistent,
-                     hipStream_t st);
+                     const cn_f32s_ctl *ctl, hipStream_t st);
 int cn_stem_pool_rows(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int KP);
 int cn_stem_pool_f32s(const float *x, const float *w_packed, const float *scale, const float *shift,
                       float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
-                      int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st);
+                      int stride, int pad, int relu, int out_pitch, int KP, const cn_f32s_ctl *ctl,
+                      hipStream_t st);
 int cn_dcn_window_f32(const float *x, const float *w_packed, const float *bias, const float *om,
                       int om_pitch, const float *scale, const float *shift, float *y, int B, int Cin,
                       int H, int W, int Cout, int mask_sigmoid, int relu, int setprio, hipStream_t st);
 int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                  int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
-                 int f16, hipStream_t st);
+                 int f16, const cn_f32s_ctl *ctl, hipStream_t st);
 int cn_conv3x3_c16(const float *x, const float *w_packed, const float *scale, const float *shift,
                    float *y, int B, int H, int W, int Ho, int Wo, int Cin, int Cout, int stride,
                    int in_pitch, int out_pitch, int relu, hipStream_t st);
@@ -888,7 +912,8 @@ extern int cn_tune_f32s_lds_weights;  // cn_conv3x3.hip
 extern int cn_tune_f32s_policy;       // cn_conv3x3.hip
 int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale, const float *shift,
                         void *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
-                        int relu, int vec_out, int setprio, int dtype_flags, hipStream_t st);
+                        int relu, int vec_out, int setprio, int dtype_flags, const cn_f32s_ctl *ctl,
+                        hipStream_t st);
 namespace {
 
 // split-K second stage: sum the partial tiles, then the usual epilogue
@@ -900,6 +925,7 @@ __global__ void splitk_reduce_kernel(const IgemmArgs a)
     const size_t total = (size_t)a.M * n4;
     const int HoWo = a.Ho * a.Wo;
     const size_t zstride = (size_t)a.M * a.cout_pad;
+    float rng_out = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % n4);
@@ -922,13 +948,16 @@ __global__ void splitk_reduce_kernel(const IgemmArgs a)
                 float t = (v[e] + bs) * sc + sf;
                 const size_t o = off * a.out_pitch + n + e;
                 if (a.residual)
-                    t += a.res_plain ? reinterpret_cast<const float *>(a.residual)[o]
-                                     : cn_load1_f32s(a.residual, off, a.out_pitch, n + e);
+                    t = fmaf(a.res_plain ? reinterpret_cast<const float *>(a.residual)[o]
+                                         : cn_load1_f32s(a.residual, off, a.out_pitch, n + e),
+                             a.res_mul, t);
                 t = a.relu ? fmaxf(t, 0.f) : t;
                 if (a.out_plain)
                     reinterpret_cast<float *>(a.y)[o] = t;
-                else
+                else {
+                    cn_rng_upd1(rng_out, t);
                     cn_store1_f32s(a.y, off, a.out_pitch, n + e, t);
+                }
             }
         } else {
             const T *res = reinterpret_cast<const T *>(a.residual);
@@ -943,6 +972,9 @@ __global__ void splitk_reduce_kernel(const IgemmArgs a)
                 y[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
             }
         }
+    }
+    if constexpr (std::is_same<T, cn_f32s>::value) {
+        if (a.range && !a.out_plain) cn_rng_commit(a.range, 0, rng_out);
     }
 }
 
@@ -960,6 +992,14 @@ inline int plan_ksplit(int M, int Cout, int KT, int bm, int bn)
     return s < 2 ? 1 : s;
 }
 inline bool is_stem(int Cin, int in_layout) { return in_layout == CN_LAYOUT_NCHW && Cin == 3; }
+inline void set_ctl(IgemmArgs &a, const cn_f32s_ctl *ctl)
+{
+    a.x_mul = (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f;
+    a.res_mul = (ctl && ctl->res_mul != 0.f) ? ctl->res_mul : 1.f;
+    a.range = ctl ? ctl->range : nullptr;
+}
+// f32s tensors are addressed in 128-byte groups of 32 channels
+inline bool aligned128(const void *p) { return (((uintptr_t)p) & 127u) == 0; }
 
 }  // namespace
 
@@ -1135,6 +1175,12 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
     if (rc != CN_OK) return rc;
     a.x = x; a.w = w_packed; a.bias = nullptr; a.scale = scale; a.shift = shift;
     a.residual = residual; a.y = y; a.om = nullptr;
+    set_ctl(a, &d->ctl);
+    if (d->dtype == CN_DTYPE_F32S) {
+        if (d->in_layout == CN_LAYOUT_NHWC && !(d->flags & CN_CONV_X_PLAIN) && !aligned128(x)) return CN_ERR_ALIGN;
+        if (d->out_layout == CN_LAYOUT_NHWC && !(d->flags & CN_CONV_Y_PLAIN) && !aligned128(y)) return CN_ERR_ALIGN;
+        if (residual && !(d->flags & CN_CONV_R_PLAIN) && !aligned128(residual)) return CN_ERR_ALIGN;
+    }
     const bool f16 = (d->dtype == CN_DTYPE_F16);
     const size_t valign = f16 ? 8 : 16;  // 4 output elements per store
     a.vec_out = (d->out_layout == CN_LAYOUT_NHWC && (d->out_pitch & 3) == 0 &&
@@ -1189,14 +1235,14 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
                 return CN_ERR_UNSUPPORTED;
             return cn_stem_pool_f32s((const float *)x, (const float *)w_packed, scale, shift,
                                      (float *)y, d->B, d->H, d->W, d->Ho, d->Wo, d->Cout, d->KH,
-                                     d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad, st);
+                                     d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad, &d->ctl, st);
         }
         if (!g_tune_nostem && d->pad_h == d->pad_w && d->dil == 1 && d->oy_mul == 1 &&
             d->ox_mul == 1 && d->OH == d->Ho && d->OW == d->Wo) {
             rc = cn_stem_conv_f32((const float *)x, (const float *)w_packed, scale, shift,
                                   (float *)y, d->B, d->H, d->W, d->Ho, d->Wo, d->Cout, d->KH,
                                   d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad,
-                                  g_tune_stem_persist | ((d->flags & CN_CONV_STEM_F32S) ? 2 : 0), st);
+                                  g_tune_stem_persist | ((d->flags & CN_CONV_STEM_F32S) ? 2 : 0), &d->ctl, st);
             if (rc != CN_ERR_UNSUPPORTED) return rc;
         }
         if (d->Cout > 64) return launch_igemm<128, 128, 2, 2, A_STEM, false>(a, st);
@@ -1220,7 +1266,8 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         return cn_conv3x3s1(x, w_packed, scale, shift, residual, y, d->B, d->H, d->W, d->Cin,
                             d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
                             g_tune_setprio | ((g_tune_bm256 & 1) << 1) | ((g_tune_bm256 >> 1) << 3) | (g_tune_waves8 << 2) | (g_tune_occ4 << 7) |
-                                ((g_tune_dbgskip & 7) << 4) | ((g_tune_dbgskip >> 3) << 9), cls, d->dtype | (d->flags << 8), st);
+                                ((g_tune_dbgskip & 7) << 4) | ((g_tune_dbgskip >> 3) << 9), cls, d->dtype | (d->flags << 8),
+                            &d->ctl, st);
     if (f32s) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_s<64, 128, 2, 2, A_DENSE, false>(a, st)
@@ -1296,7 +1343,7 @@ extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *
 {
     return cn_dcn_v2_forward_nhwc(input_nhwc, weight_packed, bias, offset_mask_nhwc, om_pitch, scale,
                                   shift, output_nhwc, Cout, B, Cin, H, W, Cout, mask_sigmoid, relu,
-                                  CN_DTYPE_F32, 0, workspace, workspace_bytes, stream);
+                                  CN_DTYPE_F32, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weight_packed,
@@ -1304,8 +1351,8 @@ extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weigh
                                       int om_pitch, const float *scale, const float *shift,
                                       void *output_nhwc, int out_pitch, int B, int Cin, int H,
                                       int W, int Cout, int mask_sigmoid, int relu, int dtype,
-                                      int flags, void *workspace, size_t workspace_bytes,
-                                      void *stream)
+                                      int flags, const cn_f32s_ctl *ctl, void *workspace,
+                                      size_t workspace_bytes, void *stream)
 {
     if (!input_nhwc || !weight_packed || !offset_mask_nhwc || !output_nhwc) return CN_ERR_NULL;
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || out_pitch < Cout) return CN_ERR_SHAPE;
@@ -1315,6 +1362,7 @@ extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weigh
     if (dtype != CN_DTYPE_F32 && !f32s) return CN_ERR_UNSUPPORTED;
     if (f32s && !(flags & CN_CONV_Y_PLAIN) && (out_pitch & 31)) return CN_ERR_UNSUPPORTED;
     if (!cn_aligned16(input_nhwc) || !cn_aligned16(weight_packed)) return CN_ERR_ALIGN;
+    if (f32s && !(flags & CN_CONV_Y_PLAIN) && !aligned128(output_nhwc)) return CN_ERR_ALIGN;
     if ((long)B * H * W * (long)(Cin > out_pitch ? Cin : out_pitch) >= (1L << 30)) return CN_ERR_UNSUPPORTED;  // 32-bit byte offsets
     // LDS-staged input window (cn_dcn.hip): measured 20-30 % SLOWER than the L1/L2-served
     // gather below on every CenterNet shape (tools/bench_dcn.py), so it is opt-in only
@@ -1329,6 +1377,7 @@ extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weigh
     a.x = input_nhwc; a.w = weight_packed; a.bias = bias; a.scale = scale; a.shift = shift;
     a.residual = nullptr; a.y = output_nhwc; a.om = offset_mask_nhwc; a.om_pitch = om_pitch;
     a.mask_sigmoid = mask_sigmoid;
+    set_ctl(a, ctl);
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = H; a.Wo = W; a.Cout = Cout;
     a.KH = 3; a.KW = 3; a.stride = 1; a.pad_h = 1; a.pad_w = 1; a.dil = 1;
     a.in_pitch = Cin; a.out_pitch = out_pitch;
@@ -1457,13 +1506,13 @@ extern "C" int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_pa
                                           int out_pitch, int relu, void *stream)
 {
     return cn_conv_transpose4x4s2(x_nhwc, w_packed, scale, shift, y_nhwc, B, H, W, Cin, Cout,
-                                  in_pitch, out_pitch, relu, CN_DTYPE_F32, 0, stream);
+                                  in_pitch, out_pitch, relu, CN_DTYPE_F32, 0, nullptr, stream);
 }
 
 extern "C" int cn_conv_transpose4x4s2(const void *x_nhwc, const void *w_packed, const float *scale,
                                       const float *shift, void *y_nhwc, int B, int H, int W,
                                       int Cin, int Cout, int in_pitch, int out_pitch, int relu,
-                                      int dtype, int flags, void *stream)
+                                      int dtype, int flags, const cn_f32s_ctl *ctl, void *stream)
 {
     if (!x_nhwc || !w_packed || !y_nhwc) return CN_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CN_ERR_SHAPE;
@@ -1473,9 +1522,13 @@ extern "C" int cn_conv_transpose4x4s2(const void *x_nhwc, const void *w_packed, 
     if (f32s && !(flags & CN_CONV_X_PLAIN) && (in_pitch & 31)) return CN_ERR_UNSUPPORTED;
     if (f32s && !(flags & CN_CONV_Y_PLAIN) && (out_pitch & 31)) return CN_ERR_UNSUPPORTED;
     if (!cn_aligned16(x_nhwc) || !cn_aligned16(w_packed)) return CN_ERR_ALIGN;
+    if (f32s && ((!(flags & CN_CONV_X_PLAIN) && !aligned128(x_nhwc)) ||
+                 (!(flags & CN_CONV_Y_PLAIN) && !aligned128(y_nhwc))))
+        return CN_ERR_ALIGN;
     if ((long)B * H * W * 4 * (long)out_pitch >= (1L << 31) || (long)B * H * W * (long)in_pitch >= (1L << 31))
         return CN_ERR_UNSUPPORTED;
     IgemmArgs a = {};
+    set_ctl(a, ctl);
     a.x = x_nhwc; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y_nhwc;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = H; a.Wo = W; a.Cout = Cout;
     a.KH = 2; a.KW = 2; a.stride = 1; a.pad_h = 1; a.pad_w = 1; a.dil = 1;
@@ -1498,7 +1551,7 @@ extern "C" int cn_conv_transpose4x4s2(const void *x_nhwc, const void *w_packed, 
     if (!g_tune_nohalo && Cout > 32 && a.vec_out && (in_pitch & 3) == 0)
         return cn_deconv4x4s2_halo(x_nhwc, w_packed, scale, shift, y_nhwc, B, H, W, Cin, Cout,
                                    in_pitch, out_pitch, relu, a.vec_out,
-                                   g_tune_setprio | (g_tune_occ4 << 7), dtype | (flags << 8), st);
+                                   g_tune_setprio | (g_tune_occ4 << 7), dtype | (flags << 8), ctl, st);
     if (f32s) {
         if (Cout > 64) return launch_igemm_s<128, 128, 2, 2, A_DENSE, false>(a, st);
         if (Cout > 32) return launch_igemm_s<128, 64, 2, 2, A_DENSE, false>(a, st);
@@ -1516,6 +1569,21 @@ extern "C" int cn_stem_maxpool_supported(const cn_conv_desc *d)
     if (round_up(d->KH * d->KW * 3, 32) > STEM_KMAX) return 0;
     return cn_stem_pool_rows(d->B, d->Ho, d->Wo, d->Cout, d->KH, d->KW, d->stride,
                              round_up(d->KH * d->KW * 3, 32)) > 0;
+}
+
+// Will cn_conv2d honour CN_CONV_STEM_F32S for this stem descriptor (mirror of its dispatch)?
+extern "C" int cn_stem_f32s_supported(const cn_conv_desc *d)
+{
+    if (!d || !is_stem(d->Cin, d->in_layout) || d->out_layout != CN_LAYOUT_NHWC) return 0;
+    if (d->dtype != CN_DTYPE_F32 || d->pad_h != d->pad_w || d->dil != 1) return 0;
+    const int kp = round_up(d->KH * d->KW * 3, 32);
+    if (kp > STEM_KMAX) return 0;
+    if (d->flags & CN_CONV_STEM_MAXPOOL) return cn_stem_maxpool_supported(d);
+    if (g_tune_nostem || !g_tune_stem_persist) return 0;
+    if (d->oy_mul != 1 || d->ox_mul != 1 || d->OH != d->Ho || d->OW != d->Wo) return 0;
+    // cn_stem_conv_f32: persistent 7x7 window kernel, rows of whole 128-pixel tiles, stride 2,
+    // more than 16 output channels
+    return (d->KH == 7 && d->KW == 7 && d->Wo % 128 == 0 && d->stride == 2 && d->Cout > 16) ? 1 : 0;
 }
 
 extern "C" int cn_set_tuning(int key, int value)

@@ -73,6 +73,8 @@ struct C3Args {
     int in_plain, out_plain, res_plain;  // f32s kernels: x / y / residual are plain fp32 tensors
     int ncb;                     // f32s: 32-channel output blocks in the packed weight (cout_pad / 32)
     size_t wfrag_off;            // f32s: byte offset of the fragment-ordered weight copy behind the row-ordered one
+    float x_mul, res_mul;        // f32s range control (cn_f32s_ctl): plain-x and residual multipliers
+    uint32_t *range;             // f32s: [0] max |stored output| / hidden tile, [1] max |split plain input|
 };
 
 // Fused detection heads (HEADS = true): blockIdx.y selects the head; its 64 hidden channels
@@ -87,6 +89,7 @@ struct C3Heads {
     float *y[MAX_HEADS];           // (B, cout, H, W)
     int cout[MAX_HEADS];
     int slices;                    // hidden width / 64: 64-channel slices of the hidden layer (1..4)
+    const float *oscale[MAX_HEADS];  // (cout) or null: y = acc * oscale + bias (cn_head_out.oscale)
 };
 
 // LDS floats of the kernel: the main loop's tiles, unioned with the epilogue staging
@@ -167,6 +170,8 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = tid >> 3, q = tid & 7;
+    const float a_x_mul = a.x_mul, a_res_mul = a.res_mul;   // scalars, not a stack copy of the struct tail
+    uint32_t *const a_range = a.range;
     const int tiles = a.tiles_x * a.tiles_y;
     const int b = blockIdx.x / tiles;
     const int tr = blockIdx.x - b * tiles;
@@ -225,6 +230,7 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     cn_f32x4 ra[NPA], rb[PB];
+    float rng_in = 0.f, rng_out = 0.f;   // largest |value| split on the input / output side
     auto load_A = [&](int chunk) {
         const int c = chunk * BKE + EPV * q;
         // f32s input: a 128-byte group holds 32 channels as high / low halves, so a 16-byte slot
@@ -246,7 +252,9 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                 for (int p = 0; p < NPA; ++p) {
                     const int hr = p * RPP + lrow;
                     cn_f16x4v hi, lo;
-                    cn_split4(ra[p], hi, lo);
+                    const cn_f32x4 xs = ra[p] * a_x_mul;   // real -> stored units (a power of two)
+                    cn_rng_upd4(rng_in, xs);
+                    cn_split4(xs, hi, lo);
                     if (hr < HR) {
                         char *row = reinterpret_cast<char *>(As + hr * LDT);
                         *reinterpret_cast<cn_f16x4v *>(row + 8 * q) = hi;
@@ -404,8 +412,11 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                 *reinterpret_cast<cn_f32x4 *>(W2 + row * LDS2 + k4 * 4) = wv;
             }
         }
-        for (int row = tid; row < rows; row += NT)
+        const float *os2 = hd.oscale[head];
+        for (int row = tid; row < rows; row += NT) {
             W2[row * LDS2 + HEAD_CONV] = (b2 && g0 + row < cout2) ? b2[g0 + row] : 0.f;
+            W2[row * LDS2 + HEAD_CONV + 1] = (os2 && g0 + row < cout2) ? os2[g0 + row] : 1.f;
+        }
     };
 
     auto main_loop = [&]() {
@@ -671,7 +682,8 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                             t = a.relu ? fmaxf(t, 0.f) : t;
                             if constexpr (SPLIT) {   // hidden channel nn of the row, as (high, low)
                                 const int nn = n + j * 32;
-                                const float c = fminf(t, 65504.0f);
+                                cn_rng_upd1(rng_out, t);
+                                const float c = fminf(fmaxf(t, -65504.0f), 65504.0f);
                                 const _Float16 hi = (_Float16)c;
                                 char *g = reinterpret_cast<char *>(S + row * LDS2) + (nn >> 5) * 128 + (nn & 31) * 2;
                                 *reinterpret_cast<_Float16 *>(g) = hi;
@@ -751,7 +763,7 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                                     const int co = g0 + rr;
                                     if (co < cout2)
                                         y2[((size_t)b * cout2 + co) * HWp + pix] =
-                                            acc2[jb][r] + W2[rr * LDS2 + HEAD_CONV];
+                                            acc2[jb][r] * W2[rr * LDS2 + HEAD_CONV + 1] + W2[rr * LDS2 + HEAD_CONV];
                                 }
                             }
                         }
@@ -759,6 +771,12 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                 }
             }
             __syncthreads();   // S and W2 fully read before the next slice restages them
+        }
+        if constexpr (SPLIT) {
+            if (a_range) {
+                cn_rng_commit(a_range, 0, rng_out);
+                if (a.in_plain) cn_rng_commit(a_range, 1, rng_in);
+            }
         }
         return;
     } else {
@@ -840,14 +858,19 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = v[e] * sc[e] + sf[e];
-                    if (a.residual) t += res[k][e];
+                    if (a.residual) {
+                        if constexpr (SPLIT) t = fmaf(res[k][e], a_res_mul, t);
+                        else t += res[k][e];
+                    }
                     v[e] = a.relu ? fmaxf(t, 0.f) : t;
                 }
                 if constexpr (SPLIT) {
                     if (a.out_plain)
                         c3_store4(reinterpret_cast<float *>(a.y) + (size_t)offs[k] * a.out_pitch + n, v);
-                    else
+                    else {
+                        cn_rng_upd4(rng_out, v);
                         cn_store4_f32s(a.y, (size_t)offs[k], a.out_pitch, n, v);
+                    }
                 } else {
                     c3_store4(reinterpret_cast<T *>(a.y) + (size_t)offs[k] * a.out_pitch + n, v);
                 }
@@ -863,19 +886,28 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                     float t = Cs[lr * LDC + c4 * 4 + e] * sc[e] + sf[e];
                     if constexpr (SPLIT) {
                         if (a.residual)
-                            t += a.res_plain ? reinterpret_cast<const float *>(a.residual)[(size_t)off * a.res_pitch + n + e]
-                                             : cn_load1_f32s(a.residual, (size_t)off, a.res_pitch, n + e);
+                            t = fmaf(a.res_plain ? reinterpret_cast<const float *>(a.residual)[(size_t)off * a.res_pitch + n + e]
+                                                 : cn_load1_f32s(a.residual, (size_t)off, a.res_pitch, n + e),
+                                     a_res_mul, t);
                         t = a.relu ? fmaxf(t, 0.f) : t;
                         if (a.out_plain)
                             reinterpret_cast<float *>(a.y)[o] = t;
-                        else
+                        else {
+                            cn_rng_upd1(rng_out, t);
                             cn_store1_f32s(a.y, (size_t)off, a.out_pitch, n + e, t);
+                        }
                     } else {
                         if (a.residual) t += (float)reinterpret_cast<const T *>(a.residual)[o];
                         reinterpret_cast<T *>(a.y)[o] = (T)(a.relu ? fmaxf(t, 0.f) : t);
                     }
                 }
             }
+        }
+    }
+    if constexpr (SPLIT) {
+        if (a_range) {   // uniform; every lane of the workgroup reaches this point
+            if (!a.out_plain) cn_rng_commit(a_range, 0, rng_out);
+            if (a.in_plain) cn_rng_commit(a_range, 1, rng_in);
         }
     }
 }
@@ -1068,14 +1100,22 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
     return wide ? launch_c3<T, 32, 32, 4, 1>(a, st) : launch_c3<T, 16, 32, 4, 1>(a, st);
 }
 
+static void c3_set_ctl(C3Args &a, const cn_f32s_ctl *ctl)
+{
+    a.x_mul = (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f;
+    a.res_mul = (ctl && ctl->res_mul != 0.f) ? ctl->res_mul : 1.f;
+    a.range = ctl ? ctl->range : nullptr;
+}
+
 // bn_class: 2 = 128-wide N tiles, 1 = 64, 0 = 32 (chosen by the caller, same rule as cn_conv.hip)
 // f16: 0 = fp32 tensors, 1 = fp16 tensors (fp32 accumulate, scale/shift fp32)
 int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                  int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
-                 int f16, hipStream_t st)
+                 int f16, const cn_f32s_ctl *ctl, hipStream_t st)
 {
     C3Args a = {};
+    c3_set_ctl(a, ctl);
     a.bm256 = ((setprio >> 1) & 1) | ((setprio >> 2) & 2);  // bits 1 and 3 of the knob word: cn_set_tuning key 14
     a.waves8 = (setprio >> 2) & 1; // bit 2: cn_set_tuning key 15
     a.dbg = ((setprio >> 4) & 7) | (((setprio >> 9) & 3) << 3);  // bits 4-6, 9-10: ablation switches (cn_set_tuning key 9)
@@ -1109,7 +1149,7 @@ extern "C" int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin,
                                    int n_heads, const cn_head_out *heads, void *stream)
 {
     return cn_heads3x3_1x1(x, B, H, W, Cin, in_pitch, w1_packed, nullptr, bias1, head_conv, n_heads,
-                           heads, CN_DTYPE_F32, 0, stream);
+                           heads, CN_DTYPE_F32, 0, nullptr, stream);
 }
 
 // dtype-generic form: CN_DTYPE_F32S takes f32s activations (or plain ones with CN_CONV_X_PLAIN)
@@ -1118,7 +1158,7 @@ extern "C" int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin,
 extern "C" int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int in_pitch,
                                const void *w1_packed, const float *scale1, const float *bias1,
                                int head_conv, int n_heads, const cn_head_out *heads, int dtype,
-                               int flags, void *stream)
+                               int flags, const cn_f32s_ctl *ctl, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!x || !w1_packed || !heads) return CN_ERR_NULL;
@@ -1130,6 +1170,7 @@ extern "C" int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int 
     if (dtype != CN_DTYPE_F32 && !f32s) return CN_ERR_UNSUPPORTED;
     if ((in_pitch & 3) || !cn_aligned16(x) || !cn_aligned16(w1_packed)) return CN_ERR_ALIGN;
     if (f32s && !(flags & CN_CONV_X_PLAIN) && (in_pitch & 31)) return CN_ERR_UNSUPPORTED;
+    if (f32s && !(flags & CN_CONV_X_PLAIN) && (((uintptr_t)x) & 127u)) return CN_ERR_ALIGN;  // 128-byte groups
     C3Heads hd = {};
     for (int h = 0; h < n_heads; ++h) {
         if (!heads[h].w || !heads[h].y) return CN_ERR_NULL;
@@ -1137,11 +1178,13 @@ extern "C" int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int 
         if (!cn_aligned16(heads[h].w)) return CN_ERR_ALIGN;
         hd.w[h] = heads[h].w; hd.bias[h] = heads[h].bias; hd.y[h] = heads[h].y;
         hd.cout[h] = heads[h].cout;
+        hd.oscale[h] = heads[h].oscale;
         // several slices accumulate into ONE register tile of 1x1 outputs
         if (head_conv > HEAD_CONV && heads[h].cout > W2_ROWS) return CN_ERR_UNSUPPORTED;
     }
     hd.slices = head_conv / HEAD_CONV;
     C3Args a = {};
+    c3_set_ctl(a, ctl);
     a.x = x; a.w = w1_packed; a.scale = scale1; a.shift = bias1; a.residual = nullptr; a.y = nullptr;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = n_heads * head_conv; a.in_pitch = in_pitch;
     a.out_pitch = 0; a.relu = 1; a.vec_out = 0; a.setprio = 1;
@@ -1168,9 +1211,11 @@ extern "C" int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int 
 // w_packed: cn_pack_deconv4x4s2_weight_f32 layout [parity 4][tap 4][cout_pad][cin_pad].
 int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale, const float *shift,
                         void *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
-                        int relu, int vec_out, int setprio, int dtype_flags, hipStream_t st)
+                        int relu, int vec_out, int setprio, int dtype_flags, const cn_f32s_ctl *ctl,
+                        hipStream_t st)
 {
     C3Args a = {};
+    c3_set_ctl(a, ctl);
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = nullptr; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_pitch = in_pitch;
     a.out_pitch = out_pitch; a.relu = relu; a.vec_out = vec_out; a.setprio = setprio & 1;

@@ -50,7 +50,7 @@ __global__ void nhwc_to_nchw_kernel(const float *__restrict__ x, float *__restri
 // is plain fp32 either way
 template <bool IN_S>
 __global__ void maxpool_nhwc_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int H,
-                                    int W, int C, int Ho, int Wo, int k, int s, int pad)
+                                    int W, int C, int Ho, int Wo, int k, int s, int pad, float out_mul)
 {
     const int c4n = C >> 2;
     const size_t total = (size_t)B * Ho * Wo * c4n;
@@ -79,6 +79,7 @@ __global__ void maxpool_nhwc_kernel(const float *__restrict__ x, float *__restri
                 m.w = fmaxf(m.w, v.w);
             }
         }
+        if (IN_S) m = m * out_mul;   // stored -> real units (a power of two; max commutes with it)
         *reinterpret_cast<cn_f32x4 *>(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4) = m;
     }
 }
@@ -192,7 +193,7 @@ inline int blocks_for(size_t total, int per_block, int cap)
 
 }  // namespace
 
-extern "C" int cn_version(void) { return 100; }  // 0.1.0
+extern "C" int cn_version(void) { return 300; }  // 0.3.0: f32s range control (cn_f32s_ctl)
 
 extern "C" const char *cn_arch(void) { return "gfx950"; }
 
@@ -247,7 +248,7 @@ extern "C" int cn_maxpool_nhwc_f32(const float *x, float *y, int B, int H, int W
     if (Ho <= 0 || Wo <= 0) return CN_ERR_SHAPE;
     const size_t total = (size_t)B * Ho * Wo * (C >> 2);
     hipLaunchKernelGGL(maxpool_nhwc_kernel<false>, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
-                       (hipStream_t)stream, x, y, B, H, W, C, Ho, Wo, k, s, pad);
+                       (hipStream_t)stream, x, y, B, H, W, C, Ho, Wo, k, s, pad, 1.f);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -255,6 +256,13 @@ extern "C" int cn_maxpool_nhwc_f32(const float *x, float *y, int B, int H, int W
 extern "C" int cn_maxpool_nhwc(const void *x, float *y, int B, int H, int W, int C, int k, int s,
                                int pad, int in_dtype, void *stream)
 {
+    return cn_maxpool_nhwc_scaled(x, y, B, H, W, C, k, s, pad, in_dtype, 1.f, stream);
+}
+
+extern "C" int cn_maxpool_nhwc_scaled(const void *x, float *y, int B, int H, int W, int C, int k,
+                                      int s, int pad, int in_dtype, float out_mul, void *stream)
+{
+    if (out_mul == 0.f) out_mul = 1.f;
     if (in_dtype == CN_DTYPE_F32)
         return cn_maxpool_nhwc_f32((const float *)x, y, B, H, W, C, k, s, pad, stream);
     if (in_dtype != CN_DTYPE_F32S) return CN_ERR_UNSUPPORTED;
@@ -266,7 +274,7 @@ extern "C" int cn_maxpool_nhwc(const void *x, float *y, int B, int H, int W, int
     if (Ho <= 0 || Wo <= 0) return CN_ERR_SHAPE;
     const size_t total = (size_t)B * Ho * Wo * (C >> 2);
     hipLaunchKernelGGL(maxpool_nhwc_kernel<true>, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
-                       (hipStream_t)stream, (const float *)x, y, B, H, W, C, Ho, Wo, k, s, pad);
+                       (hipStream_t)stream, (const float *)x, y, B, H, W, C, Ho, Wo, k, s, pad, out_mul);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -280,10 +288,11 @@ extern "C" int cn_maxpool3x3s2_nhwc_f32(const float *x, float *y, int B, int H, 
 // ---- plain fp32 <-> f32s (fp16 high/low pairs, 32-channel groups; cn_common.h) -------------
 namespace {
 __global__ void f32_to_f32s_kernel(const float *__restrict__ x, void *__restrict__ y, size_t npix,
-                                   int C, int in_pitch, int out_pitch)
+                                   int C, int in_pitch, int out_pitch, float mul, uint32_t *range)
 {
     const int c4n = (C + 3) >> 2;
     const size_t total = npix * c4n;
+    float rng = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const size_t p = i / c4n;
@@ -294,11 +303,14 @@ __global__ void f32_to_f32s_kernel(const float *__restrict__ x, void *__restrict
         } else {
             for (int e = 0; e < 4 && n + e < C; ++e) v[e] = x[p * in_pitch + n + e];
         }
+        v = v * mul;
+        cn_rng_upd4(rng, v);
         cn_store4_f32s(y, p, out_pitch, n, v);   // channels past C inside the group: zeros
     }
+    cn_rng_commit(range, 1, rng);
 }
 __global__ void f32s_to_f32_kernel(const void *__restrict__ x, float *__restrict__ y, size_t npix,
-                                   int C, int in_pitch, int out_pitch)
+                                   int C, int in_pitch, int out_pitch, float mul)
 {
     const int c4n = (C + 3) >> 2;
     const size_t total = npix * c4n;
@@ -306,7 +318,7 @@ __global__ void f32s_to_f32_kernel(const void *__restrict__ x, float *__restrict
          i += (size_t)gridDim.x * blockDim.x) {
         const size_t p = i / c4n;
         const int n = (int)(i - p * c4n) * 4;
-        const cn_f32x4 v = cn_load4_f32s(x, p, in_pitch, n);
+        const cn_f32x4 v = cn_load4_f32s(x, p, in_pitch, n) * mul;
         if (n + 4 <= C && (out_pitch & 3) == 0) {
             *reinterpret_cast<cn_f32x4 *>(y + p * out_pitch + n) = v;
         } else {
@@ -314,19 +326,81 @@ __global__ void f32s_to_f32_kernel(const void *__restrict__ x, float *__restrict
         }
     }
 }
+// max |x| of a plain fp32 NHWC tensor (calibration of the f32s exponents, engine.py)
+__global__ void absmax_f32_kernel(const float *__restrict__ x, size_t npix, int C, int pitch,
+                                  uint32_t *word)
+{
+    const size_t total = npix * (size_t)C;
+    float rng = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const float v = x[p * pitch + (i - p * C)];
+        // a NaN / inf anywhere must not pass as "small": report it as +inf
+        rng = (v - v == 0.f) ? __builtin_fmaxf(rng, __builtin_fabsf(v)) : __builtin_huge_valf();
+    }
+    cn_rng_commit1(word, rng);
+}
 }  // namespace
+
+namespace {
+// one 64-thread block per (launch, side): max over the slots -> hi / lo, slots re-zeroed
+__global__ void range_fold_kernel(uint32_t *cur, uint32_t *hi, uint32_t *lo)
+{
+    uint32_t *w = cur + ((size_t)blockIdx.x * CN_RANGE_SLOTS + threadIdx.x) * CN_RANGE_STRIDE;
+    uint32_t v = *w;
+    *w = 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    if (threadIdx.x == 0) {
+        hi[blockIdx.x] = max(hi[blockIdx.x], v);
+        lo[blockIdx.x] = min(lo[blockIdx.x], v);
+    }
+}
+}  // namespace
+
+extern "C" int cn_range_fold(uint32_t *cur, uint32_t *hi, uint32_t *lo, int n_launches, void *stream)
+{
+    if (!cur || !hi || !lo) return CN_ERR_NULL;
+    if (n_launches <= 0) return CN_OK;
+    static_assert(CN_RANGE_SLOTS == 64, "one wave per (launch, side)");
+    hipLaunchKernelGGL(range_fold_kernel, dim3(2 * n_launches), dim3(CN_RANGE_SLOTS), 0,
+                       (hipStream_t)stream, cur, hi, lo);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_absmax_f32(const float *x, size_t npix, int C, int pitch, uint32_t *word,
+                             void *stream)
+{
+    if (!x || !word) return CN_ERR_NULL;
+    if (C <= 0 || pitch < C) return CN_ERR_SHAPE;
+    const size_t total = npix * (size_t)C;
+    if (!total) return CN_OK;
+    hipLaunchKernelGGL(absmax_f32_kernel, dim3(blocks_for(total, 256, 512)), dim3(256), 0,
+                       (hipStream_t)stream, x, npix, C, pitch, word);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
 
 extern "C" int cn_f32_to_f32s(const float *x, void *y, size_t npix, int C, int in_pitch,
                               int out_pitch, void *stream)
 {
+    return cn_f32_to_f32s_scaled(x, y, npix, C, in_pitch, out_pitch, 1.f, nullptr, stream);
+}
+
+extern "C" int cn_f32_to_f32s_scaled(const float *x, void *y, size_t npix, int C, int in_pitch,
+                                     int out_pitch, float mul, uint32_t *range, void *stream)
+{
+    if (mul == 0.f) mul = 1.f;
     if (!x || !y) return CN_ERR_NULL;
     if (C <= 0 || in_pitch < C || out_pitch < C) return CN_ERR_SHAPE;
-    if ((out_pitch & 31) || !cn_aligned16(y)) return CN_ERR_ALIGN;
+    if ((out_pitch & 31) || (((uintptr_t)y) & 127u)) return CN_ERR_ALIGN;
     if ((in_pitch & 3) == 0 && !cn_aligned16(x)) return CN_ERR_ALIGN;
     const size_t total = npix * ((C + 3) >> 2);
     if (!total) return CN_OK;
     hipLaunchKernelGGL(f32_to_f32s_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
-                       (hipStream_t)stream, x, y, npix, C, in_pitch, out_pitch);
+                       (hipStream_t)stream, x, y, npix, C, in_pitch, out_pitch, mul, range);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -334,14 +408,21 @@ extern "C" int cn_f32_to_f32s(const float *x, void *y, size_t npix, int C, int i
 extern "C" int cn_f32s_to_f32(const void *x, float *y, size_t npix, int C, int in_pitch,
                               int out_pitch, void *stream)
 {
+    return cn_f32s_to_f32_scaled(x, y, npix, C, in_pitch, out_pitch, 1.f, stream);
+}
+
+extern "C" int cn_f32s_to_f32_scaled(const void *x, float *y, size_t npix, int C, int in_pitch,
+                                     int out_pitch, float mul, void *stream)
+{
+    if (mul == 0.f) mul = 1.f;
     if (!x || !y) return CN_ERR_NULL;
     if (C <= 0 || in_pitch < C || out_pitch < C) return CN_ERR_SHAPE;
-    if ((in_pitch & 31) || !cn_aligned16(x)) return CN_ERR_ALIGN;
+    if ((in_pitch & 31) || (((uintptr_t)x) & 127u)) return CN_ERR_ALIGN;
     if ((out_pitch & 3) == 0 && !cn_aligned16(y)) return CN_ERR_ALIGN;
     const size_t total = npix * ((C + 3) >> 2);
     if (!total) return CN_OK;
     hipLaunchKernelGGL(f32s_to_f32_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
-                       (hipStream_t)stream, x, y, npix, C, in_pitch, out_pitch);
+                       (hipStream_t)stream, x, y, npix, C, in_pitch, out_pitch, mul);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -29,6 +29,8 @@ struct StemArgs {
     const float *scale, *shift;
     float *y;        // (B,Ho,Wo,out_pitch)
     int H, W, Ho, Wo, Cout, KH, KW, stride, pad, relu, out_pitch, KP, tiles_per_image, cout_pad;
+    float x_mul;      // f32s kernels: the image is multiplied by this (2^-e) before it is split
+    uint32_t *range;  // f32s kernels: [1] receives max |x * x_mul| (cn_f32s_ctl), may be null
 };
 
 template <int BN>
@@ -481,7 +483,11 @@ __global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a,
         }
         vmask = mk;
     };
-    auto put = [&](int idx, float x) {
+    float rng_in = 0.f;
+    auto put = [&](int idx, float xr) {
+        const float xs = xr * a.x_mul;
+        cn_rng_upd1(rng_in, xs);
+        const float x = __builtin_fminf(__builtin_fmaxf(xs, -65504.0f), 65504.0f);
         const _Float16 hi = (_Float16)x;
         winH[idx] = hi;
         winL[idx] = (_Float16)(x - (float)hi);
@@ -577,6 +583,7 @@ __global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a,
         }
         __syncthreads();  // every wave is done reading the window
     }
+    if (a.range) cn_rng_commit(a.range, 1, rng_in);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -660,7 +667,11 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
         }
         vmask = mk;
     };
-    auto put = [&](int idx, float x) {
+    float rng_in = 0.f;
+    auto put = [&](int idx, float xr) {
+        const float xs = xr * a.x_mul;
+        cn_rng_upd1(rng_in, xs);
+        const float x = __builtin_fminf(__builtin_fmaxf(xs, -65504.0f), 65504.0f);
         const _Float16 hi = (_Float16)x;
         winH[idx] = hi;
         winL[idx] = (_Float16)(x - (float)hi);
@@ -819,6 +830,7 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
         par ^= 1;
         s = ns; y = ny; cb = ncb;
     }
+    if (a.range) cn_rng_commit(a.range, 1, rng_in);
 }
 
 template <int TPR>
@@ -878,11 +890,14 @@ int cn_stem_pool_rows(int B, int Ho, int Wo, int Cout, int KH, int KW, int strid
 
 int cn_stem_pool_f32s(const float *x, const float *w_packed, const float *scale, const float *shift,
                       float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
-                      int stride, int pad, int relu, int out_pitch, int KP, hipStream_t st)
+                      int stride, int pad, int relu, int out_pitch, int KP, const cn_f32s_ctl *ctl,
+                      hipStream_t st)
 {
     const int R = cn_stem_pool_rows(B, Ho, Wo, Cout, KH, KW, stride, KP);
     if (!R) return CN_ERR_UNSUPPORTED;
     StemArgs a;
+    a.x_mul = (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f;
+    a.range = ctl ? ctl->range : nullptr;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y;
     a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = KH; a.KW = KW;
     a.stride = stride; a.pad = pad; a.relu = relu; a.out_pitch = out_pitch; a.KP = KP;
@@ -901,12 +916,15 @@ int cn_stem_pool_f32s(const float *x, const float *w_packed, const float *scale,
 int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
                      float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
                      int stride, int pad, int relu, int out_pitch, int KP, int persistent,
-                     hipStream_t st)
+                     const cn_f32s_ctl *ctl, hipStream_t st)
 {
     if (KP & 7) return CN_ERR_UNSUPPORTED;
+    const float ctl_x_mul = (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f;
+    uint32_t *const ctl_range = ctl ? ctl->range : nullptr;
     if (persistent && KH == PKH && KW == PKW && Wo % BM == 0 && (stride == 1 || stride == 2) &&
         KP >= PKH * PKW * 3) {
         StemArgs a;
+        a.x_mul = ctl_x_mul; a.range = ctl_range;
         a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y;
         a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = KH; a.KW = KW;
         a.stride = stride; a.pad = pad; a.relu = relu; a.out_pitch = out_pitch; a.KP = KP;
@@ -942,6 +960,7 @@ int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, 
     }
     if ((long)3 * wy * (wx | 1) > WIN_MAX || wx > 2 * NT) return CN_ERR_UNSUPPORTED;
     StemArgs a;
+    a.x_mul = 1.f; a.range = nullptr;   // fp32 kernel: nothing is split
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y;
     a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = KH; a.KW = KW;
     a.stride = stride; a.pad = pad; a.relu = relu; a.out_pitch = out_pitch; a.KP = KP;

@@ -110,14 +110,22 @@ class DCN(DCNv2):
     def forward(self, input):
         """Stand-alone use (NCHW in/out).  Inside a network the plan fuses this with the
         following BatchNorm+ReLU and stays in NHWC (engine.PlanBuilder.dcn)."""
-        from .engine import PlanBuilder, Act
+        from .engine import PlanBuilder, Act, exponent_for
+        from . import native
         if not input.is_cuda:
             raise NotImplementedError
         B, C, H, W = input.shape
-        pb = PlanBuilder(input.device, B, H, W)
+        # f32s arithmetic splits x * 2^-e: e from this very input (one reduction + a host read;
+        # the stand-alone form builds its launch list per call anyway)
+        xin = input.contiguous().float()
+        word = torch.zeros(1, device=input.device, dtype=torch.int32)
+        native.check(native.lib().cn_absmax_f32(native.ptr(xin), xin.numel(), 1, 1, native.ptr(word),
+                                                native.stream_ptr()), "cn_absmax_f32")
+        ex = exponent_for(float(word.cpu().view(torch.float32)[0]))
+        pb = PlanBuilder(input.device, B, H, W, exps={"x": ex})
         if self._tuned(C):
             x_nhwc = input.permute(0, 2, 3, 1).contiguous()
-            y = pb.dcn(Act(x_nhwc, B, H, W, C), self, out_plain=True)
+            y = pb.dcn(Act(x_nhwc, B, H, W, C, exp=pb._exp("x"), lid="x"), self, out_plain=True)
             for op in pb.ops:
                 op()
             return y.t.permute(0, 3, 1, 2).contiguous()
@@ -130,8 +138,8 @@ class DCN(DCNv2):
         com = self.conv_offset_mask
         w = com.weight.detach().new_zeros((com.weight.shape[0], cp) + tuple(com.weight.shape[2:]))
         w[:, :C] = com.weight.detach()
-        om = pb.conv(Act(x_nhwc, B, H, W, cp), w, bias=com.bias, stride=self.stride,
-                     padding=self.padding, out_nchw=True)
+        om = pb.conv(Act(x_nhwc, B, H, W, cp, exp=pb._exp("x"), lid="x"), w, bias=com.bias,
+                     stride=self.stride, padding=self.padding, out_nchw=True)
         for op in pb.ops:
             op()
         n_off = 2 * self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]

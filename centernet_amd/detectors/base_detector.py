@@ -57,6 +57,8 @@ class BaseDetector(object):
         if opt.load_model:
             net = load_model(net, opt.load_model)
         self.model = net.to(opt.device).eval()
+        if getattr(opt, 'fp32_mfma', False):
+            self.model.fp32_mfma()
         self.opt = opt
         self.mean = np.asarray(opt.mean, np.float32).reshape(1, 1, 3)
         self.std = np.asarray(opt.std, np.float32).reshape(1, 1, 3)
@@ -195,7 +197,17 @@ class BaseDetector(object):
         metas = [self.pre_process_device(frame, scale, out=batch[i:i + 1])[1]
                  for i, frame in enumerate(uploaded)]
         dets = self.run_batch(batch).detach().cpu().numpy()
+        if not self.range_ok(batch):    # a clamped f32s value: re-calibrated on this batch, run again
+            dets = self.run_batch(batch).detach().cpu().numpy()
+            if not self.range_ok(batch):
+                raise native.NativeError("f32s forward clamps values after re-calibration")
         return self.results_batch(dets, metas, scale)
+
+    def range_ok(self, images=None):
+        """Synchronising look at the f32s range words of every forward since the last look
+        (``PlannedModule.range_ok``): False = a value was clamped, those results are invalid and
+        the network has been re-calibrated (on ``images`` when given) -- run the batch again."""
+        return self.model.range_ok(images)
 
     def run(self, image_or_path_or_tensor, meta=None):
         """One image (array, path, or the prefetch dict) through every test scale

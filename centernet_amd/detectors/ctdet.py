@@ -25,7 +25,9 @@ class CtdetDetector(BaseDetector):
         sigmoid of ctdet.py:31 is fused into the decode kernel (``hm`` stays logits); with it,
         the mirrored frame (image 1) is averaged in after the sigmoid, as in the reference."""
         with torch.no_grad():
-            output = self.model(images, borrow=True)[-1]   # consumed before the next run
+            # consumed before the next run; check=True: f32s range words read here (the
+            # reference synchronises at this point too), re-calibrate + re-run on a clamped value
+            output = self.model(images, borrow=True, check=True)[-1]
             hm, wh = output['hm'], output['wh']
             reg = output['reg'] if self.opt.reg_offset else None
             logits = not self.opt.flip_test
@@ -75,9 +77,13 @@ class CtdetDetector(BaseDetector):
     # ------------------------------------------------------------------ new surface
     def run_batch(self, images, probe=None):
         """``images`` (B,3,H,W) fp32, already normalised, on the device -> raw (B,K,6)
-        detections in output-grid units (device tensor).  ``probe``: optional dict for
-        measurement (bench.py): ``event_after`` (set of launch indices) in, ``net_events`` (HIP
-        events at those launch boundaries) and ``dec_events`` (before / after the decode) out."""
+        detections in output-grid units (device tensor).  Asynchronous: nothing here waits for
+        the device, so the f32s range words of the forward are NOT looked at yet -- call
+        ``range_ok()`` where the results are consumed (``run_frames`` does; a pipeline checks
+        once per synchronisation point, the words accumulate over the forwards in between).
+        ``probe``: optional dict for measurement (bench.py): ``event_after`` (set of launch
+        indices) in, ``net_events`` (HIP events at those launch boundaries) and ``dec_events``
+        (before / after the decode) out."""
         with torch.no_grad():
             if probe is None:
                 out = self.model(images, borrow=True)[-1]

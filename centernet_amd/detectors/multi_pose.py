@@ -48,7 +48,8 @@ class MultiPoseDetector(BaseDetector):
     def process(self, images, return_time=False):
         with torch.no_grad():
             torch.cuda.synchronize()
-            output = self.model(images, borrow=True)[-1]   # consumed before the next run
+            # consumed before the next run; f32s range words checked here (see CtdetDetector)
+            output = self.model(images, borrow=True, check=True)[-1]
             maps = self._head_maps(output)
             torch.cuda.synchronize()
             forward_time = time.time()

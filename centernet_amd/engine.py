@@ -14,14 +14,35 @@ Reference call sites being replaced: ``self.model(images)[-1]``
 (src/lib/models/networks/*.py ``forward``).
 """
 import ctypes
+import math
 import os
+import warnings
 
 import torch
 
 from . import native
-from .native import (ConvDesc, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTYPE_F32, DTYPE_F32S,
+from .native import (ConvDesc, F32sCtl, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTYPE_F32, DTYPE_F32S,
                      CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN, CONV_STEM_F32S,
                      CONV_STEM_MAXPOOL)
+
+# ---- f32s range policy (csrc/cn_common.h "Range") ------------------------------------------
+# A tensor of exponent e is stored as real * 2^-e.  e is chosen on a plain-fp32 calibration pass
+# so that the tensor's largest magnitude lands in [2^(TOP_LOG2-1), 2^TOP_LOG2): 2^6 of head-room
+# below the fp16 limit, and the (high, low) pair keeps its 22 bits down to values 2^-12 of that
+# maximum (absolute error floor 2^-25 stored = 2^-34 of the maximum).
+TOP_LOG2 = 10
+F16_MAX = 65504.0
+LOW_WATER = 2.0 ** -3      # a per-forward maximum below this (stored units) asks for re-calibration
+W_TOP_LOG2 = 14            # weight rows are pre-scaled to max |w| in [2^13, 2^14)
+
+
+def exponent_for(absmax):
+    """Exponent e with absmax * 2^-e in [2^(TOP_LOG2-1), 2^TOP_LOG2) (0 for an all-zero tensor)."""
+    if not absmax > 0.0:
+        return 0
+    if math.isinf(absmax) or math.isnan(absmax):
+        raise native.NativeError("non-finite activations in the f32s calibration pass")
+    return math.frexp(absmax)[1] - TOP_LOG2
 
 
 def _out_size(n, k, s, p, d=1):
@@ -34,14 +55,24 @@ class Act:
     ``fmt``: "f32" plain floats, "f16" halves, or "f32s" -- fp32 values stored as fp16
     (high, low) pairs in 128-byte groups of 32 channels (same bytes and pitch as fp32; the
     tensor is typed float32 but opaque to torch), see csrc/cn_common.h."""
-    __slots__ = ("t", "B", "H", "W", "C", "pitch", "c_off", "nchw", "fmt")
+    __slots__ = ("t", "B", "H", "W", "C", "pitch", "c_off", "nchw", "fmt", "exp", "lid")
 
-    def __init__(self, t, B, H, W, C, pitch=None, c_off=0, nchw=False, fmt="f32"):
+    def __init__(self, t, B, H, W, C, pitch=None, c_off=0, nchw=False, fmt="f32", exp=0, lid=None):
         self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
         self.pitch = C if pitch is None else pitch
         self.c_off = c_off
         self.nchw = nchw
         self.fmt = fmt
+        # ``exp``: the tensor's f32s exponent -- an f32s tensor holds real * 2^-exp; a plain one
+        # holds real values and ``exp`` is what a consumer applies when it splits them.
+        # ``lid``: logical id of the tensor in the network description (the same in every plan
+        # of a module, whatever launches the plan fuses): the key of the calibrated exponents.
+        self.exp = exp
+        self.lid = lid
+
+    @property
+    def applied_exp(self):
+        return self.exp if self.fmt == "f32s" else 0
 
     def ptr(self):
         return ctypes.c_void_p(self.t.data_ptr() + self.t.element_size() * self.c_off)
@@ -56,18 +87,25 @@ class Act:
             h = t.view(torch.float16).reshape(self.B, self.H, self.W, self.pitch // 32, 2, 32)
             t = (h[..., 0, :].float() + h[..., 1, :].float()).reshape(self.B, self.H, self.W,
                                                                       self.pitch)
+            t = torch.ldexp(t, torch.tensor(self.exp))
         return t[..., self.c_off:self.c_off + self.C].float()
 
 
 def prescale_rows(w):
-    """f32s weights: a per-output-channel power of two brings max|w| of every row into [0.5, 1)
-    so that the fp16 low parts stay normal numbers; exact, and undone by the returned factors in
-    the epilogue scale.  Returns (scaled weight, factor per row)."""
+    """f32s weights: a per-output-channel power of two brings max|w| of every row into
+    [2^13, 2^14): the fp16 (high, low) pair of a weight then keeps its 22 bits down to 2^-16 of
+    the row's largest weight (at [0.5, 1) the low parts went subnormal below 2^-3 of it).  Exact,
+    and undone by the returned factors in the epilogue scale.
+    Returns (scaled weight, factor per row): w = scaled * factor."""
     w = w.detach().float()
     m = w.abs().flatten(1).amax(dim=1).clamp_min(1e-30)
-    e = torch.frexp(m)[1]                                   # m = mantissa * 2^e
+    e = torch.frexp(m)[1] - W_TOP_LOG2                      # m = mantissa * 2^(e + 14)
     shape = (-1,) + (1,) * (w.dim() - 1)
     return torch.ldexp(w, (-e).view(shape).expand_as(w)), torch.ldexp(torch.ones_like(m), e)
+
+
+def _pow2(e):
+    return math.ldexp(1.0, int(e))
 
 
 def fold_bn(conv_bias, bn, cout, device):
@@ -94,7 +132,11 @@ def fold_bn(conv_bias, bn, cout, device):
 class PlanBuilder:
     """Records launches for one (B, H, W) input shape."""
 
-    def __init__(self, device, B, H, W, dtype=torch.float32, wcache=None, split=None):
+    RANGE_LAUNCHES = 256   # launches per plan that may split fp32 values (cn_f32s_ctl.range)
+    RANGE_WORDS = 2 * 64 * 16   # CN_RANGE_WORDS: 2 sides x 64 slots x one word per 64-byte line
+
+    def __init__(self, device, B, H, W, dtype=torch.float32, wcache=None, split=None, exps=None,
+                 calibrating=False):
         assert dtype in (torch.float32, torch.float16)
         self.device = device
         # fp32 networks compute in f32s (three fp16 MFMAs per product, fp32-level accuracy, 5.3x
@@ -102,7 +144,13 @@ class PlanBuilder:
         # plain fp32 matrix instruction
         if split is None:
             split = os.environ.get("CN_F32S", "1") != "0"
-        self.split = bool(split) and dtype == torch.float32
+        self.split = bool(split) and dtype == torch.float32 and not calibrating
+        # calibrating: a plain-fp32 plan that materialises every logical tensor (no fused heads)
+        # so that PlannedModule.calibrate can measure max |x| of each
+        self.calibrating = calibrating
+        # logical id -> f32s exponent (missing = 0: values are split as they are, the round-2
+        # behaviour, accurate for O(1) tensors only)
+        self.exps = dict(exps) if exps else {}
         # packed weights shared by every plan of one module (keyed by source storage, packing
         # and dtype): a new input shape re-uses them instead of re-packing the whole network
         self.wcache = wcache if wcache is not None else {}
@@ -117,11 +165,51 @@ class PlanBuilder:
         self.input = None
         self.trace = []        # (kind, Act) of every op output, in launch order (debugging)
         self.ws = None         # split-K scratch shared by all launches (stream-ordered)
-        self.fuse_heads = os.environ.get("CN_FUSE_HEADS", "1") != "0"
+        self.fuse_heads = os.environ.get("CN_FUSE_HEADS", "1") != "0" and not calibrating
         self.ws_bytes = 0
+        self._nlid = 0
+        self.groups = []       # lists of logical ids that must share one exponent (concat)
+        # range words of the launches that split values: [cur | hi | lo] x RANGE_WORDS, int32
+        # views of float bit patterns (non-negative floats order like integers)
+        self.range = None
+        self.range_slots = []  # slot -> logical id of the launch, for messages
+        self._pack_events = [] # completion of weight-pack kernels this plan depends on
+        self.track = self.split and os.environ.get("CN_RANGE", "1") != "0"
 
     # ---- helpers -------------------------------------------------------------
-    def _new(self, B, H, W, C, pitch=None, fmt=None):
+    def _lid(self, lid=None, tag=""):
+        """Logical id of the tensor an op produces: a counter over the public op calls of the
+        network description (identical in every plan of a module) unless the caller names it."""
+        if lid is not None:
+            return lid
+        self._nlid += 1
+        return "t%d%s" % (self._nlid, tag)
+
+    def _exp(self, lid):
+        return int(self.exps.get(lid, 0)) if self.split else 0
+
+    def _ctl(self, lid, x_mul=1.0, res_mul=1.0):
+        """A cn_f32s_ctl with fresh range words for one launch (NULL words when tracking is off)."""
+        c = F32sCtl()
+        c.x_mul, c.res_mul = float(x_mul), float(res_mul)
+        c.range = None
+        if self.track:
+            if self.range is None:
+                # cur: per launch CN_RANGE_WORDS; stat: [hi | lo] x (launch, side)
+                self.range = torch.zeros((self.RANGE_LAUNCHES, self.RANGE_WORDS), device=self.device,
+                                         dtype=torch.int32)
+                self.range_stat = torch.zeros((2, self.RANGE_LAUNCHES, 2), device=self.device,
+                                              dtype=torch.int32)
+                self.range_stat[1].fill_(0x7f800000)
+            slot = len(self.range_slots)
+            if slot >= self.RANGE_LAUNCHES:
+                raise native.NativeError("too many f32s launches for the range table")
+            self.range_slots.append(lid)
+            c.range = self.range.data_ptr() + 4 * self.RANGE_WORDS * slot
+        self.keep.append(c)
+        return c
+
+    def _new(self, B, H, W, C, pitch=None, fmt=None, lid=None):
         if fmt is None:
             fmt = "f16" if self.dtype == torch.float16 else "f32"
         pitch = C if pitch is None else pitch
@@ -131,19 +219,21 @@ class PlanBuilder:
             t = torch.zeros((B, H, W, pitch), device=self.device, dtype=torch.float32)
         else:
             t = torch.empty((B, H, W, pitch), device=self.device, dtype=self.dtype)
-        return Act(t, B, H, W, C, pitch, fmt=fmt)
+        return Act(t, B, H, W, C, pitch, fmt=fmt, exp=self._exp(lid), lid=lid)
 
     def plain(self, x):
         """``x`` as a plain fp32 activation (a converter launch when it is f32s)."""
         if x is None or x.fmt != "f32s":
             return x
         assert x.c_off % 32 == 0      # a slice starts on a 32-channel group
-        out = self._new(x.B, x.H, x.W, x.C, fmt="f32")
+        out = self._new(x.B, x.H, x.W, x.C, fmt="f32", lid=x.lid)
+        out.exp = x.exp
         lib, npix = self.lib, x.B * x.H * x.W
+        mul = _pow2(x.exp)
 
         def run():
-            rc = lib.cn_f32s_to_f32(x.ptr(), out.ptr(), npix, x.C, x.pitch, out.pitch,
-                                    native.stream_ptr())
+            rc = lib.cn_f32s_to_f32_scaled(x.ptr(), out.ptr(), npix, x.C, x.pitch, out.pitch, mul,
+                                           native.stream_ptr())
             if rc:
                 native.check(rc, "cn_f32s_to_f32")
         self._emit_simple(run, "convert", out, 8 * npix * x.C)
@@ -154,13 +244,16 @@ class PlanBuilder:
         if x is None or x.fmt == "f32s":
             return x
         assert x.fmt == "f32" and not x.nchw
-        out = self._new(x.B, x.H, x.W, x.C, fmt="f32s")
+        out = self._new(x.B, x.H, x.W, x.C, fmt="f32s", lid=x.lid)
+        out.exp = x.exp
         lib, npix = self.lib, x.B * x.H * x.W
         src = Act(x.t, x.B, x.H, x.W, x.C, x.pitch, x.c_off)
+        ctl = self._ctl(x.lid)
+        mul = _pow2(-x.exp)
 
         def run():
-            rc = lib.cn_f32_to_f32s(src.ptr(), out.ptr(), npix, x.C, x.pitch, out.pitch,
-                                    native.stream_ptr())
+            rc = lib.cn_f32_to_f32s_scaled(src.ptr(), out.ptr(), npix, x.C, x.pitch, out.pitch, mul,
+                                           ctl.range, native.stream_ptr())
             if rc:
                 native.check(rc, "cn_f32_to_f32s")
         self._emit_simple(run, "convert", out, 8 * npix * x.C)
@@ -168,24 +261,26 @@ class PlanBuilder:
 
     def _wkey(self, kind, sources):
         return (kind, self.cdtype, str(self.device)) + tuple(
-            (t.data_ptr(), tuple(t.shape)) for t in sources)
+            (id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in sources)
 
-    def _pack(self, w_oihw, sources=None, f32s=False):
+    def _pack(self, w_oihw, sources=None, f32s=False, prescale=False):
         """Packed copy of a (Cout,Cin,KH,KW) weight.  ``sources``: the parameter tensors the
         weight was assembled from (defaults to the weight itself) -- the cache key.  The pack
         kernel runs on the current stream, which also orders the temporary's release: no
-        host synchronisation.  ``f32s``: high/low fp16 form of the row-prescaled weight; returns
-        (packed, per-row factor to fold into the epilogue scale)."""
+        host synchronisation.  ``f32s``: high/low fp16 form of the row-prescaled weight;
+        ``prescale``: row-prescaled but packed as plain fp32 (the stem kernel splits it itself).
+        Both return (packed, per-row factor to fold into the epilogue scale)."""
         if sources is None:
             sources = [w_oihw]
         # only module parameters have storage that outlives the plan: temporaries are not cached
         cacheable = all(isinstance(t, torch.nn.Parameter) for t in sources)
-        key = self._wkey("conv_f32s" if f32s else "conv", sources) if cacheable else None
+        kind = "conv_f32s" if f32s else ("conv_pre" if prescale else "conv")
+        key = self._wkey(kind, sources) if cacheable else None
         hit = self.wcache.get(key) if cacheable else None
         if hit is None:
             w = w_oihw.detach().to(device=self.device, dtype=torch.float32).contiguous()
             factor = None
-            if f32s:
+            if f32s or prescale:
                 w, factor = prescale_rows(w)
                 w = w.contiguous()
             cd = DTYPE_F32S if f32s else self.cdtype
@@ -195,11 +290,16 @@ class PlanBuilder:
             native.check(self.lib.cn_pack_conv_weight(native.ptr(w), native.ptr(wp), co, ci, kh,
                                                       kw, cd, native.stream_ptr()),
                          "cn_pack_conv_weight")
-            hit = (wp, factor)
+            # a plan built on this stream may first run on another one: the packed weight must
+            # be complete before that (the pack kernel is tiny; once per weight and module)
+            ev = torch.cuda.Event()
+            ev.record()
+            hit = (wp, factor, ev)
             if cacheable:
                 self.wcache[key] = hit
         self.keep += [hit[0], hit[1]]
-        return hit if f32s else hit[0]
+        self._pack_events.append(hit[2])
+        return (hit[0], hit[1]) if (f32s or prescale) else hit[0]
 
     @staticmethod
     def _f32s_conv_form(kh, kw, stride, padding, dilation, out_nchw, ci=0, co=0):
@@ -217,18 +317,20 @@ class PlanBuilder:
 
     def set_input(self, C=3):
         """Network input: user NCHW image batch, bound at run time."""
-        self.input = Act(None, self.B, self.H, self.W, C, nchw=True)
+        self.input = Act(None, self.B, self.H, self.W, C, nchw=True, exp=self._exp("input"),
+                         lid="input")
         return self.input
 
     # ---- ops -------------------------------------------------------------------
     def conv(self, x, weight, bias=None, bn=None, relu=False, residual=None, stride=1,
              padding=0, dilation=1, out_nchw=False, out=None, wsources=None, out_plain=False,
-             pool=None):
+             pool=None, lid=None):
         """conv2d (+bias) (+BN eval) (+residual) (+ReLU) as one implicit-GEMM launch.
         ``out_plain``: in an f32s plan, write the result as plain fp32 (for consumers that read
         floats, e.g. the offset maps of the deformable kernel)."""
         co, ci, kh, kw = weight.shape
         assert ci == x.C, (ci, x.C)
+        lid = self._lid(lid)
         Ho = _out_size(x.H, kh, stride, padding, dilation)
         Wo = _out_size(x.W, kw, stride, padding, dilation)
         use_s = self.split and not x.nchw and self._f32s_conv_form(kh, kw, stride, padding,
@@ -244,10 +346,18 @@ class PlanBuilder:
             fuse_pool = bool(self.lib.cn_stem_maxpool_supported(ctypes.byref(probe)))
         scale, shift = fold_bn(bias, bn, co, self.device)
         flags = 0
+        # f32s arithmetic inside the stem kernel (image and weights split there) when the library
+        # has that form for the shape; otherwise the plain fp32 stem
+        stem_s = False
+        if self.split and x.nchw and not use_s:
+            probe = ConvDesc(B=x.B, H=x.H, W=x.W, Cin=ci, Ho=Ho, Wo=Wo, Cout=co, KH=kh, KW=kw,
+                             stride=stride, pad_h=padding, pad_w=padding, dil=dilation,
+                             in_layout=LAYOUT_NCHW, out_layout=LAYOUT_NHWC, dtype=self.cdtype,
+                             OH=Ho, OW=Wo, oy_mul=1, ox_mul=1,
+                             flags=CONV_STEM_F32S | (CONV_STEM_MAXPOOL if fuse_pool else 0))
+            stem_s = bool(self.lib.cn_stem_f32s_supported(ctypes.byref(probe)))
         if use_s:
             wp, factor = self._pack(weight, wsources, f32s=True)
-            scale = factor if scale is None else scale * factor     # undo the row prescale
-            scale = scale.contiguous()
             if x.fmt == "f32":
                 flags |= CONV_X_PLAIN
             if residual is not None and residual.fmt == "f32":
@@ -255,22 +365,26 @@ class PlanBuilder:
             cd = DTYPE_F32S
         else:
             x, residual = self.plain(x), self.plain(residual)
-            wp = self._pack(weight, wsources)
-            cd = self.cdtype
-            if self.split and x.nchw:
+            if stem_s:
+                wp, factor = self._pack(weight, wsources, prescale=True)
                 flags |= CONV_STEM_F32S     # the stem kernel splits image and weights itself
+            else:
+                wp, factor = self._pack(weight, wsources), None
+            cd = self.cdtype
             if fuse_pool:
                 flags |= CONV_STEM_MAXPOOL
-        self.keep += [scale, shift]
+        pool_lid = lid + "/pool" if pool is not None else None
         if out is None:
             if out_nchw:
                 t = torch.empty((x.B, co, Ho, Wo), device=self.device, dtype=torch.float32)
-                out = Act(t, x.B, Ho, Wo, co, nchw=True)
+                out = Act(t, x.B, Ho, Wo, co, nchw=True, lid=lid)
             elif fuse_pool:
-                out = self._new(x.B, Ho // 2, Wo // 2, co)
+                out = self._new(x.B, Ho // 2, Wo // 2, co, lid=pool_lid)
             else:
                 out = self._new(x.B, Ho, Wo, co,
-                                fmt="f32s" if (use_s and not out_plain) else None)
+                                fmt="f32s" if (use_s and not out_plain) else None, lid=lid)
+        else:
+            out.lid, out.exp = lid, self._exp(lid)
         if use_s and out.fmt != "f32s":
             flags |= CONV_Y_PLAIN
         assert use_s or out.fmt != "f32s"
@@ -285,19 +399,36 @@ class PlanBuilder:
                 residual = self.plain(residual)
                 flags |= CONV_R_PLAIN
             assert residual.pitch == out.pitch
+        # ---- exponents (csrc/cn_common.h "Range"): the matrix loop sees x * 2^-ex and
+        # w / factor; the epilogue returns to the output's stored units
+        ctl = None
+        if use_s or stem_s:
+            ex, ey = x.exp, out.applied_exp
+            k = factor * _pow2(ex - ey)
+            scale = k if scale is None else scale * k
+            if shift is not None:
+                shift = shift * _pow2(-ey)
+            res_mul = _pow2(residual.applied_exp - ey) if residual is not None else 1.0
+            x_mul = _pow2(-ex) if (x.fmt == "f32" or x.nchw) else 1.0
+            ctl = self._ctl(lid, x_mul, res_mul)
+        scale = None if scale is None else scale.contiguous()
+        shift = None if shift is None else shift.contiguous()
+        self.keep += [scale, shift]
         d = ConvDesc(B=x.B, H=x.H, W=x.W, Cin=ci, Ho=Ho, Wo=Wo, Cout=co, KH=kh, KW=kw,
                      stride=stride, pad_h=padding, pad_w=padding, dil=dilation,
                      in_layout=LAYOUT_NCHW if x.nchw else LAYOUT_NHWC, in_pitch=x.pitch,
                      out_layout=LAYOUT_NCHW if out.nchw else LAYOUT_NHWC, out_pitch=out.pitch,
                      OH=Ho, OW=Wo, oy_mul=1, oy_add=0, ox_mul=1, ox_add=0, relu=int(relu),
                      dtype=cd, flags=flags)
+        if ctl is not None:
+            d.ctl = ctl
         fl = 2 * x.B * Ho * Wo * co * ci * kh * kw
         by = 4 * (x.B * x.H * x.W * ci + x.B * out.H * out.W * co * (2 if residual is not None else 1)
                   + co * ci * kh * kw)
         self._emit_conv(d, x, wp, scale, shift, residual, out, dict(kind="conv", flops=fl, bytes=by))
         self.flops += fl
         if pool is not None and not fuse_pool:
-            return self.maxpool(out, *pool)
+            return self.maxpool(out, *pool, lid=pool_lid)
         return out
 
     def _emit_conv(self, d, x, wp, scale, shift, residual, out, meta):
@@ -328,6 +459,7 @@ class PlanBuilder:
         assert (kh, kw) == (4, 4) and ci == x.C
         assert self.dtype == torch.float32, "ConvTranspose is built for fp32 only"
         lib = self.lib
+        lid = self._lid()
         use_s = self.split
         scale, shift = fold_bn(None, bn, co, self.device)
         cacheable = isinstance(weight, torch.nn.Parameter)
@@ -346,25 +478,36 @@ class PlanBuilder:
                                                         DTYPE_F32S if use_s else DTYPE_F32,
                                                         native.stream_ptr()),
                          "cn_pack_deconv4x4s2_weight")
-            hit = (wp, factor)
+            ev = torch.cuda.Event()
+            ev.record()
+            hit = (wp, factor, ev)
             if cacheable:
                 self.wcache[key] = hit
-        wp, factor = hit
+        wp, factor, ev = hit
+        self._pack_events.append(ev)
         flags = 0
+        out = self._new(x.B, 2 * x.H, 2 * x.W, co, fmt="f32s" if (use_s and not out_plain) else None,
+                        lid=lid)
+        ctl = None
         if use_s:
-            scale = (factor if scale is None else scale * factor).contiguous()
+            ey = out.applied_exp
+            k = factor * _pow2(x.exp - ey)
+            scale = (k if scale is None else scale * k).contiguous()
+            if shift is not None:
+                shift = (shift * _pow2(-ey)).contiguous()
             if x.fmt == "f32":
                 flags |= CONV_X_PLAIN
             if out_plain:
                 flags |= CONV_Y_PLAIN
-        out = self._new(x.B, 2 * x.H, 2 * x.W, co, fmt="f32s" if (use_s and not out_plain) else None)
+            ctl = self._ctl(lid, _pow2(-x.exp) if x.fmt == "f32" else 1.0)
         self.keep += [scale, shift, wp, factor]
         sp, hp, wpp = native.ptr(scale), native.ptr(shift), native.ptr(wp)
         cd = DTYPE_F32S if use_s else DTYPE_F32
+        cref = ctypes.byref(ctl) if ctl is not None else None
 
         def run():
             rc = lib.cn_conv_transpose4x4s2(x.ptr(), wpp, sp, hp, out.ptr(), x.B, x.H, x.W, ci, co,
-                                            x.pitch, out.pitch, int(relu), cd, flags,
+                                            x.pitch, out.pitch, int(relu), cd, flags, cref,
                                             native.stream_ptr())
             if rc:
                 native.check(rc, "cn_conv_transpose4x4s2")
@@ -376,19 +519,22 @@ class PlanBuilder:
         self.flops += fl
         return out
 
-    def maxpool(self, x, k, s, pad):
+    def maxpool(self, x, k, s, pad, lid=None):
         assert self.dtype == torch.float32, "max-pool is built for fp32 only"
+        lid = self._lid(lid)
         from_s = x.fmt == "f32s" and x.C % 32 == 0     # read (high, low) pairs, write plain floats
         if not from_s:
             x = self.plain(x)
         Ho, Wo = _out_size(x.H, k, s, pad), _out_size(x.W, k, s, pad)
-        out = self._new(x.B, Ho, Wo, x.C)
+        out = self._new(x.B, Ho, Wo, x.C, lid=lid)
         lib = self.lib
         assert x.pitch == x.C and x.c_off == 0
+        mul = _pow2(x.exp) if from_s else 1.0
 
         def run():
-            rc = lib.cn_maxpool_nhwc(x.ptr(), out.ptr(), x.B, x.H, x.W, x.C, k, s, pad,
-                                     DTYPE_F32S if from_s else DTYPE_F32, native.stream_ptr())
+            rc = lib.cn_maxpool_nhwc_scaled(x.ptr(), out.ptr(), x.B, x.H, x.W, x.C, k, s, pad,
+                                            DTYPE_F32S if from_s else DTYPE_F32, mul,
+                                            native.stream_ptr())
             if rc:
                 native.check(rc, "cn_maxpool_nhwc")
         self.ops.append(run)
@@ -405,20 +551,28 @@ class PlanBuilder:
     def concat(self, acts):
         """torch.cat(acts, 1) (Root.forward, pose_dla_dcn.py:159): channel-slice copies into
         one NHWC buffer."""
+        lid = self._lid()
+        # the inputs of a concatenation share one exponent (PlannedModule.calibrate gives the
+        # whole group the exponent of its largest member)
+        self.groups.append([lid] + [a.lid for a in acts])
         # f32s tensors of whole 32-channel groups concatenate as they are: a group is 128 bytes
         # whatever the format, so the slice copy moves (high, low) groups unchanged
-        keep_s = all(a.fmt == "f32s" and a.C % 32 == 0 and a.pitch == a.C for a in acts)
+        keep_s = all(a.fmt == "f32s" and a.C % 32 == 0 and a.pitch == a.C for a in acts) and \
+            len({a.exp for a in acts}) == 1
         if not keep_s:
             acts = [self.plain(a) for a in acts]
         a0 = acts[0]
         C = sum(a.C for a in acts)
-        out = self._new(a0.B, a0.H, a0.W, C, fmt="f32s" if keep_s else None)
+        out = self._new(a0.B, a0.H, a0.W, C, fmt="f32s" if keep_s else None, lid=lid)
+        if keep_s:
+            out.exp = a0.exp
         lib = self.lib
         npix = a0.B * a0.H * a0.W
         off = 0
         for a in acts:
             assert (a.B, a.H, a.W) == (a0.B, a0.H, a0.W) and not a.nchw
-            dst = Act(out.t, out.B, out.H, out.W, a.C, pitch=C, c_off=off, fmt=out.fmt)
+            dst = Act(out.t, out.B, out.H, out.W, a.C, pitch=C, c_off=off, fmt=out.fmt,
+                      exp=out.exp, lid=a.lid)
 
             def run(a=a, dst=dst):
                 rc = lib.cn_copy_channels_f32(a.ptr(), a.pitch, dst.ptr(), C, npix, a.C,
@@ -432,13 +586,14 @@ class PlanBuilder:
     def dw_deconv(self, x, weight, f, add=None):
         """Depthwise ConvTranspose2d(C, C, 2f, stride f, padding f//2, groups=C) + add
         (IDAUp, pose_dla_dcn.py:370-373, 381-386)."""
+        lid = self._lid()
         x, add = self.plain(x), self.plain(add)
         C = x.C
         assert tuple(weight.shape) == (C, 1, 2 * f, 2 * f) and x.pitch == C and x.c_off == 0
         wt = weight.detach().to(device=self.device, dtype=torch.float32)
         wt = wt[:, 0].permute(1, 2, 0).reshape(4 * f * f, C).contiguous()
         self.keep.append(wt)
-        out = self._new(x.B, x.H * f, x.W * f, C)
+        out = self._new(x.B, x.H * f, x.W * f, C, lid=lid)
         lib = self.lib
         wp = native.ptr(wt)
         if add is not None:
@@ -455,9 +610,10 @@ class PlanBuilder:
 
     def upsample2x_add(self, x, add=None):
         """nn.Upsample(scale_factor=2) (nearest) + skip add (large_hourglass.py:102-109)."""
+        lid = self._lid()
         x, add = self.plain(x), self.plain(add)
         assert x.pitch == x.C and x.c_off == 0
-        out = self._new(x.B, 2 * x.H, 2 * x.W, x.C)
+        out = self._new(x.B, 2 * x.H, 2 * x.W, x.C, lid=lid)
         lib = self.lib
 
         fn = lib.cn_upsample2x_add_f16 if self.dtype == torch.float16 else lib.cn_upsample2x_add_f32
@@ -470,43 +626,59 @@ class PlanBuilder:
         self._emit_simple(run, "upsample", out, 4 * x.B * x.C * x.H * x.W * (1 + 4 + (4 if add is not None else 0)))
         return out
 
-    def dcn(self, x, dcn_mod, bn=None, relu=False, out_plain=False):
+    def dcn(self, x, dcn_mod, bn=None, relu=False, out_plain=False, om=None, mask_sigmoid=True):
         """DCN (DCNv2/dcn_v2.py:44-70) [+ BatchNorm + ReLU]: conv_offset_mask as an
         implicit-GEMM launch writing 27 channels at pitch 32, then the fused deformable
-        kernel (gather + MFMA contraction + bias/BN/ReLU epilogue)."""
+        kernel (gather + MFMA contraction + bias/BN/ReLU epilogue).  ``om``: a ready
+        (B, H, W, >= 27) plain Act of [18 offsets | 9 mask values] instead of the offset
+        convolution (DCNv2.forward's explicit offset / mask inputs, dcn_v2.py:35-41;
+        ``mask_sigmoid=False`` when the mask values are already probabilities)."""
         assert tuple(dcn_mod.kernel_size) == (3, 3) and dcn_mod.stride == 1 and \
             dcn_mod.padding == 1 and dcn_mod.dilation == 1 and dcn_mod.deformable_groups == 1, \
             "only the 3x3/s1/p1/d1/dg1 DCN that CenterNet instantiates is supported"
         assert self.dtype == torch.float32, "the deformable kernel is fp32 only"
+        lid = self._lid()
         com = dcn_mod.conv_offset_mask
-        om = self._new(x.B, x.H, x.W, 27, pitch=32)        # plain fp32: read as floats below
+        # plain fp32 in REAL units (offsets are pixels, the mask a logit): never an f32s tensor
         x = self.plain(x)
-        self.conv(x, com.weight, bias=com.bias, stride=1, padding=1, out=om)
+        if om is None:
+            om = self._new(x.B, x.H, x.W, 27, pitch=32, lid=lid + "/om")
+            self.conv(x, com.weight, bias=com.bias, stride=1, padding=1, out=om, lid=lid + "/om")
+        assert om.fmt == "f32" and om.pitch >= 27 and (om.B, om.H, om.W) == (x.B, x.H, x.W)
+        msig = int(bool(mask_sigmoid))
         co, ci = dcn_mod.weight.shape[0], dcn_mod.weight.shape[1]
         use_s = self.split
         bias = dcn_mod.bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
         scale, shift = fold_bn(None, bn, co, self.device)
+        out = self._new(x.B, x.H, x.W, co, fmt="f32s" if (use_s and not out_plain) else None, lid=lid)
+        ctl = None
         if use_s:
             wp, factor = self._pack(dcn_mod.weight, f32s=True)
-            bias = (bias / factor).contiguous()          # (acc' + bias') * (scale * factor)
-            scale = (factor if scale is None else scale * factor).contiguous()
+            ey = out.applied_exp
+            # (acc' + bias') * scale':  acc' = acc * 2^-ex / factor
+            bias = (bias * _pow2(-x.exp) / factor).contiguous()
+            k = factor * _pow2(x.exp - ey)
+            scale = (k if scale is None else scale * k).contiguous()
+            if shift is not None:
+                shift = (shift * _pow2(-ey)).contiguous()
+            ctl = self._ctl(lid, _pow2(-x.exp))
         else:
             wp = self._pack(dcn_mod.weight)
         self.keep += [bias, scale, shift]
-        out = self._new(x.B, x.H, x.W, co, fmt="f32s" if (use_s and not out_plain) else None)
         lib = self.lib
         assert x.pitch == x.C and x.c_off == 0 and x.fmt == "f32"
         bp, sp, hp, wpp = native.ptr(bias), native.ptr(scale), native.ptr(shift), native.ptr(wp)
         cd = DTYPE_F32S if use_s else DTYPE_F32
         flags = CONV_Y_PLAIN if (use_s and out_plain) else 0
+        cref = ctypes.byref(ctl) if ctl is not None else None
 
         self._grow_ws(lib.cn_dcn_v2_forward_nhwc_workspace_bytes(x.B, ci, x.H, x.W, co))
 
         def run():
             wsp = ctypes.c_void_p(self.ws.data_ptr()) if self.ws is not None else None
             rc = lib.cn_dcn_v2_forward_nhwc(x.ptr(), wpp, bp, om.ptr(), om.pitch, sp, hp,
-                                            out.ptr(), out.pitch, x.B, ci, x.H, x.W, co, 1,
-                                            int(relu), cd, flags, wsp, self.ws_bytes,
+                                            out.ptr(), out.pitch, x.B, ci, x.H, x.W, co, msig,
+                                            int(relu), cd, flags, cref, wsp, self.ws_bytes,
                                             native.stream_ptr())
             if rc:
                 native.check(rc, "cn_dcn_v2_forward_nhwc")
@@ -526,9 +698,10 @@ class PlanBuilder:
         if all(isinstance(s, torch.nn.Sequential) for s in seqs.values()):
             return self.heads_from_convs(x, {n: (s[0], s[-1]) for n, s in seqs.items()})
         outs = {}
+        lid = self._lid()
         for n, s in seqs.items():
             outs[n] = self.conv(x, s.weight, bias=s.bias, stride=1, padding=s.kernel_size[0] // 2,
-                                out_nchw=True)
+                                out_nchw=True, lid=lid + "/" + n)
         return outs
 
     def heads_from_convs(self, x, pairs):
@@ -536,6 +709,7 @@ class PlanBuilder:
         all heads read the same feature map, so they run as ONE launch with concatenated
         output channels; each last conv then reads its channel slice and writes the NCHW
         map the decode consumes."""
+        lid = self._lid()
         names = list(pairs.keys())
         firsts = [pairs[n][0] for n in names]
         w = torch.cat([c.weight.detach() for c in firsts], 0)
@@ -547,17 +721,32 @@ class PlanBuilder:
                                      [pairs[n][1].weight.shape[0] for n in names]) and
                 all(c.padding[0] == 1 and c.stride[0] == 1 for c in firsts) and
                 all(tuple(pairs[n][1].kernel_size) == (1, 1) for n in names)):
-            return self._heads_fused(x, names, pairs, w, b)
-        mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2,
-                        wsources=[c.weight for c in firsts])
+            return self._heads_fused(x, names, pairs, w, b, lid)
+        hcs = [c.weight.shape[0] for c in firsts]
+        # an f32s tensor is addressable in whole 32-channel groups only: hidden widths that are
+        # not a multiple of 32 keep the hidden layer in plain floats (slices then start anywhere
+        # on a 4-channel boundary); widths that are not a multiple of 4 run head by head
+        mid_plain = any(h % 32 for h in hcs)
         outs = {}
+        if any(h % 4 for h in hcs):
+            for n in names:
+                first, last = pairs[n]
+                mid = self.conv(x, first.weight, bias=first.bias, relu=True, stride=1, padding=k // 2,
+                                out_plain=True, lid=lid + "/hid")
+                outs[n] = self.conv(mid, last.weight, bias=last.bias, stride=1,
+                                    padding=last.kernel_size[0] // 2, out_nchw=True,
+                                    lid=lid + "/" + n)
+            return outs
+        mid = self.conv(x, w, bias=b, relu=True, stride=1, padding=k // 2,
+                        wsources=[c.weight for c in firsts], out_plain=mid_plain, lid=lid + "/hid")
         off = 0
         for n in names:
             first, last = pairs[n]
             hc = first.weight.shape[0]
-            sl = Act(mid.t, mid.B, mid.H, mid.W, hc, pitch=mid.pitch, c_off=off, fmt=mid.fmt)
+            sl = Act(mid.t, mid.B, mid.H, mid.W, hc, pitch=mid.pitch, c_off=off, fmt=mid.fmt,
+                     exp=mid.exp, lid=mid.lid)
             outs[n] = self.conv(sl, last.weight, bias=last.bias, stride=1,
-                                padding=last.kernel_size[0] // 2, out_nchw=True)
+                                padding=last.kernel_size[0] // 2, out_nchw=True, lid=lid + "/" + n)
             off += hc
         return outs
 
@@ -573,7 +762,7 @@ class PlanBuilder:
             return False
         return True
 
-    def _heads_fused(self, x, names, pairs, w1, b1):
+    def _heads_fused(self, x, names, pairs, w1, b1, lid):
         """All heads as ONE launch (cn_heads3x3_1x1): the hidden channels of a head stay in LDS
         between its 3x3 and its 1x1 convolution, 64 at a time."""
         lib = self.lib
@@ -581,13 +770,19 @@ class PlanBuilder:
         hc = pairs[names[0]][0].weight.shape[0]
         use_s = self.split
         scale1 = None
+        eh = self._exp(lid + "/hid")       # exponent of the hidden tile (lives in LDS only)
+        b1 = b1.to(device=self.device, dtype=torch.float32)
+        ctl = None
         if use_s:
-            wp, scale1 = self._pack(w1, [pairs[n][0].weight for n in names], f32s=True)
+            wp, factor1 = self._pack(w1, [pairs[n][0].weight for n in names], f32s=True)
+            scale1 = (factor1 * _pow2(x.exp - eh)).contiguous()
+            b1 = b1 * _pow2(-eh)
+            ctl = self._ctl(lid + "/hid", _pow2(-x.exp) if x.fmt == "f32" else 1.0)
         else:
             wp = self._pack(w1, [pairs[n][0].weight for n in names])
+        b1 = b1.contiguous()
         cd = DTYPE_F32S if use_s else DTYPE_F32
         flags = CONV_X_PLAIN if (use_s and x.fmt == "f32") else 0
-        b1 = b1.to(device=self.device, dtype=torch.float32).contiguous()
         arr = (native.HeadOut * nh)()
         outs = {}
         fl = 2 * x.B * x.H * x.W * w1.shape[0] * x.C * 9
@@ -597,24 +792,31 @@ class PlanBuilder:
             co = last.weight.shape[0]
             w2 = last.weight.detach().to(device=self.device, dtype=torch.float32)
             w2 = w2.reshape(co, hc).contiguous()
+            osc = None
+            if use_s:   # the kernel splits the 1x1 weights too: rows pre-scaled like every weight
+                w2, factor2 = prescale_rows(w2)
+                w2 = w2.contiguous()
+                osc = (factor2 * _pow2(eh)).contiguous()
             b2 = None if last.bias is None else \
                 last.bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
             t = torch.empty((x.B, co, x.H, x.W), device=self.device, dtype=torch.float32)
-            outs[n] = Act(t, x.B, x.H, x.W, co, nchw=True)
-            self.keep += [w2, b2, t]
+            outs[n] = Act(t, x.B, x.H, x.W, co, nchw=True, lid=lid + "/" + n)
+            self.keep += [w2, b2, t, osc]
             arr[i].w = w2.data_ptr()
             arr[i].bias = b2.data_ptr() if b2 is not None else None
             arr[i].y = t.data_ptr()
             arr[i].cout = co
+            arr[i].oscale = osc.data_ptr() if osc is not None else None
             fl += 2 * x.B * x.H * x.W * co * hc
             by += 4 * (x.B * x.H * x.W * co + co * hc)
         self.keep += [b1, arr, scale1]
         wpp, b1p, s1p = native.ptr(wp), native.ptr(b1), native.ptr(scale1)
         ci = x.C
+        cref = ctypes.byref(ctl) if ctl is not None else None
 
         def run():
             rc = lib.cn_heads3x3_1x1(x.ptr(), x.B, x.H, x.W, ci, x.pitch, wpp, s1p, b1p, hc, nh,
-                                     arr, cd, flags, native.stream_ptr())
+                                     arr, cd, flags, cref, native.stream_ptr())
             if rc:
                 native.check(rc, "cn_heads3x3_1x1")
         self.ops.append(run)
@@ -623,11 +825,28 @@ class PlanBuilder:
         self.flops += fl
         return outs
 
+    def finish(self):
+        """Close the launch list: one tiny launch folds this forward's range words into the
+        running (largest, smallest) per-launch maxima the host reads at its next look."""
+        if self.range is not None and self.range_slots:
+            lib, n = self.lib, len(self.range_slots)
+            cur = ctypes.c_void_p(self.range.data_ptr())
+            hi, lo = (ctypes.c_void_p(self.range_stat[i].data_ptr()) for i in range(2))
+
+            def run():
+                rc = lib.cn_range_fold(cur, hi, lo, n, native.stream_ptr())
+                if rc:
+                    native.check(rc, "cn_range_fold")
+            self.ops.append(run)
+            self.meta.append(dict(kind="range", flops=0, bytes=0))
+            self.trace.append(("range", None))
+
 
 class Plan:
     """A compiled forward pass for one input shape."""
 
     def __init__(self, builder, outputs):
+        builder.finish()
         self.b = builder
         self.outputs = outputs  # name -> Act (NCHW)
         self.graph = None
@@ -652,6 +871,12 @@ class Plan:
         native.require_f32(images)
         images = images.contiguous()
         assert tuple(images.shape) == (self.b.B, self.b.input.C, self.b.H, self.b.W), images.shape
+        if self.b._pack_events:
+            # weights packed on another stream (or just now): complete before the first launch
+            st = torch.cuda.current_stream()
+            for ev in self.b._pack_events:
+                st.wait_event(ev)
+            self.b._pack_events = []
         if self.graph is not None:
             self._static_in.copy_(images)
             self.graph.replay()
@@ -674,6 +899,41 @@ class Plan:
             return {k: v.t for k, v in self.outputs.items()}
         return {k: v.t.clone() for k, v in self.outputs.items()}
 
+    # ---- f32s range words ------------------------------------------------------------------
+    def range_report(self, reset=True):
+        """Synchronising read of the running range words of this plan since the last look:
+        per launch that splits values, (logical id, largest, smallest) of its per-forward
+        maxima -- output side and input side, in STORED units (value * 2^-exponent; anything
+        above 65504 was clamped).  None when the plan is not f32s or tracking is off."""
+        b = self.b
+        if b.range is None or not b.range_slots:
+            return None
+        n = len(b.range_slots)
+        host = b.range_stat[:, :n].cpu()            # synchronises with the launch stream
+        if reset:
+            b.range_stat[0, :n].zero_()
+            b.range_stat[1, :n].fill_(0x7f800000)
+        hi = host[0].contiguous().view(torch.float32).tolist()
+        lo = host[1].contiguous().view(torch.float32).tolist()
+        return [(lid, (hi[i][0], lo[i][0]), (hi[i][1], lo[i][1])) for i, lid in enumerate(b.range_slots)]
+
+    def range_status(self, reset=True):
+        """'ok', 'low' (some launch's largest value fell below LOW_WATER in stored units: results
+        are still within bounds but the tensor should be re-calibrated), or 'overflow' (a value
+        beyond the fp16 range was clamped: the results of the forwards since the last look are
+        INVALID); plus the offending entries."""
+        rep = self.range_report(reset)
+        if rep is None:
+            return "ok", []
+        over = [r for r in rep if r[1][0] > F16_MAX or r[2][0] > F16_MAX or
+                r[1][0] != r[1][0] or r[2][0] != r[2][0]]
+        if over:
+            return "overflow", over
+        # per side: (largest, smallest) per-forward maximum.  smallest == +inf: no forward since
+        # the last look; largest == 0: this side of the launch splits nothing (or only zeros)
+        low = [r for r in rep if any(side[0] > 0.0 and side[1] < LOW_WATER for side in r[1:])]
+        return ("low", low) if low else ("ok", [])
+
     def capture(self):
         """Capture the launch list in a HIP graph (launch-bound small batches)."""
         self._static_in = torch.zeros((self.b.B, self.b.input.C, self.b.H, self.b.W),
@@ -692,6 +952,10 @@ class Plan:
                 op()
         self.graph = g
         return self
+
+
+class RangeError(native.NativeError):
+    """An f32s forward clamped a value although it had just been calibrated on that very input."""
 
 
 class PlannedModule(torch.nn.Module):
@@ -719,6 +983,64 @@ class PlannedModule(torch.nn.Module):
 
     max_plans = int(os.environ.get("CN_PLAN_CACHE", "8"))   # LRU bound on cached input shapes
 
+    # ---- f32s exponents ---------------------------------------------------------------------
+    def uses_f32s(self):
+        split = self.f32s if self.f32s is not None else os.environ.get("CN_F32S", "1") != "0"
+        return bool(split) and self.compute_dtype == torch.float32
+
+    @property
+    def exponents(self):
+        """logical tensor id -> f32s exponent, or None before the first calibration."""
+        return self.__dict__.get("_exps")
+
+    def calibrate(self, x, merge=False):
+        """Measure max |value| of every tensor of the network on the batch ``x`` with the plain
+        fp32 kernels (no splits, nothing can saturate) and derive the f32s exponents from it:
+        tensor t is then stored as real * 2^-e_t with its largest magnitude in [2^9, 2^10).
+        Runs by itself on the first f32s forward, and again when a forward reports a clamped
+        value (inputs far outside the calibration batch).  ``merge``: keep the larger of the old
+        and the new exponent per tensor.  Costs one fp32-MFMA forward + one pass over the
+        activations; the f32s plans are rebuilt (the packed weights are kept)."""
+        if not x.is_cuda:
+            raise native.NativeError("calibration needs a batch on a HIP device")
+        B, C, H, W = x.shape
+        lib = native.lib()
+        with torch.no_grad():
+            pb = PlanBuilder(x.device, B, H, W, dtype=torch.float32, wcache={}, calibrating=True)
+            outs = self.describe(pb, pb.set_input(C))
+            plan = Plan(pb, outs)
+            plan.run(x.contiguous().float(), borrow=True)
+            acts = [a for _, a in pb.trace if a is not None and a.lid is not None and not a.nchw]
+            words = torch.zeros(len(acts) + 1, device=x.device, dtype=torch.int32)
+            st = native.stream_ptr()
+            xc = x.contiguous()
+            native.check(lib.cn_absmax_f32(native.ptr(xc), xc.numel(), 1, 1, native.ptr(words), st),
+                         "cn_absmax_f32")
+            for i, a in enumerate(acts):
+                wptr = ctypes.c_void_p(words.data_ptr() + 4 * (i + 1))
+                native.check(lib.cn_absmax_f32(a.ptr(), a.B * a.H * a.W, a.C, a.pitch, wptr, st),
+                             "cn_absmax_f32")
+            vals = words.cpu().view(torch.float32).tolist()
+        amax = {"input": vals[0]}
+        for a, v in zip(acts, vals[1:]):
+            amax[a.lid] = max(amax.get(a.lid, 0.0), v)
+        exps = {lid: exponent_for(v) for lid, v in amax.items()}
+        for grp in pb.groups:        # concatenated tensors share the exponent of the largest
+            have = [exps[l] for l in grp if l in exps and amax.get(l, 0.0) > 0.0]
+            if have:
+                e = max(have)
+                for l in grp:
+                    exps[l] = e
+        old = self.__dict__.get("_exps")
+        if merge and old:
+            for l, e in old.items():
+                exps[l] = max(e, exps.get(l, e))
+        self.__dict__["_exps"] = exps
+        self.__dict__["_absmax"] = amax
+        self.__dict__["_plans"] = {}      # plans bake the exponents into their epilogue constants
+        self.__dict__["_calibrations"] = self.__dict__.get("_calibrations", 0) + 1
+        return exps
+
     def plan_for(self, B, H, W, device):
         """The plan of one input shape.  Plans (activations + launch list) are kept in an LRU of
         ``max_plans`` shapes -- --keep_res / multi-scale evaluation sees many (H, W) -- while the
@@ -730,7 +1052,8 @@ class PlannedModule(torch.nn.Module):
             native.lib()  # raises if the HIP library is missing
             with torch.no_grad():
                 pb = PlanBuilder(device, B, H, W, dtype=self.compute_dtype,
-                                 wcache=self.__dict__.setdefault("_wcache", {}), split=self.f32s)
+                                 wcache=self.__dict__.setdefault("_wcache", {}), split=self.f32s,
+                                 exps=self.__dict__.get("_exps"))
                 x = pb.set_input(3)
                 outs = self.describe(pb, x)
             plan = Plan(pb, outs)
@@ -740,18 +1063,55 @@ class PlannedModule(torch.nn.Module):
         return plan
 
     def invalidate_plans(self):
-        """Drop every plan and packed weight (call after changing parameters in place)."""
+        """Drop every plan, packed weight and calibrated exponent (call after changing
+        parameters in place)."""
         self.__dict__["_plans"] = {}
         self.__dict__["_wcache"] = {}
+        self.__dict__["_exps"] = None
 
     def load_state_dict(self, *a, **kw):
         r = super().load_state_dict(*a, **kw)
         self.invalidate_plans()
         return r
 
-    def forward(self, x, borrow=False, events=None, event_after=None):
+    def _apply(self, fn, *a, **kw):
+        # .to() / .cuda() / .cpu() / .float(): parameter storage moves, the packed copies and the
+        # plans that point at them are stale
+        r = super()._apply(fn, *a, **kw)
+        self.invalidate_plans()
+        return r
+
+    def range_ok(self, x=None):
+        """Synchronising look at the range words of every f32s plan of this module since the
+        last look.  True: nothing was clamped.  False: some forward since then produced INVALID
+        results; the module has been re-calibrated (on ``x`` when given) so that re-running the
+        batch is valid.  A tensor that drifted far BELOW its calibrated range only schedules a
+        re-calibration on the next forward (its results are still within the error bound)."""
+        worst = "ok"
+        for plan in list(self.__dict__.get("_plans", {}).values()):
+            st, bad = plan.range_status()
+            if st == "overflow":
+                worst = "overflow"
+                self.__dict__["_last_range_event"] = ("overflow", bad)
+            elif st == "low" and worst == "ok":
+                worst = "low"
+                self.__dict__["_last_range_event"] = ("low", bad)
+        if worst == "overflow":
+            if x is not None:
+                self.calibrate(x, merge=True)
+            else:
+                self.__dict__["_recalibrate"] = "merge"
+            return False
+        if worst == "low":
+            self.__dict__["_recalibrate"] = "replace"
+        return True
+
+    def forward(self, x, borrow=False, events=None, event_after=None, check=None):
         """[{head: (B,C,H/4,W/4)}] like the reference modules (fresh tensors).  ``borrow`` /
-        ``events``: see Plan.run."""
+        ``events``: see Plan.run.  ``check``: f32s range check of THIS forward before it returns
+        (one stream synchronisation; on a clamped value the module re-calibrates on ``x`` and
+        runs again).  Default: on for the fresh-tensor form, off with ``borrow=True`` -- those
+        callers (the detectors) synchronise anyway and call ``range_ok`` there."""
         if self.training:
             raise native.NativeError("centernet_amd implements the inference path only; call .eval()")
         if not x.is_cuda:
@@ -759,5 +1119,26 @@ class PlannedModule(torch.nn.Module):
                 "centernet_amd runs on MI355X only (input is on %s). There is no CPU path: the "
                 "CPU restatement under oracle/ is test infrastructure." % x.device)
         B, C, H, W = x.shape
+        f32s = self.uses_f32s()
+        if f32s:
+            pending = self.__dict__.pop("_recalibrate", None)
+            if self.__dict__.get("_exps") is None:
+                self.calibrate(x)
+            elif pending:
+                self.calibrate(x, merge=(pending == "merge"))
+        if check is None:
+            check = f32s and not borrow
         plan = self.plan_for(B, H, W, x.device)
-        return [plan.run(x, events=events, event_after=event_after, borrow=borrow)]
+        out = plan.run(x, events=events, event_after=event_after, borrow=borrow)
+        if check and f32s:
+            st, bad = plan.range_status()
+            if st == "overflow":
+                self.calibrate(x, merge=True)
+                plan = self.plan_for(B, H, W, x.device)
+                out = plan.run(x, events=events, event_after=event_after, borrow=borrow)
+                st, bad = plan.range_status()
+                if st == "overflow":
+                    raise RangeError("f32s forward still clamps after re-calibration: %r" % (bad[:3],))
+            elif st == "low":
+                self.__dict__["_recalibrate"] = "replace"
+        return [out]

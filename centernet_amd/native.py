@@ -31,18 +31,24 @@ class NativeError(RuntimeError):
     pass
 
 
+class F32sCtl(ctypes.Structure):
+    """Mirror of ``cn_f32s_ctl``: range control of the f32s kernels (multipliers that carry the
+    per-tensor exponents + the device words that receive the largest |value| a launch split)."""
+    _fields_ = [("x_mul", ctypes.c_float), ("res_mul", ctypes.c_float), ("range", ctypes.c_void_p)]
+
+
 class ConvDesc(ctypes.Structure):
     """Mirror of ``cn_conv_desc`` (include/centernet_amd.h)."""
     _fields_ = [(n, ctypes.c_int) for n in (
         "B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad_h", "pad_w",
         "dil", "in_layout", "in_pitch", "out_layout", "out_pitch", "OH", "OW", "oy_mul",
-        "oy_add", "ox_mul", "ox_add", "relu", "dtype", "flags")]
+        "oy_add", "ox_mul", "ox_add", "relu", "dtype", "flags")] + [("ctl", F32sCtl)]
 
 
 class HeadOut(ctypes.Structure):
     """Mirror of ``cn_head_out`` (include/centernet_amd.h)."""
     _fields_ = [("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p),
-                ("cout", ctypes.c_int), ("reserved", ctypes.c_int)]
+                ("cout", ctypes.c_int), ("reserved", ctypes.c_int), ("oscale", ctypes.c_void_p)]
 
 
 def build(force=False, verbose=False):
@@ -77,20 +83,34 @@ def _declare(lib):
     lib.cn_f32_to_f32s.argtypes = [vp, vp, sz, i, i, i, vp]
     lib.cn_f32s_to_f32.restype = i
     lib.cn_f32s_to_f32.argtypes = [vp, vp, sz, i, i, i, vp]
+    f = ctypes.c_float
+    ctl = ctypes.POINTER(F32sCtl)
+    lib.cn_f32_to_f32s_scaled.restype = i
+    lib.cn_f32_to_f32s_scaled.argtypes = [vp, vp, sz, i, i, i, f, vp, vp]
+    lib.cn_f32s_to_f32_scaled.restype = i
+    lib.cn_f32s_to_f32_scaled.argtypes = [vp, vp, sz, i, i, i, f, vp]
+    lib.cn_absmax_f32.restype = i
+    lib.cn_absmax_f32.argtypes = [vp, sz, i, i, vp, vp]
+    lib.cn_range_fold.restype = i
+    lib.cn_range_fold.argtypes = [vp, vp, vp, i, vp]
+    lib.cn_maxpool_nhwc_scaled.restype = i
+    lib.cn_maxpool_nhwc_scaled.argtypes = [vp, vp, i, i, i, i, i, i, i, i, f, vp]
     lib.cn_dcn_v2_forward_nhwc.restype = i
-    lib.cn_dcn_v2_forward_nhwc.argtypes = [vp, vp, vp, vp, i, vp, vp, vp] + [i] * 10 + [vp, sz, vp]
+    lib.cn_dcn_v2_forward_nhwc.argtypes = [vp, vp, vp, vp, i, vp, vp, vp] + [i] * 10 + [ctl, vp, sz, vp]
     lib.cn_pack_deconv4x4s2_weight.restype = i
     lib.cn_pack_deconv4x4s2_weight.argtypes = [vp, vp, i, i, i, vp]
     lib.cn_conv_transpose4x4s2.restype = i
-    lib.cn_conv_transpose4x4s2.argtypes = [vp, vp, vp, vp, vp] + [i] * 10 + [vp]
+    lib.cn_conv_transpose4x4s2.argtypes = [vp, vp, vp, vp, vp] + [i] * 10 + [ctl, vp]
     lib.cn_heads3x3_1x1.restype = i
-    lib.cn_heads3x3_1x1.argtypes = [vp, i, i, i, i, i, vp, vp, vp, i, i, vp, i, i, vp]
+    lib.cn_heads3x3_1x1.argtypes = [vp, i, i, i, i, i, vp, vp, vp, i, i, vp, i, i, ctl, vp]
     lib.cn_packed_conv_weight_floats.restype = sz
     lib.cn_packed_conv_weight_floats.argtypes = [i] * 4
     lib.cn_pack_conv_weight_f32.restype = i
     lib.cn_pack_conv_weight_f32.argtypes = [vp, vp, i, i, i, i, vp]
     lib.cn_stem_maxpool_supported.restype = i
     lib.cn_stem_maxpool_supported.argtypes = [ctypes.POINTER(ConvDesc)]
+    lib.cn_stem_f32s_supported.restype = i
+    lib.cn_stem_f32s_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.cn_conv2d_f32.restype = i
     lib.cn_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     lib.cn_packed_conv_weight_elems.restype = sz

@@ -8,6 +8,7 @@ task, --arch, --head_conv, --down_ratio, --input_res/_h/_w, --load_model, --gpus
 --not_hm_hp, --not_reg_hp_offset, --debug, --vis_thresh.
 """
 import argparse
+import os
 
 # (flag, kwargs) -- table form; names and defaults as in opts.py:13-225
 _FLAGS = [
@@ -35,6 +36,9 @@ _FLAGS = [
     ("--keep_res", dict(action="store_true")), ("--not_rand_crop", dict(action="store_true")),
     # new (not in the reference): keep pre_process on the host instead of the device kernels
     ("--host_pre_process", dict(action="store_true")),
+    # new: compute on the plain fp32 matrix instruction instead of f32s (three fp16 MFMAs per
+    # product on range-controlled fp16 pairs) -- the A/B reference mode
+    ("--fp32_mfma", dict(action="store_true")),
     ("--shift", dict(type=float, default=0.1)), ("--scale", dict(type=float, default=0.4)),
     ("--rotate", dict(type=float, default=0)), ("--flip", dict(type=float, default=0.5)),
     ("--no_color_aug", dict(action="store_true")), ("--aug_rot", dict(type=float, default=0)),
@@ -96,8 +100,28 @@ class opts(object):
             opt.head_conv = 256 if 'dla' in opt.arch else 64
         opt.pad = 127 if 'hourglass' in opt.arch else 31
         opt.num_stacks = 2 if opt.arch == 'hourglass' else 1
-        # training / experiment-directory bookkeeping of the reference's parse() (chunk sizes,
-        # save_dir, resume paths) is not derived: nothing on the inference path reads it
+        # Derived fields reference-style scripts read off the namespace (opts.py:251-281): the
+        # debug overrides, the per-GPU batch split (first GPU's share, the rest spread evenly,
+        # remainder to the lowest ranks), and the experiment directories under the package root.
+        if opt.trainval:
+            opt.val_intervals = 100000000
+        if opt.debug > 0:
+            opt.num_workers, opt.batch_size, opt.master_batch_size = 0, 1, -1
+            opt.gpus = opt.gpus[:1]
+        n = len(opt.gpus)
+        if opt.master_batch_size == -1:
+            opt.master_batch_size = opt.batch_size // n
+        rest = opt.batch_size - opt.master_batch_size
+        opt.chunk_sizes = [opt.master_batch_size] + \
+            [rest // (n - 1) + (1 if i < rest % (n - 1) else 0) for i in range(n - 1)]
+        opt.root_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+        opt.data_dir = os.path.join(opt.root_dir, 'data')
+        opt.exp_dir = os.path.join(opt.root_dir, 'exp', opt.task)
+        opt.save_dir = os.path.join(opt.exp_dir, opt.exp_id)
+        opt.debug_dir = os.path.join(opt.save_dir, 'debug')
+        if opt.resume and opt.load_model == '':
+            base = opt.save_dir[:-4] if opt.save_dir.endswith('TEST') else opt.save_dir
+            opt.load_model = os.path.join(base, 'model_last.pth')
         return opt
 
     def update_dataset_info_and_set_heads(self, opt, dataset):

@@ -69,14 +69,20 @@ def ctdet_results_batch(dets, metas, num_classes, scale=1, max_per_image=100):
     rows = np.concatenate([xy, dets[:, :, 4:5].astype(np.float32)], axis=2)
     rows[:, :, :4] /= scale
     cls = dets[:, :, 5].astype(np.int64)
-    if K > max_per_image:
+    stray = bool(((cls < 0) | (cls >= num_classes)).any())
+    if K > max_per_image or stray:
         # keep the max_per_image best of every image (ties at the threshold kept, as the
-        # reference's np.partition test does): rare, handled image by image
+        # reference's np.partition test does): rare, handled image by image.  The same path
+        # serves class ids outside [0, num_classes) (a head with more channels than
+        # opt.num_classes): such rows match no `classes == j` of the reference
+        # (post_process.py:93-99) and are dropped, never moved into another image's rows.
         out = []
         for i in range(B):
-            kth = K - max_per_image
-            thresh = np.partition(rows[i, :, 4], kth)[kth]
-            keep = rows[i, :, 4] >= thresh
+            keep = np.ones(K, bool)
+            if K > max_per_image:
+                kth = K - max_per_image
+                thresh = np.partition(rows[i, :, 4], kth)[kth]
+                keep = rows[i, :, 4] >= thresh
             r, c = rows[i][keep], cls[i][keep]
             order = np.argsort(c, kind='stable')
             r, c = r[order], c[order]

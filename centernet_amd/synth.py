@@ -183,3 +183,36 @@ def uniform(shape, lo, hi, seed):
 def normal(shape, std, seed, mean=0.0):
     rng = np.random.RandomState(seed)
     return (rng.standard_normal(shape) * std + mean).astype(np.float32)
+
+
+def rescale_activations_(module, log2_scale):
+    """Multiply every INTERNAL activation of a ResNet-type network (``networks.resnet.PoseResNet``)
+    by 2^log2_scale while leaving its outputs unchanged: the first BatchNorm scales its
+    (gamma, beta), every later one its (running_mean, beta); DCN offset convolutions divide
+    their weights (offsets and masks stay what they were) and DCN / first-head-conv biases
+    scale; the last convolution of each head divides its weights.  Powers of two commute with
+    fp32 rounding, so the rescaled network is the SAME function bit for bit in fp32 -- a network
+    whose feature maps sit at 1e-4 or 1e+4 instead of O(1), for the f32s range tests."""
+    s = float(2.0 ** log2_scale)
+    with torch.no_grad():
+        first_bn = True
+        for name, m in module.named_modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                if first_bn:
+                    assert name == "bn1", name
+                    m.weight.mul_(s)
+                    first_bn = False
+                else:
+                    m.running_mean.mul_(s)
+                m.bias.mul_(s)
+            elif hasattr(m, "conv_offset_mask"):
+                m.conv_offset_mask.weight.div_(s)
+                m.bias.mul_(s)
+        for h in module.heads:
+            seq = getattr(module, h)
+            assert isinstance(seq, torch.nn.Sequential)
+            seq[0].bias.mul_(s)
+            seq[-1].weight.div_(s)
+    if hasattr(module, "invalidate_plans"):
+        module.invalidate_plans()
+    return module

@@ -50,6 +50,29 @@ typedef enum cn_status {
  * with three fp16 MFMAs per product at fp32-level accuracy (csrc/cn_common.h) */
 #define CN_DTYPE_F32S 2
 
+/* f32s range control (csrc/cn_common.h "Range").  An f32s tensor holds  stored = real * 2^-e  with a
+ * per-tensor exponent e owned by the caller (centernet_amd/engine.py picks it so that the tensor's
+ * largest magnitude sits near 2^9; the fp16 pair then keeps its 22 bits over 12 binades below
+ * and has 2^6 of head-room above).  The kernels never see e: its effect is folded by the caller
+ * into the per-channel epilogue `scale` / `shift` they apply anyway, and into the two multipliers
+ * below (powers of two, hence exact).  `range`, when not NULL, points to CN_RANGE_WORDS device
+ * words the caller zeroed: the launch max-es into them, as float bit patterns, the largest
+ * |value| it split -- side 0 = the output side (the stored tensor / the hidden tile of the fused
+ * heads), side 1 = the input side (a plain x, the blended deformable samples); word
+ * [(side * CN_RANGE_SLOTS + slot) * CN_RANGE_STRIDE], the maximum over the slots is the
+ * launch's (cn_range_fold reduces them).  A maximum > 65504 means a
+ * value was clamped: the result is invalid and the caller must re-scale (the reference's plain
+ * fp32 never saturates; neither does this library silently).  NULL ctl = all defaults. */
+#define CN_RANGE_SLOTS 64   /* words per side a launch spreads its per-wave maxima over ... */
+#define CN_RANGE_STRIDE 16  /* ... one per 64-byte line (atomics on one address serialise) */
+#define CN_RANGE_WORDS (2 * CN_RANGE_SLOTS * CN_RANGE_STRIDE)  /* words of one launch's `range` */
+typedef struct cn_f32s_ctl {
+    float x_mul;     /* plain fp32 x (CN_CONV_X_PLAIN, deformable input, stem image): multiplied by
+                        this before it is split; 0 = 1 */
+    float res_mul;   /* the residual is multiplied by this before it is added; 0 = 1 */
+    uint32_t *range; /* device, CN_RANGE_WORDS words, or NULL */
+} cn_f32s_ctl;
+
 /* Library / ABI version (major*10000 + minor*100 + patch). */
 int cn_version(void);
 /* Human-readable text for a cn_status. */
@@ -165,7 +188,8 @@ int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weight_packed, c
                            const float *offset_mask_nhwc, int om_pitch, const float *scale,
                            const float *shift, void *output_nhwc, int out_pitch, int B, int Cin,
                            int H, int W, int Cout, int mask_sigmoid, int relu, int dtype, int flags,
-                           void *workspace, size_t workspace_bytes, void *stream);
+                           const cn_f32s_ctl *ctl, void *workspace, size_t workspace_bytes,
+                           void *stream);
 int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_packed,
                                const float *bias, const float *offset_mask_nhwc,
                                int om_pitch, const float *scale, const float *shift,
@@ -180,6 +204,20 @@ int cn_f32_to_f32s(const float *x, void *y, size_t npix, int C, int in_pitch, in
                    void *stream);
 int cn_f32s_to_f32(const void *x, float *y, size_t npix, int C, int in_pitch, int out_pitch,
                    void *stream);
+/* the same with the tensor's exponent: y = split(x * mul) (side 1 of `range`, CN_RANGE_WORDS words, receives max |x * mul|) and
+ * y = join(x) * mul; mul is a power of two (0 = 1), range may be NULL */
+int cn_f32_to_f32s_scaled(const float *x, void *y, size_t npix, int C, int in_pitch, int out_pitch,
+                          float mul, uint32_t *range, void *stream);
+int cn_f32s_to_f32_scaled(const void *x, float *y, size_t npix, int C, int in_pitch, int out_pitch,
+                          float mul, void *stream);
+/* max |x| over the C channels of npix pixels of a plain fp32 NHWC tensor, max-ed into *word as a
+ * float bit pattern (the caller zeroes it): the calibration pass of the f32s exponents */
+int cn_absmax_f32(const float *x, size_t npix, int C, int pitch, uint32_t *word, void *stream);
+/* end-of-forward bookkeeping of the range words of n_launches launches (cur: n_launches x
+ * CN_RANGE_WORDS; hi, lo: n_launches x 2 sides): m = max over the slots, hi = max(hi, m),
+ * lo = min(lo, m), slots = 0 -- the host reads hi / lo whenever it synchronises anyway (largest
+ * and smallest per-forward maximum since its last look) instead of after every forward */
+int cn_range_fold(uint32_t *cur, uint32_t *hi, uint32_t *lo, int n_launches, void *stream);
 
 /* ------------------------------------------------------------------------
  * Dense convolution as an implicit GEMM on fp32 MFMA (no im2col buffer).
@@ -209,6 +247,7 @@ typedef struct cn_conv_desc {
     int relu;
     int dtype;              /* CN_DTYPE_F32 / CN_DTYPE_F16 / CN_DTYPE_F32S (x, w, residual, NHWC y) */
     int flags;              /* CN_CONV_* bits, 0 by default */
+    cn_f32s_ctl ctl;        /* dtype = CN_DTYPE_F32S (and the CN_CONV_STEM_F32S stem): range control */
 } cn_conv_desc;
 /* dtype = CN_DTYPE_F32S only: x (and the residual) / y are plain fp32 NHWC tensors; the kernel
  * converts while staging / storing (e.g. the offset maps the deformable kernel reads). */
@@ -228,6 +267,9 @@ typedef struct cn_conv_desc {
  * output channels, rows of 1..4 whole 128-pixel tiles, even Ho, batch * Ho large enough to fill
  * the chip with row strips), else 0.  Host-only, no GPU needed. */
 int cn_stem_maxpool_supported(const cn_conv_desc *d);
+/* 1 when cn_conv2d runs this stem descriptor with CN_CONV_STEM_F32S arithmetic (only then are
+ * ctl.x_mul / ctl.range used: the fp32 stem kernels split nothing), else 0.  Host-only. */
+int cn_stem_f32s_supported(const cn_conv_desc *d);
 
 /* Number of floats of the packed weight for (Cout,Cin,KH,KW). */
 size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
@@ -264,7 +306,8 @@ int cn_pack_deconv4x4s2_weight(const float *w_iohw, void *w_packed, int Cin, int
                                void *stream);
 int cn_conv_transpose4x4s2(const void *x_nhwc, const void *w_packed, const float *scale,
                            const float *shift, void *y_nhwc, int B, int H, int W, int Cin, int Cout,
-                           int in_pitch, int out_pitch, int relu, int dtype, int flags, void *stream);
+                           int in_pitch, int out_pitch, int relu, int dtype, int flags,
+                           const cn_f32s_ctl *ctl, void *stream);
 int cn_pack_deconv4x4s2_weight_f32(const float *w_iohw, float *w_packed, int Cin, int Cout,
                                    void *stream);
 int cn_conv_transpose4x4s2_f32(const float *x_nhwc, const float *w_packed, const float *scale,
@@ -281,6 +324,9 @@ int cn_maxpool_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, in
  * above); the output is plain fp32 */
 int cn_maxpool_nhwc(const void *x_nhwc, float *y_nhwc, int B, int H, int W, int C, int k, int s,
                     int pad, int in_dtype, void *stream);
+/* f32s input of exponent e: out_mul = 2^e brings the pooled values back to real units */
+int cn_maxpool_nhwc_scaled(const void *x_nhwc, float *y_nhwc, int B, int H, int W, int C, int k,
+                           int s, int pad, int in_dtype, float out_mul, void *stream);
 
 /* Depthwise ConvTranspose2d(C, C, kernel 2f, stride f, padding f/2, groups=C, bias=False)
  * -- the up-sampling of IDAUp (pose_dla_dcn.py:370-373) -- fused with the element-wise
@@ -317,6 +363,8 @@ typedef struct cn_head_out {
     float *y;          /* (B, cout, H, W) */
     int cout;
     int reserved;
+    const float *oscale; /* (cout) or NULL: y = acc * oscale + bias -- undoes a per-row pre-scale of w
+                            and the exponent of the hidden tile (f32s; see cn_f32s_ctl) */
 } cn_head_out;
 int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin, int in_pitch,
                         const float *w1_packed, const float *bias1, int head_conv, int n_heads,
@@ -326,7 +374,8 @@ int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin, int in_pit
  * the hidden tile and the 1x1 weights are split inside the kernel; outputs are fp32 NCHW. */
 int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int in_pitch,
                     const void *w1_packed, const float *scale1, const float *bias1, int head_conv,
-                    int n_heads, const cn_head_out *heads, int dtype, int flags, void *stream);
+                    int n_heads, const cn_head_out *heads, int dtype, int flags,
+                    const cn_f32s_ctl *ctl, void *stream);
 
 /* ------------------------------------------------------------------------
  * Pre-process on the device: BaseDetector.pre_process

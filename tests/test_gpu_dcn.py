@@ -231,3 +231,90 @@ def test_lds_window_variant_matches_oracle(dev):
             _check(y.cpu().numpy(), want)
     finally:
         lib.cn_set_tuning(11, 0)
+
+
+# ---- the kernel the benchmark runs: cn_dcn_v2_forward_nhwc with CN_DTYPE_F32S (NHWC input,
+# f32s-packed weight, tap split 1 / 3 / 9), entered with explicit offsets and masks
+def _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain):
+    """x (B,C,H,W), off (B,18,H,W), mask (B,9,H,W) numpy -> (B,Cout,H,W) numpy through
+    PlanBuilder.dcn(om=...) = cn_dcn_v2_forward_nhwc(dtype = CN_DTYPE_F32S)."""
+    from centernet_amd import native
+    from centernet_amd.dcn_v2 import DCNv2
+    from centernet_amd.engine import PlanBuilder, Act, exponent_for
+    B, C, H, W = x.shape
+    Co = w.shape[0]
+    m = DCNv2(C, Co, (3, 3), 1, 1)
+    with torch.no_grad():
+        m.weight.copy_(torch.from_numpy(w))
+        m.bias.copy_(torch.from_numpy(b))
+    m.conv_offset_mask = None
+    om = np.zeros((B, H, W, 32), np.float32)
+    om[..., :18] = off.transpose(0, 2, 3, 1)
+    om[..., 18:27] = mask.transpose(0, 2, 3, 1)
+    want_scale = float(np.abs(x).max())
+    lib = native.lib()
+    lib.cn_set_tuning(13, tap_split)
+    try:
+        pb = PlanBuilder(dev, B, H, W, split=True,
+                         exps={"x": exponent_for(want_scale), "t1": exponent_for(4.0 * want_scale)})
+        xa = Act(torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).to(dev), B, H, W, C,
+                 exp=pb._exp("x"), lid="x")
+        oma = Act(torch.from_numpy(om).to(dev), B, H, W, 27, pitch=32)
+        y = pb.dcn(xa, m, om=oma, mask_sigmoid=False, out_plain=out_plain)
+        assert y.fmt == ("f32" if out_plain else "f32s")
+        for op in pb.ops:
+            op()
+        torch.cuda.synchronize()
+    finally:
+        lib.cn_set_tuning(13, 0)
+    return y.to_float().permute(0, 3, 1, 2).cpu().numpy()
+
+
+@pytest.mark.parametrize("tap_split", [1, 3, 9])
+def test_f32s_nhwc_kernel_vs_reference_kernel_fixtures(dev, tap_split):
+    """The product kernel against outputs of the REFERENCE's own kernel (ref_golden.npz) for
+    every fixture in its domain (3x3 / stride 1 / pad 1 / one group, Cin % 4 == 0), stress
+    offsets included."""
+    gen = _gen_ref()
+    z = np.load(os.path.join(GOLDEN, "ref_golden.npz"))
+    ran = 0
+    for name, cfg in gen.DCN_CASES.items():
+        if (cfg["k"], cfg["stride"], cfg["pad"], cfg["dil"], cfg["dg"]) != (3, 1, 1, 1, 1) or cfg["Cin"] % 4:
+            continue
+        x, off, mask, w, b, _ = gen.dcn_inputs(cfg)
+        for out_plain in (False, True):
+            y = _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain)
+            want = z["dcn_" + name + "_y"]
+            err = np.abs(y - want) / (1 + np.abs(want))
+            assert err.max() < TOL, (name, tap_split, out_plain, err.max())
+        ran += 1
+    assert ran >= 3
+
+
+def test_f32s_nhwc_kernel_stress_offsets(dev):
+    """Offsets ~ U(-H, H) and exactly -1 / H / integers (dcn_v2_im2col_cuda.cu:165, :30-41)."""
+    B, Cin, H, W, Cout = 2, 64, 12, 12, 64
+    x, off, mask, w, b = _case(B, Cin, H, W, Cout, 77)
+    off = synth.uniform((B, 18, H, W), -H, H, 78)
+    off[0, :, 0, :] = -1.0
+    off[0, :, 1, :] = float(H)
+    off[1, :, 2, :] = np.round(off[1, :, 2, :])
+    want = ref.dcn_v2_forward(x, off, mask, w, b) if ref.available() else \
+        cref.dcn_v2_forward(x, off, mask, w, b)
+    for tap_split in (1, 3, 9):
+        _check(_dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, False), want)
+
+
+@pytest.mark.parametrize("shape", [(512, 16, 256), (256, 32, 128), (128, 64, 64),     # resdcn_18
+                                   (64, 128, 64), (256, 32, 64)])                       # dla_34
+def test_f32s_nhwc_kernel_at_benchmark_batch(dev, shape):
+    """B = 32, the layer shapes of resdcn_18 and dla_34: the launch the benchmark
+    times, default tap split; images 0, 13 and 31 against the C oracle (the operator is per
+    image, dcn_v2_cuda.c:61)."""
+    Cin, HW, Cout = shape
+    B = 32
+    x, off, mask, w, b = _case(B, Cin, HW, HW, Cout, 300 + Cin)
+    y = _dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, False)
+    for i in (0, 13, 31):
+        want = cref.dcn_v2_forward(x[i:i + 1], off[i:i + 1], mask[i:i + 1], w, b)
+        _check(y[i:i + 1], want)

@@ -1,0 +1,504 @@
+"""f32s arithmetic outside the O(1) regime.
+
+The reference computes plain fp32 at any activation scale (resnet_dcn.py:38-67,
+large_hourglass.py:17-74).  f32s carries every tensor as real * 2^-e with a per-tensor exponent
+(csrc/cn_common.h "Range", centernet_amd/engine.py) so that the fp16 (high, low) pairs keep
+their 22 bits at any scale; every split site reports the largest |value| it split, and the host
+re-calibrates when one was clamped.  Here:
+  * every kernel family (LDS-halo 3x3, implicit GEMM incl. split-K and NCHW outputs, transposed
+    conv, deformable conv, fused heads, stems, converters, max-pool) against torch fp64 at
+    activation scales 1e-4 ... 1e+6 (values far beyond 65504), with mixed-scale channels and
+    tiny weights: max |err| / rms <= 4e-6 at EVERY scale -- or, where the plain fp32 matrix
+    instruction itself is above that on the same data (heavy-tailed mixed-scale channels put
+    max / rms of fp32 rounding at 3-5e-6), within 1.5x of ITS error, measured in the same test;
+  * the range words equal the true stored maxima; a wrong exponent reads > 65504;
+  * a whole network whose feature maps sit at 2^-13 / 2^+13 of the synthetic one gives the
+    same detections as the CPU oracle; inputs 1000x beyond the calibration batch are caught,
+    the network re-calibrates by itself and the re-run result is valid.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from centernet_amd import synth
+
+pytestmark = pytest.mark.gpu
+BAR = 4e-6
+SCALES = [1e-4, 1e-2, 1.0, 1e2, 1e4, 1e6]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _report(**kw):
+    """Measured errors, appended to gpurun_out/f32s_sweep.jsonl (evidence next to the asserts)."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "f32s_sweep.jsonl"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
+def _exp(t):
+    from centernet_amd.engine import exponent_for
+    return exponent_for(float(t.abs().max()))
+
+
+def _act(x_nchw, dev, pb, lid):
+    from centernet_amd.engine import Act
+    B, C, H, W = x_nchw.shape
+    return Act(x_nchw.permute(0, 2, 3, 1).contiguous().float().to(dev), B, H, W, C,
+               exp=pb._exp(lid), lid=lid)
+
+
+def _run(pb):
+    for op in pb.ops:
+        op()
+    torch.cuda.synchronize()
+
+
+def _words(pb):
+    """lid -> (output-side, input-side) range words of the launches of a builder (not folded)."""
+    n = len(pb.range_slots)
+    w = pb.range[:n].cpu().view(torch.float32).reshape(n, 2, 64, 16)[..., 0].amax(dim=2).tolist()
+    out = {}
+    for i, lid in enumerate(pb.range_slots):
+        o, m = out.get(lid, (0.0, 0.0))
+        out[lid] = (max(o, w[i][0]), max(m, w[i][1]))
+    return out
+
+
+def _bar(fp32_err):
+    """f32s is held to 4e-6 of the output rms, or to 1.5x what the fp32 matrix instruction
+    (v_mfma_f32_32x32x2_f32, an exact fp32 FMA chain) does on the same data when that is more."""
+    return max(BAR, 1.5 * fp32_err)
+
+
+def _rel(y, ref):
+    ref = ref.double()
+    return float((y.double() - ref).abs().max()) / float(ref.pow(2).mean().sqrt())
+
+
+def _input(shape, scale, seed, mixed=False):
+    x = torch.from_numpy(synth.normal(shape, 1.0, seed)).double()
+    if mixed:   # every channel at its own scale, 10^-3 ... 10^2 of the tensor's
+        u = torch.from_numpy(synth.uniform((shape[1],), -3.0, 2.0, seed + 1)).double()
+        x = x * torch.pow(10.0, u).view(1, -1, 1, 1)
+    return x * scale
+
+
+CONVS = [
+    # name, B, Cin, H, W, Cout, k, stride, pad, residual, nchw out
+    ("halo64", 2, 64, 32, 32, 64, 3, 1, 1, True, False),
+    ("halo128", 2, 128, 16, 32, 128, 3, 1, 1, True, False),
+    ("halo27", 2, 128, 16, 16, 27, 3, 1, 1, False, False),
+    ("igemm_s2", 2, 64, 32, 32, 128, 3, 2, 1, False, False),
+    ("igemm_1x1s2", 2, 64, 32, 32, 128, 1, 2, 0, False, False),
+    ("igemm_1x1", 2, 128, 16, 16, 256, 1, 1, 0, True, False),
+    ("splitk", 1, 256, 16, 16, 256, 3, 1, 1, True, False),
+    ("nchw_out", 2, 64, 16, 32, 80, 1, 1, 0, False, True),
+]
+
+
+@pytest.mark.parametrize("scale", SCALES)
+@pytest.mark.parametrize("cfg", CONVS, ids=[c[0] for c in CONVS])
+def test_conv_kernels_at_every_activation_scale(dev, cfg, scale):
+    from centernet_amd.engine import PlanBuilder
+    name, B, Cin, H, W, Cout, k, s, p, use_res, nchw = cfg
+    mixed = name in ("halo64", "igemm_s2")
+    x = _input((B, Cin, H, W), scale, 1, mixed=mixed)
+    wscale = 1e-6 if name == "halo128" else 1.0     # tiny weights: the row pre-scale's job
+    w = torch.from_numpy(synth.normal((Cout, Cin, k, k), (2.0 / (Cin * k * k)) ** 0.5, 2)).double() * wscale
+    bn = torch.nn.BatchNorm2d(Cout)
+    synth.fill_state_dict_(bn, 4)
+    bn = bn.eval().double()
+    with torch.no_grad():   # BN shift / residual at the scale of the layer's output
+        oscale = scale * wscale
+        bn.bias.mul_(oscale)
+        bn.running_mean.mul_(oscale)
+        ref = bn(F.conv2d(x, w, None, s, p))
+        res = None
+        if use_res:
+            res = torch.from_numpy(synth.normal(tuple(ref.shape), 1.0, 5)).double() * oscale
+            ref = ref + res
+        ref = F.relu(ref)
+    exps = {"x": _exp(x), "r": _exp(res) if use_res else 0, "t1": _exp(ref)}
+    errs = {}
+    for form in ("packed_in", "plain_in", "fp32_mfma"):
+        pb = PlanBuilder(dev, B, H, W, split=form != "fp32_mfma", exps=exps)
+        xa = _act(x, dev, pb, "x")
+        ra = _act(res, dev, pb, "r") if use_res else None
+        if form == "packed_in":
+            xa = pb.packed(xa)
+            ra = pb.packed(ra) if use_res else None
+        y = pb.conv(xa, w.float(), bn=bn, relu=True, residual=ra, stride=s, padding=p,
+                    out_nchw=nchw)
+        assert nchw or y.fmt == ("f32" if form == "fp32_mfma" else "f32s")
+        _run(pb)
+        got = y.t.cpu() if nchw else y.to_float().permute(0, 3, 1, 2).cpu()
+        errs[form] = _rel(got, ref)
+        if form == "fp32_mfma":
+            continue
+        wd = _words(pb)
+        if not nchw:   # the stored output maximum is what the launch reported (22-bit rounding)
+            want = float(ref.abs().max()) * 2.0 ** -exps["t1"]
+            assert abs(wd["t1"][0] - want) <= 1e-5 * want, (wd["t1"], want)
+            assert 2.0 ** 9 <= wd["t1"][0] < 2.0 ** 10
+        if form == "plain_in":
+            want = float(x.float().abs().max()) * 2.0 ** -exps["x"]
+            assert abs(wd["t1"][1] - want) <= 1e-6 * want, (wd["t1"], want)
+    _report(test="conv", name=name, scale=scale, **errs)
+    assert max(errs["packed_in"], errs["plain_in"]) <= _bar(errs["fp32_mfma"]), errs
+
+
+@pytest.mark.parametrize("scale", SCALES)
+def test_conv_transpose_at_every_activation_scale(dev, scale):
+    from centernet_amd.engine import PlanBuilder
+    for (B, Cin, H, W, Cout) in [(2, 128, 16, 16, 64), (2, 64, 8, 32, 128), (1, 64, 8, 8, 24)]:
+        x = _input((B, Cin, H, W), scale, 7, mixed=True)
+        up = torch.nn.ConvTranspose2d(Cin, Cout, 4, 2, 1, bias=False)
+        synth.fill_state_dict_(up, 3)
+        bn = torch.nn.BatchNorm2d(Cout)
+        synth.fill_state_dict_(bn, 4)
+        bn = bn.eval().double()
+        with torch.no_grad():
+            bn.bias.mul_(scale)
+            bn.running_mean.mul_(scale)
+            ref = F.relu(bn(F.conv_transpose2d(x, up.weight.double(), None, 2, 1)))
+        exps = {"x": _exp(x), "t1": _exp(ref)}
+        err = {}
+        for split in (True, False):
+            pb = PlanBuilder(dev, B, H, W, split=split, exps=exps)
+            xa = _act(x, dev, pb, "x")
+            y = pb.conv_transpose4x4s2(pb.packed(xa) if split else xa, up.weight, bn=bn, relu=True)
+            _run(pb)
+            err[split] = _rel(y.to_float().permute(0, 3, 1, 2).cpu(), ref)
+        _report(test="deconv", shape=[B, Cin, H, W, Cout], scale=scale, f32s=err[True], fp32_mfma=err[False])
+        assert err[True] <= _bar(err[False]), (err, Cin, Cout)
+
+
+def _dcn_ref64(x, dy, dx, mask, w, bias):
+    """Modulated deformable 3x3 / pad 1 convolution in fp64 for per-tap CONSTANT offsets and
+    masks (dcn_v2_im2col_cuda.cu:18-47,151-176: zero outside the map per corner)."""
+    B, C, H, W = x.shape
+    P = 8
+    xp = F.pad(x, (P, P, P, P))
+    out = torch.zeros((B, w.shape[0], H, W), dtype=torch.float64)
+    for kk in range(9):
+        i, j = kk // 3, kk % 3
+        sy, sx = i - 1 + dy[kk], j - 1 + dx[kk]
+        fy, fx = int(np.floor(sy)), int(np.floor(sx))
+        ly, lx = sy - fy, sx - fx
+        samp = torch.zeros_like(x)
+        for (oy, wy) in ((fy, 1 - ly), (fy + 1, ly)):
+            for (ox, wx) in ((fx, 1 - lx), (fx + 1, lx)):
+                samp = samp + wy * wx * xp[:, :, P + oy:P + oy + H, P + ox:P + ox + W]
+        out = out + mask[kk] * torch.einsum("oc,bchw->bohw", w[:, :, i, j], samp)
+    return out + bias.view(1, -1, 1, 1)
+
+
+@pytest.mark.parametrize("scale", SCALES)
+def test_deformable_kernel_at_every_activation_scale(dev, scale):
+    """The f32s deformable kernel (gather + blend in fp32, the blended sample split with the
+    input's exponent folded into the modulation factor) with fractional offsets, every tap split
+    (1 / 3 / 9 workgroups per tile) -- offsets and mask logits constant per tap, so that the
+    offset convolution is exact (zero weights) and both sides sample the same positions."""
+    from centernet_amd import native
+    from centernet_amd.dcn_v2 import DCN
+    from centernet_amd.engine import PlanBuilder
+    rng = np.random.RandomState(11)
+    dy = rng.uniform(-2.5, 2.5, 9).astype(np.float32).astype(np.float64)
+    dx = rng.uniform(-2.5, 2.5, 9).astype(np.float32).astype(np.float64)
+    logit = rng.standard_normal(9).astype(np.float32)
+    mask = torch.sigmoid(torch.from_numpy(logit)).double().numpy()
+    lib = native.lib()
+    for (B, C, H, W, Co), split in [((2, 128, 16, 16, 64), 0), ((2, 64, 32, 32, 64), 1),
+                                    ((1, 256, 16, 16, 128), 3), ((1, 128, 16, 16, 64), 9)]:
+        x = _input((B, C, H, W), scale, 3, mixed=True)
+        m = DCN(C, Co, (3, 3), 1, 1)
+        synth.fill_state_dict_(m, 5)
+        with torch.no_grad():
+            m.conv_offset_mask.weight.zero_()
+            b = torch.zeros(27)
+            b[0:18:2] = torch.from_numpy(dy).float()
+            b[1:18:2] = torch.from_numpy(dx).float()
+            b[18:] = torch.from_numpy(logit)
+            m.conv_offset_mask.bias.copy_(b)
+            m.bias.mul_(scale)
+            ref = F.relu(_dcn_ref64(x, dy, dx, mask, m.weight.double(), m.bias.double()))
+        exps = {"x": _exp(x), "t1": _exp(ref)}
+        lib.cn_set_tuning(13, split)
+        try:
+            pb32 = PlanBuilder(dev, B, H, W, split=False)
+            y32 = pb32.dcn(_act(x, dev, pb32, "x"), m, relu=True)
+            _run(pb32)
+            pb = PlanBuilder(dev, B, H, W, split=True, exps=exps)
+            y = pb.dcn(_act(x, dev, pb, "x"), m, relu=True)
+            _run(pb)
+        finally:
+            lib.cn_set_tuning(13, 0)
+        err = _rel(y.to_float().permute(0, 3, 1, 2).cpu(), ref)
+        err32 = _rel(y32.to_float().permute(0, 3, 1, 2).cpu(), ref)
+        wd = _words(pb)
+        _report(test="dcn", shape=[B, C, H, W, Co], tap_split=split, scale=scale, f32s=err, fp32_mfma=err32)
+        assert err <= _bar(err32), (err, err32, split)
+        # blended samples never exceed the input maximum (convex combination x mask <= 1)
+        assert 0 < wd["t1"][1] <= float(x.float().abs().max()) * 2.0 ** -exps["x"] * (1 + 1e-6)
+        assert 2.0 ** 9 <= wd["t1"][0] < 2.0 ** 10
+
+
+@pytest.mark.parametrize("scale", SCALES)
+@pytest.mark.parametrize("hidden", [64, 256])
+def test_fused_heads_at_every_activation_scale(dev, hidden, scale):
+    from centernet_amd.engine import PlanBuilder
+    B, Fc, H, W = 2, 64, 16, 32
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    x = _input((B, Fc, H, W), scale, 11, mixed=True).abs()
+    pairs, ref, hmax = {}, {}, 0.0
+    for i, (name, classes) in enumerate(heads.items()):
+        c1 = torch.nn.Conv2d(Fc, hidden, 3, padding=1, bias=True)
+        c2 = torch.nn.Conv2d(hidden, classes, 1, bias=True)
+        with torch.no_grad():
+            c1.weight.copy_(torch.from_numpy(synth.normal(tuple(c1.weight.shape), (2.0 / (Fc * 9)) ** 0.5, 20 + i)))
+            c1.bias.copy_(torch.from_numpy(synth.normal((hidden,), 0.2 * scale, 30 + i)))
+            # the last layer brings the maps back to O(1), with a wide spread of row magnitudes
+            c2.weight.copy_(torch.from_numpy(synth.normal(tuple(c2.weight.shape), 0.15 / scale, 40 + i)) *
+                            torch.logspace(-3, 0, classes).view(-1, 1, 1, 1))
+            c2.bias.copy_(torch.from_numpy(synth.normal((classes,), 0.5, 50 + i)))
+            hid = F.relu(F.conv2d(x, c1.weight.double(), c1.bias.double(), padding=1))
+            hmax = max(hmax, float(hid.abs().max()))
+            ref[name] = F.conv2d(hid, c2.weight.double(), c2.bias.double())
+        pairs[name] = (c1, c2)
+    from centernet_amd.engine import exponent_for
+    exps = {"x": _exp(x), "t1/hid": exponent_for(hmax)}
+    pb32 = PlanBuilder(dev, B, H, W, split=False)
+    outs32 = pb32.heads_from_convs(_act(x, dev, pb32, "x"), pairs)
+    _run(pb32)
+    errs32 = {n: _rel(outs32[n].t.cpu(), ref[n]) for n in heads}
+    pb = PlanBuilder(dev, B, H, W, split=True, exps=exps)
+    outs = pb.heads_from_convs(pb.packed(_act(x, dev, pb, "x")), pairs)
+    assert len(pb.ops) == 2, "converter + ONE fused launch"
+    _run(pb)
+    errs = {n: _rel(outs[n].t.cpu(), ref[n]) for n in heads}
+    _report(test="heads", hidden=hidden, scale=scale, f32s=errs, fp32_mfma=errs32)
+    for n in heads:
+        assert errs[n] <= _bar(errs32[n]), (n, errs, errs32)
+    hw = _words(pb)["t1/hid"][0]
+    assert 2.0 ** 9 <= hw < 2.0 ** 10, hw      # the hidden tile (LDS only) is tracked too
+
+
+@pytest.mark.parametrize("scale", SCALES)
+@pytest.mark.parametrize("pool", [True, False], ids=["stem_pool", "stem"])
+def test_stem_at_every_image_scale(dev, pool, scale):
+    """7x7 / stride-2 stems on an image of any scale (un-normalised 0..255 frames, 1e-4 ...):
+    the image is split inside the kernel with its exponent, the weights come pre-scaled."""
+    from centernet_amd.engine import PlanBuilder
+    B, H, W = (48, 64, 256) if pool else (2, 64, 256)
+    x = (synth.images(B, H, W, 3).double() * scale)
+    w = torch.from_numpy(synth.normal((64, 3, 7, 7), (2.0 / 147) ** 0.5, 2)).double() * 1e-3
+    bn = torch.nn.BatchNorm2d(64)
+    synth.fill_state_dict_(bn, 4)
+    bn = bn.eval().double()
+    with torch.no_grad():
+        bn.bias.mul_(scale * 1e-3)
+        bn.running_mean.mul_(scale * 1e-3)
+        nb = 2
+        ref = F.relu(bn(F.conv2d(x[:nb], w, None, 2, 3)))
+        if pool:
+            ref = F.max_pool2d(ref, 3, 2, 1)
+    pb32 = PlanBuilder(dev, B, H, W, split=False)
+    y32 = pb32.conv(pb32.set_input(3), w.float(), bn=bn, relu=True, stride=2, padding=3,
+                    pool=(3, 2, 1) if pool else None)
+    pb32.input.t = x.float().to(dev)
+    _run(pb32)
+    err32 = _rel(y32.t[:nb].permute(0, 3, 1, 2).cpu(), ref)
+    pb = PlanBuilder(dev, B, H, W, split=True, exps={"input": _exp(x)})
+    y = pb.conv(pb.set_input(3), w.float(), bn=bn, relu=True, stride=2, padding=3,
+                pool=(3, 2, 1) if pool else None)
+    pb.input.t = x.float().to(dev)
+    assert len(pb.ops) == 1
+    _run(pb)
+    err = _rel(y.t[:nb].permute(0, 3, 1, 2).cpu(), ref)
+    _report(test="stem", pool=pool, scale=scale, f32s=err, fp32_mfma=err32)
+    assert err <= _bar(err32), (err, err32)
+    wd = _words(pb)["t1"]
+    want = float(x.float().abs().max()) * 2.0 ** -_exp(x)
+    assert abs(wd[1] - want) <= 1e-6 * want, (wd, want)
+
+
+@pytest.mark.parametrize("scale", SCALES)
+def test_converters_and_maxpool_carry_the_exponent(dev, scale):
+    from centernet_amd.engine import PlanBuilder
+    B, C, H, W = 2, 64, 16, 16
+    x = _input((B, C, H, W), scale, 9, mixed=True).float()
+    pb = PlanBuilder(dev, B, H, W, split=True, exps={"x": _exp(x)})
+    xs = pb.packed(_act(x, dev, pb, "x"))
+    back = pb.plain(xs)
+    pooled = pb.maxpool(xs, 2, 2, 0)
+    _run(pb)
+    top = float(x.abs().max())
+    assert float((back.t.permute(0, 3, 1, 2).cpu() - x).abs().max()) <= 2.0 ** -21 * top
+    assert float((pooled.t.permute(0, 3, 1, 2).cpu() - F.max_pool2d(x, 2, 2)).abs().max()) <= 2.0 ** -21 * top
+    # a value is stored with 22 bits relative to ITSELF down to 2^-12 of the tensor maximum
+    big = x.abs() > top * 2.0 ** -12
+    rel = ((back.t.permute(0, 3, 1, 2).cpu() - x).abs() / x.abs().clamp_min(1e-30))[big]
+    assert float(rel.max()) <= 2.0 ** -21
+
+
+def test_wrong_exponent_is_reported_not_silently_clamped(dev):
+    """An exponent 2^8 too small for the data: values are clamped at 65504 -- and the range words
+    say so (> 65504), on the input side of the launch that split them and on the output side of
+    the launch that produced them.  The round-2 kernels clamped silently."""
+    from centernet_amd.engine import PlanBuilder, F16_MAX
+    B, C, H, W = 2, 64, 16, 16
+    x = _input((B, C, H, W), 1.0, 1).float()
+    w = torch.from_numpy(synth.normal((64, C, 3, 3), (2.0 / (C * 9)) ** 0.5, 2))
+    ref = F.conv2d(x, w, padding=1)
+    good = {"x": _exp(x), "t1": _exp(ref)}
+    for bad_key in ("x", "t1"):
+        exps = dict(good)
+        exps[bad_key] -= 8
+        pb = PlanBuilder(dev, B, H, W, split=True, exps=exps)
+        y = pb.conv(_act(x, dev, pb, "x"), w, stride=1, padding=1)
+        _run(pb)
+        o, i = _words(pb)["t1"]
+        assert (i if bad_key == "x" else o) > F16_MAX, (bad_key, o, i)
+        if bad_key == "t1":
+            assert 0 < i <= F16_MAX, (o, i)
+        if bad_key == "t1":   # the stored tensor is clamped, never NaN / inf
+            assert bool(torch.isfinite(y.to_float()).all())
+
+
+# ------------------------------------------------------------------------------------------
+# whole networks
+def _detect(m, x, dev, K=50):
+    from centernet_amd.decode import ctdet_decode
+    with torch.no_grad():
+        out = m(x.to(dev))[-1]
+        dets, inds = ctdet_decode(out["hm"], out["wh"], out["reg"], K=K, apply_sigmoid=True,
+                                  return_inds=True)
+    torch.cuda.synchronize()
+    return out, dets.cpu().numpy(), inds.cpu().numpy()
+
+
+def _oracle(arch, m, x, heads, K=50):
+    from oracle import net_oracle, cref
+    ref_out, ref = net_oracle.ctdet_process(arch, m.state_dict(), x, list(heads), K=K)
+    rinds = cref.ctdet_decode(ref_out["hm"].numpy(), ref_out["wh"].numpy(), ref_out["reg"].numpy(),
+                              K=K, return_inds=True)[1]
+    return ref_out, ref, rinds
+
+
+@pytest.mark.parametrize("log2_scale", [-13, 0, 13])
+@pytest.mark.parametrize("arch", ["resdcn_18", "res_18"])
+def test_network_with_feature_maps_at_any_scale(dev, arch, log2_scale):
+    """The synthetic network with every internal activation multiplied by 2^-13 (1.2e-4) or 2^+13
+    (8192) -- bit for bit the same fp32 function (synth.rescale_activations_) -- gives the
+    oracle's detections: heads within 1e-4 of the map scale, every detection paired."""
+    from centernet_amd.model import create_model
+    from oracle.parity import compare_topk
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    m = create_model(arch, dict(heads), 64)
+    synth.fill_state_dict_(m, 317)
+    synth.rescale_activations_(m, log2_scale)
+    m = m.to(dev).eval()
+    x = synth.images(2, 128, 128, seed=3)
+    out, got, inds = _detect(m, x, dev)
+    assert m.uses_f32s() and m.__dict__["_calibrations"] == 1
+    _, ref, rinds = _oracle(arch, m, x, heads)
+    from oracle import net_oracle
+    ref_out = net_oracle.forward(arch, m.state_dict(), x, list(heads))    # head maps (logits)
+    errs = {}
+    for h in heads:
+        r = ref_out[h]
+        errs[h] = float((out[h].cpu() - r).abs().max()) / max(1.0, float(r.abs().max()))
+        assert errs[h] < 1e-4, (h, errs[h])
+    ids = np.stack([inds, got[..., 5].astype(np.int64)], -1)
+    rids = np.stack([rinds, ref[..., 5].astype(np.int64)], -1)
+    r = compare_topk(got, ref, got_ids=ids, ref_ids=rids)
+    _report(test="network", arch=arch, log2_scale=log2_scale, paired=r["paired"],
+            in_place=r["in_place"], **errs)
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.98, r
+    # internal tensors really sit at the requested scale
+    e = m.exponents
+    assert e is not None and len(e) > 20
+    inner = [v for k, v in e.items() if k != "input" and "/" not in k]
+    assert min(inner) <= log2_scale - 3 if log2_scale < 0 else max(inner) >= log2_scale - 10
+
+
+def test_inputs_far_outside_the_calibration_batch_are_caught_and_rerun(dev):
+    """Calibrated on N(0,1) images; then a batch 1000x larger: the stem's split (and everything
+    behind it) exceeds 65504 * 2^e, the range words say so, forward() re-calibrates on that
+    batch and runs again -- the caller gets the fp32-accurate result, never a clamped one."""
+    from centernet_amd.model import create_model
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    m = create_model("res_18", dict(heads), 64)
+    synth.fill_state_dict_(m, 317)
+    m = m.to(dev).eval()
+    x = synth.images(1, 128, 128, seed=5)
+    _detect(m, x, dev)
+    assert m.__dict__["_calibrations"] == 1
+    big = x * 1000.0
+    out, _, _ = _detect(m, big, dev)
+    assert m.__dict__["_calibrations"] == 2, "the overflow must have triggered a re-calibration"
+    from oracle import net_oracle
+    ref = net_oracle.forward("res_18", m.state_dict(), big, list(heads))
+    for h in heads:
+        err = float((out[h].cpu() - ref[h]).abs().max()) / max(1.0, float(ref[h].abs().max()))
+        assert err < 1e-4, (h, err)
+    # the detector-style path: borrow=True does not look by itself, range_ok() does
+    m2 = create_model("res_18", dict(heads), 64)
+    synth.fill_state_dict_(m2, 317)
+    m2 = m2.to(dev).eval()
+    with torch.no_grad():
+        m2(x.to(dev), borrow=True)
+        assert m2.range_ok()
+        m2(big.to(dev), borrow=True)
+        assert not m2.range_ok(big.to(dev)), "clamped values must be reported"
+        out2 = m2(big.to(dev), borrow=True)[-1]
+        assert m2.range_ok()
+    for h in heads:
+        err = float((out2[h].cpu() - ref[h]).abs().max()) / max(1.0, float(ref[h].abs().max()))
+        assert err < 1e-4, (h, err)
+
+
+def test_inputs_far_below_the_calibration_batch_schedule_a_recalibration(dev):
+    from centernet_amd.model import create_model
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    m = create_model("res_18", dict(heads), 64)
+    synth.fill_state_dict_(m, 317)
+    m = m.to(dev).eval()
+    x = synth.images(1, 128, 256, seed=5)     # 128-pixel stem rows: the f32s stem splits the image
+    _detect(m, x, dev)
+    small = x * 2.0 ** -16
+    out, _, _ = _detect(m, small, dev)      # valid (floor 2^-25 stored), but flagged 'low'
+    assert m.__dict__.get("_recalibrate") == "replace"
+    _detect(m, small, dev)                  # this forward re-calibrates first
+    assert m.__dict__["_calibrations"] == 2 and "_recalibrate" not in m.__dict__
+    from oracle import net_oracle
+    ref = net_oracle.forward("res_18", m.state_dict(), small, list(heads))
+    for h in heads:
+        err = float((out[h].cpu() - ref[h]).abs().max()) / max(1.0, float(ref[h].abs().max()))
+        assert err < 1e-4, (h, err)
+
+
+def test_detector_reruns_a_clamped_batch(dev):
+    """detector.run() / process() look at the range words where the reference synchronises;
+    run_frames() where it copies the detections to the host."""
+    from centernet_amd.opts import opts
+    from centernet_amd.detectors import detector_factory
+    opt = opts().init(["ctdet", "--arch", "res_18", "--input_res", "128"])
+    det = detector_factory[opt.task](opt)
+    synth.fill_state_dict_(det.model, 317)
+    x = synth.images(2, 128, 128, seed=1).to(dev)
+    _, d0 = det.process(x)
+    n0 = det.model.__dict__["_calibrations"]
+    _, d1 = det.process(x * 1000.0)
+    assert det.model.__dict__["_calibrations"] == n0 + 1
+    from oracle import net_oracle
+    ref_out, ref = net_oracle.ctdet_process("res_18", det.model.state_dict(), (x * 1000.0).cpu(),
+                                            list(opt.heads), K=opt.K)
+    assert float(np.abs(d1.cpu().numpy()[..., 4] - ref[..., 4]).max()) < 1e-4

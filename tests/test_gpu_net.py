@@ -12,6 +12,20 @@ from oracle.parity import compare_topk
 pytestmark = pytest.mark.gpu
 
 
+def _report_fracs(r):
+    """Achieved pairing fractions, appended to gpurun_out/parity_fractions.jsonl (the asserts
+    below hold the bar; this keeps the measured figure next to them)."""
+    import inspect, json, os
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_fractions.jsonl"), "a") as f:
+            f.write(json.dumps({"test": inspect.stack()[1].function, "paired": r["paired"],
+                                "in_place": r["in_place"]}) + "\n")
+    except OSError:
+        pass
+
+
 def _model(arch, heads, seed, dev):
     from centernet_amd.model import create_model
     m = create_model(arch, dict(heads), 256 if arch.startswith("dla") else 64)
@@ -71,7 +85,8 @@ def test_end_to_end_boxes_512(dev, arch, B):
     rids = np.stack([ref_inds, ref[..., 5].astype(np.int64)], -1)
     r = compare_topk(dets, ref, got_ids=ids, ref_ids=rids)
     print("%s B=%d: paired %.4f, same rank %.4f" % (arch, B, r["paired"], r["in_place"]))
-    assert r["paired"] >= 0.99 and r["in_place"] >= 0.95
+    _report_fracs(r)
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.98, r
 
 
 def _safe_positions(scores, gap_min=2e-6):
@@ -116,7 +131,8 @@ def test_end_to_end_boxes_at_benchmark_batch(dev, arch, B):
     r = compare_topk(dets, ref, got_ids=ids, ref_ids=rids)
     print("%s B=%d: paired %.4f, same rank %.4f, heat-map max err %.2e, score max err %.2e" % (
         arch, B, r["paired"], r["in_place"], hm_err, np.abs(dets[..., 4] - ref[..., 4]).max()))
-    assert r["paired"] >= 0.99 and r["in_place"] >= 0.95
+    _report_fracs(r)
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.98, r
 
 
 @pytest.mark.slow
@@ -138,7 +154,8 @@ def test_end_to_end_pose_at_benchmark_batch(dev):
     assert np.abs(dets[..., 4] - ref[..., 4]).max() < 1e-4
     r = compare_topk(dets, ref, box_tol=1e-4)
     print("dla_34 multi_pose B=32: paired %.4f, same rank %.4f" % (r["paired"], r["in_place"]))
-    assert r["paired"] >= 0.99 and r["in_place"] >= 0.9   # one class: scores crowd more
+    _report_fracs(r)
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.95, r   # one class: scores crowd more
     safe = _safe_positions(ref[..., 4])
     # keypoints: regression branch to 1e-3 grid cells; the heat-map-snapped ones are discrete
     # choices that may flip where the reject rule sits on its threshold
@@ -172,7 +189,8 @@ def test_end_to_end_hourglass_512_batch8(dev):
     rids = np.stack([ref_inds, ref[..., 5].astype(np.int64)], -1)
     r = compare_topk(dets, ref, got_ids=ids, ref_ids=rids)
     print("hourglass fp32 B=8 512^2: paired %.4f, same rank %.4f" % (r["paired"], r["in_place"]))
-    assert r["paired"] >= 0.99 and r["in_place"] >= 0.95
+    _report_fracs(r)
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.98, r
     m.half_compute()
     with torch.no_grad():
         o16 = m(x.to(dev))[-1]
