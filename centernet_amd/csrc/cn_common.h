@@ -83,31 +83,38 @@ __device__ __forceinline__ void cn_rng_upd4(float &m, cn_f32x4 v)
                         __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
 }
 __device__ __forceinline__ void cn_rng_upd1(float &m, float v) { m = __builtin_fmaxf(m, __builtin_fabsf(v)); }
+// wave-wide maximum of non-negative floats, returned (uniform) as a bit pattern: integer max
+// over the bit patterns -- four DPP steps inside each row of 16 lanes, then the four rows
+// through SGPRs.  ~12 instructions, no LDS traffic (a __shfl_xor ladder is six dependent
+// ds_bpermute round trips at the very end of every workgroup).  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t cn_wave_max_bits(float m)
+{
+    int v = __builtin_bit_cast(int, m);
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return (uint32_t)max(max(r0, r1), max(r2, r3));
+}
 // single-word form (cn_absmax_f32)
 __device__ __forceinline__ void cn_rng_commit1(uint32_t *word, float m)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) {
-        const uint32_t bits = __builtin_bit_cast(uint32_t, m);
-        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(word, bits);
-    }
+    const uint32_t bits = cn_wave_max_bits(m);
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(word, bits);
 }
 // call with the whole wave active (no early-returned lanes); `range` may be null;
-// side 0 = output side, 1 = input side (cn_f32s_ctl.range)
+// side 0 = output side, 1 = input side (cn_f32s_ctl.range).  The atomic returns nothing: the
+// wave does not wait for it.
 __device__ __forceinline__ void cn_rng_commit(uint32_t *range, int side, float m)
 {
     if (!range) return;   // uniform
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) {
+    const uint32_t bits = cn_wave_max_bits(m);
+    if ((threadIdx.x & 63) == 0 && bits) {
         const unsigned slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) + blockIdx.y * 7u +
                                blockIdx.z * 13u) & (CN_RANGE_SLOTS - 1);
-        uint32_t *word = range + ((size_t)side * CN_RANGE_SLOTS + slot) * CN_RANGE_STRIDE;
-        const uint32_t bits = __builtin_bit_cast(uint32_t, m);
-        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(word, bits);
+        atomicMax(range + ((size_t)side * CN_RANGE_SLOTS + slot) * CN_RANGE_STRIDE, bits);
     }
 }
 __device__ __forceinline__ cn_f32x4 cn_join4(cn_f16x4v hi, cn_f16x4v lo)

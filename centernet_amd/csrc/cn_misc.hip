@@ -628,60 +628,6 @@ extern "C" int cn_normalize_u8_chw_f32_host(const uint8_t *img, int h, int w, co
     return CN_OK;
 }
 
-// Bilinear warp / resize of a uint8 HWC image on the HOST (BaseDetector.pre_process when the
-// caller keeps the pre-process on host cores, e.g. DataLoader workers: base_detector.py:37-65 ->
-// cv2.resize / cv2.warpAffine).  The arithmetic contract of csrc/cn_pre.hip and
-// centernet_amd/image.py::warp_bilinear_u8, operation for operation in float64 (no FMA
-// contraction): Mi = dst -> src 2x3 matrix; taps outside the image are zero, or clamped when
-// `replicate`; round-half-even to uint8.  30 ms in numpy per 512x512 frame, ~2 ms here.
-extern "C" int cn_warp_bilinear_u8_host(const uint8_t *img, int h_in, int w_in, int channels,
-                                        const double *Mi, int h_out, int w_out, int replicate,
-                                        uint8_t *out)
-{
-#pragma clang fp contract(off)
-    if (!img || !Mi || !out) return CN_ERR_NULL;
-    if (h_in <= 0 || w_in <= 0 || h_out <= 0 || w_out <= 0 || channels <= 0 || channels > 4)
-        return CN_ERR_SHAPE;
-    const size_t row_in = (size_t)w_in * channels;
-    for (int y = 0; y < h_out; ++y) {
-        const double yd = (double)y;
-        for (int x = 0; x < w_out; ++x) {
-            const double xd = (double)x;
-            const double sx = (Mi[0] * xd + Mi[1] * yd) + Mi[2];
-            const double sy = (Mi[3] * xd + Mi[4] * yd) + Mi[5];
-            const double fx0 = __builtin_floor(sx), fy0 = __builtin_floor(sy);
-            const bool far = !((fx0 > -4.0) && (fx0 < (double)w_in + 4.0) && (fy0 > -4.0) &&
-                               (fy0 < (double)h_in + 4.0));
-            const long x0 = far ? -4 : (long)fx0, y0 = far ? -4 : (long)fy0;
-            const double fx = far ? 0.0 : sx - fx0, fy = far ? 0.0 : sy - fy0;
-            const double gx = 1.0 - fx, gy = 1.0 - fy;
-            uint8_t *o = out + ((size_t)y * w_out + x) * channels;
-            const long xs[2] = {x0, x0 + 1}, ys[2] = {y0, y0 + 1};
-            const uint8_t *p[2][2];
-            double ok[2][2];
-            for (int a = 0; a < 2; ++a)
-                for (int b = 0; b < 2; ++b) {
-                    const long yy = ys[a], xx = xs[b];
-                    const bool in = replicate ? !far
-                                              : (yy >= 0 && yy < h_in && xx >= 0 && xx < w_in);
-                    const long yc = yy < 0 ? 0 : (yy > h_in - 1 ? h_in - 1 : yy);
-                    const long xc = xx < 0 ? 0 : (xx > w_in - 1 ? w_in - 1 : xx);
-                    p[a][b] = img + (size_t)yc * row_in + (size_t)xc * channels;
-                    ok[a][b] = in ? 1.0 : 0.0;
-                }
-            for (int c = 0; c < channels; ++c) {
-                double v = (((double)p[0][0][c] * ok[0][0]) * gx) * gy;
-                v = v + (((double)p[0][1][c] * ok[0][1]) * fx) * gy;
-                v = v + (((double)p[1][0][c] * ok[1][0]) * gx) * fy;
-                v = v + (((double)p[1][1][c] * ok[1][1]) * fx) * fy;
-                v = __builtin_nearbyint(v);   // round half to even (default rounding mode)
-                o[c] = (uint8_t)(v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v));
-            }
-        }
-    }
-    return CN_OK;
-}
-
 // ---- soft-NMS on a small host array (merge_outputs, detectors/ctdet.py:63-64) -------------
 // Host-side, in place, same greedy/swap/discard order as src/lib/external/nms.pyx:77-170
 // (soft_nms) and :172-275 (soft_nms_39): `stride` floats per row, box in [0..3], score in [4].

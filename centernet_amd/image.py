@@ -1,51 +1,91 @@
 """Host-side geometry helpers (mirror of src/lib/utils/image.py:19-66).
 
-OpenCV is not available in this image, so the cv2 calls the reference makes are restated:
-``cv2.getAffineTransform`` of the reference's three-point construction (a similarity, written
-in closed form in float64), ``cv2.warpAffine(..., INTER_LINEAR)``
-and ``cv2.resize`` (float64 bilinear, round-half-even to uint8; the same arithmetic, operation for
-operation, as the device kernels in csrc/cn_pre.hip).  For the benchmark configuration
-(512x512 input, fix_res) the warp is the identity.
+OpenCV is not available in this image, so the three cv2 calls the reference makes are restated
+from OpenCV's published algorithms (the restatement with citations lives in oracle/pre_oracle.py;
+everything here is tested bit for bit against it):
+``cv2.getAffineTransform`` -- the reference's three float32 point pairs, solved in float64 by LU
+with partial pivoting (the 6 x 6 system of cv::getAffineTransform splits into two 3 x 3 systems
+with the same matrix, eliminated identically); ``cv2.warpAffine(..., INTER_LINEAR)`` and
+``cv2.resize`` -- OpenCV's uint8 fixed-point bilinear (1/32-pixel sample positions, 15-bit /
+11-bit weights), in the library's host routines ``cn_warp_affine_u8_host`` /
+``cn_resize_linear_u8_host`` and, for frames that are already on the device, in csrc/cn_pre.hip.
 """
 import numpy as np
 
 
-def _rotation(rot_deg):
-    """(cos, sin) of the augmentation angle; exactly (1, 0) for the inference case rot = 0."""
-    theta = np.pi * rot_deg / 180
-    return float(np.cos(theta)), float(np.sin(theta))
+def _lu3(a, r):
+    """Solve the 3 x 3 system a @ x = r: Gaussian elimination with partial pivoting (the first
+    row holding the largest |pivot| wins), separate multiply / add, back substitution left to
+    right -- the row operations cv::solve(DECOMP_LU) performs (core/src/matrix_decomp.cpp)."""
+    a = [[float(v) for v in row] for row in a]
+    r = [float(v) for v in r]
+    for i in range(3):
+        k = max(range(i, 3), key=lambda j: (abs(a[j][i]), -j))
+        if abs(a[k][i]) < 2.220446049250313e-14:
+            raise ZeroDivisionError("degenerate point triple")
+        if k != i:
+            a[i], a[k] = a[k], a[i]
+            r[i], r[k] = r[k], r[i]
+        d = -1.0 / a[i][i]
+        for j in range(i + 1, 3):
+            alpha = a[j][i] * d
+            for c in range(i + 1, 3):
+                a[j][c] = a[j][c] + alpha * a[i][c]
+            r[j] = r[j] + alpha * r[i]
+    x = [0.0, 0.0, 0.0]
+    for i in (2, 1, 0):
+        s = r[i]
+        for c in range(i + 1, 3):
+            s = s - a[i][c] * x[c]
+        x[i] = s / a[i][i]
+    return x
+
+
+def affine_through(src, dst):
+    """cv2.getAffineTransform(np.float32(src), np.float32(dst)): the 2 x 3 float64 matrix that
+    takes three source points onto three destination points.
+
+    OpenCV eliminates ONE 6 x 6 system whose rows alternate (x-equation, y-equation) of points
+    0, 1, 2.  The two coordinate blocks never mix (each row is zero in the other block's
+    columns), so the result is two 3 x 3 eliminations of the same matrix [x y 1] -- but not in
+    the same row order: while columns 0-2 are eliminated, the pivot search of column 1 always
+    finds row 1 (the y-equation of point 0, zero there) in its way and swaps it down, and the
+    y-equations come out of that phase ordered (point 1, point 0, point 2).  Pivot ties -- the
+    reference's points 0 and 1 share their x for rot = 0 -- are broken by row order, so the order
+    is part of the result, bit for bit."""
+    s = np.asarray(src, np.float32).astype(np.float64)
+    d = np.asarray(dst, np.float32).astype(np.float64)
+    row = [[s[i, 0], s[i, 1], 1.0] for i in range(3)]
+    mx = _lu3([row[0], row[1], row[2]], [d[0, 0], d[1, 0], d[2, 0]])
+    my = _lu3([row[1], row[0], row[2]], [d[1, 1], d[0, 1], d[2, 1]])
+    return np.array([mx, my], np.float64)
 
 
 def get_affine_transform(center, scale, rot, output_size, shift=(0.0, 0.0), inv=0):
     """2x3 float64 matrix between the source frame and an ``output_size`` = (w, h) crop
     (call-compatible with utils/image.py:27-60).
 
-    The reference pins the map with three point pairs -- the crop centre, a point half the
-    source extent above it (turned by ``rot``), and a third at a right angle -- and asks OpenCV
-    for the affine through them.  Right-angle constructions on both sides make that map a
-    similarity, so it is written down directly here:
-
-        dst = q0 + k * R(-rot) * (src - p0),      k = dst_w / src_w
-
-    with p0 = centre + scale * shift (held in float32, as the reference's point array holds
-    it), q0 = the crop centre, and src_w = scale[0] (the reference uses the x extent for both
-    axes).  ``inv`` returns the opposite direction, src = p0 + R(rot) * (dst - q0) / k.  For
-    rot = 0 -- every call on the inference path -- the entries are exact ratios of the inputs.
-    """
+    The reference pins the map with three point pairs held in float32 arrays -- the crop centre,
+    a point half the source x-extent above it (turned by ``rot``), and a third at a right angle
+    to those two -- and asks OpenCV for the affine through them.  The float32 rounding of the
+    points is part of the result (it moves the matrix by ~1e-5 px at the image border, enough to
+    change which 1/32-pixel position a warp samples), so the same construction is used here."""
     extent = np.asarray(scale, np.float32).reshape(-1)
     if extent.size == 1:
         extent = np.repeat(extent, 2)
-    p0 = (np.asarray(center, np.float32).reshape(2) +
-          extent * np.asarray(shift, np.float32).reshape(2)).astype(np.float64)
-    q0 = np.array([output_size[0] * 0.5, output_size[1] * 0.5], np.float64)
-    cs, sn = _rotation(rot)
-    if inv:
-        k = float(extent[0]) / float(output_size[0])
-        lin = k * np.array([[cs, -sn], [sn, cs]], np.float64)
-        return np.concatenate([lin, (p0 - lin @ q0)[:, None]], axis=1)
-    k = float(output_size[0]) / float(extent[0])
-    lin = k * np.array([[cs, sn], [-sn, cs]], np.float64)
-    return np.concatenate([lin, (q0 - lin @ p0)[:, None]], axis=1)
+    theta = np.pi * rot / 180
+    sn, cs = np.sin(theta), np.cos(theta)
+    up = extent[0] * -0.5                               # float32, as the reference's src_w * -0.5
+    offset = extent * np.asarray(shift, np.float32)
+    pts = np.zeros((2, 3, 2), np.float32)               # [source | crop][point][x, y]
+    pts[0, 0] = np.asarray(center, np.float32) + offset
+    pts[0, 1] = np.asarray(center, np.float32) + np.array([-up * sn, up * cs]) + offset
+    pts[1, 0] = [output_size[0] * 0.5, output_size[1] * 0.5]
+    pts[1, 1] = pts[1, 0] + np.array([0, output_size[0] * -0.5], np.float32)
+    for side in pts:                                    # third point: second + perpendicular
+        delta = side[0] - side[1]
+        side[2] = side[1] + np.array([-delta[1], delta[0]], np.float32)
+    return affine_through(pts[1], pts[0]) if inv else affine_through(pts[0], pts[1])
 
 
 def apply_affine(points, trans):
@@ -76,94 +116,50 @@ def transform_preds(coords, center, scale, output_size):
 
 
 def invert_affine(trans):
-    """dst -> src 2x3 float64 matrix of a src -> dst 2x3 affine (what cv2.warpAffine does
-    with its M unless WARP_INVERSE_MAP is set)."""
-    M = np.vstack([np.asarray(trans, np.float64), [0, 0, 1]])
-    return np.linalg.inv(M)[:2].copy()
+    """dst -> src 2x3 float64 matrix of a src -> dst 2x3 affine, formed the way cv::warpAffine
+    forms it from its M (closed 2 x 2 inverse, then the translation from the inverted entries)."""
+    m00, m01, m02, m10, m11, m12 = (float(v) for v in np.asarray(trans, np.float64).reshape(-1)[:6])
+    det = m00 * m11 - m01 * m10
+    r = 1.0 / det if det != 0.0 else 0.0
+    i00, i01, i10, i11 = m11 * r, m01 * -r, m10 * -r, m00 * r
+    return np.array([[i00, i01, -i00 * m02 - i01 * m12],
+                     [i10, i11, -i10 * m02 - i11 * m12]], np.float64)
 
 
-def resize_matrix(in_size, out_size):
-    """dst -> src matrix of cv2.resize(INTER_LINEAR): src = (dst + 0.5) * (in/out) - 0.5."""
-    (w_in, h_in), (w_out, h_out) = in_size, out_size
-    sx, sy = float(w_in) / float(w_out), float(h_in) / float(h_out)
-    return np.array([[sx, 0.0, 0.5 * sx - 0.5], [0.0, sy, 0.5 * sy - 0.5]], np.float64)
-
-
-def warp_bilinear_u8(img, Mi, dsize, replicate=False):
-    """The arithmetic contract shared with the device kernel (csrc/cn_pre.hip) and
-    oracle/pre_oracle.py: float64 bilinear in a fixed operation order, taps outside the image
-    zero (or clamped when ``replicate``), round-half-even to uint8.  Runs in the library's host
-    routine ``cn_warp_bilinear_u8_host`` (the same operations in C, ~2 ms per 512x512 frame);
-    ``warp_bilinear_u8_numpy`` below is the array-at-once statement of it (30 ms), kept as the
-    readable definition and checked against it bit for bit (tests/test_host.py)."""
-    import ctypes
-    from . import native
+def _host_u8(img):
     img = np.ascontiguousarray(img)
-    assert img.dtype == np.uint8 and img.ndim in (2, 3)
-    w_out, h_out = int(dsize[0]), int(dsize[1])
-    ch = 1 if img.ndim == 2 else img.shape[2]
-    if ch > 4:
-        return warp_bilinear_u8_numpy(img, Mi, dsize, replicate)
-    out = np.empty((h_out, w_out) if img.ndim == 2 else (h_out, w_out, ch), np.uint8)
-    m = (ctypes.c_double * 6)(*np.asarray(Mi, np.float64).reshape(-1)[:6])
-    native.check(native.lib().cn_warp_bilinear_u8_host(
-        img.ctypes.data_as(ctypes.c_void_p), img.shape[0], img.shape[1], ch, m, h_out, w_out,
-        int(bool(replicate)), out.ctypes.data_as(ctypes.c_void_p)), "cn_warp_bilinear_u8_host")
-    return out
-
-
-def warp_bilinear_u8_numpy(img, Mi, dsize, replicate=False):
-    """``warp_bilinear_u8`` written with whole-array numpy operations (the definition the C
-    routine and the device kernels follow operation for operation)."""
-    w_out, h_out = int(dsize[0]), int(dsize[1])
-    h_in, w_in = img.shape[:2]
-    Mi = np.asarray(Mi, np.float64)
-    xs, ys = np.meshgrid(np.arange(w_out, dtype=np.float64), np.arange(h_out, dtype=np.float64))
-    sx = (Mi[0, 0] * xs + Mi[0, 1] * ys) + Mi[0, 2]
-    sy = (Mi[1, 0] * xs + Mi[1, 1] * ys) + Mi[1, 2]
-    fx0, fy0 = np.floor(sx), np.floor(sy)
-    far = ~((fx0 > -4.0) & (fx0 < w_in + 4.0) & (fy0 > -4.0) & (fy0 < h_in + 4.0))
-    x0 = np.where(far, -4, fx0).astype(np.int64)
-    y0 = np.where(far, -4, fy0).astype(np.int64)
-    fx = np.where(far, 0.0, sx - fx0)[..., None]
-    fy = np.where(far, 0.0, sy - fy0)[..., None]
-    gx, gy = 1.0 - fx, 1.0 - fy
-    src = img.astype(np.float64)
-    if src.ndim == 2:
-        src = src[..., None]
-
-    def tap(yy, xx):
-        if replicate:
-            ok = ~far
-        else:
-            ok = (yy >= 0) & (yy < h_in) & (xx >= 0) & (xx < w_in)
-        v = src[np.clip(yy, 0, h_in - 1), np.clip(xx, 0, w_in - 1)]
-        return v * ok[..., None]
-
-    out = (tap(y0, x0) * gx) * gy
-    out = out + (tap(y0, x0 + 1) * fx) * gy
-    out = out + (tap(y0 + 1, x0) * gx) * fy
-    out = out + (tap(y0 + 1, x0 + 1) * fx) * fy
-    out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
-    return out if img.ndim == 3 else out[..., 0]
+    if img.dtype != np.uint8 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] > 4):
+        raise ValueError("uint8 (H, W) or (H, W, C <= 4) images only")
+    return img, (1 if img.ndim == 2 else img.shape[2])
 
 
 def warp_affine(img, trans, dsize):
-    """cv2.warpAffine(img, trans, dsize, flags=INTER_LINEAR), zero border (float bilinear; see
-    warp_bilinear_u8 for the exact arithmetic).  uint8 images only."""
-    assert img.dtype == np.uint8, "warp_affine restates the uint8 path the detectors use"
-    return warp_bilinear_u8(img, invert_affine(trans), dsize, replicate=False)
+    """cv2.warpAffine(img, trans, dsize, flags=cv2.INTER_LINEAR) for uint8 images, zero border
+    (library host routine ``cn_warp_affine_u8_host``)."""
+    import ctypes
+    from . import native
+    img, ch = _host_u8(img)
+    w_out, h_out = int(dsize[0]), int(dsize[1])
+    out = np.empty((h_out, w_out) + img.shape[2:], np.uint8)
+    m = (ctypes.c_double * 6)(*invert_affine(trans).reshape(-1))
+    native.check(native.lib().cn_warp_affine_u8_host(
+        img.ctypes.data_as(ctypes.c_void_p), img.shape[0], img.shape[1], ch, m, h_out, w_out,
+        out.ctypes.data_as(ctypes.c_void_p)), "cn_warp_affine_u8_host")
+    return out
 
 
 def resize_bilinear(img, dsize):
-    """cv2.resize(img, (w, h)) with INTER_LINEAR (half-pixel centres, replicated border)."""
+    """cv2.resize(img, (w, h)) with the default INTER_LINEAR for uint8 images (library host
+    routine ``cn_resize_linear_u8_host``)."""
+    import ctypes
+    from . import native
+    img, ch = _host_u8(img)
     w_out, h_out = int(dsize[0]), int(dsize[1])
-    h_in, w_in = img.shape[:2]
-    if (h_in, w_in) == (h_out, w_out):
-        return img.copy()
-    assert img.dtype == np.uint8
-    return warp_bilinear_u8(img, resize_matrix((w_in, h_in), (w_out, h_out)), (w_out, h_out),
-                            replicate=True)
+    out = np.empty((h_out, w_out) + img.shape[2:], np.uint8)
+    native.check(native.lib().cn_resize_linear_u8_host(
+        img.ctypes.data_as(ctypes.c_void_p), img.shape[0], img.shape[1], ch, h_out, w_out,
+        out.ctypes.data_as(ctypes.c_void_p)), "cn_resize_linear_u8_host")
+    return out
 
 
 def normalize_chw(inp_u8, mean, std):

@@ -149,8 +149,10 @@ def _declare(lib):
                                              ctypes.POINTER(ctypes.c_float), i, vp, vp]
     lib.cn_resize_bilinear_u8.restype = i
     lib.cn_resize_bilinear_u8.argtypes = [vp, i, i, i, i, i, vp, vp]
-    lib.cn_warp_bilinear_u8_host.restype = i
-    lib.cn_warp_bilinear_u8_host.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_double), i, i, i, vp]
+    lib.cn_warp_affine_u8_host.restype = i
+    lib.cn_warp_affine_u8_host.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_double), i, i, vp]
+    lib.cn_resize_linear_u8_host.restype = i
+    lib.cn_resize_linear_u8_host.argtypes = [vp, i, i, i, i, i, vp]
     lib.cn_normalize_u8_chw_f32_host.restype = i
     lib.cn_normalize_u8_chw_f32_host.argtypes = [vp, i, i, vp, vp, vp]
     lib.cn_soft_nms_f32.restype = i

@@ -383,15 +383,17 @@ int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int in_pitch,
  * cv2.warpAffine(INTER_LINEAR, zero border) + (x/255 - mean)/std + HWC->CHW (+ flip concat).
  *
  * cn_warp_normalize_u8_f32: image (H, W, 3) uint8 on the device (row pitch in bytes),
- *   dst_to_src_2x3 = six HOST doubles mapping output pixel (x, y) to the source position
- *   (the inverse of trans_input), out = (1 + flip_concat, 3, out_h, out_w) fp32 NCHW with
- *   out[1] = out[0] flipped along x (base_detector.py:59-60).  mean3 / std3: HOST floats.
- * cn_resize_bilinear_u8: cv2.resize(image, (out_w, out_h)) with half-pixel centres and a
- *   replicated border, uint8 HWC -> dense uint8 HWC.
- * Arithmetic: float64 bilinear, round-half-even to uint8, float64 normalise rounded once to
- * fp32 -- bit-identical to centernet_amd/image.py and oracle/pre_oracle.py.  OpenCV's
- * fixed-point bilinear may differ by one uint8 level on non-identity warps (unpinned: OpenCV
- * is not available to this build).
+ *   dst_to_src_2x3 = six HOST doubles: trans_input inverted the way cv::warpAffine inverts its M
+ *   (centernet_amd/image.py invert_affine), out = (1 + flip_concat, 3, out_h, out_w) fp32 NCHW
+ *   with out[1] = out[0] flipped along x (base_detector.py:59-60).  mean3 / std3: HOST floats.
+ * cn_resize_bilinear_u8: cv2.resize(image, (out_w, out_h)), uint8 HWC -> dense uint8 HWC.
+ * Arithmetic: OpenCV's uint8 INTER_LINEAR path -- fixed point, not float bilinear: warpAffine
+ * samples at 1/32-pixel positions (AB_BITS = 10, INTER_BITS = 5) with 15-bit weights
+ * (INTER_REMAP_COEF_BITS) and round-half-up, zero border; resize is separable with 11-bit
+ * coefficients and its own uint8 vertical pass, a copy at equal size and the 2 x 2 mean at
+ * exactly half size.  The published algorithm is restated with its constants in
+ * oracle/pre_oracle.py (OpenCV is a third-party dependency that is absent here); these entry
+ * points equal that restatement bit for bit.  Normalisation: float64, rounded once to fp32.
  * ------------------------------------------------------------------------ */
 int cn_warp_normalize_u8_f32(const uint8_t *image_hwc, int H, int W, int pitch_bytes,
                              const double *dst_to_src_2x3, int out_h, int out_w,
@@ -400,14 +402,13 @@ int cn_warp_normalize_u8_f32(const uint8_t *image_hwc, int H, int W, int pitch_b
 int cn_resize_bilinear_u8(const uint8_t *image_hwc, int H, int W, int pitch_bytes, int out_h,
                           int out_w, uint8_t *out_hwc, void *stream);
 
-/* cv2.resize / cv2.warpAffine (INTER_LINEAR) of a uint8 HWC image on the HOST, for callers that keep
- * BaseDetector.pre_process on host cores (base_detector.py:37-65).  Mi = dst -> src 2x3 matrix
- * (6 doubles, row-major); taps outside the image are zero, or clamped when `replicate` (resize);
- * float64 bilinear in the operation order of the device kernels above, round-half-even: results
- * equal cn_warp_normalize_u8_f32 / cn_resize_bilinear_u8 bit for bit.  channels <= 4. */
-int cn_warp_bilinear_u8_host(const uint8_t *image_hwc, int h_in, int w_in, int channels,
-                             const double *Mi, int h_out, int w_out, int replicate,
-                             uint8_t *out_hwc);
+/* The same two operations on the HOST, for callers that keep BaseDetector.pre_process on host
+ * cores (DataLoader workers; base_detector.py:37-65): identical integer arithmetic, results
+ * equal the device kernels bit for bit.  channels <= 4; dst_to_src_2x3 as above. */
+int cn_warp_affine_u8_host(const uint8_t *image_hwc, int h_in, int w_in, int channels,
+                           const double *dst_to_src_2x3, int h_out, int w_out, uint8_t *out_hwc);
+int cn_resize_linear_u8_host(const uint8_t *image_hwc, int h_in, int w_in, int channels, int h_out,
+                             int w_out, uint8_t *out_hwc);
 
 /* ((image / 255. - mean) / std).astype(float32) + HWC -> CHW of a 3-channel uint8 image on the HOST
  * (base_detector.py:56-58), numpy's float64 arithmetic, one rounding to float32. */

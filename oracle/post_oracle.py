@@ -5,9 +5,10 @@ statement (including its per-point Python loop):
   transform_preds / get_affine_transform / affine_transform   utils/image.py:19-66
   ctdet_post_process                                           utils/post_process.py:83-100
   CtdetDetector.post_process / merge_outputs                   detectors/ctdet.py:47-73
-cv2.getAffineTransform (third-party, absent here) is restated as the exact solution of the
-3-point system in float64, which is what OpenCV computes; the closed-form cases in
-tests/test_host.py pin it (parity otherwise unpinned: no reference test covers it).
+cv2.getAffineTransform (third-party, absent here) is restated from OpenCV's published source
+(pre_oracle.cv_get_affine_transform: its 6x6 system, LU with partial pivoting in double); the
+closed-form cases in tests/test_host.py / tests/test_oracle_pre.py pin it (no reference test
+covers it, no OpenCV build is available offline).
 """
 import numpy as np
 
@@ -23,15 +24,10 @@ def _third(a, b):
 
 
 def _cv_get_affine(src, dst):
-    # 6x6 system exactly as OpenCV sets it up (imgwarp.cpp getAffineTransform)
-    A = np.zeros((6, 6), np.float64)
-    b = np.zeros(6, np.float64)
-    for i in range(3):
-        A[i, 0:3] = [src[i][0], src[i][1], 1]
-        A[i + 3, 3:6] = [src[i][0], src[i][1], 1]
-        b[i] = dst[i][0]
-        b[i + 3] = dst[i][1]
-    return np.linalg.solve(A, b).reshape(2, 3)
+    # cv::getAffineTransform: the interleaved 6x6 system + LU with partial pivoting, restated once
+    # in oracle/pre_oracle.py (cv_get_affine_transform)
+    from .pre_oracle import cv_get_affine_transform
+    return cv_get_affine_transform(src, dst)
 
 
 def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0], dtype=np.float32),

@@ -1,6 +1,6 @@
 """Device pre-process (cn_resize_bilinear_u8 / cn_warp_normalize_u8_f32, through the C ABI)
-vs oracle/pre_oracle.py -- bit-exact (uint8 levels and fp32 bits), and the detector's
-pre_process_device vs its host pre_process."""
+vs oracle/pre_oracle.py -- OpenCV's fixed-point INTER_LINEAR restated -- bit-exact (uint8 levels
+and fp32 bits), and the detector's pre_process_device vs its host pre_process."""
 import ctypes
 
 import numpy as np
@@ -38,14 +38,14 @@ def _warp_norm(dev, img, Mi, oh, ow, flip):
     ((24, 31), (32, 32), [1, 0, 3, 0, 1, -2]),                      # integer shift + zero border
     ((20, 28), (32, 40), [0.7, 0.05, -1.3, -0.04, 0.66, 2.2]),      # general affine
     ((33, 17), (16, 48), [1.9, 0, -20.5, 0, 2.3, -4.25]),           # mostly outside the image
-    ((8, 8), (8, 8), [1, 0, 1e7, 0, 1, -1e7]),                      # far outside: all zero
+    ((8, 8), (8, 8), [1, 0, 1e5, 0, 1, -1e5]),                      # far outside: all zero
 ])
 @pytest.mark.parametrize("flip", [False, True])
 def test_warp_normalize_bit_exact(dev, case, flip):
     (h, w), (oh, ow), m = case
     img = _img(h, w, 3)
     got = _warp_norm(dev, img, m, oh, ow, flip)
-    u8 = P.warp_bilinear_u8(img, m, (ow, oh))
+    u8 = P.cv_warp_affine_u8(img, np.array(m, np.float64).reshape(2, 3), (ow, oh), inverse_map=True)
     ref = I.normalize_chw(u8, MEAN, STD)[None]
     if flip:
         ref = np.concatenate((ref, ref[:, :, :, ::-1]), axis=0)
@@ -54,7 +54,8 @@ def test_warp_normalize_bit_exact(dev, case, flip):
 
 
 @pytest.mark.parametrize("shape,out", [((12, 16), (24, 32)), ((40, 30), (17, 23)), ((9, 9), (9, 9)),
-                                       ((31, 64), (48, 23))])
+                                       ((31, 64), (48, 23)), ((40, 30), (20, 15)), ((375, 500), (281, 375)),
+                                       ((6, 7), (1, 1)), ((1, 1), (5, 3))])
 def test_resize_bit_exact(dev, shape, out):
     lib = native.lib()
     img = _img(shape[0], shape[1], 5)
@@ -64,7 +65,7 @@ def test_resize_bit_exact(dev, shape, out):
                                            out[0], out[1], native.ptr(dst), native.stream_ptr()),
                  "resize")
     torch.cuda.synchronize()
-    assert np.array_equal(dst.cpu().numpy(), P.resize_bilinear_u8(img, (out[1], out[0])))
+    assert np.array_equal(dst.cpu().numpy(), P.cv_resize_linear_u8(img, (out[1], out[0])))
 
 
 @pytest.mark.parametrize("shape,scale,keep,flip", [((512, 512), 1.0, False, False),
@@ -104,7 +105,7 @@ def test_warp_random_sweep_bit_exact(dev):
         img = _img(h, w, 100 + case)
         flip = bool(case & 1)
         got = _warp_norm(dev, img, m, oh, ow, flip)
-        ref = I.normalize_chw(P.warp_bilinear_u8(img, m, (ow, oh)), MEAN, STD)[None]
+        ref = I.normalize_chw(P.cv_warp_affine_u8(img, np.array(m, np.float64).reshape(2, 3), (ow, oh), inverse_map=True), MEAN, STD)[None]
         if flip:
             ref = np.concatenate((ref, ref[:, :, :, ::-1]), axis=0)
         assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref).view(np.uint32)), case
