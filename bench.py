@@ -91,6 +91,54 @@ def pmc_traffic(tag):
     return {c: (cls[c], n[c]) for c in cls if n[c]}, os.path.basename(hits[-1])
 
 
+def rocprof_kernel_for(avg_us, cfg):
+    """The kernel of the newest committed `rocprofv3 --kernel-trace --stats` summary of this
+    configuration whose average duration is closest to ``avg_us`` (and within 20 %): name + its
+    rocprof figures, so the line names a kernel, not only a class."""
+    import csv
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats_*cfg%d.csv" % cfg)))
+    if not hits:
+        return None
+    best = None
+    with open(hits[-1]) as f:
+        for row in csv.DictReader(f):
+            try:
+                us = float(row["AverageNs"]) / 1e3
+            except (KeyError, ValueError):
+                continue
+            if best is None or abs(us - avg_us) < abs(best[0] - avg_us):
+                best = (us, row)
+    if best is None or abs(best[0] - avg_us) > 0.2 * avg_us:
+        return None
+    name = best[1]["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    return {"name": name, "rocprof_avg_us": best[0], "rocprof_calls": int(best[1]["Calls"]),
+            "rocprof_pct": float(best[1]["Percentage"]), "file": "profiles/" + os.path.basename(hits[-1])}
+
+
+def dominant_launch(det, images, plan, steps, peak_tf, cfg):
+    """The single longest launch of the step: HIP events after EVERY launch over a few extra
+    steps (outside the timed region: a marker per launch costs ~7 us of bubble each)."""
+    import torch
+    metas, trace = plan.b.meta, plan.b.trace
+    acc = [0.0] * len(metas)
+    for _ in range(steps):
+        probe = {"event_after": set(range(len(metas)))}
+        det.run_batch(images, probe=probe)
+        torch.cuda.synchronize()
+        ev = probe["net_events"]
+        for i in range(len(metas)):
+            acc[i] += ev[i].elapsed_time(ev[i + 1])
+    i = max(range(len(metas)), key=lambda j: acc[j])
+    ms = acc[i] / steps
+    kind, act = trace[i]
+    tf = metas[i]["flops"] / ms / 1e9 if ms > 0 else 0.0
+    out = {"op_index": i, "kind": kind, "out_shape_BHWC": [act.B, act.H, act.W, act.C] if act is not None else None,
+           "avg_ms": ms, "share_of_step": ms / (sum(acc) / steps), "achieved_TFLOPs": tf,
+           "frac_of_peak": tf / peak_tf if peak_tf else None,
+           "algorithmic_bytes": metas[i]["bytes"], "rocprof": rocprof_kernel_for(ms * 1e3, cfg)}
+    return out
+
+
 def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -186,6 +234,12 @@ def cpu_baseline(task, arch, state_dict, heads, res, seconds):
            "sample": "%d images %dx%d batch 1 in %.1f s: oracle/net_oracle %s %s -- a PORT (torch-CPU "
                      "convs + C DCNv2 + C decode), not the reference's code: the reference has no "
                      "CPU DCNv2" % (done, res, res, dt, task, arch)}
+    # the reference's OWN CPU path (BASELINE configs[0]) as recorded in the build container --
+    # /root/reference does not exist on the GPU box, so it cannot be timed in this run there
+    rec = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference_res18.json")))
+    if rec:
+        with open(rec[-1]) as f:
+            out["reference_res18_recorded"] = dict(json.load(f), file="profiles/" + os.path.basename(rec[-1]))
     ref_src = "/root/reference/src/lib"
     if os.path.isdir(ref_src):
         try:
@@ -223,6 +277,53 @@ def _reference_cpu_res18(ref_src, res, seconds, cores):
                       "models/decode.ctdet_decode, torch CPU" % (done, res, res, dt)}
 
 
+class _StubEvent(object):
+    """HIP-event stand-in of the stub run (BENCH_STUB=1): wall-clock stamps."""
+
+    def __init__(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class _StubDetector(object):
+    """BENCH_STUB=1 (tests/test_sharding.py): the detector replaced by a few CPU matmuls so that
+    the whole rank logic of this file -- process group, weight broadcast, barriers, max-over-ranks
+    timing, rank 0's JSON line -- runs under gloo on a host without a GPU.  The line says
+    "data": "stub"; nothing in it is a measurement of the product."""
+
+    class _Plan(object):
+        def __init__(self):
+            from types import SimpleNamespace as NS
+            act = NS(B=1, H=1, W=1, C=1)
+            self.b = NS(meta=[dict(kind="conv", flops=2 * 64 ** 3, bytes=3 * 4 * 64 * 64)],
+                        trace=[("conv", act)])
+            self.flops = 2 * 64 ** 3
+
+    def __init__(self, opt, dev):
+        import torch
+        self.opt = opt
+        self.model = torch.nn.Linear(64, 64).to(dev)
+        self.model.invalidate_plans = lambda: None
+        self.model.plan_for = lambda *a: self._Plan()
+        self.model.half_compute = self.model.fp32_mfma = lambda *a: None
+
+    def run_batch(self, images, probe=None):
+        import torch
+        e = [_StubEvent()]
+        with torch.no_grad():
+            y = self.model(images.reshape(-1)[:64 * 64].reshape(64, 64))
+        e.append(_StubEvent())
+        if probe is not None:
+            probe["net_events"] = e
+            probe["dec_events"] = (e[1], _StubEvent())
+        return y
+
+    def range_ok(self, images=None):
+        return True
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -234,13 +335,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # BENCH_STUB=1: CPU + gloo + _StubDetector -- the rank logic below under test on a host
+    # without a GPU (tests/test_sharding.py); the driver never sets it
+    stub = os.environ.get("BENCH_STUB") == "1"
+    assert stub or torch.cuda.is_available(), "bench.py needs a HIP device"
     # BENCH_DEVICE / BENCH_BACKEND exist only so the multi-rank control flow can be exercised on
     # a single-GPU box (two ranks sharing cuda:0 over gloo); the driver never sets them.
     dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
-    backend = os.environ.get("BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    backend = "gloo" if stub else os.environ.get("BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    if stub:
+        dev = torch.device("cpu")
+        sync = lambda: None   # noqa: E731
+    else:
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        sync = torch.cuda.synchronize
     dist = None
     world = 1
     if env_world > 1:
@@ -261,14 +370,18 @@ def main():
         k, v = kv.split("=")
         assert native.lib().cn_set_tuning(int(k), int(v)) == 0, kv
     from centernet_amd.opts import opts
-    from centernet_amd.detectors import detector_factory
     from centernet_amd.sharding import broadcast_weights
 
     opt = opts().init([a.task, "--arch", a.arch, "--input_res", str(a.res)])
     import contextlib
-    with contextlib.redirect_stdout(sys.stderr):   # the detector prints 'Creating model...'
-        det = detector_factory[opt.task](opt)
-    if rank == 0:
+    if stub:
+        torch.manual_seed(rank)            # ranks start with DIFFERENT weights
+        det = _StubDetector(opt, dev)
+    else:
+        from centernet_amd.detectors import detector_factory
+        with contextlib.redirect_stdout(sys.stderr):   # the detector prints 'Creating model...'
+            det = detector_factory[opt.task](opt)
+    if rank == 0 and not stub:
         synth.fill_state_dict_(det.model, 317)
     bcast_bytes = 0
     if world > 1:
@@ -283,13 +396,13 @@ def main():
 
     for _ in range(max(a.warmup, 1)):
         dets = det.run_batch(images)
-    torch.cuda.synchronize()
+    sync()
     # f32s: the first forward calibrated the per-tensor exponents on this batch; a clamped value
     # here would mean the calibration is broken -- never time a run that is not range-clean
     assert det.range_ok(images), "f32s range check failed during warm-up"
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
 
     plan = det.model.plan_for(B, a.res, a.res, dev)
     # HIP events on the launch stream, inside the timed region.  A marker after every launch
@@ -311,10 +424,10 @@ def main():
         probes.append(probe)
     # inside the timed region: the (synchronising) look at the f32s range words of all K steps
     range_clean = det.range_ok()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -324,7 +437,7 @@ def main():
     if not range_clean:
         raise SystemExit("bench.py: an f32s forward clamped a value inside the timed region")
     fp32_leg = None
-    if rank == 0 and not a.fp16 and not a.fp32_mfma and not a.no_fp32_leg:
+    if rank == 0 and not a.fp16 and not a.fp32_mfma and not a.no_fp32_leg and not stub:
         # the same step on the plain fp32 matrix instruction (v_mfma_f32_32x32x2_f32), a few
         # steps, so that the headline is never ambiguous about what the f32s arithmetic buys
         det.model.fp32_mfma(True)
@@ -410,7 +523,7 @@ def main():
             "metric": "images/sec whole-node, 512x512 ctdet", "value": total_imgs / dt,
             "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": compute_dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": compute_dtype, "data": "stub" if stub else "synthetic",
             "config": {"workload": "%s %s %dx%d, batch %d per GPU (BASELINE configs[%d]%s), network "
                                    "+ fused sigmoid/peak-NMS/top-K decode, K=%d"
                                    % (a.task, a.arch, a.res, a.res, B, a.config,
@@ -424,8 +537,15 @@ def main():
             "roofline_dcn_mfma": roof("dcn", "mfma") if "dcn" in kinds else None,
             "roofline_dcn_hbm": roof("dcn", "hbm") if "dcn" in kinds else None,
             "roofline_decode_hbm": roof("decode", "hbm"),
+            "dominant_launch": None if stub else dominant_launch(
+                det, images, plan, 5,
+                F16_MFMA_PEAK_TF if a.fp16 else (F32_MFMA_PEAK_TF if a.fp32_mfma else F32S_MFMA_PEAK_TF),
+                a.config),
             "pmc_profile": pmc_file,
-            "precision_check": precision_check(dev) if not a.fp16 else None,
+            "traffic_source": None if pmc_file is None else
+            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/%s "
+            "(counters cannot be read from inside the run)" % pmc_file,
+            "precision_check": precision_check(dev) if not (a.fp16 or stub) else None,
             "fp32_mfma_leg": fp32_leg,
             "f32s_range": None if (a.fp16 or a.fp32_mfma) else {
                 "clean": bool(range_clean),
@@ -434,7 +554,7 @@ def main():
                           "split site max-es |value| into range words, read inside the timed region"},
             "time_share": {k: round(v["ms"] / (dt * 1e3), 4) for k, v in kinds.items()},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not stub:
             sd = {k: v.detach().cpu() for k, v in det.model.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(a.task, a.arch, sd, list(opt.heads), a.res,
                                                a.cpu_seconds)

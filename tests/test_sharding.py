@@ -128,3 +128,62 @@ def test_bench_refuses_world_mismatch():
     assert (a.arch, a.batch, a.fp16) == ("hourglass", 8, True)
     a = bench.parse([])
     assert (a.gpus, a.task, a.arch, a.batch, a.fp16, a.res) == (1, "ctdet", "resdcn_18", 32, False, 512)
+
+
+def _run_bench_stub(args, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_STUB="1", OMP_NUM_THREADS="2")
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env,
+                       capture_output=True, text=True, timeout=600)
+    return p, [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rank_logic_end_to_end_two_ranks_gloo():
+    """`python bench.py --gpus 2` end to end on CPU: the file's own control flow -- self-spawned
+    ranks (torchrun, 127.0.0.1), process group, ONE flat weight broadcast, warm-up, barrier,
+    K timed steps, barrier, max-over-ranks clock, exactly one JSON line from rank 0 -- with the
+    detector replaced by bench._StubDetector (BENCH_STUB=1; gloo instead of RCCL).  What an 8-GPU
+    lease runs differs only in the backend string and the detector."""
+    p, lines = _run_bench_stub(["--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "4",
+                                "--res", "64"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["world_size_seen"] == 2 and r["backend"] == "gloo"
+    assert r["steps"] == 6 and r["warmup"] == 2 and r["scaling"] == "weak" and r["data"] == "stub"
+    assert r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "image-sharded x2"
+    assert r["weight_broadcast_bytes"] == 4 * (64 * 64 + 64)
+    # whole-job rate = images of ALL ranks / the slowest rank's time
+    assert abs(r["value"] - 8 * 6 / (r["ms_per_step"] * 6e-3)) <= 1e-6 * r["value"]
+    assert r["metric"].startswith("images/sec whole-node") and r["higher_is_better"] is True
+
+
+def test_bench_config2_over_eight_ranks_is_global_batch_256():
+    """BASELINE configs[2]: dla_34, batch 256 sharded over 8 GPUs = 32 per rank -- the line of an
+    8-rank run says so (stub detector, 8 CPU ranks over gloo)."""
+    p, lines = _run_bench_stub(["--gpus", "8", "--config", "2", "--steps", "2", "--warmup", "1",
+                                "--res", "64"], {"OMP_NUM_THREADS": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    r = lines[0]
+    assert r["n_gpus"] == 8 and r["world_size_seen"] == 8
+    assert r["config"]["global_batch"] == 256 and "dla_34" in r["config"]["workload"]
+    assert "batch 32 per GPU" in r["config"]["workload"]
+
+
+def test_bench_under_a_launcher_with_the_wrong_world_fails(tmp_path):
+    """torchrun --nproc-per-node 2 bench.py --gpus 4: refused (an N > 1 line can never come from a
+    different world than it claims)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = sharding.launch_command(os.path.join(root, "bench.py"),
+                                  ["--gpus", "4", "--steps", "1", "--warmup", "1", "--batch", "2", "--res", "64"], 2)
+    p = subprocess.run(cmd, env=dict(os.environ, BENCH_STUB="1", OMP_NUM_THREADS="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "--gpus 4 but the process group has 2" in (p.stderr + p.stdout)
