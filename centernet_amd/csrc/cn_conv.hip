@@ -78,6 +78,7 @@ struct IgemmArgs {
     int ksplit;    // split-K: blockIdx.z owns chunks [z*KT/ksplit, (z+1)*KT/ksplit)
     float *partial; // split-K: raw fp32 partial sums [ksplit][M][cout_pad]
     int in_plain, out_plain, res_plain;  // f32s kernels: x / y / residual are plain fp32 tensors
+    int tile2d;                          // deformable kernel: tile rows are an 8-wide pixel BLOCK of one image
     float x_mul, res_mul;                // f32s range control (cn_f32s_ctl)
     uint32_t *range;                     // f32s: [0] max |stored output|, [1] max |split input|
 };
@@ -200,11 +201,28 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
             a_pix[p] = -1;
         }
     }
+    // Deformable kernel, maps whose sides are multiples of the block: a tile is an 8 x (BM/8)
+    // pixel BLOCK of one image instead of BM consecutive pixels of a row.  The nine taps of a
+    // block sample a (8 + 2 + reach)^2 neighbourhood -- 41 KB per 32-channel chunk at reach 4 --
+    // where a 64 x 1 row segment touches 66 x (3 + 2 reach): the gather's lines stay in the
+    // 32 KB L1 / in L2 far better (the gather moves 16 B per sample and is L1 / L2-bandwidth
+    // bound on the narrow layers: 39 B/clk/CU measured on 128->64@64^2).
+    auto tile_pixel = [&](int r) -> int {   // linear pixel index (b*Ho + oy)*Wo + ox of tile row r, or -1
+        if (DCN && a.tile2d) {
+            constexpr int TH = BM / 8;
+            const int tx_n = a.Wo >> 3, tpi = tx_n * (a.Ho / TH);
+            const int b = bx / tpi, t = bx - b * tpi;
+            const int ty = t / tx_n, tx = t - ty * tx_n;
+            return (b * a.Ho + ty * TH + (r >> 3)) * a.Wo + tx * 8 + (r & 7);
+        }
+        const int m = m0 + r;
+        return m < a.M ? m : -1;
+    };
     // ---- output pixel index of every tile row (epilogue + residual)
     for (int r = tid; r < BM; r += NT) {
-        const int m = m0 + r;
+        const int m = tile_pixel(r);
         int off = -1;
-        if (m < a.M) {
+        if (m >= 0) {
             const int b = m / HoWo;
             const int rr = m - b * HoWo;
             const int oy = rr / a.Wo;
@@ -218,10 +236,10 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
         for (int i = tid; i < (tap_hi - tap_lo) * BM; i += NT) {
             const int tap = tap_lo + i / BM, r = i % BM;
             const int pb = tap;
-            const int m = m0 + r;
+            const int m = tile_pixel(r);
             int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
             float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
-            if (m < a.M) {
+            if (m >= 0) {
                 const int b = m / HoWo;
                 const int rr = m - b * HoWo;
                 const int oy = rr / a.Wo;
@@ -618,8 +636,10 @@ __global__ __launch_bounds__(NT) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
                     const int lr = it * RPI + r0;
-                    const int m = m0 + rbase + lr;
-                    if (lr < TM && m < a.M && n < a.cout_pad)
+                    // partial rows are indexed by the OUTPUT pixel (split-K layers write y in
+                    // conv-grid order: rowoff == the linear pixel index, whatever the tile shape)
+                    const int m = lr < TM ? rowoff[rbase + lr] : -1;
+                    if (m >= 0 && n < a.cout_pad)
                         *reinterpret_cast<cn_f32x4 *>(pz + (size_t)m * a.cout_pad + n) =
                             *reinterpret_cast<const cn_f32x4 *>(Cs + lr * LDC + c4 * 4);
                 }
@@ -750,6 +770,7 @@ int g_tune_dcn_split = 0;   // cn_set_tuning key 13: 0 = auto, 1 = never, 3 / 9 
 int g_tune_bm256 = 0;       // cn_set_tuning key 14: 1 = 256-pixel tiles for 64-wide layers in the halo kernel (no gain, measured)
 int g_tune_waves8 = 1;      // cn_set_tuning key 15: 8-wave workgroups for the 128-wide halo tiles
 int g_tune_occ4 = 0;        // cn_set_tuning key 19: 4-workgroups-per-CU form of the 64-wide halo tiles: 0 = by rounds rule, 1 = always, 2 = never
+int g_tune_dcn_tile2d = 1; // cn_set_tuning key 22: deformable kernel, 1 = 8-wide pixel blocks as tiles (default), 0 = row segments
 int g_tune_dcn_window = 0; // cn_set_tuning key 11: 1 = LDS-window DCN (cn_dcn.hip); default global gather (faster, measured)
 int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip
 int g_tune_nostem = 0;   // cn_set_tuning key 6: 1 = generic implicit-GEMM stem instead of cn_stem.hip
@@ -1392,6 +1413,9 @@ extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weigh
     a.KT = 9 * a.nchunk;
     a.vec_out = ((Cout & 3) == 0 && (out_pitch & 3) == 0 && cn_aligned16(output_nhwc)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
+    // tiles as pixel blocks (8 x 8, or 8 x 16 for the 128-pixel tiles of Cout <= 32) when the map
+    // divides into them
+    a.tile2d = (g_tune_dcn_tile2d && (W & 7) == 0 && (H % (Cout > 32 ? 8 : 16)) == 0) ? 1 : 0;
     // 64-pixel tiles: 128-pixel tiles were measured slower at every CenterNet shape
     // (tools/bench_dcn.py) and are no longer built
     // tap split (needs the caller's workspace; without one the layer runs unsplit)
@@ -1667,6 +1691,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 12 && (value == 0 || value == 1)) {
         g_tune_stem_persist = value;
+        return CN_OK;
+    }
+    if (key == 22 && (value == 0 || value == 1)) {
+        g_tune_dcn_tile2d = value;
         return CN_OK;
     }
     return CN_ERR_UNSUPPORTED;

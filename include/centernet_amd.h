@@ -115,7 +115,10 @@ const char *cn_arch(void);
  *         0 = weights streamed into registers from the fragment-ordered copy (+5-20 % in a
  *         back-to-back micro-benchmark, no gain inside the network: measured).
  * key 12: 0 = one-tile-per-workgroup stem kernel instead of the persistent, prefetching one
- *         (default 1; both in cn_stem.hip). */
+ *         (default 1; both in cn_stem.hip).
+ * key 22: deformable kernel: 1 = a tile is an 8-wide BLOCK of pixels (8 x 8 / 8 x 16) when the map
+ *         divides into them (default: the nine taps of a block sample a compact neighbourhood that
+ *         stays in L1 / L2), 0 = BM consecutive pixels of a row. */
 int cn_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------

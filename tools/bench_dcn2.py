@@ -1,0 +1,42 @@
+"""Deformable layer micro-benchmark with REAL offset maps (the offset convolution of the synthetic
+DCN module runs first) under cn_set_tuning knobs.  GPU box only.
+    KNOB=22 VALUES=0,1 python tools/bench_dcn2.py        # default: tile shape A/B
+Columns: one per knob value; rows: the resdcn_18 / dla_34 layer shapes at B = 32 (and B = 1)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from centernet_amd import native, synth
+from centernet_amd.dcn_v2 import DCN
+from centernet_amd.engine import PlanBuilder, Act, exponent_for
+
+dev = torch.device("cuda:0")
+lib = native.lib()
+KNOB = int(os.environ.get("KNOB", "22"))
+VALUES = [int(v) for v in os.environ.get("VALUES", "0,1").split(",")]
+SHAPES = [(512, 16, 16, 256), (256, 32, 32, 128), (128, 64, 64, 64), (64, 128, 128, 64), (256, 32, 32, 64),
+          (128, 64, 64, 128), (256, 32, 32, 256)]
+for B in [int(b) for b in os.environ.get("B", "32").split(",")]:
+    print("B=%d  %-22s" % (B, "Cin,H,W,Cout"), "   ".join("key%d=%-10d" % (KNOB, v) for v in VALUES))
+    for ci, H, W, co in SHAPES:
+        m = DCN(ci, co, (3, 3), 1, 1)
+        synth.fill_state_dict_(m, 3)
+        xt = torch.randn((B, H, W, ci), device=dev).relu_()
+        row = []
+        for v in VALUES:
+            lib.cn_set_tuning(KNOB, v)
+            pb = PlanBuilder(dev, B, H, W, exps={"x": exponent_for(float(xt.max())), "t1": exponent_for(8.0)})
+            x = Act(xt, B, H, W, ci, exp=pb._exp("x"), lid="x")
+            pb.dcn(x, m, relu=True)
+            for op in pb.ops:        # offset conv -> real offsets (sigma ~ 1.4 px), then the DCN
+                op()
+            op = pb.ops[-1]
+            for _ in range(3): op()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(20): op()
+            e.record(); torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / 20
+            row.append("%.3fms %5.1fTF" % (ms, pb.meta[-1]["flops"] / ms / 1e9))
+        print("      %-22s" % str((ci, H, W, co)), "   ".join("%-16s" % r for r in row))
+lib.cn_set_tuning(KNOB, 1 if KNOB == 22 else 0)
