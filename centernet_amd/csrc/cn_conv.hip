@@ -770,6 +770,7 @@ int g_tune_dcn_split = 0;   // cn_set_tuning key 13: 0 = auto, 1 = never, 3 / 9 
 int g_tune_bm256 = 0;       // cn_set_tuning key 14: 1 = 256-pixel tiles for 64-wide layers in the halo kernel (no gain, measured)
 int g_tune_waves8 = 1;      // cn_set_tuning key 15: 8-wave workgroups for the 128-wide halo tiles
 int g_tune_occ4 = 0;        // cn_set_tuning key 19: 4-workgroups-per-CU form of the 64-wide halo tiles: 0 = by rounds rule, 1 = always, 2 = never
+int g_tune_dcn_form = 1;   // cn_set_tuning key 23: f32s deformable kernel, 0 = register-sampling window form (cn_dcn2.hip) when the shape takes it and the grid fills the chip, 1 = global-gather form always, 2 = register-sampling form for every shape it takes, 3 = wave-specialised window form for every shape it takes (comparison)
 int g_tune_dcn_tile2d = 1; // cn_set_tuning key 22: deformable kernel, 1 = 8-wide pixel blocks as tiles (default), 0 = row segments
 int g_tune_dcn_window = 0; // cn_set_tuning key 11: 1 = LDS-window DCN (cn_dcn.hip); default global gather (faster, measured)
 int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip
@@ -921,6 +922,10 @@ int cn_stem_pool_f32s(const float *x, const float *w_packed, const float *scale,
 int cn_dcn_window_f32(const float *x, const float *w_packed, const float *bias, const float *om,
                       int om_pitch, const float *scale, const float *shift, float *y, int B, int Cin,
                       int H, int W, int Cout, int mask_sigmoid, int relu, int setprio, hipStream_t st);
+int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, const float *om,
+                       int om_pitch, const float *scale, const float *shift, void *y, int out_pitch,
+                       int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
+                       float x_mul, uint32_t *range, int min_wgs, int variant, int dbg, hipStream_t st);
 int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                  int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
@@ -1394,6 +1399,18 @@ extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weigh
                                          mask_sigmoid, relu, g_tune_setprio, (hipStream_t)stream);
         if (rc != CN_ERR_UNSUPPORTED) return rc;
     }
+    // f32s: the LDS-window form with sampling / multiplying waves (cn_dcn2.hip) for every shape it
+    // takes and every grid that fills the chip; the gather form below (tap split) serves the rest
+    if (f32s && g_tune_dcn_form != 1) {
+        const bool forced = g_tune_dcn_form >= 2;
+        const int rc = cn_dcn_window_f32s(input_nhwc, weight_packed, bias, offset_mask_nhwc, om_pitch,
+                                          scale, shift, output_nhwc, out_pitch,
+                                          (flags & CN_CONV_Y_PLAIN) ? 1 : 0, B, Cin, H, W, Cout,
+                                          mask_sigmoid, relu, (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f,
+                                          ctl ? ctl->range : nullptr, forced ? 1 : 192,
+                                          g_tune_dcn_form == 3 ? 1 : 0, g_tune_dbgskip, (hipStream_t)stream);
+        if (rc != CN_ERR_UNSUPPORTED) return rc;
+    }
     IgemmArgs a = {};
     a.x = input_nhwc; a.w = weight_packed; a.bias = bias; a.scale = scale; a.shift = shift;
     a.residual = nullptr; a.y = output_nhwc; a.om = offset_mask_nhwc; a.om_pitch = om_pitch;
@@ -1645,7 +1662,7 @@ extern "C" int cn_set_tuning(int key, int value)
         g_tune_setprio = value;
         return CN_OK;
     }
-    if (key == 9 && value >= 0 && value <= 31) {
+    if (key == 9 && value >= 0 && value <= 1023) {
         g_tune_dbgskip = value;
         return CN_OK;
     }
@@ -1695,6 +1712,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 22 && (value == 0 || value == 1)) {
         g_tune_dcn_tile2d = value;
+        return CN_OK;
+    }
+    if (key == 23 && value >= 0 && value <= 3) {
+        g_tune_dcn_form = value;
         return CN_OK;
     }
     return CN_ERR_UNSUPPORTED;

@@ -1,0 +1,724 @@
+// cn_dcn2.hip -- fused modulated deformable convolution (DCNv2) forward, f32s arithmetic, with
+// the input staged as an LDS WINDOW and the workgroup split into sampling and multiplying waves.
+//
+// Replaces: DCN.forward -> DCNv2Function.forward -> dcn_v2_cuda_forward
+//   (DCNv2/dcn_v2.py:64-70, dcn_v2_func.py:22-38, src/dcn_v2_cuda.c:10-102): per sample a bias
+//   SGEMM, modulated_deformable_im2col_gpu_kernel (src/cuda/dcn_v2_im2col_cuda.cu:118-180, bilinear
+//   sampler :18-47) writing a Cin*9*HW column buffer, and the main SGEMM.
+//
+// Why (measured, round 3): the global-gather form (cn_conv.hip igemm_kernel<A_DCN>) moves 16 bytes
+// through L1 / L2 per (pixel, tap, channel quad) -- 4 corners x fp32 -- i.e. 295 KB per 64-pixel
+// tile and 32-channel chunk; on 64->64@128^2 that is 17 TB/s of L2 -> L1 traffic at 108 TFLOP/s
+// with the matrix pipe 15 % busy: every (tap, chunk) step is a dependent chain record -> four
+// gathers -> blend -> LDS -> barrier -> MFMA of ~2.4 us.  Here
+//   * a workgroup owns an 8 x 8 block of output pixels of one image and stages, per 32-channel
+//     chunk, the (8 + 2 + 2R)^2 input WINDOW around it ONCE (37 KB at R = 3: 8x less L2 traffic;
+//     NHWC, so the copy is whole 128-byte lines); the four bilinear corners of every sample are
+//     then LDS reads (LDS: 256 B/clk/CU against ~64 B/clk of L1);
+//   * waves 0-3 SAMPLE: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask per (pixel, 4 channels) into the
+//     A tile of step k+1 (a two-tile ring), and stage the weight tile of step k+1;
+//     waves 4-7 MULTIPLY step k: fragments from LDS, three fp16 MFMAs per product (f32s).
+//     One barrier per step; the two halves never wait for each other's memory latency;
+//   * a sample whose corners leave the window (offset beyond the reach) takes its four corners
+//     from global memory instead -- requested one step ahead -- so unbounded offsets
+//     (dcn_v2.py:65-67: raw conv output) stay exact;
+//   * sampling records (bilinear fractions, modulation factor with the sigmoid of dcn_v2.py:67
+//     and the f32s input exponent folded in, top-left corner) are computed once per (pixel, tap)
+//     in the prologue: 16 bytes each, all nine taps resident.
+// Epilogue as everywhere: y = relu?((acc + bias) * scale + shift), plain fp32 or f32s, range words.
+#include "cn_common.h"
+
+namespace {
+
+constexpr int NT = 512;        // 8 waves
+constexpr int NS = 256;        // sampling threads (waves 0-3); waves 4-7 multiply
+constexpr int TS = 8;          // output tile is TS x TS pixels
+constexpr int BM = TS * TS;    // 64
+constexpr int LDT = 36;        // floats per LDS row of the A / weight tiles (128 B + 16 B pad)
+
+struct Dcn2Args {
+    const float *x;            // (B, H, W, Cin) plain fp32
+    const void *w;             // f32s-packed [tap][cout_pad][cin_pad] (row form)
+    const float *bias, *scale, *shift, *om;
+    void *y;
+    int B, H, W, Cin, Cout, om_pitch, mask_sigmoid, relu;
+    int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, out_pitch, out_plain;
+    float x_mul;
+    uint32_t *range;
+    int dbg;                   // debug switches (cn_set_tuning key 9)
+};
+
+typedef _Float16 d2_f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char d2_lds_char;
+typedef __attribute__((address_space(1))) char d2_glb_char;
+typedef __attribute__((address_space(3))) cn_f32x4 d2_lds_f32x4;
+typedef __attribute__((address_space(1))) cn_f32x4 d2_glb_f32x4;
+
+__device__ __forceinline__ float d2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int BN, int WD>
+constexpr size_t dcn2_lds_bytes()
+{
+    return (size_t)WD * WD * 128 + (size_t)2 * BM * LDT * 4 + (size_t)2 * BN * LDT * 4 + (size_t)9 * BM * 16;
+}
+
+// WD: window side; reach = (WD - TS - 2) / 2 pixels of offset on either side
+template <int BN, int WD>
+__global__ __launch_bounds__(NT, BN == 64 ? 4 : 2) void dcn_win_kernel(const Dcn2Args a)
+{
+    constexpr int RCH = (WD - TS - 2) / 2;
+    constexpr int WPIX = WD * WD;
+    constexpr int NPW = (WPIX * 8 + NT - 1) / NT;     // window pieces (16 B) per thread
+    constexpr int NB = BN / 64;                        // 32-wide N blocks per multiplying wave
+    constexpr int PBW = BN * 8 / NS;                   // weight pieces per sampling thread
+    static_assert(BN == 64 || BN == 128, "N tile");
+    static_assert((size_t)32 * (BN + 4) * 4 <= (size_t)2 * BM * LDT * 4 + (size_t)2 * BN * LDT * 4, "epilogue staging");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Win = reinterpret_cast<float *>(smem);                  // [WPIX][32] plain fp32
+    float *As = Win + WPIX * 32;                                   // [2][BM][LDT] f32s rows
+    float *Bs = As + 2 * BM * LDT;                                 // [2][BN][LDT] f32s rows
+    cn_i32x4 *Rec = reinterpret_cast<cn_i32x4 *>(Bs + 2 * BN * LDT);  // [9][BM] {lh, lw, mask' (float bits), yl | xl << 16}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool sampler = wave < 4;
+    const int H = a.H, W = a.W;
+    // XCD-aware tile order: contiguous tile ranges per XCD (block b runs on XCD b % 8)
+    int bx = blockIdx.x;
+    {
+        const int q8 = gridDim.x >> 3;
+        if (bx < (q8 << 3)) bx = (bx & 7) * q8 + (bx >> 3);
+    }
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = bx / tiles;
+    const int tr = bx - b * tiles;
+    const int ty0 = (tr / a.tiles_x) * TS, tx0 = (tr % a.tiles_x) * TS;
+    const int wy0 = ty0 - 1 - RCH, wx0 = tx0 - 1 - RCH;     // window origin in the image
+    const int n0 = blockIdx.y * BN;
+    const float a_x_mul = a.x_mul;
+    const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const char *xb = reinterpret_cast<const char *>(a.x);
+    const unsigned pix_bytes = (unsigned)a.Cin * 4u;
+
+    // ---- sampling records of all nine taps (dcn_v2_im2col_cuda.cu:151-176): 576 over 512 threads
+    for (int i = tid; i < 9 * BM; i += NT) {
+        const int tap = i / BM, m = i - tap * BM;
+        const int oy = ty0 + (m >> 3), ox = tx0 + (m & 7);
+        const float *om = a.om + (size_t)((b * H + oy) * W + ox) * a.om_pitch;
+        const float off_h = om[2 * tap], off_w = om[2 * tap + 1];
+        float mk = om[18 + tap];
+        if (a.mask_sigmoid) mk = d2_sigmoid(mk);   // dcn_v2.py:67
+        mk *= a_x_mul;                              // plain input -> stored units (a power of two)
+        const int ki = tap / 3, kj = tap - ki * 3;
+        const float h_im = (float)(oy - 1 + ki) + off_h;
+        const float w_im = (float)(ox - 1 + kj) + off_w;
+        cn_i32x4 rec = {0, 0, 0, 0};
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {   // :165
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int yl = (int)hf, xl = (int)wf;      // -1 .. H-1 / W-1: fit 16 bits
+            rec[0] = __builtin_bit_cast(int, h_im - hf);
+            rec[1] = __builtin_bit_cast(int, w_im - wf);
+            rec[2] = __builtin_bit_cast(int, mk);
+            rec[3] = (yl & 0xffff) | (int)((uint32_t)(xl & 0xffff) << 16);
+        } else {
+            // outside the sampling domain (:165): the sample is 0 (mask' = 0); the pixel's own
+            // position as "corner" keeps the reads inside the window
+            rec[3] = (oy & 0xffff) | (int)((uint32_t)(ox & 0xffff) << 16);
+        }
+        Rec[i] = rec;
+    }
+
+    // ---- window staging: piece = (window pixel, 16-byte channel quad); by all 512 threads
+    cn_f32x4 rw[NPW];
+    unsigned woff[NPW];       // byte offset of the pixel's chunk-0 piece in x, or ~0u (zero fill)
+#pragma unroll
+    for (int p = 0; p < NPW; ++p) {
+        const int i = p * NT + tid;
+        const int wp = i >> 3, q = i & 7;
+        const int wy = wp / WD, wx = wp - wy * WD;
+        const int iy = wy0 + wy, ix = wx0 + wx;
+        woff[p] = (wp < WPIX && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                      ? (unsigned)((b * H + iy) * W + ix) * pix_bytes + 16u * q : 0xffffffffu;
+    }
+    auto load_win = [&](int chunk) {
+        const unsigned cb = (unsigned)chunk * 128u;
+#pragma unroll
+        for (int p = 0; p < NPW; ++p) {
+            const bool ok = woff[p] != 0xffffffffu && !(a.dbg & 2);
+            const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(xb + (ok ? woff[p] + cb : 0u));
+            rw[p] = ok ? v : zero4;
+        }
+    };
+    auto store_win = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPW; ++p) {
+            const int i = p * NT + tid;
+            if (i < WPIX * 8) *reinterpret_cast<cn_f32x4 *>(Win + i * 4) = rw[p];
+        }
+    };
+
+    // ---- weight tile of one (tap, chunk): BN rows of 128 bytes, by the sampling threads
+    cn_f32x4 rb[PBW];
+    const char *wb = reinterpret_cast<const char *>(a.w);
+    auto load_B = [&](int step) {
+        const int c = step / 9, t = step - c * 9;
+#pragma unroll
+        for (int p = 0; p < PBW; ++p) {
+            const int i = p * NS + tid, row = i >> 3, q = i & 7;
+            const int n = min(n0 + row, a.cout_pad - 1);
+            rb[p] = (a.dbg & 4) ? zero4 : *reinterpret_cast<const cn_f32x4 *>(
+                wb + ((size_t)(t * a.cout_pad + n) * a.cin_pad + (size_t)c * 32) * 4 + 16 * q);
+        }
+    };
+    auto store_B = [&](int buf) {
+        float *Bd = Bs + buf * BN * LDT;
+#pragma unroll
+        for (int p = 0; p < PBW; ++p) {
+            const int i = p * NS + tid, row = i >> 3, q = i & 7;
+            *reinterpret_cast<cn_f32x4 *>(Bd + row * LDT + 4 * q) = rb[p];
+        }
+    };
+
+    // ---- sampling: this thread's two (pixel, channel quad) items per step
+    const int sq = tid & 7, srow = (tid >> 3) & 31;    // sampling threads: rows srow, srow + 32
+    float rng_in = 0.f, rng_out = 0.f;
+    cn_f32x4 fb[2][4];          // corners fetched from global memory for the NEXT step's items
+    unsigned fbmask = 0u;       // bit p: item p of the next step samples outside the window
+    struct Item { float lh, lw, mk; int yl, xl; };
+    auto item_of = [&](int step, int p) -> Item {
+        const int t = step % 9;
+        const cn_i32x4 r = Rec[t * BM + p * 32 + srow];
+        const uint32_t pk = (uint32_t)r[3];
+        Item it;
+        // by value through locals: __builtin_bit_cast on a vector ELEMENT expression reads
+        // element 0 whatever the index (hipcc 7.2) -- seen as lh == lw == mask' in the ISA
+        const int r0 = r[0], r1 = r[1], r2 = r[2];
+        it.lh = __int_as_float(r0);
+        it.lw = __int_as_float(r1);
+        it.mk = __int_as_float(r2);
+        it.yl = (int)(short)(pk & 0xffffu);
+        it.xl = (int)(short)(pk >> 16);
+        return it;
+    };
+    auto in_window = [&](const Item &it) -> bool {
+        return (unsigned)(it.yl - wy0) <= (unsigned)(WD - 2) && (unsigned)(it.xl - wx0) <= (unsigned)(WD - 2);
+    };
+    // request the four corners of the out-of-window items of `step` (chunk of that step)
+    auto prefetch_far = [&](int step) {
+        const unsigned cb = (unsigned)(step / 9) * 128u + 16u * sq;
+        fbmask = 0u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const Item it = item_of(step, p);
+            if (!in_window(it) && !(a.dbg & 1)) {
+                fbmask |= 1u << p;
+                const int y0 = max(it.yl, 0), y1 = min(it.yl + 1, H - 1);
+                const int x0 = max(it.xl, 0), x1 = min(it.xl + 1, W - 1);
+                const unsigned base = (unsigned)(b * H) * (unsigned)W;
+                fb[p][0] = *reinterpret_cast<const cn_f32x4 *>(xb + (base + y0 * W + x0) * pix_bytes + cb);
+                fb[p][1] = *reinterpret_cast<const cn_f32x4 *>(xb + (base + y0 * W + x1) * pix_bytes + cb);
+                fb[p][2] = *reinterpret_cast<const cn_f32x4 *>(xb + (base + y1 * W + x0) * pix_bytes + cb);
+                fb[p][3] = *reinterpret_cast<const cn_f32x4 *>(xb + (base + y1 * W + x1) * pix_bytes + cb);
+            }
+        }
+    };
+    // A tile of `step` into ring slot `buf`: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask'
+    // (dcn_v2_im2col_cuda.cu:43-45,174; corner weights zeroed per :30-41)
+    auto sample = [&](int step, int buf) {
+        float *Ad = As + buf * BM * LDT;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const Item it = item_of(step, p);
+            const float hh = 1.f - it.lh, hw = 1.f - it.lw;
+            const bool yl_ok = it.yl >= 0, xl_ok = it.xl >= 0;
+            const bool yh_ok = it.yl + 1 <= H - 1, xh_ok = it.xl + 1 <= W - 1;
+            const float w1 = (yl_ok && xl_ok) ? hh * hw : 0.f;
+            const float w2 = (yl_ok && xh_ok) ? hh * it.lw : 0.f;
+            const float w3 = (yh_ok && xl_ok) ? it.lh * hw : 0.f;
+            const float w4 = (yh_ok && xh_ok) ? it.lh * it.lw : 0.f;
+            cn_f32x4 v1, v2, v3, v4;
+            if (fbmask & (1u << p)) {
+                v1 = fb[p][0]; v2 = fb[p][1]; v3 = fb[p][2]; v4 = fb[p][3];
+            } else {
+                const float *c0 = Win + ((it.yl - wy0) * WD + (it.xl - wx0)) * 32 + 4 * sq;
+                v1 = *reinterpret_cast<const cn_f32x4 *>(c0);
+                v2 = *reinterpret_cast<const cn_f32x4 *>(c0 + 32);
+                v3 = *reinterpret_cast<const cn_f32x4 *>(c0 + WD * 32);
+                v4 = *reinterpret_cast<const cn_f32x4 *>(c0 + WD * 32 + 32);
+            }
+            cn_f32x4 v = v1 * w1 + v2 * w2 + v3 * w3 + v4 * w4;
+            v = v * it.mk;
+            if (a.dbg & 64) { v[0] = v[1] = v[2] = v[3] = 1.0f; }
+            if (a.dbg & 128) v = v1;
+            if (a.dbg & 256) { v[0] = it.lh; v[1] = it.mk; v[2] = (float)it.yl; v[3] = (float)it.xl; }
+            cn_rng_upd4(rng_in, v);
+            cn_f16x4v hi, lo;
+            cn_split4(v, hi, lo);
+            char *row = reinterpret_cast<char *>(Ad + (p * 32 + srow) * LDT);
+            *reinterpret_cast<cn_f16x4v *>(row + 8 * sq) = hi;
+            *reinterpret_cast<cn_f16x4v *>(row + 64 + 8 * sq) = lo;
+        }
+    };
+
+    // ---- multiplying waves: 2 x 2 over the 64 x BN tile, wave tile 32 x BN/2
+    const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    cn_f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    auto multiply = [&](int buf) {
+        const float *Ab = As + buf * BM * LDT + (wm * 32 + l31) * LDT + 4 * lh;
+        const float *Bb = Bs + buf * BN * LDT + (wn * (BN / 2) + l31) * LDT + 4 * lh;
+        d2_f16x8 af[4], bf[4][NB];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            af[kk] = *reinterpret_cast<const d2_f16x8 *>(Ab + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bf[kk][j] = *reinterpret_cast<const d2_f16x8 *>(Bb + j * 32 * LDT + kk * 8);
+        }
+        // every fragment read is issued before the first MFMA and stays there (operand hazard
+        // note in cn_conv.hip)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)     // lo*hi, hi*lo, hi*hi
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int ka = (term == 0) ? 2 + s2 : s2;
+                    const int kb = (term == 1) ? 2 + s2 : s2;
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ka], bf[kb][j], acc[j], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: window of chunk 0, weights of step 0, then the A tile of step 0
+    const int total = a.nchunk * 9;
+    load_win(0);
+    if (sampler) load_B(0);
+    store_win();
+    if (sampler) store_B(0);
+    __syncthreads();                     // records, window, weights of step 0 visible
+    if (sampler) {
+        fbmask = 0u;
+        prefetch_far(0);
+        sample(0, 0);
+        if (total > 1) { load_B(1); prefetch_far(1); }
+    }
+    __syncthreads();                     // A tile of step 0 ready
+
+    // ---- main loop: in the span of step k the sampling waves build step k+1 and the multiplying
+    // waves consume step k.  A chunk boundary (step k+1 opens a new chunk) first replaces the
+    // window: an extra barrier separates the window write from its first readers.
+    for (int k = 0; k < total; ++k) {
+        const int t = k % 9;
+        const bool more = (k + 1) < total;
+        const bool new_chunk = more && t == 8;
+        if (t == 0 && (k / 9 + 1) < a.nchunk) load_win(k / 9 + 1);   // lands during the chunk's nine steps
+        if (new_chunk) {
+            store_win();                 // nobody reads the old window any more (its last reader ran in step k-1's span)
+            __syncthreads();
+        }
+        if (sampler) {
+            if (more) {
+                store_B((k + 1) & 1);    // requested in the previous span
+                sample(k + 1, (k + 1) & 1);
+                if (k + 2 < total) { load_B(k + 2); prefetch_far(k + 2); }
+            }
+        } else {
+            multiply(k & 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: y = relu?((acc + bias) * scale + shift); the 64 x BN tile goes through LDS one
+    // 32-row half at a time so that stores are 16-byte accesses along Cout (all 512 threads store)
+    constexpr int LDC = BN + 4;
+    float *Cs = As;                      // A / weight rings are free after the loop's last barrier
+    constexpr int C4 = BN / 4;
+    constexpr int RPI = NT / C4;         // rows per pass of the block (32 for BN = 64, 16 for 128)
+    constexpr int ITERS = 32 / RPI;
+    const int c4 = tid % C4, r0 = tid / C4;
+    const int n = n0 + c4 * 4;
+    float bs[4], sc[4], sf[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool ok = (n + e) < a.Cout;
+        bs[e] = (a.bias && ok) ? a.bias[n + e] : 0.f;
+        sc[e] = (a.scale && ok) ? a.scale[n + e] : 1.f;
+        sf[e] = (a.shift && ok) ? a.shift[n + e] : 0.f;
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+        if (!sampler && wm == pass) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    Cs[row * LDC + wn * (BN / 2) + j * 32 + l31] = acc[j][r];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int lr = it * RPI + r0;                 // row inside the 32-row half
+            const int m = pass * 32 + lr;
+            const size_t off = (size_t)((b * H + ty0 + (m >> 3)) * W + tx0 + (m & 7));
+            if (n + 4 <= a.Cout && !(a.dbg & 8)) {
+                cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(Cs + lr * LDC + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tt = (v[e] + bs[e]) * sc[e] + sf[e];
+                    v[e] = a.relu ? fmaxf(tt, 0.f) : tt;
+                    if (a.dbg & 32) v[e] = 7.0f;
+                }
+                if (a.out_plain)
+                    *reinterpret_cast<cn_f32x4 *>(reinterpret_cast<float *>(a.y) + off * a.out_pitch + n) = v;
+                else {
+                    cn_rng_upd4(rng_out, v);
+                    cn_store4_f32s(a.y, off, a.out_pitch, n, v);
+                }
+            }
+        }
+    }
+    if (a.range && !(a.dbg & 16)) {
+        if (!a.out_plain) cn_rng_commit(a.range, 0, rng_out);
+        cn_rng_commit(a.range, 1, rng_in);
+    }
+}
+
+template <int BN, int WD>
+int launch_dcn2(const Dcn2Args &a, hipStream_t st)
+{
+    constexpr size_t lds = dcn2_lds_bytes<BN, WD>();
+    CN_SET_MAX_LDS_ONCE((dcn_win_kernel<BN, WD>), lds);
+    dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), cn_cdiv(a.Cout, BN));
+    hipLaunchKernelGGL((dcn_win_kernel<BN, WD>), grid, dim3(NT), lds, st, a);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+
+// ======================================================================================
+// Register-sampling form (round 3, second design).  The wave-specialised kernel above lost to
+// the global-gather form (70-97 against 100-155 TFLOP/s at B = 32): its A tile and weight tile
+// cross LDS once more than the window reads themselves, and each (tap, chunk) step of a 64-pixel
+// tile is far shorter than the one-step-ahead global loads and the barrier that close it.  Here
+//   * a workgroup of four waves owns 8 x 16 output pixels; the (8 + 8) x (16 + 8) input window
+//     of one 32-channel chunk sits in LDS (144-byte pixel rows: 16 consecutive pixels touch
+//     16 distinct bank groups);
+//   * every lane SAMPLES ITS OWN MFMA OPERAND: lane (l31, h) of a wave is output pixel
+//     32 * wave + l31 and channels 8h..8h+7, 16+8h..16+8h+7 of the chunk -- four 16-byte quads,
+//     four bilinear corners each (16 ds_read_b128), blended in fp32, modulated, split into
+//     (high, low) fp16 and used directly as the 32x32x16 MFMA's B operand.  No A tile in LDS;
+//   * the weights are the MFMA's A operand, read from the FRAGMENT-ordered packed copy
+//     (cn_conv.hip pack_weight_f32s_frag_kernel: 64 bytes per lane per (tap, chunk, 32 rows)),
+//     global -> registers, requested at the top of the step and landed under the sampling;
+//   * no barrier inside a chunk: waves run free over the nine taps; two barriers per chunk
+//     swap the window.  Two workgroups per CU (72 KB of LDS each) overlap each other's swaps.
+// acc[j][r]: output channel 32j + (r & 3) + 8 (r >> 2) + 4h of pixel l31 -- four consecutive
+// channels per register quad, staged through (wave-private) LDS for whole-line stores.
+constexpr int R_NT = 256;
+constexpr int R_TX = 16, R_TY = 8, R_PM = R_TX * R_TY;
+constexpr int R_RCH = 3;                         // offsets up to +-3 px sample inside the window
+constexpr int R_WX = R_TX + 2 + 2 * R_RCH;       // 24
+constexpr int R_WY = R_TY + 2 + 2 * R_RCH;       // 16
+constexpr int R_WPIX = R_WX * R_WY;              // 384
+constexpr int R_WROW = 36;                       // floats per window pixel (128 B + 16 B pad)
+constexpr size_t R_LDS = (size_t)R_WPIX * R_WROW * 4 + (size_t)9 * R_PM * 16;   // 55296 + 18432
+
+template <int BN>
+__global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
+{
+    constexpr int NB = BN / 32;
+    constexpr int LDC = BN + 4;
+    static_assert((size_t)4 * 32 * LDC * 4 <= R_LDS, "epilogue staging");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Win = reinterpret_cast<float *>(smem);
+    cn_i32x4 *Rec = reinterpret_cast<cn_i32x4 *>(Win + R_WPIX * R_WROW);   // [9][R_PM]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int H = a.H, W = a.W;
+    int bx = blockIdx.x;
+    {   // XCD-aware tile order: contiguous tile ranges per XCD (block b runs on XCD b % 8)
+        const int q8 = gridDim.x >> 3;
+        if (bx < (q8 << 3)) bx = (bx & 7) * q8 + (bx >> 3);
+    }
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = bx / tiles;
+    const int tr = bx - b * tiles;
+    const int ty0 = (tr / a.tiles_x) * R_TY, tx0 = (tr % a.tiles_x) * R_TX;
+    const int wy0 = ty0 - 1 - R_RCH, wx0 = tx0 - 1 - R_RCH;
+    const int n0 = blockIdx.y * BN;
+    const float a_x_mul = a.x_mul;
+    const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const char *xb = reinterpret_cast<const char *>(a.x);
+    const unsigned pix_bytes = (unsigned)a.Cin * 4u;
+    const unsigned img_base = (unsigned)(b * H) * (unsigned)W;
+
+    // ---- sampling records of all nine taps (dcn_v2_im2col_cuda.cu:151-176)
+    for (int i = tid; i < 9 * R_PM; i += R_NT) {
+        const int tap = i / R_PM, m = i - tap * R_PM;
+        const int oy = ty0 + (m >> 4), ox = tx0 + (m & 15);
+        const float *om = a.om + (size_t)((b * H + oy) * W + ox) * a.om_pitch;
+        const float off_h = om[2 * tap], off_w = om[2 * tap + 1];
+        float mk = om[18 + tap];
+        if (a.mask_sigmoid) mk = d2_sigmoid(mk);   // dcn_v2.py:67
+        mk *= a_x_mul;                              // plain input -> stored units (a power of two)
+        const int ki = tap / 3, kj = tap - ki * 3;
+        const float h_im = (float)(oy - 1 + ki) + off_h;
+        const float w_im = (float)(ox - 1 + kj) + off_w;
+        cn_i32x4 rec = {0, 0, 0, 0};
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {   // :165
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int yl = (int)hf, xl = (int)wf;
+            rec[0] = __float_as_int(h_im - hf);
+            rec[1] = __float_as_int(w_im - wf);
+            rec[2] = __float_as_int(mk);
+            rec[3] = (yl & 0xffff) | (int)((uint32_t)(xl & 0xffff) << 16);
+        } else {
+            rec[3] = (oy & 0xffff) | (int)((uint32_t)(ox & 0xffff) << 16);   // mask' = 0, corner in the window
+        }
+        Rec[i] = rec;
+    }
+
+    // ---- window of one chunk: 3072 16-byte pieces, 12 per thread; 8 lanes = one pixel's 128 bytes
+    auto fill_window = [&](int chunk) {
+        constexpr int NP = R_WPIX * 8 / R_NT;
+        cn_f32x4 rw[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = p * R_NT + tid;
+            const int wp = i >> 3, q = i & 7;
+            const int wy = wp / R_WX, wx = wp - wy * R_WX;
+            const int iy = wy0 + wy, ix = wx0 + wx;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned off = ok ? (img_base + (unsigned)(iy * W + ix)) * pix_bytes + (unsigned)chunk * 128u + 16u * q : 0u;
+            const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(xb + off);
+            rw[p] = ok ? v : zero4;
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = p * R_NT + tid;
+            *reinterpret_cast<cn_f32x4 *>(Win + (i >> 3) * R_WROW + (i & 7) * 4) = rw[p];
+        }
+    };
+
+    const int m = wave * 32 + l31;                 // this lane's pixel of the tile
+    const d2_lds_char *win_lds = (const d2_lds_char *)smem;
+    const d2_glb_char *xg = (const d2_glb_char *)a.x;
+    const char *wfrag = reinterpret_cast<const char *>(a.w) + (size_t)9 * a.cout_pad * a.cin_pad * 4;
+    const int ncb = a.cout_pad >> 5;
+    const int nb0 = n0 >> 5;
+    float rng_in = 0.f, rng_out = 0.f;
+    cn_f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        if (chunk) __syncthreads();                // every wave is done with the previous window
+        fill_window(chunk);
+        __syncthreads();                           // window (and, first time, the records) visible
+        const unsigned cb = (unsigned)chunk * 128u;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            // weights of this (tap, chunk): the MFMA's A operand, straight from the fragment copy
+            d2_f16x8 wf[NB][4];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int nb = min(nb0 + j, ncb - 1);
+                const char *g = wfrag + ((size_t)((t * a.nchunk + chunk) * ncb + nb) * 64 + lane) * 64;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) wf[j][kk] = *reinterpret_cast<const d2_f16x8 *>(g + kk * 16);
+            }
+            const cn_i32x4 r = Rec[t * R_PM + m];
+            const int r0 = r[0], r1 = r[1], r2 = r[2];
+            const uint32_t pk = (uint32_t)r[3];
+            const float lh = __int_as_float(r0), lw = __int_as_float(r1), mk = __int_as_float(r2);
+            const int yl = (int)(short)(pk & 0xffffu), xl = (int)(short)(pk >> 16);
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const bool yl_ok = yl >= 0, xl_ok = xl >= 0;
+            const bool yh_ok = yl + 1 <= H - 1, xh_ok = xl + 1 <= W - 1;
+            // corner weights, zero where the corner is off the map (dcn_v2_im2col_cuda.cu:30-45)
+            const float w1 = (yl_ok && xl_ok) ? hh * hw : 0.f;
+            const float w2 = (yl_ok && xh_ok) ? hh * lw : 0.f;
+            const float w3 = (yh_ok && xl_ok) ? lh * hw : 0.f;
+            const float w4 = (yh_ok && xh_ok) ? lh * lw : 0.f;
+            const bool inwin = (unsigned)(yl - wy0) <= (unsigned)(R_WY - 2) &&
+                               (unsigned)(xl - wx0) <= (unsigned)(R_WX - 2) && !(a.dbg & 1);
+            // Corners: every lane reads the window (a lane whose sample lies beyond the window's
+            // reach reads its own pixel's position instead and replaces the values below).
+            // Explicit address spaces: left generic, the compiler turns the two sources into
+            // flat loads of a selected pointer.
+            cn_f32x4 c1[4], c2[4], c3[4], c4[4];
+            {
+                const int wyl = inwin ? yl - wy0 : (m >> 4) + 1 + R_RCH;
+                const int wxl = inwin ? xl - wx0 : (m & 15) + 1 + R_RCH;
+                const d2_lds_f32x4 *c0 = reinterpret_cast<const d2_lds_f32x4 *>(
+                    win_lds + (unsigned)((wyl * R_WX + wxl) * R_WROW + 8 * h) * 4u);
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+                    const int fo = (qi >> 1) * 4 + (qi & 1);          // in 16-byte units
+                    c1[qi] = c0[fo];
+                    c2[qi] = c0[R_WROW / 4 + fo];
+                    c3[qi] = c0[R_WX * R_WROW / 4 + fo];
+                    c4[qi] = c0[R_WX * R_WROW / 4 + R_WROW / 4 + fo];
+                }
+            }
+            if (!inwin) {
+                // beyond the window's reach: the four corners from global memory (clamped
+                // addresses; off-map corners carry zero weight)
+                const int y0 = max(yl, 0), y1 = min(yl + 1, H - 1);
+                const int x0 = max(xl, 0), x1 = min(xl + 1, W - 1);
+                const d2_glb_char *g = xg + cb + 32u * h;
+                const unsigned o1 = (img_base + (unsigned)(y0 * W + x0)) * pix_bytes;
+                const unsigned o2 = (img_base + (unsigned)(y0 * W + x1)) * pix_bytes;
+                const unsigned o3 = (img_base + (unsigned)(y1 * W + x0)) * pix_bytes;
+                const unsigned o4 = (img_base + (unsigned)(y1 * W + x1)) * pix_bytes;
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+                    const int fo = ((qi >> 1) * 16 + (qi & 1) * 4) * 4;
+                    c1[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o1 + fo);
+                    c2[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o2 + fo);
+                    c3[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o3 + fo);
+                    c4[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o4 + fo);
+                }
+                // drain here, inside the rare branch: waited for at the join, these loads would
+                // make every step wait for its weight fragments as well (vmcnt counts in order)
+                __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+            }
+            cn_f16x4v shi[4], slo[4];
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask'  (dcn_v2_im2col_cuda.cu:43-45,174)
+                cn_f32x4 v = c1[qi] * w1 + c2[qi] * w2 + c3[qi] * w3 + c4[qi] * w4;
+                v = v * mk;
+                cn_rng_upd4(rng_in, v);
+                cn_split4(v, shi[qi], slo[qi]);
+            }
+            d2_f16x8 sf[4];
+            sf[0] = __builtin_shufflevector(shi[0], shi[1], 0, 1, 2, 3, 4, 5, 6, 7);   // high, channels 8h..
+            sf[1] = __builtin_shufflevector(shi[2], shi[3], 0, 1, 2, 3, 4, 5, 6, 7);   // high, 16 + 8h..
+            sf[2] = __builtin_shufflevector(slo[0], slo[1], 0, 1, 2, 3, 4, 5, 6, 7);   // low parts
+            sf[3] = __builtin_shufflevector(slo[2], slo[3], 0, 1, 2, 3, 4, 5, 6, 7);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int term = 0; term < 3; ++term)     // w_lo*s_hi, w_hi*s_lo, w_hi*s_hi
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int kw = (term == 0) ? 2 + s2 : s2;
+                        const int ks = (term == 1) ? 2 + s2 : s2;
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][kw], sf[ks], acc[j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    // ---- epilogue: y = relu?((acc + bias) * scale + shift).  Each wave stages its 32 pixels x BN
+    // channels in its own LDS region (the window and records are dead) and stores whole lines.
+    __syncthreads();
+    float *Cs = reinterpret_cast<float *>(smem) + wave * 32 * LDC;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const cn_f32x4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+            *reinterpret_cast<cn_f32x4 *>(Cs + l31 * LDC + 32 * j + 8 * g + 4 * h) = v;
+        }
+    constexpr int C4 = BN / 4;               // lanes per pixel row
+    constexpr int RPP = 64 / C4;             // pixel rows per pass of the wave
+    const int c4 = lane % C4, rr = lane / C4;
+    const int n = n0 + c4 * 4;
+    float bs[4], sc[4], sf2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool ok = (n + e) < a.Cout;
+        bs[e] = (a.bias && ok) ? a.bias[n + e] : 0.f;
+        sc[e] = (a.scale && ok) ? a.scale[n + e] : 1.f;
+        sf2[e] = (a.shift && ok) ? a.shift[n + e] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 32 / RPP; ++it) {
+        const int row = it * RPP + rr;
+        const int mm = wave * 32 + row;
+        const size_t off = (size_t)((b * H + ty0 + (mm >> 4)) * W + tx0 + (mm & 15));
+        if (n + 4 <= a.Cout) {
+            cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(Cs + row * LDC + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float tt = (v[e] + bs[e]) * sc[e] + sf2[e];
+                v[e] = a.relu ? fmaxf(tt, 0.f) : tt;
+            }
+            if (a.out_plain)
+                *reinterpret_cast<cn_f32x4 *>(reinterpret_cast<float *>(a.y) + off * a.out_pitch + n) = v;
+            else {
+                cn_rng_upd4(rng_out, v);
+                cn_store4_f32s(a.y, off, a.out_pitch, n, v);
+            }
+        }
+    }
+    if (a.range) {
+        if (!a.out_plain) cn_rng_commit(a.range, 0, rng_out);
+        cn_rng_commit(a.range, 1, rng_in);
+    }
+}
+
+template <int BN>
+int launch_dcn_reg(const Dcn2Args &a, hipStream_t st)
+{
+    CN_SET_MAX_LDS_ONCE((dcn_reg_kernel<BN>), R_LDS);
+    dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), cn_cdiv(a.Cout, BN));
+    hipLaunchKernelGGL((dcn_reg_kernel<BN>), grid, dim3(R_NT), R_LDS, st, a);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+}  // namespace
+
+// Shapes these kernels take (the caller falls back to the global-gather form otherwise): maps of
+// whole pixel blocks (8 x 16 register-sampling form, 8 x 8 wave-specialised form), whole
+// 32-channel chunks, Cout a multiple of 4 and >= 33, and at least `min_wgs` workgroups (the
+// tap-split gather form serves the small grids).  variant: 0 = register-sampling form,
+// 1 = wave-specialised form (kept for comparison; slower, see the note above dcn_reg_kernel).
+int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, const float *om,
+                       int om_pitch, const float *scale, const float *shift, void *y, int out_pitch,
+                       int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
+                       float x_mul, uint32_t *range, int min_wgs, int variant, int dbg, hipStream_t st)
+{
+    if ((H & 7) || (W & 7) || (Cin & 31) || (Cout & 3) || Cout <= 32) return CN_ERR_UNSUPPORTED;
+    if (variant == 0 && (W & 15)) return CN_ERR_UNSUPPORTED;
+    if (H > 32767 || W > 32767 || (out_pitch & 3) || !cn_aligned16(y) || !cn_aligned16(x)) return CN_ERR_UNSUPPORTED;
+    if ((size_t)B * H * W * Cin * 4 >= ((size_t)1 << 32)) return CN_ERR_UNSUPPORTED;   // 32-bit byte offsets
+    const int bn = Cout > 64 ? 128 : 64;
+    const int tsx = variant == 0 ? R_TX : TS;
+    const long wgs = (long)B * (H / TS) * (W / tsx) * cn_cdiv(Cout, bn);
+    if (wgs < min_wgs) return CN_ERR_UNSUPPORTED;
+    Dcn2Args a = {};
+    a.x = x; a.w = w_packed; a.bias = bias; a.scale = scale; a.shift = shift; a.om = om; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.om_pitch = om_pitch;
+    a.mask_sigmoid = mask_sigmoid; a.relu = relu; a.out_pitch = out_pitch; a.out_plain = out_plain;
+    a.cin_pad = (Cin + 31) / 32 * 32;
+    a.cout_pad = (Cout + 31) / 32 * 32;
+    a.nchunk = a.cin_pad / 32;
+    a.tiles_x = W / tsx;
+    a.tiles_y = H / TS;
+    a.x_mul = x_mul; a.range = range; a.dbg = dbg;
+    if (variant == 0) {
+        if (bn == 64) return launch_dcn_reg<64>(a, st);
+        return launch_dcn_reg<128>(a, st);
+    }
+    // 64-wide N tiles: window of reach 3 (32 KB) -> 77 KB of LDS, two workgroups per CU;
+    // 128-wide: one workgroup per CU anyway, window of reach 4
+    if (bn == 64) return launch_dcn2<64, 16>(a, st);
+    return launch_dcn2<128, 18>(a, st);
+}

@@ -118,7 +118,10 @@ const char *cn_arch(void);
  *         (default 1; both in cn_stem.hip).
  * key 22: deformable kernel: 1 = a tile is an 8-wide BLOCK of pixels (8 x 8 / 8 x 16) when the map
  *         divides into them (default: the nine taps of a block sample a compact neighbourhood that
- *         stays in L1 / L2), 0 = BM consecutive pixels of a row. */
+ *         stays in L1 / L2), 0 = BM consecutive pixels of a row.
+ * key 23: f32s deformable kernel: 0 = the LDS-window form with sampling / multiplying waves
+ *         (cn_dcn2.hip) for the shapes it takes when the grid fills the chip (default), 1 = the
+ *         global-gather form always, 2 = the window form for every shape it takes (tests). */
 int cn_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------

@@ -18,6 +18,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
+DCN_FORM_DEFAULT = 1     # cn_set_tuning key 23 as the library starts (csrc/cn_conv.hip g_tune_dcn_form)
 
 
 def _check(y, ref):
@@ -235,7 +236,7 @@ def test_lds_window_variant_matches_oracle(dev):
 
 # ---- the kernel the benchmark runs: cn_dcn_v2_forward_nhwc with CN_DTYPE_F32S (NHWC input,
 # f32s-packed weight, tap split 1 / 3 / 9), entered with explicit offsets and masks
-def _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain):
+def _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain, form=1):
     """x (B,C,H,W), off (B,18,H,W), mask (B,9,H,W) numpy -> (B,Cout,H,W) numpy through
     PlanBuilder.dcn(om=...) = cn_dcn_v2_forward_nhwc(dtype = CN_DTYPE_F32S)."""
     from centernet_amd import native
@@ -254,6 +255,7 @@ def _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain):
     want_scale = float(np.abs(x).max())
     lib = native.lib()
     lib.cn_set_tuning(13, tap_split)
+    lib.cn_set_tuning(23, form)    # 1 = global-gather form, 2 / 3 = LDS-window forms, 0 = by grid size
     try:
         pb = PlanBuilder(dev, B, H, W, split=True,
                          exps={"x": exponent_for(want_scale), "t1": exponent_for(4.0 * want_scale)})
@@ -267,6 +269,7 @@ def _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain):
         torch.cuda.synchronize()
     finally:
         lib.cn_set_tuning(13, 0)
+        lib.cn_set_tuning(23, DCN_FORM_DEFAULT)
     return y.to_float().permute(0, 3, 1, 2).cpu().numpy()
 
 
@@ -318,3 +321,83 @@ def test_f32s_nhwc_kernel_at_benchmark_batch(dev, shape):
     for i in (0, 13, 31):
         want = cref.dcn_v2_forward(x[i:i + 1], off[i:i + 1], mask[i:i + 1], w, b)
         _check(y[i:i + 1], want)
+
+
+# ---- the LDS-window forms (csrc/cn_dcn2.hip: input window in LDS; form 2 = every lane samples its
+# own MFMA operand, 8 x 16 pixel tiles; form 3 = sampling + multiplying waves, 8 x 8 tiles)
+WINDOW_FORMS = [2, 3]
+
+
+def _window_takes(form, Cin, H, W, Cout):
+    return Cin % 32 == 0 and H % 8 == 0 and W % (16 if form == 2 else 8) == 0 and Cout > 32 and Cout % 4 == 0
+
+
+@pytest.mark.parametrize("form", WINDOW_FORMS)
+def test_f32s_window_kernel_vs_reference_kernel_fixtures(dev, form):
+    gen = _gen_ref()
+    z = np.load(os.path.join(GOLDEN, "ref_golden.npz"))
+    ran = 0
+    for name, cfg in gen.DCN_CASES.items():
+        if (cfg["k"], cfg["stride"], cfg["pad"], cfg["dil"], cfg["dg"]) != (3, 1, 1, 1, 1):
+            continue
+        if not _window_takes(form, cfg["Cin"], cfg["H"], cfg["W"], cfg["Cout"]):
+            continue
+        x, off, mask, w, b, _ = gen.dcn_inputs(cfg)
+        for out_plain in (False, True):
+            y = _dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, out_plain, form=form)
+            want = z["dcn_" + name + "_y"]
+            err = np.abs(y - want) / (1 + np.abs(want))
+            assert err.max() < TOL, (name, out_plain, err.max())
+        ran += 1
+    assert ran >= 1
+
+
+@pytest.mark.parametrize("form", WINDOW_FORMS)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16, 64), (1, 128, 24, 48, 128), (3, 96, 8, 16, 64),
+                                   (1, 512, 16, 16, 256), (2, 32, 16, 32, 36), (1, 64, 32, 32, 100),
+                                   (1, 64, 8, 24, 192)])
+@pytest.mark.parametrize("off_std", [0.5, 2.0, 6.0])
+def test_f32s_window_kernel_vs_oracle(dev, shape, off_std, form):
+    """Offsets well inside the window (0.5 px), around its reach (2 px: a few per cent of the samples
+    take the global fallback) and mostly beyond it (6 px); several chunks, two N tiles, ragged
+    Cout, non-square maps, map = one tile."""
+    B, Cin, H, W, Cout = shape
+    if not _window_takes(form, Cin, H, W, Cout):
+        pytest.skip("shape outside this form's domain")
+    x, off, mask, w, b = _case(B, Cin, H, W, Cout, 500 + Cin + H, off_std=off_std)
+    want = cref.dcn_v2_forward(x, off, mask, w, b)
+    for out_plain in (False, True):
+        _check(_dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, out_plain, form=form), want)
+
+
+@pytest.mark.parametrize("form", WINDOW_FORMS)
+def test_f32s_window_kernel_stress_offsets(dev, form):
+    """Offsets ~ U(-H, H) and exactly -1 / H / integers (dcn_v2_im2col_cuda.cu:165, :30-41): every
+    sample takes the fallback or lies on a rule boundary."""
+    B, Cin, H, W, Cout = 2, 64, 16, 16, 64
+    x, off, mask, w, b = _case(B, Cin, H, W, Cout, 77)
+    off = synth.uniform((B, 18, H, W), -H, H, 78)
+    off[0, :, 0, :] = -1.0
+    off[0, :, 1, :] = float(H)
+    off[1, :, 2, :] = np.round(off[1, :, 2, :])
+    off[1, :, 3, :] = 0.0
+    off[1, 0::2, 4, :] = -3.0          # exactly on the window's reach
+    off[1, 1::2, 4, :] = 2.999
+    want = ref.dcn_v2_forward(x, off, mask, w, b) if ref.available() else \
+        cref.dcn_v2_forward(x, off, mask, w, b)
+    _check(_dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, False, form=form), want)
+
+
+@pytest.mark.parametrize("form", WINDOW_FORMS)
+def test_f32s_window_kernel_is_run_to_run_deterministic_at_benchmark_batch(dev, form):
+    """B = 32 (a launch of the size the benchmark times): identical bits over repeated launches."""
+    B, Cin, HW, Cout = 32, 128, 64, 64
+    x, off, mask, w, b = _case(B, Cin, HW, HW, Cout, 900)
+    first = None
+    for _ in range(4):
+        y = _dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, False, form=form)
+        if first is None:
+            first = y
+            for i in (0, 17, 31):
+                _check(y[i:i + 1], cref.dcn_v2_forward(x[i:i + 1], off[i:i + 1], mask[i:i + 1], w, b))
+        assert np.array_equal(y, first)

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r3f; mkdir -p $O
+timeout 300 python tools/dbg_dcn2c.py > $O/dbg.txt 2>&1; tail -3 $O/dbg.txt
+timeout 600 python -m pytest tests/test_gpu_dcn.py -m gpu -q --timeout 300 -p no:cacheprovider -k "window" 2>&1 | tail -15 > $O/pytest_win.log
+tail -8 $O/pytest_win.log
+KNOB=23 VALUES=1,2 timeout 300 python tools/bench_dcn2.py > $O/dcn_form.txt 2>&1
+cat $O/dcn_form.txt
