@@ -62,15 +62,35 @@ typedef _Float16 cn_f16x8v __attribute__((ext_vector_type(8)));
 // asked to split and the launch max-es it into the caller's `range` words (cn_rng_* below); a
 // value beyond 65504 is still clamped (its low part would be NaN) but the word then reads
 // > 65504 and the host re-calibrates and re-runs (engine.Plan.check_range).
+// Two values: high parts by one v_cvt_pk_f16_f32, low parts by v_fma_mixlo/mixhi_f16 -- fp16(fma(high
+// as fp16 operand, -1, c)) in ONE instruction each.  c - high is exact in fp32 (high is c rounded
+// to 11 bits), so this is bit for bit the (_Float16)(c - (float)high) it replaces, in 3 instructions
+// per pair instead of 5 (cvt_pk, 2 x cvt_f32_f16, pk_add, cvt_pk): the split is the largest
+// single item of VALU work in every f32s staging loop and epilogue.
+typedef _Float16 cn_f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cn_split2_bits(float c0, float c1, uint32_t &hi, uint32_t &lo)
+{
+    const cn_f16x2v h = {(_Float16)c0, (_Float16)c1};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const float m1 = -1.0f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(m1), "v"(c0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(m1), "v"(c1));
+}
+// CLAMP = false only where the values are known to lie inside the fp16 range already
+template <bool CLAMP = true>
 __device__ __forceinline__ void cn_split4(cn_f32x4 v, cn_f16x4v &hi, cn_f16x4v &lo)
 {
+    float c[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 4; ++e)
         // clamp to the fp16 range: an overflow would make the low part NaN (inf - inf)
-        const float c = __builtin_fminf(__builtin_fmaxf(v[e], -65504.0f), 65504.0f);
-        hi[e] = (_Float16)c;
-        lo[e] = (_Float16)(c - (float)hi[e]);
-    }
+        c[e] = CLAMP ? __builtin_fminf(__builtin_fmaxf(v[e], -65504.0f), 65504.0f) : v[e];
+    uint32_t h[2], l[2];
+    cn_split2_bits(c[0], c[1], h[0], l[0]);
+    cn_split2_bits(c[2], c[3], h[1], l[1]);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(cn_f16x4v, u32x2{h[0], h[1]});
+    lo = __builtin_bit_cast(cn_f16x4v, u32x2{l[0], l[1]});
 }
 // ---- range words: running max |v| of everything a launch split, as float bit patterns
 // (non-negative floats order like unsigned integers).  One conditional atomic per wave, spread

@@ -432,11 +432,16 @@ constexpr int R_WPIX = R_WX * R_WY;              // 384
 constexpr int R_WROW = 36;                       // floats per window pixel (128 B + 16 B pad)
 constexpr size_t R_LDS = (size_t)R_WPIX * R_WROW * 4 + (size_t)9 * R_PM * 16;   // 55296 + 18432
 
-template <int BN>
+// DBG: probe build (cn_set_tuning key 9 != 0): bit 1 = every sample takes the global path,
+// 8 = no MFMAs, 128 = no taps at all (prologue + window swaps + epilogue only)
+template <int BN, bool DBG>
 __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
 {
     constexpr int NB = BN / 32;
     constexpr int LDC = BN + 4;
+    // 64-wide tiles have the registers to request the NEXT chunk's window while the current
+    // chunk's nine taps run; 128-wide tiles request it at the swap
+    constexpr bool PREF = (BN == 64);
     static_assert((size_t)4 * 32 * LDC * 4 <= R_LDS, "epilogue staging");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Win = reinterpret_cast<float *>(smem);
@@ -455,43 +460,29 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
     const int tr = bx - b * tiles;
     const int ty0 = (tr / a.tiles_x) * R_TY, tx0 = (tr % a.tiles_x) * R_TX;
     const int wy0 = ty0 - 1 - R_RCH, wx0 = tx0 - 1 - R_RCH;
+    const int dbg = DBG ? a.dbg : 0;
     const int n0 = blockIdx.y * BN;
     const float a_x_mul = a.x_mul;
+    const bool msig = a.mask_sigmoid != 0;
     const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const char *xb = reinterpret_cast<const char *>(a.x);
     const unsigned pix_bytes = (unsigned)a.Cin * 4u;
     const unsigned img_base = (unsigned)(b * H) * (unsigned)W;
+    const d2_glb_char *xg = (const d2_glb_char *)a.x;
+    const d2_lds_char *win_lds = (const d2_lds_char *)smem;
+    float rng_in = 0.f, rng_out = 0.f;
 
-    // ---- sampling records of all nine taps (dcn_v2_im2col_cuda.cu:151-176)
-    for (int i = tid; i < 9 * R_PM; i += R_NT) {
-        const int tap = i / R_PM, m = i - tap * R_PM;
-        const int oy = ty0 + (m >> 4), ox = tx0 + (m & 15);
-        const float *om = a.om + (size_t)((b * H + oy) * W + ox) * a.om_pitch;
-        const float off_h = om[2 * tap], off_w = om[2 * tap + 1];
-        float mk = om[18 + tap];
-        if (a.mask_sigmoid) mk = d2_sigmoid(mk);   // dcn_v2.py:67
-        mk *= a_x_mul;                              // plain input -> stored units (a power of two)
-        const int ki = tap / 3, kj = tap - ki * 3;
-        const float h_im = (float)(oy - 1 + ki) + off_h;
-        const float w_im = (float)(ox - 1 + kj) + off_w;
-        cn_i32x4 rec = {0, 0, 0, 0};
-        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {   // :165
-            const float hf = floorf(h_im), wf = floorf(w_im);
-            const int yl = (int)hf, xl = (int)wf;
-            rec[0] = __float_as_int(h_im - hf);
-            rec[1] = __float_as_int(w_im - wf);
-            rec[2] = __float_as_int(mk);
-            rec[3] = (yl & 0xffff) | (int)((uint32_t)(xl & 0xffff) << 16);
-        } else {
-            rec[3] = (oy & 0xffff) | (int)((uint32_t)(ox & 0xffff) << 16);   // mask' = 0, corner in the window
-        }
-        Rec[i] = rec;
-    }
-
-    // ---- window of one chunk: 3072 16-byte pieces, 12 per thread; 8 lanes = one pixel's 128 bytes
-    auto fill_window = [&](int chunk) {
-        constexpr int NP = R_WPIX * 8 / R_NT;
-        cn_f32x4 rw[NP];
+    // ---- window of one chunk: 3072 16-byte pieces, 12 per thread; 8 lanes = one pixel's 128
+    // bytes.  The window holds x' = x * x_mul (the f32s input exponent, a power of two) clamped to
+    // the fp16 range, and the range word is fed HERE, 48 values per thread and chunk: a sample is
+    // a convex blend of window values times a mask in [0, 1] (dcn_v2.py:67), so neither the
+    // clamp nor the running maximum is needed per sample (64 values per lane and tap).
+    constexpr int NP = R_WPIX * 8 / R_NT;
+    cn_f32x4 rw[NP];
+    unsigned okbits = 0u;
+    auto fill_load = [&](int chunk) {
+        // all twelve requests first; the zero fill of off-map pixels happens at the LDS write (a
+        // select right behind each load would wait for the loads one by one)
+        okbits = 0u;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int i = p * R_NT + tid;
@@ -499,37 +490,90 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
             const int wy = wp / R_WX, wx = wp - wy * R_WX;
             const int iy = wy0 + wy, ix = wx0 + wx;
             const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            okbits |= ok ? (1u << p) : 0u;
             const unsigned off = ok ? (img_base + (unsigned)(iy * W + ix)) * pix_bytes + (unsigned)chunk * 128u + 16u * q : 0u;
-            const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(xb + off);
-            rw[p] = ok ? v : zero4;
+            rw[p] = *reinterpret_cast<const d2_glb_f32x4 *>(xg + off);
         }
+    };
+    auto fill_store = [&]() {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int i = p * R_NT + tid;
-            *reinterpret_cast<cn_f32x4 *>(Win + (i >> 3) * R_WROW + (i & 7) * 4) = rw[p];
+            cn_f32x4 v = ((okbits >> p) & 1u) ? rw[p] * a_x_mul : zero4;
+            cn_rng_upd4(rng_in, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fminf(__builtin_fmaxf(v[e], -65504.0f), 65504.0f);
+            *reinterpret_cast<cn_f32x4 *>(Win + (i >> 3) * R_WROW + (i & 7) * 4) = v;
         }
     };
 
+    // ---- prologue: offsets / masks of the tile (1152 records over 256 threads: every load is
+    // requested before the first record is formed -- one memory latency for the lot), the window
+    // of chunk 0 requested behind them, then the sampling records of all nine taps
+    // (dcn_v2_im2col_cuda.cu:151-176)
+    {
+        constexpr int NR = (9 * R_PM + R_NT - 1) / R_NT;   // 5 (the last trip half full)
+        float off_h[NR], off_w[NR], mkv[NR];
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int i = min(p * R_NT + tid, 9 * R_PM - 1);
+            const int tap = i / R_PM, m = i - tap * R_PM;
+            const int oy = ty0 + (m >> 4), ox = tx0 + (m & 15);
+            const float *om = a.om + (size_t)((b * H + oy) * W + ox) * a.om_pitch;
+            off_h[p] = om[2 * tap];
+            off_w[p] = om[2 * tap + 1];
+            mkv[p] = om[18 + tap];
+        }
+        fill_load(0);
+#pragma unroll
+        for (int p = 0; p < NR; ++p) {
+            const int i = p * R_NT + tid;
+            const int tap = i / R_PM, m = i - tap * R_PM;
+            const int oy = ty0 + (m >> 4), ox = tx0 + (m & 15);
+            float mk = mkv[p];
+            if (msig) mk = d2_sigmoid(mk);              // dcn_v2.py:67
+            const int ki = tap / 3, kj = tap - ki * 3;
+            const float h_im = (float)(oy - 1 + ki) + off_h[p];
+            const float w_im = (float)(ox - 1 + kj) + off_w[p];
+            cn_i32x4 rec = {0, 0, 0, 0};
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {   // :165
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int yl = (int)hf, xl = (int)wf;
+                rec[0] = __float_as_int(h_im - hf);
+                rec[1] = __float_as_int(w_im - wf);
+                rec[2] = __float_as_int(mk);
+                rec[3] = (yl & 0xffff) | (int)((uint32_t)(xl & 0xffff) << 16);
+            } else {
+                rec[3] = (oy & 0xffff) | (int)((uint32_t)(ox & 0xffff) << 16);   // mask = 0, corner in the window
+            }
+            if (i < 9 * R_PM) Rec[i] = rec;
+        }
+        fill_store();
+    }
+    __syncthreads();                               // records and the window of chunk 0 visible
+
     const int m = wave * 32 + l31;                 // this lane's pixel of the tile
-    const d2_lds_char *win_lds = (const d2_lds_char *)smem;
-    const d2_glb_char *xg = (const d2_glb_char *)a.x;
     const char *wfrag = reinterpret_cast<const char *>(a.w) + (size_t)9 * a.cout_pad * a.cin_pad * 4;
     const int ncb = a.cout_pad >> 5;
     const int nb0 = n0 >> 5;
-    float rng_in = 0.f, rng_out = 0.f;
     cn_f32x16 acc[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    cn_i32x4 rnext = Rec[m];                       // record of the next step, one step ahead
 
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        if (chunk) __syncthreads();                // every wave is done with the previous window
-        fill_window(chunk);
-        __syncthreads();                           // window (and, first time, the records) visible
+        if (chunk) {
+            __syncthreads();                       // every wave is done with the previous window
+            if (!PREF) fill_load(chunk);
+            fill_store();
+            __syncthreads();
+        }
+        if (PREF && chunk + 1 < a.nchunk) fill_load(chunk + 1);
         const unsigned cb = (unsigned)chunk * 128u;
 #pragma unroll 1
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < ((dbg & 128) ? 0 : 9); ++t) {
             // weights of this (tap, chunk): the MFMA's A operand, straight from the fragment copy
             d2_f16x8 wf[NB][4];
 #pragma unroll
@@ -539,7 +583,10 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) wf[j][kk] = *reinterpret_cast<const d2_f16x8 *>(g + kk * 16);
             }
-            const cn_i32x4 r = Rec[t * R_PM + m];
+            const cn_i32x4 r = PREF ? rnext : Rec[t * R_PM + m];
+            if (PREF) rnext = Rec[(t == 8 ? 0 : t + 1) * R_PM + m];
+            // by value through locals: __builtin_bit_cast / casts on a vector ELEMENT expression
+            // have read element 0 whatever the index (hipcc 7.2)
             const int r0 = r[0], r1 = r[1], r2 = r[2];
             const uint32_t pk = (uint32_t)r[3];
             const float lh = __int_as_float(r0), lw = __int_as_float(r1), mk = __int_as_float(r2);
@@ -553,7 +600,7 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
             const float w3 = (yh_ok && xl_ok) ? lh * hw : 0.f;
             const float w4 = (yh_ok && xh_ok) ? lh * lw : 0.f;
             const bool inwin = (unsigned)(yl - wy0) <= (unsigned)(R_WY - 2) &&
-                               (unsigned)(xl - wx0) <= (unsigned)(R_WX - 2) && !(a.dbg & 1);
+                               (unsigned)(xl - wx0) <= (unsigned)(R_WX - 2) && !(dbg & 1);
             // Corners: every lane reads the window (a lane whose sample lies beyond the window's
             // reach reads its own pixel's position instead and replaces the values below).
             // Explicit address spaces: left generic, the compiler turns the two sources into
@@ -573,9 +620,15 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
                     c4[qi] = c0[R_WX * R_WROW / 4 + R_WROW / 4 + fo];
                 }
             }
+            // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask  (dcn_v2_im2col_cuda.cu:43-45,174); the
+            // power-of-two x_mul inside v1..v4 commutes with every rounding on the way
+            cn_f32x4 vq[4];
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) vq[qi] = c1[qi] * w1 + c2[qi] * w2 + c3[qi] * w3 + c4[qi] * w4;
             if (!inwin) {
                 // beyond the window's reach: the four corners from global memory (clamped
-                // addresses; off-map corners carry zero weight)
+                // addresses; off-map corners carry zero weight), scaled and clamped like the
+                // window, blended inside the branch (only the four blends cross the join)
                 const int y0 = max(yl, 0), y1 = min(yl + 1, H - 1);
                 const int x0 = max(xl, 0), x1 = min(xl + 1, W - 1);
                 const d2_glb_char *g = xg + cb + 32u * h;
@@ -583,32 +636,48 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
                 const unsigned o2 = (img_base + (unsigned)(y0 * W + x1)) * pix_bytes;
                 const unsigned o3 = (img_base + (unsigned)(y1 * W + x0)) * pix_bytes;
                 const unsigned o4 = (img_base + (unsigned)(y1 * W + x1)) * pix_bytes;
+                cn_f32x4 g1[4], g2[4], g3[4], g4[4];
 #pragma unroll
                 for (int qi = 0; qi < 4; ++qi) {
                     const int fo = ((qi >> 1) * 16 + (qi & 1) * 4) * 4;
-                    c1[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o1 + fo);
-                    c2[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o2 + fo);
-                    c3[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o3 + fo);
-                    c4[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o4 + fo);
+                    g1[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o1 + fo);
+                    g2[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o2 + fo);
+                    g3[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o3 + fo);
+                    g4[qi] = *reinterpret_cast<const d2_glb_f32x4 *>(g + o4 + fo);
                 }
                 // drain here, inside the rare branch: waited for at the join, these loads would
                 // make every step wait for its weight fragments as well (vmcnt counts in order)
                 __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+                auto prep = [&](cn_f32x4 v) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fminf(__builtin_fmaxf(v[e] * a_x_mul, -65504.0f), 65504.0f);
+                    return v;
+                };
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi)
+                    vq[qi] = prep(g1[qi]) * w1 + prep(g2[qi]) * w2 + prep(g3[qi]) * w3 + prep(g4[qi]) * w4;
             }
             cn_f16x4v shi[4], slo[4];
 #pragma unroll
             for (int qi = 0; qi < 4; ++qi) {
-                // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask'  (dcn_v2_im2col_cuda.cu:43-45,174)
-                cn_f32x4 v = c1[qi] * w1 + c2[qi] * w2 + c3[qi] * w3 + c4[qi] * w4;
-                v = v * mk;
-                cn_rng_upd4(rng_in, v);
-                cn_split4(v, shi[qi], slo[qi]);
+                const cn_f32x4 v = vq[qi] * mk;
+                if (msig) {
+                    cn_split4<false>(v, shi[qi], slo[qi]);      // |v| <= max |x'| <= 65504
+                } else {
+                    cn_rng_upd4(rng_in, v);                     // caller-supplied mask: any size
+                    cn_split4<true>(v, shi[qi], slo[qi]);
+                }
             }
             d2_f16x8 sf[4];
             sf[0] = __builtin_shufflevector(shi[0], shi[1], 0, 1, 2, 3, 4, 5, 6, 7);   // high, channels 8h..
             sf[1] = __builtin_shufflevector(shi[2], shi[3], 0, 1, 2, 3, 4, 5, 6, 7);   // high, 16 + 8h..
             sf[2] = __builtin_shufflevector(slo[0], slo[1], 0, 1, 2, 3, 4, 5, 6, 7);   // low parts
             sf[3] = __builtin_shufflevector(slo[2], slo[3], 0, 1, 2, 3, 4, 5, 6, 7);
+            if (dbg & 8) {
+                acc[0][0] += (float)sf[0][0] + (float)sf[1][0] + (float)sf[2][0] + (float)sf[3][0] +
+                             (float)wf[0][0][0] + (float)wf[NB - 1][3][0];
+                continue;
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int term = 0; term < 3; ++term)     // w_lo*s_hi, w_hi*s_lo, w_hi*s_hi
@@ -676,9 +745,14 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
 template <int BN>
 int launch_dcn_reg(const Dcn2Args &a, hipStream_t st)
 {
-    CN_SET_MAX_LDS_ONCE((dcn_reg_kernel<BN>), R_LDS);
     dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), cn_cdiv(a.Cout, BN));
-    hipLaunchKernelGGL((dcn_reg_kernel<BN>), grid, dim3(R_NT), R_LDS, st, a);
+    if (a.dbg) {
+        CN_SET_MAX_LDS_ONCE((dcn_reg_kernel<BN, true>), R_LDS);
+        hipLaunchKernelGGL((dcn_reg_kernel<BN, true>), grid, dim3(R_NT), R_LDS, st, a);
+    } else {
+        CN_SET_MAX_LDS_ONCE((dcn_reg_kernel<BN, false>), R_LDS);
+        hipLaunchKernelGGL((dcn_reg_kernel<BN, false>), grid, dim3(R_NT), R_LDS, st, a);
+    }
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

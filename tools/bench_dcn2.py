@@ -13,6 +13,12 @@ dev = torch.device("cuda:0")
 lib = native.lib()
 KNOB = int(os.environ.get("KNOB", "22"))
 VALUES = [int(v) for v in os.environ.get("VALUES", "0,1").split(",")]
+# DBG=0,2,4: columns are probe builds of the register-sampling kernel (key 23 = 2, key 9 = value)
+DBG = [int(v) for v in os.environ["DBG"].split(",")] if os.environ.get("DBG") else None
+ZERO_OFF = os.environ.get("ZERO_OFF") == "1"     # zero offsets (no LDS bank conflicts, nothing beyond the window)
+if DBG:
+    KNOB, VALUES = 9, DBG
+    lib.cn_set_tuning(23, 2)
 SHAPES = [(512, 16, 16, 256), (256, 32, 32, 128), (128, 64, 64, 64), (64, 128, 128, 64), (256, 32, 32, 64),
           (128, 64, 64, 128), (256, 32, 32, 256)]
 for B in [int(b) for b in os.environ.get("B", "32").split(",")]:
@@ -20,6 +26,9 @@ for B in [int(b) for b in os.environ.get("B", "32").split(",")]:
     for ci, H, W, co in SHAPES:
         m = DCN(ci, co, (3, 3), 1, 1)
         synth.fill_state_dict_(m, 3)
+        if ZERO_OFF:
+            with torch.no_grad():
+                m.conv_offset_mask.weight.zero_(); m.conv_offset_mask.bias.zero_()
         xt = torch.randn((B, H, W, ci), device=dev).relu_()
         row = []
         for v in VALUES:
@@ -39,4 +48,5 @@ for B in [int(b) for b in os.environ.get("B", "32").split(",")]:
             ms = s.elapsed_time(e) / 20
             row.append("%.3fms %5.1fTF" % (ms, pb.meta[-1]["flops"] / ms / 1e9))
         print("      %-22s" % str((ci, H, W, co)), "   ".join("%-16s" % r for r in row))
-lib.cn_set_tuning(KNOB, 1 if KNOB == 22 else 0)
+lib.cn_set_tuning(KNOB, 1 if KNOB in (22, 23) else 0)
+lib.cn_set_tuning(23, 1)
