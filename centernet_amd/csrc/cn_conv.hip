@@ -770,7 +770,7 @@ int g_tune_dcn_split = 0;   // cn_set_tuning key 13: 0 = auto, 1 = never, 3 / 9 
 int g_tune_bm256 = 0;       // cn_set_tuning key 14: 1 = 256-pixel tiles for 64-wide layers in the halo kernel (no gain, measured)
 int g_tune_waves8 = 1;      // cn_set_tuning key 15: 8-wave workgroups for the 128-wide halo tiles
 int g_tune_occ4 = 0;        // cn_set_tuning key 19: 4-workgroups-per-CU form of the 64-wide halo tiles: 0 = by rounds rule, 1 = always, 2 = never
-int g_tune_dcn_form = 1;   // cn_set_tuning key 23: f32s deformable kernel, 0 = register-sampling window form (cn_dcn2.hip) when the shape takes it and the grid fills the chip, 1 = global-gather form always, 2 = register-sampling form for every shape it takes, 3 = wave-specialised window form for every shape it takes (comparison)
+int g_tune_dcn_form = 0;   // cn_set_tuning key 23: f32s deformable kernel, 0 = register-sampling window form (cn_dcn2.hip) when the shape takes it and the grid fills the chip, 1 = global-gather form always, 2 = register-sampling form for every shape it takes, 3 = wave-specialised window form for every shape it takes (comparison)
 int g_tune_dcn_tile2d = 1; // cn_set_tuning key 22: deformable kernel, 1 = 8-wide pixel blocks as tiles (default), 0 = row segments
 int g_tune_dcn_window = 0; // cn_set_tuning key 11: 1 = LDS-window DCN (cn_dcn.hip); default global gather (faster, measured)
 int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip

@@ -119,9 +119,11 @@ const char *cn_arch(void);
  * key 22: deformable kernel: 1 = a tile is an 8-wide BLOCK of pixels (8 x 8 / 8 x 16) when the map
  *         divides into them (default: the nine taps of a block sample a compact neighbourhood that
  *         stays in L1 / L2), 0 = BM consecutive pixels of a row.
- * key 23: f32s deformable kernel: 0 = the LDS-window form with sampling / multiplying waves
- *         (cn_dcn2.hip) for the shapes it takes when the grid fills the chip (default), 1 = the
- *         global-gather form always, 2 = the window form for every shape it takes (tests). */
+ * key 23: f32s deformable kernel: 0 = the register-sampling LDS-window form (cn_dcn2.hip: every
+ *         lane samples its own MFMA operand from a window of the input in LDS) for the shapes it
+ *         takes when the grid has >= 192 workgroups (default), 1 = the global-gather form always,
+ *         2 = the register-sampling form for every shape it takes (tests), 3 = the earlier
+ *         wave-specialised window form for every shape it takes (kept for comparison: slower). */
 int cn_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------

@@ -18,7 +18,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
-DCN_FORM_DEFAULT = 1     # cn_set_tuning key 23 as the library starts (csrc/cn_conv.hip g_tune_dcn_form)
+DCN_FORM_DEFAULT = 0     # cn_set_tuning key 23 as the library starts (csrc/cn_conv.hip g_tune_dcn_form)
 
 
 def _check(y, ref):
