@@ -24,6 +24,7 @@
 // cn_set_tuning key 18: phase shift of co-resident workgroups, percent of one tile's MFMA time
 // (0 = off); see the kernel prologue
 int cn_tune_stagger_pct = 100;
+int cn_tune_heads_remap = 1;   // cn_set_tuning key 24 (A/B): bit 0 = fused heads, bit 1 = multi-block Cout, on a 1-D row-interleaved grid
 int cn_tune_f32s_policy = 0;   // cn_set_tuning key 21 (A/B): bit 0 = 128-wide tiles as eight waves three taps ahead, bit 1 = 64-wide tiles two taps ahead
 // f32s: taps a weight tile is requested ahead of its use (1 = the fp32 schedule; build-time so that
 // the register allocation of each form is its own: -DCN_F32S_PREFETCH_TAPS=1 for A/B builds)
@@ -72,6 +73,7 @@ struct C3Args {
     int stagger, stagger_slots;  // phase shift of co-resident workgroups (cycles per slot, slots)
     int in_plain, out_plain, res_plain;  // f32s kernels: x / y / residual are plain fp32 tensors
     int ncb;                     // f32s: 32-channel output blocks in the packed weight (cout_pad / 32)
+    int heads_remap;             // number of grid rows (heads / output-channel blocks) when the grid is 1-D and row-interleaved (0: blockIdx.y = row)
     size_t wfrag_off;            // f32s: byte offset of the fragment-ordered weight copy behind the row-ordered one
     float x_mul, res_mul;        // f32s range control (cn_f32s_ctl): plain-x and residual multipliers
     uint32_t *range;             // f32s: [0] max |stored output| / hidden tile, [1] max |split plain input|
@@ -173,10 +175,22 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     const float a_x_mul = a.x_mul, a_res_mul = a.res_mul;   // scalars, not a stack copy of the struct tail
     uint32_t *const a_range = a.range;
     const int tiles = a.tiles_x * a.tiles_y;
-    const int b = blockIdx.x / tiles;
-    const int tr = blockIdx.x - b * tiles;
+    // 1-D row-interleaved grid (fused heads; key 24 bit 1: output-channel blocks too): the heads
+    // of one pixel tile are workgroups 8 ids apart inside a run of 8 * heads consecutive ids -- dispatched together and onto the SAME XCD (id % 8), so the
+    // tile's input halo is fetched into that XCD's L2 once instead of once per head at three
+    // different times (the 2-D grid ran all tiles of head 0, then head 1, ...: 4.7x the feature
+    // map in HBM / MALL reads, r02 counters).
+    int vbx = blockIdx.x, vby = blockIdx.y;
+    if (a.heads_remap) {
+        const int run = 8 * a.heads_remap;
+        const int g = vbx / run, r = vbx - g * run;
+        vby = r >> 3;
+        vbx = g * 8 + (r & 7);
+    }
+    const int b = vbx / tiles;
+    const int tr = vbx - b * tiles;
     const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;
-    int n0 = blockIdx.y * BN;   // fused heads: first hidden channel of the current slice (set per slice)
+    int n0 = vby * BN;   // fused heads: first hidden channel of the current slice (set per slice)
     const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     if (a.stagger) {
@@ -391,7 +405,7 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     // begins without a global round trip (the W2 region lies behind the main loop's tiles)
     auto stage_W2 = [&](int g0, int sl) {
         float *W2 = As + UNION - W2_ROWS * LDS2;
-        const int head = blockIdx.y;
+        const int head = vby;
         const int cout2 = hd.cout[head];
         const float *w2 = hd.w[head];
         const float *b2 = hd.bias[head];
@@ -638,7 +652,7 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         // accumulates out[cout][pixel] += W2[cout][slice] . S^T (D rows = cout, cols = pixel, so
         // that a wave's stores run along x of the NCHW map the decode consumes).  head_conv = 64
         // is one slice; 256 (dla_34, hourglass) four: the 256-channel hidden tensor never exists.
-        const int head = blockIdx.y;
+        const int head = vby;
         const int cout2 = hd.cout[head];
         // the multi-slice form keeps the 1x1 accumulators (48 registers) live across the main loop:
         // it is the PDQ = 1 instantiation (one tap of weight prefetch, 232 registers, two workgroups
@@ -969,6 +983,11 @@ int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
     // fused heads: one workgroup row per HEAD (its hidden slices run inside the workgroup)
     const int ny = (HEADS && hd) ? cn_cdiv(a.Cout, BN * (hd->slices > 0 ? hd->slices : 1)) : cn_cdiv(a.Cout, BN);
     dim3 grid((unsigned)(a.B * b.tiles_x * b.tiles_y), ny, DECONV ? 4 : 1);
+    b.heads_remap = 0;
+    if (!DECONV && ny > 1 && grid.x % 8 == 0 && (HEADS ? (cn_tune_heads_remap & 1) : (cn_tune_heads_remap & 2))) {
+        b.heads_remap = ny;
+        grid = dim3(grid.x * ny, 1, 1);
+    }
     {
         // resident workgroups per CU of this variant (registers / LDS), MFMA cycles one tile
         // needs per SIMD, and the number of dispatch rounds of this launch

@@ -123,7 +123,9 @@ const char *cn_arch(void);
  *         lane samples its own MFMA operand from a window of the input in LDS) for the shapes it
  *         takes when the grid has >= 192 workgroups (default), 1 = the global-gather form always,
  *         2 = the register-sampling form for every shape it takes (tests), 3 = the earlier
- *         wave-specialised window form for every shape it takes (kept for comparison: slower). */
+ *         wave-specialised window form for every shape it takes (kept for comparison: slower).
+ * key 24: fused heads: 1 = 1-D grid with the heads of a pixel tile dispatched together on one XCD
+ *         (default), 0 = one grid row per head. */
 int cn_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------
