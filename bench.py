@@ -68,9 +68,20 @@ def pmc_traffic(tag):
         base = name.split("<")[0]
         args = [a.strip() for a in name[len(base):].strip("<>").split(",")] if "<" in name else []
         return base, [int(a) if a.lstrip("-").isdigit() else a for a in args[1:]]
-    # profiled forward steps = launches of the stem kernel (exactly one per step in every network)
-    steps = sum(v.get("launches", 0) for k, v in raw.items()
-                if isinstance(v, dict) and short(k)[0].startswith("stem_"))
+    # profiled forward steps = launches of the fused-heads kernel in the arithmetic the run is
+    # quoted in (exactly one per forward in every network; the fp32 calibration pass that precedes
+    # an f32s run uses the <float> instantiation and is not counted -- its launches stay in the
+    # class sums, a 2-in-36 overestimate with the profile command's 30 + 3 steps)
+    def is_heads(k):
+        base, targs = short(k)
+        return base == "conv3x3s1_kernel" and len(targs) > 4 and targs[4] in ("true", 1)
+    heads = {k: v.get("launches", 0) for k, v in raw.items() if isinstance(v, dict) and is_heads(k)}
+    main = [n_ for k, n_ in heads.items() if "cn_f32s" in k] or [n_ for k, n_ in heads.items() if "DF16_" in k] \
+        or list(heads.values())
+    steps = sum(main)
+    if not steps:   # networks without fused heads: the stem kernels (one per forward)
+        steps = sum(v.get("launches", 0) for k, v in raw.items()
+                    if isinstance(v, dict) and short(k)[0].startswith("stem_"))
     steps = max(1, steps or raw.get("nms_topk_kernel", {}).get("launches", 1))
     for k, v in raw.items():
         if not isinstance(v, dict) or "hbm_bytes_per_launch" not in v:
@@ -78,6 +89,8 @@ def pmc_traffic(tag):
         base, targs = short(k)
         if base == "igemm_kernel":
             c = "dcn" if len(targs) > 4 and targs[4] in (2, 3) else "conv"   # AMODE
+        elif base.startswith(("dcn_reg_kernel", "dcn_win_kernel")):   # LDS-window forms (cn_dcn2.hip)
+            c = "dcn"
         elif base.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_")):
             c = "conv"
         elif base.startswith(("nms_topk", "merge_topk", "peak_", "group_", "pose_match", "decode_")):
@@ -87,7 +100,7 @@ def pmc_traffic(tag):
         else:
             continue
         cls[c] += v["hbm_bytes_per_launch"] * v["launches"] / steps   # bytes per forward step
-        n[c] += v["launches"] // steps
+        n[c] += int(round(v["launches"] / steps))
     return {c: (cls[c], n[c]) for c in cls if n[c]}, os.path.basename(hits[-1])
 
 

@@ -4,14 +4,14 @@
 # 1. rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; counters only + kernel trace) -> pmc_traffic json
 # 2. python bench.py (same flags) -> bench json (+ per-op listing)
 # 3. rocprofv3 --kernel-trace --stats of the same command -> kernel stats csv
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 TAG=${2:-v1}
 CFG=${3:-1}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_${ROUND}_${TAG}_cfg$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline"
+BENCH="python $R/bench.py --config $CFG --steps 30 --warmup 3 --no-cpu-baseline --no-fp32-leg"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/f -o p -- $BENCH > $OUT/pmc_f.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/w -o p -- $BENCH > $OUT/pmc_w.log 2>&1
 python $R/tools/pmc_traffic.py $OUT/f $OUT/w $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
