@@ -9,7 +9,9 @@ dev = torch.device("cuda:0")
 m = create_model(arch, {"hm": 80, "wh": 2, "reg": 2}, 256 if arch.startswith("dla") else 64)
 synth.fill_state_dict_(m, 317)
 m = m.to(dev).eval()
-for B in (1, 4, 32):
+if os.environ.get("FP16") == "1":       # BASELINE configs[4]: hourglass fp16
+    m.half_compute(True)
+for B in [int(b) for b in os.environ.get("B", "1,4,32").split(",")]:
     x = synth.images(B, 512, 512, 0).to(dev)
     plan = m.plan_for(B, 512, 512, dev)
     def t(n=20):
@@ -20,5 +22,6 @@ for B in (1, 4, 32):
     eager = t()
     plan.capture()
     graph = t()
+    print("launches per forward: %d" % len(plan.b.ops))
     print("%s B=%2d  eager %.3f ms  graph %.3f ms  (%.0f vs %.0f img/s)" % (arch, B, eager, graph, B / eager * 1e3, B / graph * 1e3))
     m.invalidate_plans()
