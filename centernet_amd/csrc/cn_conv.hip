@@ -925,7 +925,8 @@ int cn_dcn_window_f32(const float *x, const float *w_packed, const float *bias, 
 int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, const float *om,
                        int om_pitch, const float *scale, const float *shift, void *y, int out_pitch,
                        int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
-                       float x_mul, uint32_t *range, int min_wgs, int variant, int dbg, hipStream_t st);
+                       float x_mul, uint32_t *range, int min_wgs, int variant, int dbg, float *partial,
+                       size_t partial_bytes, int *ksplit_out, hipStream_t st);
 int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                  int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
@@ -1357,8 +1358,10 @@ static int dcn_ksplit(int B, int H, int W, int Cout)
 extern "C" size_t cn_dcn_v2_forward_nhwc_workspace_bytes(int B, int Cin, int H, int W, int Cout)
 {
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    // slabs of the gather form's tap split (3 / 9) or of the window form's K-chunk split (<= 8):
+    // small grids only (either form splits when its plain grid has < 1024 / < 192 workgroups)
     const int s = dcn_ksplit(B, H, W, Cout);
-    return s > 1 ? (size_t)s * B * H * W * round_up(Cout, 32) * sizeof(float) : 0;
+    return s > 1 ? (size_t)(s > 8 ? s : 8) * B * H * W * round_up(Cout, 32) * sizeof(float) : 0;
 }
 
 extern "C" int cn_dcn_v2_forward_nhwc_f32(const float *input_nhwc, const float *weight_packed,
@@ -1404,12 +1407,32 @@ extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weigh
     // takes and every grid that fills the chip; the gather form below (tap split) serves the rest
     if (f32s && g_tune_dcn_form != 1) {
         const bool forced = g_tune_dcn_form >= 2;
+        const bool ws_ok = workspace && cn_aligned16(workspace) && !g_tune_nosplit;
+        int ks = 1;
         const int rc = cn_dcn_window_f32s(input_nhwc, weight_packed, bias, offset_mask_nhwc, om_pitch,
                                           scale, shift, output_nhwc, out_pitch,
                                           (flags & CN_CONV_Y_PLAIN) ? 1 : 0, B, Cin, H, W, Cout,
                                           mask_sigmoid, relu, (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f,
                                           ctl ? ctl->range : nullptr, forced ? 1 : 192,
-                                          g_tune_dcn_form == 3 ? 1 : 0, g_tune_dbgskip, (hipStream_t)stream);
+                                          g_tune_dcn_form == 3 ? 1 : 0, g_tune_dbgskip,
+                                          ws_ok ? (float *)workspace : nullptr, ws_ok ? workspace_bytes : 0,
+                                          &ks, (hipStream_t)stream);
+        if (rc == CN_OK && ks > 1) {
+            // second stage of the K split: fixed-order sum of the slabs + the usual epilogue
+            IgemmArgs r = {};
+            r.bias = bias; r.scale = scale; r.shift = shift; r.residual = nullptr; r.y = output_nhwc;
+            set_ctl(r, ctl);
+            r.B = B; r.H = H; r.W = W; r.Ho = H; r.Wo = W; r.Cout = Cout; r.out_pitch = out_pitch;
+            r.out_plain = (flags & CN_CONV_Y_PLAIN) ? 1 : 0;
+            r.OH = H; r.OW = W; r.oy_mul = 1; r.oy_add = 0; r.ox_mul = 1; r.ox_add = 0;
+            r.relu = relu; r.M = B * H * W; r.cout_pad = round_up(Cout, 32);
+            r.ksplit = ks; r.partial = (float *)workspace;
+            const size_t tot = (size_t)r.M * (r.cout_pad >> 2);
+            const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+            hipLaunchKernelGGL(splitk_reduce_kernel<cn_f32s>, dim3(nb), dim3(256), 0, (hipStream_t)stream, r);
+            CN_CHECK_LAUNCH();
+            return CN_OK;
+        }
         if (rc != CN_ERR_UNSUPPORTED) return rc;
     }
     IgemmArgs a = {};

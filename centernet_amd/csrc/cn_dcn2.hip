@@ -46,6 +46,8 @@ struct Dcn2Args {
     float x_mul;
     uint32_t *range;
     int dbg;                   // debug switches (cn_set_tuning key 9)
+    int ksplit;                // register-sampling kernel: K-chunk ranges per tile (blockIdx.z), > 1: raw partial sums
+    float *partial;            // [ksplit][B*H*W][cout_pad] fp32 (splitk_reduce_kernel applies the epilogue)
 };
 
 typedef _Float16 d2_f16x8 __attribute__((ext_vector_type(8)));
@@ -476,6 +478,9 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
     const d2_glb_char *xg = (const d2_glb_char *)a.x;
     const d2_lds_char *win_lds = (const d2_lds_char *)smem;
     float rng_in = 0.f, rng_out = 0.f;
+    // K split (small maps with deep K): this workgroup's share of the 32-channel chunks
+    const int cpw = a.nchunk / a.ksplit;
+    const int c_lo = (int)blockIdx.z * cpw, c_hi = c_lo + cpw;
 
     // ---- window of one chunk: 3072 16-byte pieces, 12 per thread; 8 lanes = one pixel's 128
     // bytes.  The window holds x' = x * x_mul (the f32s input exponent, a power of two) clamped to
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
             off_w[p] = om[2 * tap + 1];
             mkv[p] = om[18 + tap];
         }
-        fill_load(0);
+        fill_load(c_lo);
 #pragma unroll
         for (int p = 0; p < NR; ++p) {
             const int i = p * R_NT + tid;
@@ -623,8 +628,8 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
     Samp cur = decode(Rec[m]);
     if (PIPE) request_corners(cur);
     cn_i32x4 rnext = Rec[R_PM + m];
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        if (chunk) {
+    for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+        if (chunk != c_lo) {
             __syncthreads();                       // every wave is done with the previous window
             fill_load(chunk);
             fill_store();
@@ -756,7 +761,11 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
         const int row = it * RPP + rr;
         const int mm = wave * 32 + row;
         const size_t off = (size_t)((b * H + ty0 + (mm >> 4)) * W + tx0 + (mm & 15));
-        if (n + 4 <= a.Cout) {
+        if (a.partial) {   // K split: raw sums, one slab per split; the reduce kernel does the rest
+            if (n < a.cout_pad)
+                *reinterpret_cast<cn_f32x4 *>(a.partial + ((size_t)blockIdx.z * ((size_t)a.B * H * W) + off) * a.cout_pad + n) =
+                    *reinterpret_cast<const cn_f32x4 *>(Cs + row * LDC + cq * 4);
+        } else if (n + 4 <= a.Cout) {
             cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(Cs + row * LDC + cq * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -772,7 +781,7 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
         }
     }
     if (a.range) {
-        if (!a.out_plain) cn_rng_commit(a.range, 0, rng_out);
+        if (!a.out_plain && !a.partial) cn_rng_commit(a.range, 0, rng_out);
         cn_rng_commit(a.range, 1, rng_in);
     }
 }
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
 template <int BN>
 int launch_dcn_reg(const Dcn2Args &a, hipStream_t st)
 {
-    dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), cn_cdiv(a.Cout, BN));
+    dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), cn_cdiv(a.Cout, BN), (unsigned)a.ksplit);
     if (a.dbg && a.mask_sigmoid) {
         CN_SET_MAX_LDS_ONCE((dcn_reg_kernel<BN, true, true>), R_LDS);
         hipLaunchKernelGGL((dcn_reg_kernel<BN, true, true>), grid, dim3(R_NT), R_LDS, st, a);
@@ -805,8 +814,10 @@ int launch_dcn_reg(const Dcn2Args &a, hipStream_t st)
 int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, const float *om,
                        int om_pitch, const float *scale, const float *shift, void *y, int out_pitch,
                        int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
-                       float x_mul, uint32_t *range, int min_wgs, int variant, int dbg, hipStream_t st)
+                       float x_mul, uint32_t *range, int min_wgs, int variant, int dbg, float *partial,
+                       size_t partial_bytes, int *ksplit_out, hipStream_t st)
 {
+    if (ksplit_out) *ksplit_out = 1;
     if ((H & 7) || (W & 7) || (Cin & 31) || (Cout & 3) || Cout <= 32) return CN_ERR_UNSUPPORTED;
     if (variant == 0 && (W & 15)) return CN_ERR_UNSUPPORTED;
     if (H > 32767 || W > 32767 || (out_pitch & 3) || !cn_aligned16(y) || !cn_aligned16(x)) return CN_ERR_UNSUPPORTED;
@@ -814,7 +825,19 @@ int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, 
     const int bn = Cout > 64 ? 128 : 64;
     const int tsx = variant == 0 ? R_TX : TS;
     const long wgs = (long)B * (H / TS) * (W / tsx) * cn_cdiv(Cout, bn);
-    if (wgs < min_wgs) return CN_ERR_UNSUPPORTED;
+    // Too few tiles for the chip but a deep K (512 -> 256 @ 16^2): split the 32-channel chunks over
+    // 2 / 4 / 8 workgroups per tile -- raw fp32 partial sums in the caller's workspace, summed in a
+    // fixed order by splitk_reduce_kernel (deterministic) -- when that yields >= 256 workgroups
+    int ksplit = 1;
+    if (wgs < min_wgs) {
+        const int nchunk = (Cin + 31) / 32;
+        const int cout_pad = (Cout + 31) / 32 * 32;
+        for (int s2 = 2; s2 <= 8 && variant == 0 && partial && ksplit == 1; s2 *= 2)
+            if (nchunk % s2 == 0 && nchunk / s2 >= 2 && wgs * s2 >= 256 &&
+                (size_t)s2 * B * H * W * cout_pad * sizeof(float) <= partial_bytes)
+                ksplit = s2;
+        if (ksplit == 1) return CN_ERR_UNSUPPORTED;
+    }
     Dcn2Args a = {};
     a.x = x; a.w = w_packed; a.bias = bias; a.scale = scale; a.shift = shift; a.om = om; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.om_pitch = om_pitch;
@@ -825,6 +848,9 @@ int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, 
     a.tiles_x = W / tsx;
     a.tiles_y = H / TS;
     a.x_mul = x_mul; a.range = range; a.dbg = dbg;
+    a.ksplit = ksplit;
+    a.partial = ksplit > 1 ? partial : nullptr;
+    if (ksplit_out) *ksplit_out = ksplit;
     if (variant == 0) {
         if (bn == 64) return launch_dcn_reg<64>(a, st);
         return launch_dcn_reg<128>(a, st);

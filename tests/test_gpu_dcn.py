@@ -401,3 +401,21 @@ def test_f32s_window_kernel_is_run_to_run_deterministic_at_benchmark_batch(dev, 
             for i in (0, 17, 31):
                 _check(y[i:i + 1], cref.dcn_v2_forward(x[i:i + 1], off[i:i + 1], mask[i:i + 1], w, b))
         assert np.array_equal(y, first)
+
+
+def test_f32s_window_kernel_k_split_small_map(dev):
+    """A map with too few tiles for the chip but a deep K (the 512 -> 256 @ 16 x 16 layer of resdcn_18):
+    under the default form selection the register-sampling kernel splits the 32-channel chunks
+    over 8 workgroups per tile (raw partial slabs + fixed-order reduce): against the oracle, both
+    output formats, and bit-identical over repeated launches."""
+    B, Cin, H, W, Cout = 8, 512, 16, 16, 256
+    x, off, mask, w, b = _case(B, Cin, H, W, Cout, 4242, off_std=1.5)
+    want = cref.dcn_v2_forward(x, off, mask, w, b)
+    first = None
+    for out_plain in (False, True, False):
+        y = _dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, out_plain, form=0)
+        _check(y, want)
+        if not out_plain:
+            if first is None:
+                first = y
+            assert np.array_equal(y, first)
