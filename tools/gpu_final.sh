@@ -1,9 +1,15 @@
 #!/bin/bash
-# end-of-round GPU session: full GPU suite, then the profile sets of configs 1 and 2
+# end-of-round GPU session: full GPU suite, smoke, the profile sets of configs 1 and 2, the
+# driver's default command, one bench line each for configs 3 and 4, host-boundary rates
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
+RND=${1:-r03}; TAG=${2:-v3}
 O=gpurun_out/final; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider 2>&1 | tail -6 > $O/pytest_gpu.log
 tail -3 $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-bash tools/profile_round.sh ${1:-r03} ${2:-v2} 1 > $O/prof1.log 2>&1; tail -30 $O/prof1.log | cut -c1-300
-bash tools/profile_round.sh ${1:-r03} ${2:-v2} 2 > $O/prof2.log 2>&1; tail -30 $O/prof2.log | cut -c1-300
+bash tools/profile_round.sh $RND $TAG 1 > $O/prof1.log 2>&1; tail -12 $O/prof1.log | cut -c1-200
+bash tools/profile_round.sh $RND $TAG 2 > $O/prof2.log 2>&1; tail -12 $O/prof2.log | cut -c1-200
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-400 $O/bench_default.json
+python bench.py --config 3 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err; cut -c1-200 $O/bench_cfg3.json
+python bench.py --config 4 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err; cut -c1-200 $O/bench_cfg4.json
+timeout 300 python tools/bench_e2e.py > $O/e2e.txt 2>&1; tail -6 $O/e2e.txt
