@@ -345,7 +345,7 @@ __global__ void absmax_f32_kernel(const float *__restrict__ x, size_t npix, int 
 
 namespace {
 // one 64-thread block per (launch, side): max over the slots -> hi / lo, slots re-zeroed
-__global__ void range_fold_kernel(uint32_t *cur, uint32_t *hi, uint32_t *lo)
+__global__ void range_fold_kernel(uint32_t *cur, uint32_t *hi, uint32_t *lo, uint32_t *summary)
 {
     uint32_t *w = cur + ((size_t)blockIdx.x * CN_RANGE_SLOTS + threadIdx.x) * CN_RANGE_STRIDE;
     uint32_t v = *w;
@@ -355,17 +355,27 @@ __global__ void range_fold_kernel(uint32_t *cur, uint32_t *hi, uint32_t *lo)
     if (threadIdx.x == 0) {
         hi[blockIdx.x] = max(hi[blockIdx.x], v);
         lo[blockIdx.x] = min(lo[blockIdx.x], v);
+        if (summary) {   // sticky two-word digest: largest value seen, smallest non-zero per-forward maximum
+            atomicMax(&summary[0], v);
+            if (v) atomicMin(&summary[1], v);
+        }
     }
 }
 }  // namespace
 
 extern "C" int cn_range_fold(uint32_t *cur, uint32_t *hi, uint32_t *lo, int n_launches, void *stream)
 {
+    return cn_range_fold_digest(cur, hi, lo, nullptr, n_launches, stream);
+}
+
+extern "C" int cn_range_fold_digest(uint32_t *cur, uint32_t *hi, uint32_t *lo, uint32_t *summary,
+                                    int n_launches, void *stream)
+{
     if (!cur || !hi || !lo) return CN_ERR_NULL;
     if (n_launches <= 0) return CN_OK;
     static_assert(CN_RANGE_SLOTS == 64, "one wave per (launch, side)");
     hipLaunchKernelGGL(range_fold_kernel, dim3(2 * n_launches), dim3(CN_RANGE_SLOTS), 0,
-                       (hipStream_t)stream, cur, hi, lo);
+                       (hipStream_t)stream, cur, hi, lo, summary);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -33,6 +33,8 @@ from .native import (ConvDesc, F32sCtl, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTY
 TOP_LOG2 = 10
 F16_MAX = 65504.0
 LOW_WATER = 2.0 ** -3      # a per-forward maximum below this (stored units) asks for re-calibration
+F16_MAX_BITS = 0x477FE000  # float32 bit patterns of the two bounds (non-negative floats order like
+LOW_WATER_BITS = 0x3E000000  # unsigned integers: the range words are compared as bits)
 W_TOP_LOG2 = 14            # weight rows are pre-scaled to max |w| in [2^13, 2^14)
 
 
@@ -201,6 +203,11 @@ class PlanBuilder:
                 self.range_stat = torch.zeros((2, self.RANGE_LAUNCHES, 2), device=self.device,
                                               dtype=torch.int32)
                 self.range_stat[1].fill_(0x7f800000)
+                # sticky digest of the tables (cn_range_fold_digest) + its pinned host mirror: what
+                # the per-forward check reads (8 bytes, no table walk)
+                self.range_sum = torch.tensor([0, 0x7f800000], device=self.device, dtype=torch.int32)
+                self.range_sum_host = torch.tensor([0, 0x7f800000], dtype=torch.int32).pin_memory()
+                self.range_sum_event = torch.cuda.Event()
             slot = len(self.range_slots)
             if slot >= self.RANGE_LAUNCHES:
                 raise native.NativeError("too many f32s launches for the range table")
@@ -832,11 +839,15 @@ class PlanBuilder:
             lib, n = self.lib, len(self.range_slots)
             cur = ctypes.c_void_p(self.range.data_ptr())
             hi, lo = (ctypes.c_void_p(self.range_stat[i].data_ptr()) for i in range(2))
+            dig = ctypes.c_void_p(self.range_sum.data_ptr())
+            dev_sum, host_sum, ev = self.range_sum, self.range_sum_host, self.range_sum_event
 
             def run():
-                rc = lib.cn_range_fold(cur, hi, lo, n, native.stream_ptr())
+                rc = lib.cn_range_fold_digest(cur, hi, lo, dig, n, native.stream_ptr())
                 if rc:
-                    native.check(rc, "cn_range_fold")
+                    native.check(rc, "cn_range_fold_digest")
+                host_sum.copy_(dev_sum, non_blocking=True)   # 8 bytes; read after ev completes
+                ev.record()
             self.ops.append(run)
             self.meta.append(dict(kind="range", flops=0, bytes=0))
             self.trace.append(("range", None))
@@ -917,12 +928,32 @@ class Plan:
         lo = host[1].contiguous().view(torch.float32).tolist()
         return [(lid, (hi[i][0], lo[i][0]), (hi[i][1], lo[i][1])) for i, lid in enumerate(b.range_slots)]
 
+    def range_quick(self):
+        """The same verdict as ``range_status`` from the two-word digest the fold launch keeps
+        (largest value ever split, smallest non-zero per-forward maximum): waits for the last
+        forward's 8-byte copy, reads two integers.  The digest is sticky until ``range_status``
+        has looked at the tables."""
+        b = self.b
+        if b.range is None or not b.range_slots:
+            return "ok"
+        b.range_sum_event.synchronize()
+        hi, lo = (int(v) & 0xffffffff for v in b.range_sum_host.tolist())
+        if hi > F16_MAX_BITS:                     # beyond 65504, inf or NaN bit patterns
+            return "overflow"
+        return "low" if lo < LOW_WATER_BITS else "ok"
+
     def range_status(self, reset=True):
         """'ok', 'low' (some launch's largest value fell below LOW_WATER in stored units: results
         are still within bounds but the tensor should be re-calibrated), or 'overflow' (a value
         beyond the fp16 range was clamped: the results of the forwards since the last look are
-        INVALID); plus the offending entries."""
+        INVALID); plus the offending entries.  The tables are only walked when the digest says
+        something is out of bounds."""
+        if self.range_quick() == "ok":
+            return "ok", []
         rep = self.range_report(reset)
+        if reset and rep is not None:
+            self.b.range_sum.copy_(torch.tensor([0, 0x7f800000], dtype=torch.int32))
+            self.b.range_sum_host.copy_(torch.tensor([0, 0x7f800000], dtype=torch.int32))
         if rep is None:
             return "ok", []
         over = [r for r in rep if r[1][0] > F16_MAX or r[2][0] > F16_MAX or

@@ -93,6 +93,8 @@ def _declare(lib):
     lib.cn_absmax_f32.argtypes = [vp, sz, i, i, vp, vp]
     lib.cn_range_fold.restype = i
     lib.cn_range_fold.argtypes = [vp, vp, vp, i, vp]
+    lib.cn_range_fold_digest.restype = i
+    lib.cn_range_fold_digest.argtypes = [vp, vp, vp, vp, i, vp]
     lib.cn_maxpool_nhwc_scaled.restype = i
     lib.cn_maxpool_nhwc_scaled.argtypes = [vp, vp, i, i, i, i, i, i, i, i, f, vp]
     lib.cn_dcn_v2_forward_nhwc.restype = i

@@ -228,6 +228,12 @@ int cn_absmax_f32(const float *x, size_t npix, int C, int pitch, uint32_t *word,
  * lo = min(lo, m), slots = 0 -- the host reads hi / lo whenever it synchronises anyway (largest
  * and smallest per-forward maximum since its last look) instead of after every forward */
 int cn_range_fold(uint32_t *cur, uint32_t *hi, uint32_t *lo, int n_launches, void *stream);
+/* The same, plus a sticky two-word digest for a cheap host check: summary[0] = max over all
+ * (launch, side) values seen so far (float bits; > 65504 or NaN bits = something was clamped),
+ * summary[1] = the smallest NON-ZERO per-forward maximum so far (initialise to 0x7f800000).  The
+ * host reads 8 bytes per forward and walks the hi / lo tables only when the digest is out of bounds. */
+int cn_range_fold_digest(uint32_t *cur, uint32_t *hi, uint32_t *lo, uint32_t *summary,
+                         int n_launches, void *stream);
 
 /* ------------------------------------------------------------------------
  * Dense convolution as an implicit GEMM on fp32 MFMA (no im2col buffer).
