@@ -938,6 +938,7 @@ extern int cn_tune_stagger_pct;  // cn_conv3x3.hip
 extern int cn_tune_f32s_lds_weights;  // cn_conv3x3.hip
 extern int cn_tune_f32s_policy;       // cn_conv3x3.hip
 extern int cn_tune_heads_remap;       // cn_conv3x3.hip
+extern int cn_tune_heads_reg;         // cn_conv3x3.hip
 int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale, const float *shift,
                         void *y, int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
                         int relu, int vec_out, int setprio, int dtype_flags, const cn_f32s_ctl *ctl,
@@ -1736,6 +1737,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 22 && (value == 0 || value == 1)) {
         g_tune_dcn_tile2d = value;
+        return CN_OK;
+    }
+    if (key == 26 && value >= 0 && value <= 3) {
+        cn_tune_heads_reg = value;
         return CN_OK;
     }
     if (key == 24 && value >= 0 && value <= 3) {

@@ -24,6 +24,7 @@
 // cn_set_tuning key 18: phase shift of co-resident workgroups, percent of one tile's MFMA time
 // (0 = off); see the kernel prologue
 int cn_tune_stagger_pct = 100;
+int cn_tune_heads_reg = 1;     // cn_set_tuning key 26 (A/B): fused f32s heads with the hidden layer in registers
 int cn_tune_heads_remap = 1;   // cn_set_tuning key 24 (A/B): bit 0 = fused heads, bit 1 = multi-block Cout, on a 1-D row-interleaved grid
 int cn_tune_f32s_policy = 0;   // cn_set_tuning key 21 (A/B): bit 0 = 128-wide tiles as eight waves three taps ahead, bit 1 = 64-wide tiles two taps ahead
 // f32s: taps a weight tile is requested ahead of its use (1 = the fp32 schedule; build-time so that
@@ -103,6 +104,11 @@ constexpr int c3_epi_rows()
     return ((size_t)BM * (BN + 4) <= 17408) ? BM : BM / WM;
 }
 
+// fused heads with the hidden layer in registers: [2][BN] hidden scale / shift of the slice,
+// [W2_ROWS][2] bias / output scale of the 1x1 rows (behind rowoff)
+template <int BN, int WM, bool HEADS>
+constexpr size_t c3_table_floats() { return (HEADS && WM == 4) ? (size_t)(2 * BN + 2 * W2_ROWS) : 0; }
+
 template <int TW, int BN, int WM, bool HEADS, int BM, int NBUFB = 2>
 constexpr size_t c3_union_floats()
 {
@@ -110,6 +116,8 @@ constexpr size_t c3_union_floats()
     constexpr size_t tiles = (size_t)((TH + 2) * (TW + 2) * LDT + NBUFB * BN * LDT);
     // fused heads: S[128][LDS2] shares the main loop's tile space; the 1x1 weights sit behind it
     constexpr size_t cs = HEADS ? (size_t)128 * LDS2 : (size_t)c3_epi_rows<BN, WM, BM>() * (BN + 4);
+    // register-resident hidden layer (fused heads as 4 x 1 waves, f32s): no S, no 1x1 weights in LDS
+    if (HEADS && WM == 4) return tiles;
     return (tiles > cs ? tiles : cs) + (HEADS ? (size_t)W2_ROWS * LDS2 : 0);
 }
 
@@ -143,7 +151,11 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     constexpr int RPP = NT / 8;       // LDS rows staged per pass of the block
     static_assert(!HEADS || NT == 256, "fused heads are built for 4 waves");
     static_assert(!HEADS || BM == 128, "fused heads are built for 128-pixel tiles");
-    static_assert(!HEADS || (BN == HEAD_CONV && sizeof(T) == 4), "fused heads: fp32 / f32s, 64 hidden channels");
+    // HREG: the head's hidden layer never leaves the registers (4 x 1 waves, f32s; BN = 64 or 128)
+    constexpr bool HREG = HEADS && SPLIT && WM == 4 && WN == 1;
+    static_assert(!HEADS || (WM == 4) == HREG, "4 x 1 fused heads are the f32s register form");
+    static_assert(!HEADS || sizeof(T) == 4, "fused heads: fp32 / f32s");
+    static_assert(!HEADS || HREG || BN == HEAD_CONV, "LDS-staged fused heads: 64 hidden channels per slice");
     static_assert(LDS2 * 4 >= 2 * 128 + 16, "a hidden row holds two 128-byte f32s groups + the bias column");
     constexpr int EPV = C3Elem<T>::EPV;
     constexpr int BKE = 8 * EPV;
@@ -362,8 +374,12 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
                         for (int j = 0; j < NB; ++j) {
                             const int ka = (term == 0) ? 2 + s : s;
                             const int kb = (term == 1) ? 2 + s : s;
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ka][i], bf[kb][j],
-                                                                               acc[i][j], 0, 0, 0);
+                            if constexpr (HREG)   // D[hidden][pixel]: the hidden layer lands lane = pixel
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kb][j], af[ka][i],
+                                                                                   acc[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ka][i], bf[kb][j],
+                                                                                   acc[i][j], 0, 0, 0);
                         }
             if (a.setprio) __builtin_amdgcn_s_setprio(0);
             return;
@@ -646,6 +662,138 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     };   // main_loop
 
     if constexpr (HEADS) {
+        if constexpr (HREG) {
+            // ---- register-resident hidden layer (f32s, waves 4 x 1: wave w owns the tile's pixel row
+            // w = 32 pixels and ALL hidden channels of the slice).  The 3x3 GEMM is computed as
+            // D[hidden][pixel] (operands swapped in compute()), so lane (l31, h) holds, per 32-wide
+            // hidden block j and register group g, the four CONSECUTIVE hidden channels
+            // 32j + 8g + 4h + {0..3} of pixel l31: relu(acc * scale + bias1) is split there and fed
+            // to the 1x1 GEMM as its B operand straight from registers -- no S tile in LDS, no
+            // barrier between the two GEMMs, and slices of 128 hidden channels (the 128-wide main
+            // loop of the trunk) instead of 64.  K order of a 16-deep step s of block j: lane half h
+            // contributes hidden 32j + 16s + 4h + {0..3} and 32j + 16s + 8 + 4h + {0..3} -- the 1x1
+            // weights are read from the row-major (cout, hidden) matrix in exactly that order (two
+            // 16-byte loads per fragment, L1 / L2 resident: a head's matrix is <= 96 KB) and split
+            // on the way.
+            const int head = vby;
+            const int cout2 = hd.cout[head];
+            const int slices = hd.slices;
+            const int hidden = slices * BN;
+            float *y2 = hd.y[head];
+            const float *w2 = hd.w[head];
+            float *tab = reinterpret_cast<float *>(rowoff + BM);   // [2][BN] scale1 / bias1 of the slice
+            float *tab2 = tab + 2 * BN;                              // [W2_ROWS][2] bias2 / oscale
+            const int HWp = a.H * a.W;
+            const int mpix = wave * 32 + l31;            // this lane's pixel (column of both D's)
+            constexpr int NJB = W2_ROWS / 32;
+            const int nblk = (cout2 + 31) / 32;          // <= NJB (checked by the caller)
+            for (int row = tid; row < W2_ROWS; row += NT) {
+                const float *b2 = hd.bias[head], *os2 = hd.oscale[head];
+                tab2[2 * row] = (b2 && row < cout2) ? b2[row] : 0.f;
+                tab2[2 * row + 1] = (os2 && row < cout2) ? os2[row] : 1.f;
+            }
+            cn_f32x16 acc2[NJB];
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[jb][r] = 0.f;
+            // this lane's rows of the 1x1 matrix (padded rows: computed, never stored)
+            const float *w2row[NJB];
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) w2row[jb] = w2 + (size_t)min(jb * 32 + l31, cout2 - 1) * hidden + 4 * lh;
+            for (int sl = 0; sl < slices; ++sl) {
+                n0 = (head * slices + sl) * BN;
+                set_weight_rows();
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                if (sl) __syncthreads();              // every wave has read the previous slice's table
+                for (int n = tid; n < BN; n += NT) {
+                    tab[n] = a.scale ? a.scale[n0 + n] : 1.f;
+                    tab[BN + n] = a.shift ? a.shift[n0 + n] : 0.f;
+                }
+                main_loop();                           // (its first barrier publishes the tables)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    // 1x1 weights of hidden block j for one output block: 2 steps x 2 runs of 4
+                    // (requested one output block ahead; the first under the hidden block's VALU work)
+                    cn_f32x4 wq[2][2][2];
+                    auto load_w2 = [&](cn_f32x4 (&dst)[2][2], int jb) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int pq = 0; pq < 2; ++pq)
+                                dst[s2][pq] = *reinterpret_cast<const cn_f32x4 *>(
+                                    w2row[jb] + sl * BN + 32 * j + 16 * s2 + 8 * pq);
+                    };
+                    load_w2(wq[0], 0);
+                    // hidden values of block j -> (high, low) B fragments
+                    c3_f16x8 shi[2], slo[2];
+                    {
+                        cn_f16x4v hq[4], lq[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = 32 * j + 8 * g + 4 * lh;
+                            const cn_f32x4 s1 = *reinterpret_cast<const cn_f32x4 *>(tab + n);
+                            const cn_f32x4 b1 = *reinterpret_cast<const cn_f32x4 *>(tab + BN + n);
+                            cn_f32x4 t = {acc[0][j][4 * g], acc[0][j][4 * g + 1], acc[0][j][4 * g + 2], acc[0][j][4 * g + 3]};
+                            t = t * s1 + b1;
+                            if (a.relu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
+                            }
+                            cn_rng_upd4(rng_out, t);
+                            cn_split4(t, hq[g], lq[g]);
+                        }
+                        shi[0] = __builtin_shufflevector(hq[0], hq[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        shi[1] = __builtin_shufflevector(hq[2], hq[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                        slo[0] = __builtin_shufflevector(lq[0], lq[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        slo[1] = __builtin_shufflevector(lq[2], lq[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int jb = 0; jb < NJB; ++jb)
+                        if (jb < nblk) {   // uniform
+                            if (jb + 1 < nblk) load_w2(wq[(jb + 1) & 1], jb + 1);
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                cn_f16x4v wh0, wl0, wh1, wl1;
+                                cn_split4(wq[jb & 1][s2][0], wh0, wl0);
+                                cn_split4(wq[jb & 1][s2][1], wh1, wl1);
+                                const c3_f16x8 whi = __builtin_shufflevector(wh0, wh1, 0, 1, 2, 3, 4, 5, 6, 7);
+                                const c3_f16x8 wlo = __builtin_shufflevector(wl0, wl1, 0, 1, 2, 3, 4, 5, 6, 7);
+                                acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, shi[s2], acc2[jb], 0, 0, 0);
+                                acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, slo[s2], acc2[jb], 0, 0, 0);
+                                acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, shi[s2], acc2[jb], 0, 0, 0);
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);   // hidden blocks one after the other (registers)
+                }
+            }
+            {
+                const int off = rowoff[mpix];                // (b*H + oy)*W + ox, or -1
+                const int pix = off - b * HWp;
+                if (off >= 0) {
+#pragma unroll
+                    for (int jb = 0; jb < NJB; ++jb)
+                        if (jb < nblk) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int co = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                if (co < cout2)
+                                    y2[((size_t)b * cout2 + co) * HWp + pix] = acc2[jb][r] * tab2[2 * co + 1] + tab2[2 * co];
+                            }
+                        }
+                }
+            }
+            if (a_range) {
+                cn_rng_commit(a_range, 0, rng_out);
+                if (a.in_plain) cn_rng_commit(a_range, 1, rng_in);
+            }
+            return;
+        } else {
         // ---- fused heads (resnet_dcn.py:155-177, pose_dla_dcn.py:456-468, large_hourglass.py:
         // make_kp_layer): per 64-channel slice of the head's hidden layer, hidden =
         // relu(conv3x3 + bias1) stays in LDS as S[128 pixels][64] and the 1x1 convolution
@@ -793,6 +941,7 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
             }
         }
         return;
+        }   // !HREG
     } else {
         main_loop();
     }
@@ -975,7 +1124,8 @@ template <typename T, int TW, int BN, int WM, int WN, bool HEADS = false, int BM
 int launch_c3(const C3Args &a, hipStream_t st, const C3Heads *hd = nullptr)
 {
     constexpr int TH = BM / TW;
-    constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS, BM, NBUFB>() * 4 + BM * 4;
+    constexpr size_t lds = c3_union_floats<TW, BN, WM, HEADS, BM, NBUFB>() * 4 + BM * 4 +
+                           c3_table_floats<BN, WM, HEADS>() * 4;
     CN_SET_MAX_LDS_ONCE((conv3x3s1_kernel<T, TW, BN, WM, WN, HEADS, BM, KSKIP, DECONV, NBUFB, PDQ>), lds);
     C3Args b = a;
     b.tiles_x = cn_cdiv(a.W, TW);
@@ -1211,6 +1361,21 @@ extern "C" int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int 
     a.cin_pad = (Cin + 31) / 32 * 32;
     a.cout_pad = a.Cout;
     a.nchunk = a.cin_pad / 32;
+    // f32s, maps of whole 32-pixel rows, every head <= 96 outputs: the hidden layer stays in registers
+    // (4 x 1 waves; 128-wide slices when the hidden width allows); cn_set_tuning key 26 = 0: LDS form
+    // (one 64-channel slice, i.e. res / resdcn heads: the LDS form below with its deeper weight prefetch
+    // measured faster, 0.453 vs 0.492 ms; from two slices on this form wins: dla_34 1.84 -> 1.72 ms)
+    if (f32s && W >= 32 && cn_tune_heads_reg && (head_conv > HEAD_CONV || cn_tune_heads_reg == 3)) {
+        bool small = true;
+        for (int h = 0; h < n_heads; ++h) small = small && heads[h].cout <= W2_ROWS;
+        if (small) {
+            if (head_conv % 128 == 0 && cn_tune_heads_reg == 2) {   // 128-wide slices: register-bound (107 spills), A/B only
+                hd.slices = head_conv / 128;
+                return launch_c3<cn_f32s, 32, 128, 4, 1, true, 128, false, false, 2, 1>(a, st, &hd);
+            }
+            return launch_c3<cn_f32s, 32, 64, 4, 1, true, 128, false, false, 2, 1>(a, st, &hd);
+        }
+    }
     if (hd.slices > 1) {
         if (f32s)
             return (W >= 32) ? launch_c3<cn_f32s, 32, 64, 2, 2, true, 128, false, false, 2, 1>(a, st, &hd)

@@ -124,6 +124,9 @@ const char *cn_arch(void);
  *         takes when the grid has >= 192 workgroups (default), 1 = the global-gather form always,
  *         2 = the register-sampling form for every shape it takes (tests), 3 = the earlier
  *         wave-specialised window form for every shape it takes (kept for comparison: slower).
+ * key 26: fused f32s heads with a hidden layer wider than 64: 1 = hidden layer kept in registers
+ *         (default), 0 = staged through LDS; 2 = 128-wide slices (register-bound, A/B only),
+ *         3 = the register form for 64-wide hidden layers too (slower there, A/B only).
  * key 24: fused heads: 1 = 1-D grid with the heads of a pixel tile dispatched together on one XCD
  *         (default), 0 = one grid row per head. */
 int cn_set_tuning(int key, int value);

@@ -388,6 +388,59 @@ def test_fused_heads(dev, cfg, split):
             _check(outs[name].t.cpu(), ref[name])
 
 
+@pytest.mark.parametrize("form", [0, 1, 2, 3])
+def test_fused_heads_hidden_layer_forms(dev, form):
+    """cn_set_tuning key 26: the f32s fused heads with the hidden layer staged through LDS (0), kept
+    in registers for hidden widths > 64 (1, default), in 128-wide slices (2) and for 64-wide hidden
+    layers too (3) -- all against the per-head Sequential on torch CPU, plus run-to-run bit equality
+    at a batch that puts several workgroups on every CU."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder
+    lib = native.lib()
+    assert lib.cn_set_tuning(26, form) == 0
+    try:
+        for (B, Fc, H, W, heads, hidden) in [(2, 64, 32, 32, {"hm": 80, "wh": 2, "reg": 2}, 256),
+                                              (1, 64, 19, 33, {"hm": 1, "hps": 34, "hm_hp": 17}, 256),
+                                              (1, 96, 8, 64, {"hm": 5, "wh": 2}, 128),
+                                              (2, 64, 16, 32, {"hm": 80, "wh": 2}, 64)]:
+            x = torch.from_numpy(synth.normal((B, Fc, H, W), 1.0, 11))
+            pairs, ref = {}, {}
+            for i, (name, classes) in enumerate(heads.items()):
+                c1 = torch.nn.Conv2d(Fc, hidden, 3, padding=1, bias=True)
+                c2 = torch.nn.Conv2d(hidden, classes, 1, bias=True)
+                with torch.no_grad():
+                    c1.weight.copy_(torch.from_numpy(synth.normal(tuple(c1.weight.shape), (2.0 / (Fc * 9)) ** 0.5, 20 + i)))
+                    c1.bias.copy_(torch.from_numpy(synth.normal((hidden,), 0.2, 30 + i)))
+                    c2.weight.copy_(torch.from_numpy(synth.normal(tuple(c2.weight.shape), 0.15, 40 + i)))
+                    c2.bias.copy_(torch.from_numpy(synth.normal((classes,), 0.5, 50 + i)))
+                    ref[name] = c2(F.relu(c1(x)))
+                pairs[name] = (c1, c2)
+            pb = PlanBuilder(dev, B, H, W, split=True)
+            outs = pb.heads_from_convs(pb.packed(_nhwc_act(x, dev)), pairs)
+            _run(pb)
+            for name in heads:
+                _check(outs[name].t.cpu(), ref[name])
+        # determinism at B = 32, 64 x 64 maps (2048 tiles x heads: several workgroups per CU)
+        B, Fc, H, W, hidden = 32, 64, 64, 64, 256
+        pairs = {}
+        for i, (name, classes) in enumerate({"hm": 80, "wh": 2}.items()):
+            c1 = torch.nn.Conv2d(Fc, hidden, 3, padding=1, bias=True)
+            c2 = torch.nn.Conv2d(hidden, classes, 1, bias=True)
+            pairs[name] = (c1, c2)
+        pb = PlanBuilder(dev, B, H, W, split=True)
+        xa = pb.packed(_nhwc_act(torch.randn((B, Fc, H, W)).relu_(), dev))
+        outs = pb.heads_from_convs(xa, pairs)
+        first = None
+        for _ in range(6):
+            _run(pb)
+            cur = torch.cat([outs[n].t.reshape(-1) for n in outs]).clone().view(torch.int32)
+            if first is None:
+                first = cur
+            assert torch.equal(cur, first)
+    finally:
+        lib.cn_set_tuning(26, 1)
+
+
 def test_f32s_kernels_are_run_to_run_deterministic(dev):
     """Repeated launches at the benchmark batch (several workgroups per CU) give bit-identical
     results.  Guards the operand hazard found in round 2: a fragment read scheduled behind an
