@@ -934,6 +934,9 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
 int cn_conv3x3_c16(const float *x, const float *w_packed, const float *scale, const float *shift,
                    float *y, int B, int H, int W, int Ho, int Wo, int Cin, int Cout, int stride,
                    int in_pitch, int out_pitch, int relu, hipStream_t st);
+int cn_conv3x3_c16s(const float *x, const void *w_packed, const float *scale, const float *shift,
+                    float *y, int B, int H, int W, int Ho, int Wo, int Cin, int Cout, int stride,
+                    int in_pitch, int out_pitch, int relu, const cn_f32s_ctl *ctl, hipStream_t st);
 extern int cn_tune_stagger_pct;  // cn_conv3x3.hip
 extern int cn_tune_f32s_lds_weights;  // cn_conv3x3.hip
 extern int cn_tune_f32s_policy;       // cn_conv3x3.hip
@@ -1286,6 +1289,16 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         rc = cn_conv3x3_c16((const float *)x, (const float *)w_packed, scale, shift, (float *)y, d->B,
                             d->H, d->W, d->Ho, d->Wo, d->Cin, d->Cout, d->stride, d->in_pitch,
                             d->out_pitch, d->relu, st);
+        if (rc != CN_ERR_UNSUPPORTED) return rc;
+    }
+    // the same layers in f32s arithmetic: plain input split while staged, plain output (cn_conv16.hip)
+    if (!g_tune_nohalo && f32s && (d->flags & CN_CONV_X_PLAIN) && (d->flags & CN_CONV_Y_PLAIN) && !residual &&
+        a.ksplit == 1 && d->Cin == 16 && d->Cout <= 32 && d->KH == 3 && d->KW == 3 && d->pad_h == 1 &&
+        d->pad_w == 1 && d->dil == 1 && d->oy_mul == 1 && d->ox_mul == 1 && d->oy_add == 0 &&
+        d->ox_add == 0 && d->OH == d->Ho && d->OW == d->Wo && d->in_layout == CN_LAYOUT_NHWC) {
+        rc = cn_conv3x3_c16s((const float *)x, w_packed, scale, shift, (float *)y, d->B, d->H, d->W,
+                             d->Ho, d->Wo, d->Cin, d->Cout, d->stride, d->in_pitch, d->out_pitch,
+                             d->relu, &d->ctl, st);
         if (rc != CN_ERR_UNSUPPORTED) return rc;
     }
     // 3x3 / stride 1 / pad 1: the LDS-halo kernel (cn_conv3x3.hip) unless split-K applies

@@ -309,12 +309,22 @@ class PlanBuilder:
         return (hit[0], hit[1]) if (f32s or prescale) else hit[0]
 
     @staticmethod
-    def _f32s_conv_form(kh, kw, stride, padding, dilation, out_nchw, ci=0, co=0):
-        """Convolution forms that run in f32s: every NHWC-input form except DLA's 16-channel
-        3x3 layers (level0 / level1), which are HBM-bound at full resolution and keep their
-        dedicated 16x16x4 kernel (cn_conv16.hip: half the K padding of a 32-channel chunk)."""
-        return not (ci == 16 and co <= 32 and (kh, kw, padding, dilation) == (3, 3, 1, 1)
-                    and not out_nchw)
+    def _narrow_form(kh, kw, padding, dilation, out_nchw, ci, co):
+        """DLA's 16-channel 3x3 layers (level0 / level1, pose_dla_dcn.py:237-240): plain fp32 tensors
+        at full resolution (an f32s tensor would be padded to 32 channels: twice the bytes) and
+        their own kernels (cn_conv16.hip)."""
+        return ci == 16 and co <= 32 and (kh, kw, padding, dilation) == (3, 3, 1, 1) and not out_nchw
+
+    @classmethod
+    def _f32s_conv_form(cls, kh, kw, stride, padding, dilation, out_nchw, ci=0, co=0):
+        """Convolution forms that run in f32s: every NHWC-input form; of the 16-channel layers the
+        stride-1 one, and only in f32s ARITHMETIC (plain input split while it is staged, plain
+        output: conv16s_kernel; CN_C16_F32S=0 keeps it on the fp32 16x16x4 kernel)."""
+        if cls._narrow_form(kh, kw, padding, dilation, out_nchw, ci, co):
+            # stride 1 (level0: 0.485 -> 0.334 ms at B = 32); the stride-2 form (level1) is
+            # register-bound in f32s (0.245 -> 0.476 ms) and stays on the fp32 kernel
+            return stride == 1 and os.environ.get("CN_C16_F32S", "1") != "0"
+        return True
 
     def _grow_ws(self, need):
         # split-K scratch shared by every launch (stream-ordered; ops read self.ws at run time)
@@ -342,6 +352,8 @@ class PlanBuilder:
         Wo = _out_size(x.W, kw, stride, padding, dilation)
         use_s = self.split and not x.nchw and self._f32s_conv_form(kh, kw, stride, padding,
                                                                   dilation, out_nchw, ci, co)
+        if use_s and self._narrow_form(kh, kw, padding, dilation, out_nchw, ci, co) and residual is None:
+            x, out_plain = self.plain(x), True     # plain in, plain out: only the arithmetic is f32s
         # ``pool`` = (kernel, stride, padding) of a MaxPool2d behind the layer (the ResNet stem,
         # resnet_dcn.py:138-141): inside the stem kernel when it takes the shape, else a second launch
         fuse_pool = False

@@ -54,7 +54,8 @@ def _bn(C, seed):
     # partially filled last K chunk (DLA level0: 16 -> 16): empty 8-channel groups are skipped
     (2, 16, 64, 64, 16, 3, 1, 1, False, True, True, False),
     (1, 40, 20, 24, 24, 3, 1, 1, True, False, False, True),
-    # 16-channel input on 128-pixel-multiple rows: the 16x16x4-MFMA kernel (cn_conv16.hip)
+    # 16-channel input on 128-pixel-multiple rows: the 16-channel kernels (cn_conv16.hip: fp32
+    # 16x16x4 MFMA / f32s 16x16x32 f16 MFMA with plain tensors on both sides)
     (2, 16, 20, 128, 16, 3, 1, 1, False, True, True, False),    # DLA level0 form
     (1, 16, 33, 256, 32, 3, 2, 1, False, True, True, False),    # DLA level1 form (stride 2)
     (2, 16, 12, 256, 24, 3, 1, 1, True, False, False, False),   # two N blocks, ragged Cout
@@ -125,7 +126,9 @@ def _conv_case(dev, cfg, split=False):
     pb = PlanBuilder(dev, B, H, W, split=split)
     y = pb.conv(_nhwc_act(x, dev), w, bias=bias, bn=bn, relu=relu,
                 residual=_nhwc_act(res, dev) if use_res else None, stride=s, padding=p)
-    want_s = split and PlanBuilder._f32s_conv_form(k, k, s, p, 1, False, Cin, Cout)
+    # (the 16-channel layers compute in f32s but keep plain tensors on both sides)
+    want_s = split and PlanBuilder._f32s_conv_form(k, k, s, p, 1, False, Cin, Cout) and \
+        not PlanBuilder._narrow_form(k, k, p, 1, False, Cin, Cout)
     assert y.fmt == ("f32s" if want_s else "f32")
     y = pb.plain(y)
     _run(pb)
