@@ -1,16 +1,23 @@
 // cn_dcn2.hip -- fused modulated deformable convolution (DCNv2) forward, f32s arithmetic, with
-// the input staged as an LDS WINDOW and the workgroup split into sampling and multiplying waves.
+// the input staged as an LDS WINDOW.  Two kernels:
+//   dcn_reg_kernel  (the product kernel, second half of this file): every lane samples its own
+//                   MFMA operand from the window; no A tile, no per-step barrier;
+//   dcn_win_kernel  (first half; kept for comparison, cn_set_tuning key 23 = 3): sampling waves
+//                   write an A tile that multiplying waves consume -- correct, but slower than
+//                   the global-gather form on every shape (see the note above dcn_reg_kernel).
 //
 // Replaces: DCN.forward -> DCNv2Function.forward -> dcn_v2_cuda_forward
 //   (DCNv2/dcn_v2.py:64-70, dcn_v2_func.py:22-38, src/dcn_v2_cuda.c:10-102): per sample a bias
 //   SGEMM, modulated_deformable_im2col_gpu_kernel (src/cuda/dcn_v2_im2col_cuda.cu:118-180, bilinear
 //   sampler :18-47) writing a Cin*9*HW column buffer, and the main SGEMM.
 //
-// Why (measured, round 3): the global-gather form (cn_conv.hip igemm_kernel<A_DCN>) moves 16 bytes
-// through L1 / L2 per (pixel, tap, channel quad) -- 4 corners x fp32 -- i.e. 295 KB per 64-pixel
-// tile and 32-channel chunk; on 64->64@128^2 that is 17 TB/s of L2 -> L1 traffic at 108 TFLOP/s
-// with the matrix pipe 15 % busy: every (tap, chunk) step is a dependent chain record -> four
-// gathers -> blend -> LDS -> barrier -> MFMA of ~2.4 us.  Here
+// Why a window at all (measured, round 3): the global-gather form (cn_conv.hip igemm_kernel<A_DCN>)
+// moves 16 bytes through L1 / L2 per (pixel, tap, channel quad) -- 4 corners x fp32 -- i.e. 295 KB
+// per 64-pixel tile and 32-channel chunk; on 64->64@128^2 that is 17 TB/s of L2 -> L1 traffic at
+// 108 TFLOP/s with the matrix pipe 15 % busy: every (tap, chunk) step is a dependent chain
+// record -> four gathers -> blend -> LDS -> barrier -> MFMA of ~2.4 us.
+//
+// dcn_win_kernel (the first design):
 //   * a workgroup owns an 8 x 8 block of output pixels of one image and stages, per 32-channel
 //     chunk, the (8 + 2 + 2R)^2 input WINDOW around it ONCE (37 KB at R = 3: 8x less L2 traffic;
 //     NHWC, so the copy is whole 128-byte lines); the four bilinear corners of every sample are
@@ -422,7 +429,7 @@ int launch_dcn2(const Dcn2Args &a, hipStream_t st)
 //     (cn_conv.hip pack_weight_f32s_frag_kernel: 64 bytes per lane per (tap, chunk, 32 rows)),
 //     global -> registers, requested at the top of the step and landed under the sampling;
 //   * no barrier inside a chunk: waves run free over the nine taps; two barriers per chunk
-//     swap the window.  Two workgroups per CU (72 KB of LDS each) overlap each other's swaps.
+//     swap the window.  Two workgroups per CU (74 KB of LDS each) overlap each other's swaps.
 // acc[j][r]: output channel 32j + (r & 3) + 8 (r >> 2) + 4h of pixel l31 -- four consecutive
 // channels per register quad, staged through (wave-private) LDS for whole-line stores.
 constexpr int R_NT = 256;
