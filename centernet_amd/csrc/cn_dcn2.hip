@@ -828,6 +828,7 @@ int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, 
     if ((H & 7) || (W & 7) || (Cin & 31) || (Cout & 3) || Cout <= 32) return CN_ERR_UNSUPPORTED;
     if (variant == 0 && (W & 15)) return CN_ERR_UNSUPPORTED;
     if (H > 32767 || W > 32767 || (out_pitch & 3) || !cn_aligned16(y) || !cn_aligned16(x)) return CN_ERR_UNSUPPORTED;
+    if ((om_pitch & 1) || (((uintptr_t)om) & 7u)) return CN_ERR_UNSUPPORTED;   // (offset pairs are 8-byte loads)
     if ((size_t)B * H * W * Cin * 4 >= ((size_t)1 << 32)) return CN_ERR_UNSUPPORTED;   // 32-bit byte offsets
     const int bn = Cout > 64 ? 128 : 64;
     const int tsx = variant == 0 ? R_TX : TS;
