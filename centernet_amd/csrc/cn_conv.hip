@@ -771,6 +771,7 @@ int g_tune_bm256 = 0;       // cn_set_tuning key 14: 1 = 256-pixel tiles for 64-
 int g_tune_waves8 = 1;      // cn_set_tuning key 15: 8-wave workgroups for the 128-wide halo tiles
 int g_tune_occ4 = 0;        // cn_set_tuning key 19: 4-workgroups-per-CU form of the 64-wide halo tiles: 0 = by rounds rule, 1 = always, 2 = never
 int g_tune_dcn_form = 0;   // cn_set_tuning key 23: f32s deformable kernel, 0 = register-sampling window form (cn_dcn2.hip) when the shape takes it and the grid fills the chip, 1 = global-gather form always, 2 = register-sampling form for every shape it takes, 3 = wave-specialised window form for every shape it takes (comparison)
+int g_tune_stem16s = 1;     // cn_set_tuning key 27: f32s form of the stride-1 16-channel stem (DLA base_layer); 0 = fp32 kernel
 int g_tune_dcn_tile2d = 1; // cn_set_tuning key 22: deformable kernel, 1 = 8-wide pixel blocks as tiles (default), 0 = row segments
 int g_tune_dcn_window = 0; // cn_set_tuning key 11: 1 = LDS-window DCN (cn_dcn.hip); default global gather (faster, measured)
 int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip
@@ -1662,7 +1663,10 @@ extern "C" int cn_stem_f32s_supported(const cn_conv_desc *d)
     if (d->oy_mul != 1 || d->ox_mul != 1 || d->OH != d->Ho || d->OW != d->Wo) return 0;
     // cn_stem_conv_f32: persistent 7x7 window kernel, rows of whole 128-pixel tiles, stride 2,
     // more than 16 output channels
-    return (d->KH == 7 && d->KW == 7 && d->Wo % 128 == 0 && d->stride == 2 && d->Cout > 16) ? 1 : 0;
+    if (d->KH != 7 || d->KW != 7 || d->Wo % 128 != 0) return 0;
+    if (d->stride == 2 && d->Cout > 16) return 1;
+    // stem16s_kernel: stride 1, pad 3, <= 16 output channels (DLA base_layer)
+    return (d->stride == 1 && d->Cout <= 16 && d->pad_h == 3 && (d->W & 3) == 0 && g_tune_stem16s) ? 1 : 0;
 }
 
 extern "C" int cn_set_tuning(int key, int value)
@@ -1750,6 +1754,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 22 && (value == 0 || value == 1)) {
         g_tune_dcn_tile2d = value;
+        return CN_OK;
+    }
+    if (key == 27 && (value == 0 || value == 1)) {
+        g_tune_stem16s = value;
         return CN_OK;
     }
     if (key == 26 && value >= 0 && value <= 3) {

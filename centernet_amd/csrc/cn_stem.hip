@@ -858,6 +858,186 @@ int launch_stem_persist_f32s(const StemArgs &a, int B, hipStream_t st)
     return CN_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// f32s form of the 7x7 / stride 1 / pad 3 stem with <= 16 output channels (DLA base_layer,
+// pose_dla_dcn.py:229-233) on v_mfma_f32_16x16x32_f16.  The fp32 form (stem_persist_f32_kernel
+// <16, 1>) spends 37 x 32-cycle matrix instructions per 16 x 16 block (0.58 ms at B = 32, 512^2, twice
+// the fp32 matrix roof's 0.25 ms); here K = 21 window rows (c, ky) x 8 (kx = 0..6 + a zero-weight
+// pad) is walked as six steps of four rows -- lane group q = lane >> 4 holds k = 8q..8q+7 = row
+// 4s + q, kx = 0..7 -- i.e. 18 instructions of 16 cycles per block.
+// A lane's eight kx of a row are eight CONSECUTIVE fp16 of the window starting at its own pixel:
+// 2-byte granularity at stride 1.  Every plane is therefore kept twice, the second copy shifted
+// by one element, so that even and odd start columns both read four aligned dwords with
+// immediate offsets (copy E: column e at index e; copy O: column e at index e + 1).
+// Window = image columns x0 - 4 .. x0 + 131 (origin even: pairs of columns are 8-byte loads),
+// rows (c, ky) 0..20 + three zero rows for the zero-weight tail of step 5; high and low planes;
+// split ONCE while staged (image * x_mul, range word fed there).  Weights: the fp32 stem pack
+// [cout_pad][KP], k = (ky*7 + kx)*3 + c, split into registers at kernel start.  Output plain fp32.
+constexpr int S16_ROWB = 288;                    // bytes per window row of one copy (136 + 1 columns, padded)
+constexpr int S16_ROWS = 24;
+constexpr int S16_COPY = S16_ROWS * S16_ROWB;    // 6912 bytes per copy
+constexpr int S16_PAIRS = 68;                    // column pairs per row
+typedef _Float16 s16_f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t s16_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(NT, 2) void stem16s_kernel(const StemArgs a, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [hi E | hi O | lo E | lo O]
+    char *hiE = smem, *hiO = smem + S16_COPY, *loE = smem + 2 * S16_COPY, *loO = smem + 3 * S16_COPY;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int tpr = a.Wo / BM;
+    const float x_mul = a.x_mul;
+
+    // zero rows 21..23 of every copy (finite data under the zero weights of step 5)
+    for (int i = tid; i < 4 * 3 * (S16_ROWB / 4); i += NT) {
+        const int cp = i / (3 * (S16_ROWB / 4)), r = i - cp * (3 * (S16_ROWB / 4));
+        *reinterpret_cast<uint32_t *>(smem + cp * S16_COPY + 21 * S16_ROWB + r * 4) = 0u;
+    }
+
+    // weights of this lane: output channel l15, step s: window row 4s + lq = (c, ky), kx = 0..6 (+ zero)
+    s16_f16x8 wh[6], wl[6];
+#pragma unroll
+    for (int s2 = 0; s2 < 6; ++s2) {
+        const int r = 4 * s2 + lq;
+        const int c = r / 7, ky = r - c * 7;
+        float w8[8];
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) {
+            const bool ok = r < 21 && kx < 7 && l15 < a.Cout;
+            w8[kx] = ok ? a.w[(size_t)l15 * a.KP + ((ky * 7 + (kx < 7 ? kx : 0)) * 3 + c)] : 0.f;
+        }
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cn_split2_bits(w8[2 * e], w8[2 * e + 1], h[e], l[e]);
+        wh[s2] = __builtin_bit_cast(s16_f16x8, s16_u32x4{h[0], h[1], h[2], h[3]});
+        wl[s2] = __builtin_bit_cast(s16_f16x8, s16_u32x4{l[0], l[1], l[2], l[3]});
+    }
+    const float sc = (a.scale && l15 < a.Cout) ? a.scale[l15] : 1.f;
+    const float sf = (a.shift && l15 < a.Cout) ? a.shift[l15] : 0.f;
+
+    // staging: 21 rows x 68 column pairs over 256 threads; per pair the two columns and the one to
+    // their left (the shifted copy's pair)
+    constexpr int NPR = (21 * S16_PAIRS + NT - 1) / NT;   // 6
+    float v0[NPR], v1[NPR], vm[NPR];
+    float rng_in = 0.f;
+    auto prefetch = [&](int tile) {
+        const int xt = tile % tpr;
+        const int rowid = tile / tpr;                    // b*Ho + oy
+        const int b = rowid / a.Ho, oy = rowid - b * a.Ho;
+        const int ix0 = xt * BM - 4;
+        const float *img = a.x + (size_t)b * 3 * a.H * a.W;
+#pragma unroll
+        for (int u = 0; u < NPR; ++u) {
+            const int i = tid + u * NT;
+            const int row = min(i / S16_PAIRS, 20), pp = i % S16_PAIRS;   // (idle slots of the last trip: clamped, unused)
+            const int c = row / 7, ky = row - c * 7;
+            const int iy = oy - 3 + ky, ix = ix0 + 2 * pp;
+            const bool rok = i < 21 * S16_PAIRS && iy >= 0 && iy < a.H;
+            const bool ok = rok && ix >= 0 && ix < a.W;            // (W even: the pair is in or out as a whole)
+            const bool okm = rok && ix - 1 >= 0 && ix - 1 < a.W;
+            const float *rowp = img + ((size_t)c * a.H + (rok ? iy : 0)) * a.W;
+            const float2 pr = *reinterpret_cast<const float2 *>(rowp + (ok ? ix : 0));
+            const float lm = rowp[okm ? ix - 1 : 0];
+            v0[u] = ok ? pr.x : 0.f;
+            v1[u] = ok ? pr.y : 0.f;
+            vm[u] = okm ? lm : 0.f;
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int u = 0; u < NPR; ++u) {
+            const int i = tid + u * NT;
+            if (i < 21 * S16_PAIRS) {
+                const int row = i / S16_PAIRS, pp = i - row * S16_PAIRS;
+                const float s0 = v0[u] * x_mul, s1 = v1[u] * x_mul, sm = vm[u] * x_mul;   // real -> stored units
+                rng_in = fmaxf(rng_in, fmaxf(fabsf(s0), fabsf(s1)));
+                const float c0 = fminf(fmaxf(s0, -65504.f), 65504.f), c1 = fminf(fmaxf(s1, -65504.f), 65504.f);
+                const float cm = fminf(fmaxf(sm, -65504.f), 65504.f);
+                uint32_t he, le, ho, lo;
+                cn_split2_bits(c0, c1, he, le);       // copy E: columns (2p, 2p+1) at indices (2p, 2p+1)
+                cn_split2_bits(cm, c0, ho, lo);       // copy O: columns (2p-1, 2p) at indices (2p, 2p+1)
+                const int o = row * S16_ROWB + 4 * pp;
+                *reinterpret_cast<uint32_t *>(hiE + o) = he;
+                *reinterpret_cast<uint32_t *>(loE + o) = le;
+                *reinterpret_cast<uint32_t *>(hiO + o) = ho;
+                *reinterpret_cast<uint32_t *>(loO + o) = lo;
+            }
+        }
+    };
+
+    // A fragment base of (16-pixel block mb): start column x + 1 of the lane's pixel, row lq
+    unsigned abase[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int sc0 = wave * 32 + mb * 16 + l15 + 1;          // window column of kx = 0
+        abase[mb] = (unsigned)(((sc0 & 1) ? S16_COPY : 0) + lq * S16_ROWB + 2 * (sc0 + (sc0 & 1)));
+    }
+
+    int tile = blockIdx.x;
+    if (tile < total_tiles) prefetch(tile);
+    for (; tile < total_tiles; tile += gridDim.x) {
+        store_window();
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < total_tiles) prefetch(next);
+
+        s16_u32x4 ah[2][6], al[2][6];
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const char *ph = smem + abase[mb] + s2 * 4 * S16_ROWB;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ah[mb][s2][e] = *reinterpret_cast<const uint32_t *>(ph + 4 * e);
+                    al[mb][s2][e] = *reinterpret_cast<const uint32_t *>(ph + 2 * S16_COPY + 4 * e);
+                }
+            }
+        // every fragment is in registers before the first MFMA (operand hazard note, cn_conv.hip)
+        __builtin_amdgcn_sched_barrier(0);
+        cn_f32x4 acc[2] = {cn_f32x4{0.f, 0.f, 0.f, 0.f}, cn_f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s2 = 0; s2 < 6; ++s2)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const s16_f16x8 fh = __builtin_bit_cast(s16_f16x8, ah[mb][s2]);
+                const s16_f16x8 fl = __builtin_bit_cast(s16_f16x8, al[mb][s2]);
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, wh[s2], acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, wl[s2], acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, wh[s2], acc[mb], 0, 0, 0);
+            }
+        // D: col = lane & 15 (cout), rows 4*(lane >> 4) + r (pixels)
+        const int xt = tile % tpr;
+        const int rowid = tile / tpr;
+        float *yb = a.y + ((size_t)rowid * a.Wo + (size_t)xt * BM) * a.out_pitch;
+        if (l15 < a.Cout) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = wave * 32 + mb * 16 + 4 * lq + r;
+                    float t = acc[mb][r] * sc + sf;
+                    if (a.relu) t = fmaxf(t, 0.f);
+                    yb[(size_t)m * a.out_pitch + l15] = t;
+                }
+        }
+        __syncthreads();
+    }
+    if (a.range) cn_rng_commit(a.range, 1, rng_in);
+}
+
+int launch_stem16s(const StemArgs &a, int B, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)4 * S16_COPY;
+    const long total = (long)B * a.tiles_per_image;
+    const int wgs = (int)(total < 512 ? total : 512);  // two resident workgroups per CU
+    hipLaunchKernelGGL(stem16s_kernel, dim3(wgs), dim3(NT), lds, st, a, (int)total);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
 template <int BN, int S>
 int launch_stem_persist(const StemArgs &a, int B, hipStream_t st)
 {
@@ -935,6 +1115,9 @@ int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, 
         if ((persistent & 2) && stride == 2 && Cout > 16)
             return Cout > 32 ? launch_stem_persist_f32s<64>(a, B, st)
                              : launch_stem_persist_f32s<32>(a, B, st);
+        // ... and the stride-1 stem of <= 16 output channels (DLA base_layer)
+        if ((persistent & 2) && stride == 1 && Cout <= 16 && pad == 3 && (W & 3) == 0)
+            return launch_stem16s(a, B, st);
         if (Cout > 32)
             return stride == 2 ? launch_stem_persist<64, 2>(a, B, st)
                                : launch_stem_persist<64, 1>(a, B, st);

@@ -124,6 +124,8 @@ const char *cn_arch(void);
  *         takes when the grid has >= 192 workgroups (default), 1 = the global-gather form always,
  *         2 = the register-sampling form for every shape it takes (tests), 3 = the earlier
  *         wave-specialised window form for every shape it takes (kept for comparison: slower).
+ * key 27: 7x7 / stride 1 stem of <= 16 output channels with CN_CONV_STEM_F32S: 1 = f32s kernel
+ *         (default), 0 = the fp32 16x16x4 kernel (then cn_stem_f32s_supported answers 0 for it).
  * key 26: fused f32s heads with a hidden layer wider than 64: 1 = hidden layer kept in registers
  *         (default), 0 = staged through LDS; 2 = 128-wide slices (register-bound, A/B only),
  *         3 = the register form for 64-wide hidden layers too (slower there, A/B only).

@@ -207,7 +207,9 @@ def test_stem_conv_nchw_input(dev):
     # B, H, W, Cout, stride, persistent-eligible (output rows a multiple of 128 px)
     (2, 20, 256, 64, 2, True),     # resnet / hourglass stem shape class (Wo = 128)
     (3, 9, 512, 128, 2, True),     # Wo = 256: two tiles per row, two N tiles (hourglass: 128 ch)
-    (2, 11, 128, 16, 1, True),     # DLA base_layer: stride 1, 16 channels (16x16x4 MFMA form)
+    (2, 11, 128, 16, 1, True),     # DLA base_layer: stride 1, 16 channels (f32s: stem16s_kernel)
+    (1, 5, 256, 9, 1, True),       # the same form: two tiles per row, ragged channel count
+    (4, 140, 128, 16, 1, True),    # 560 tiles > 512 persistent workgroups
     (1, 40, 256, 12, 2, True),     # <= 16 channels, stride 2, ragged channel count
     (2, 9, 128, 24, 1, True),      # 17..32 channels: 32-wide N tile
     (4, 300, 256, 64, 2, True),    # 600 tiles > 512 persistent workgroups: the tile loop runs > 1x
@@ -235,6 +237,33 @@ def test_stem_kernels_vs_torch(dev, cfg):
             _check(y.t.permute(0, 3, 1, 2).cpu(), ref)
     finally:
         lib.cn_set_tuning(12, 1)
+
+
+def test_stem16_f32s_and_fp32_forms(dev):
+    """DLA base_layer (7x7 / stride 1, 3 -> 16): the f32s kernel (two shifted copies of the fp16
+    window, v_mfma_f32_16x16x32_f16; cn_set_tuning key 27 = 1, default) and the fp32 16x16x4 kernel
+    (key 27 = 0) against torch, on an image whose borders matter (7 rows only) and at a scale far
+    from 1 (the image exponent is applied while the window is split)."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder, exponent_for
+    lib = native.lib()
+    try:
+        for form in (1, 0):
+            assert lib.cn_set_tuning(27, form) == 0
+            for (B, H, W, Cout, mul) in [(2, 7, 128, 16, 1.0), (1, 33, 384, 13, 300.0)]:
+                x = synth.images(B, H, W, 7) * mul
+                w = torch.from_numpy(synth.normal((Cout, 3, 7, 7), (2.0 / 147) ** 0.5, 2))
+                bn = _bn(Cout, 4)
+                ref = F.relu(bn(F.conv2d(x, w, None, 1, 3))).detach()
+                pb = PlanBuilder(dev, B, H, W, split=True, exps={"input": exponent_for(float(x.abs().max()))})
+                y = pb.conv(pb.set_input(3), w, bn=bn, relu=True, stride=1, padding=3)
+                pb.input.t = x.to(dev)
+                _run(pb)
+                got = y.t.permute(0, 3, 1, 2).cpu()
+                err = float((got - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+                assert err < 2e-5, (form, B, H, W, Cout, err)
+    finally:
+        lib.cn_set_tuning(27, 1)
 
 
 @pytest.mark.parametrize("split", [True, False], ids=["f32s", "fp32mfma"])
