@@ -16,6 +16,7 @@
 //     from the window (address = row base of the pixel + table offset of k), B fragments with
 //     ds_read_b128.
 #include "cn_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -920,9 +921,12 @@ __global__ __launch_bounds__(NT, 2) void stem16s_kernel(const StemArgs a, int to
     // staging: 21 rows x 68 column pairs over 256 threads; per pair the two columns and the one to
     // their left (the shifted copy's pair)
     constexpr int NPR = (21 * S16_PAIRS + NT - 1) / NT;   // 6
-    float v0[NPR], v1[NPR], vm[NPR];
+    // TWO tiles ahead: a tile is ~1 us of work, a window row comes from HBM in 2-3 us -- one tile
+    // of prefetch distance left every tile waiting for its loads (0.43 ms)
+    float v0[2][NPR], v1[2][NPR], vm[2][NPR];
     float rng_in = 0.f;
-    auto prefetch = [&](int tile) {
+    auto prefetch = [&](auto SET, int tile) {
+        constexpr int st = decltype(SET)::value;
         const int xt = tile % tpr;
         const int rowid = tile / tpr;                    // b*Ho + oy
         const int b = rowid / a.Ho, oy = rowid - b * a.Ho;
@@ -940,18 +944,19 @@ __global__ __launch_bounds__(NT, 2) void stem16s_kernel(const StemArgs a, int to
             const float *rowp = img + ((size_t)c * a.H + (rok ? iy : 0)) * a.W;
             const float2 pr = *reinterpret_cast<const float2 *>(rowp + (ok ? ix : 0));
             const float lm = rowp[okm ? ix - 1 : 0];
-            v0[u] = ok ? pr.x : 0.f;
-            v1[u] = ok ? pr.y : 0.f;
-            vm[u] = okm ? lm : 0.f;
+            v0[st][u] = ok ? pr.x : 0.f;
+            v1[st][u] = ok ? pr.y : 0.f;
+            vm[st][u] = okm ? lm : 0.f;
         }
     };
-    auto store_window = [&]() {
+    auto store_window = [&](auto SET) {
+        constexpr int st = decltype(SET)::value;
 #pragma unroll
         for (int u = 0; u < NPR; ++u) {
             const int i = tid + u * NT;
             if (i < 21 * S16_PAIRS) {
                 const int row = i / S16_PAIRS, pp = i - row * S16_PAIRS;
-                const float s0 = v0[u] * x_mul, s1 = v1[u] * x_mul, sm = vm[u] * x_mul;   // real -> stored units
+                const float s0 = v0[st][u] * x_mul, s1 = v1[st][u] * x_mul, sm = vm[st][u] * x_mul;   // real -> stored units
                 rng_in = fmaxf(rng_in, fmaxf(fabsf(s0), fabsf(s1)));
                 const float c0 = fminf(fmaxf(s0, -65504.f), 65504.f), c1 = fminf(fmaxf(s1, -65504.f), 65504.f);
                 const float cm = fminf(fmaxf(sm, -65504.f), 65504.f);
@@ -975,39 +980,56 @@ __global__ __launch_bounds__(NT, 2) void stem16s_kernel(const StemArgs a, int to
         abase[mb] = (unsigned)(((sc0 & 1) ? S16_COPY : 0) + lq * S16_ROWB + 2 * (sc0 + (sc0 & 1)));
     }
 
-    int tile = blockIdx.x;
-    if (tile < total_tiles) prefetch(tile);
-    for (; tile < total_tiles; tile += gridDim.x) {
-        store_window();
+    auto one_tile = [&](auto SET, int tile) {   // SET: the register set that holds this tile's window
+        store_window(SET);
         __syncthreads();
-        const int next = tile + gridDim.x;
-        if (next < total_tiles) prefetch(next);
+        const int next = tile + 2 * (int)gridDim.x;
+        if (next < total_tiles) prefetch(SET, next);
 
-        s16_u32x4 ah[2][6], al[2][6];
+        // three phases of two K steps; fragments in two register sets: a set is reloaded only when
+        // the MFMAs that read it are a full phase back (operand hazard note, cn_conv.hip)
+        s16_u32x4 fh[2][2][2], fl[2][2][2];    // [set][step of the phase][mb]
+        auto load_phase = [&](auto SET, int ph) {
+            constexpr int st = decltype(SET)::value;
 #pragma unroll
-        for (int s2 = 0; s2 < 6; ++s2)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const char *ph = smem + abase[mb] + s2 * 4 * S16_ROWB;
+                for (int mb = 0; mb < 2; ++mb) {
+                    const char *pa = smem + abase[mb] + (2 * ph + q) * 4 * S16_ROWB;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ah[mb][s2][e] = *reinterpret_cast<const uint32_t *>(ph + 4 * e);
-                    al[mb][s2][e] = *reinterpret_cast<const uint32_t *>(ph + 2 * S16_COPY + 4 * e);
+                    for (int e = 0; e < 4; ++e) {
+                        fh[st][q][mb][e] = *reinterpret_cast<const uint32_t *>(pa + 4 * e);
+                        fl[st][q][mb][e] = *reinterpret_cast<const uint32_t *>(pa + 2 * S16_COPY + 4 * e);
+                    }
                 }
-            }
-        // every fragment is in registers before the first MFMA (operand hazard note, cn_conv.hip)
-        __builtin_amdgcn_sched_barrier(0);
+        };
         cn_f32x4 acc[2] = {cn_f32x4{0.f, 0.f, 0.f, 0.f}, cn_f32x4{0.f, 0.f, 0.f, 0.f}};
+        auto mfma_phase = [&](auto SET, auto PH) {
+            constexpr int st = decltype(SET)::value;
+            constexpr int ph = decltype(PH)::value;
 #pragma unroll
-        for (int s2 = 0; s2 < 6; ++s2)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const s16_f16x8 fh = __builtin_bit_cast(s16_f16x8, ah[mb][s2]);
-                const s16_f16x8 fl = __builtin_bit_cast(s16_f16x8, al[mb][s2]);
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, wh[s2], acc[mb], 0, 0, 0);
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, wl[s2], acc[mb], 0, 0, 0);
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, wh[s2], acc[mb], 0, 0, 0);
-            }
+                for (int mb = 0; mb < 2; ++mb) {
+                    const s16_f16x8 xh = __builtin_bit_cast(s16_f16x8, fh[st][q][mb]);
+                    const s16_f16x8 xl = __builtin_bit_cast(s16_f16x8, fl[st][q][mb]);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wh[2 * ph + q], acc[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl[2 * ph + q], acc[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wh[2 * ph + q], acc[mb], 0, 0, 0);
+                }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        load_phase(I0{}, 0);
+        load_phase(I1{}, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase(I0{}, I0{});
+        mfma_phase(I1{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        load_phase(I0{}, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase(I0{}, I2{});
         // D: col = lane & 15 (cout), rows 4*(lane >> 4) + r (pixels)
         const int xt = tile % tpr;
         const int rowid = tile / tpr;
@@ -1024,6 +1046,16 @@ __global__ __launch_bounds__(NT, 2) void stem16s_kernel(const StemArgs a, int to
                 }
         }
         __syncthreads();
+    };
+    {
+        const int g = (int)gridDim.x;
+        int tile = blockIdx.x;
+        if (tile < total_tiles) prefetch(std::integral_constant<int, 0>{}, tile);
+        if (tile + g < total_tiles) prefetch(std::integral_constant<int, 1>{}, tile + g);
+        for (; tile < total_tiles; tile += 2 * g) {
+            one_tile(std::integral_constant<int, 0>{}, tile);
+            if (tile + g < total_tiles) one_tile(std::integral_constant<int, 1>{}, tile + g);
+        }
     }
     if (a.range) cn_rng_commit(a.range, 1, rng_in);
 }
