@@ -40,10 +40,10 @@ W_TOP_LOG2 = 14            # weight rows are pre-scaled to max |w| in [2^13, 2^1
 
 def exponent_for(absmax):
     """Exponent e with absmax * 2^-e in [2^(TOP_LOG2-1), 2^TOP_LOG2) (0 for an all-zero tensor)."""
-    if not absmax > 0.0:
-        return 0
     if math.isinf(absmax) or math.isnan(absmax):
         raise native.NativeError("non-finite activations in the f32s calibration pass")
+    if not absmax > 0.0:
+        return 0
     return math.frexp(absmax)[1] - TOP_LOG2
 
 
@@ -100,8 +100,9 @@ def prescale_rows(w):
     and undone by the returned factors in the epilogue scale.
     Returns (scaled weight, factor per row): w = scaled * factor."""
     w = w.detach().float()
-    m = w.abs().flatten(1).amax(dim=1).clamp_min(1e-30)
-    e = torch.frexp(m)[1] - W_TOP_LOG2                      # m = mantissa * 2^(e + 14)
+    m = w.abs().flatten(1).amax(dim=1)
+    e = torch.frexp(m.clamp_min(1e-30))[1] - W_TOP_LOG2     # m = mantissa * 2^(e + 14)
+    e = torch.where(m > 0, e, torch.zeros_like(e))          # an all-zero row keeps factor 1
     shape = (-1,) + (1,) * (w.dim() - 1)
     return torch.ldexp(w, (-e).view(shape).expand_as(w)), torch.ldexp(torch.ones_like(m), e)
 
