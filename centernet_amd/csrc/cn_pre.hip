@@ -25,6 +25,7 @@
 // Normalisation: ((v/255.) - mean)/std in float64, rounded once to float32 (numpy's arithmetic
 // for a uint8 array and float32 mean / std arrays).  No FMA contraction anywhere.
 #include "cn_common.h"
+#include <cstdlib>
 
 // hipcc defaults to -ffp-contract=fast-honor-pragmas, and HIP's __dmul_rn/__dadd_rn are inline
 // header functions compiled under that default (their results still fuse after inlining), so
@@ -233,14 +234,57 @@ extern "C" int cn_resize_bilinear_u8(const uint8_t *image_hwc, int H, int W, int
 template <int C>
 static void warp_host(const uint8_t *img, int h_in, int w_in, const double *m, int h_out, int w_out, uint8_t *out)
 {
+    // the per-column terms rn(m0*x*1024), rn(m3*x*1024) once per call (cv::warpAffine's adelta /
+    // bdelta tables), so that the pixel loop is integer-only; interior pixels (all four taps on
+    // the image) skip the border tests.  Same integers as warp_pixel<C>.
+    int *adelta = (int *)malloc((size_t)2 * w_out * sizeof(int));
+    if (!adelta) {   // out of memory: the plain per-pixel form
+        for (int y = 0; y < h_out; ++y) {
+            const int rx0 = row_base(m, 1, 2, y), ry0 = row_base(m, 4, 5, y);
+            for (int x = 0; x < w_out; ++x) {
+                int v[C];
+                warp_pixel<C>(img, h_in, w_in, (size_t)w_in * C, m, x, y, rx0, ry0, v);
+                for (int c = 0; c < C; ++c) out[((size_t)y * w_out + x) * C + c] = (uint8_t)v[c];
+            }
+        }
+        return;
+    }
+    int *bdelta = adelta + w_out;
+    for (int x = 0; x < w_out; ++x) {
+        adelta[x] = (int)__builtin_nearbyint((m[0] * (double)x) * 1024.0);
+        bdelta[x] = (int)__builtin_nearbyint((m[3] * (double)x) * 1024.0);
+    }
+    const size_t pitch = (size_t)w_in * C;
     for (int y = 0; y < h_out; ++y) {
         const int rx0 = row_base(m, 1, 2, y), ry0 = row_base(m, 4, 5, y);
+        uint8_t *orow = out + (size_t)y * w_out * C;
         for (int x = 0; x < w_out; ++x) {
-            int v[C];
-            warp_pixel<C>(img, h_in, w_in, (size_t)w_in * C, m, x, y, rx0, ry0, v);
-            for (int c = 0; c < C; ++c) out[((size_t)y * w_out + x) * C + c] = (uint8_t)v[c];
+            const int X = (rx0 + adelta[x]) >> (AB_BITS - INTER_BITS), Y = (ry0 + bdelta[x]) >> (AB_BITS - INTER_BITS);
+            const int sx = clamp_i(X >> INTER_BITS, -32768, 32767), sy = clamp_i(Y >> INTER_BITS, -32768, 32767);
+            int w[4];
+            frac_weights(X & (INTER_TAB - 1), Y & (INTER_TAB - 1), w);
+            if (sx >= 0 && sx + 1 < w_in && sy >= 0 && sy + 1 < h_in) {
+                const uint8_t *p0 = img + (size_t)sy * pitch + (size_t)sx * C, *p1 = p0 + pitch;
+                for (int c = 0; c < C; ++c) {
+                    const int sum = p0[c] * w[0] + p0[C + c] * w[1] + p1[c] * w[2] + p1[C + c] * w[3];
+                    orow[x * C + c] = (uint8_t)clamp_i((sum + (1 << (COEF_BITS - 1))) >> COEF_BITS, 0, 255);
+                }
+                continue;
+            }
+            const bool x0 = sx >= 0 && sx < w_in, x1 = sx + 1 >= 0 && sx + 1 < w_in;
+            const bool y0 = sy >= 0 && sy < h_in, y1 = sy + 1 >= 0 && sy + 1 < h_in;
+            const uint8_t *r0 = img + (size_t)clamp_i(sy, 0, h_in - 1) * pitch;
+            const uint8_t *r1 = img + (size_t)clamp_i(sy + 1, 0, h_in - 1) * pitch;
+            const int c0 = clamp_i(sx, 0, w_in - 1) * C, c1 = clamp_i(sx + 1, 0, w_in - 1) * C;
+            for (int c = 0; c < C; ++c) {
+                const int t00 = (x0 && y0) ? r0[c0 + c] : 0, t01 = (x1 && y0) ? r0[c1 + c] : 0;
+                const int t10 = (x0 && y1) ? r1[c0 + c] : 0, t11 = (x1 && y1) ? r1[c1 + c] : 0;
+                const int sum = t00 * w[0] + t01 * w[1] + t10 * w[2] + t11 * w[3];
+                orow[x * C + c] = (uint8_t)clamp_i((sum + (1 << (COEF_BITS - 1))) >> COEF_BITS, 0, 255);
+            }
         }
     }
+    free(adelta);
 }
 
 extern "C" int cn_warp_affine_u8_host(const uint8_t *img, int h_in, int w_in, int channels,
