@@ -36,6 +36,13 @@ int cn_tune_f32s_policy = 0;   // cn_set_tuning key 21 (A/B): bit 0 = 128-wide t
 #define CN_F16_PREFETCH_TAPS 2
 #endif
 
+bool cn_conv3x3p_takes(int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch, int res_pitch,
+                       bool in_plain, bool has_res);
+int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale, const float *shift,
+                         const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
+                         int in_pitch, int out_pitch, int res_pitch, int relu, int out_plain, int res_plain,
+                         const cn_f32s_ctl *ctl, hipStream_t st);
+
 namespace {
 
 constexpr int LDT = 36;  // floats per LDS row (32 + 4 pad = 144 bytes, conflict-free b128 reads)
@@ -1306,6 +1313,11 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     a.nkk_last = f16 != CN_DTYPE_F32 ? 4 : ((Cin - (a.nchunk - 1) * 32) + 7) / 8;
     a.ncb = a.cout_pad / 32;
     a.wfrag_off = (size_t)9 * a.cout_pad * a.cin_pad * 4;   // behind the row-ordered copy
+    // f32s tensors on both sides: the persistent loader / consumer kernel (cn_conv3x3p.hip)
+    if (f16 == CN_DTYPE_F32S && !a.dbg && vec_out && scale &&
+        cn_conv3x3p_takes(B, H, W, Cin, Cout, in_pitch, out_pitch, out_pitch, a.in_plain != 0, residual != nullptr))
+        return cn_conv3x3s1_persist(x, w_packed, scale, shift, residual, y, B, H, W, Cin, Cout, in_pitch,
+                                    out_pitch, out_pitch, relu, a.out_plain, a.res_plain, ctl, st);
     if (f16 == CN_DTYPE_F32S) return c3_dispatch<cn_f32s>(a, bn_class, st);
     return f16 == CN_DTYPE_F16 ? c3_dispatch<_Float16>(a, bn_class, st) : c3_dispatch<float>(a, bn_class, st);
 }

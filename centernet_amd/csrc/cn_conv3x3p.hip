@@ -1,0 +1,520 @@
+// cn_conv3x3p.hip -- persistent, loader / consumer specialised 3x3 / stride-1 / pad-1 convolution
+// in f32s arithmetic (fp32 values as fp16 (high, low) pairs, cn_common.h): the trunk convolutions
+// of every backbone (resnet_dcn.py:38-67 BasicBlock, pose_dla_dcn.py:31-62, large_hourglass.py:48-74)
+// when input and output are f32s tensors.
+//
+// Why a third 3x3 kernel.  Probes of the one-tile-per-workgroup halo kernel (cn_conv3x3.hip,
+// DESIGN.md section 3.1b) show a tile's life as prologue (address set-up, first halo + weight
+// round trip) -> taps -> epilogue, one after the other, with 52 staging registers and one
+// ds_write pass per tile in the way of deeper prefetch.  Here
+//   * a workgroup is PERSISTENT: it walks a list of (pixel tile, 64-channel output block) items,
+//     and the load stream never drains at an item boundary -- the next item's halo and weight
+//     tiles are in flight while the current item's epilogue runs;
+//   * every global -> LDS byte moves by LDS-DMA (global_load_lds_dwordx4): no staging registers,
+//     no ds_write, no VALU.  The LDS images are unpadded 128-byte rows, XOR-swizzled through the
+//     per-lane SOURCE address (the destination of an LDS-DMA is lane-linear) so that the
+//     ds_read_b128 fragment reads stay conflict-free;
+//   * the work is split by wave role: wave 4 of the 320-thread workgroup is the LOADER (issues all
+//     DMA pieces, owns every vmcnt wait), waves 0-3 are CONSUMERS (ds_read + MFMA + epilogue).
+//     Consumers never have a DMA in flight, so their compiler-managed waits for residual loads /
+//     output stores do not drain the pipeline, and the loader's issue stalls do not block MFMAs;
+//   * two such workgroups share a CU (79.9 KB of LDS, <= 168 registers): one's epilogue and
+//     barrier waits are covered by the other's matrix work.
+//
+// Geometry: tile = 8 rows x 16 columns of output pixels (halo 10 x 18 = 180 rows of 128 bytes per
+// 32-channel chunk, double-buffered), BN = 64 output channels, four consumer waves as 2 (pixels)
+// x 2 (channels): a wave owns 64 pixels x 32 channels = two 32x32 accumulators.  The MFMA
+// operands are swapped (D[channel][pixel]) so that a lane ends up with four CONSECUTIVE output
+// channels of its pixel: the epilogue splits them in place and transposes through a wave-private
+// LDS strip into full 128-byte output rows (coalesced 16-byte stores, no cross-wave barrier).
+// Weight tiles (64 rows x 128 bytes per (tap, chunk)) stream through a ring of four 8 KB slots,
+// three steps ahead of their use; one s_barrier per (tap, chunk) step.
+#include "cn_common.h"
+#include <type_traits>
+
+int cn_tune_c3p = 1;        // cn_set_tuning key 28: 0 = off, 1 = on for the shapes it takes
+int cn_tune_c3p_stagger = 0;  // cn_set_tuning key 29: start delay of the second resident workgroup, in units of 256 cycles
+
+// one 128-byte line of zeros: the DMA source of halo pixels outside the image
+__device__ __attribute__((aligned(128))) unsigned char cn_p3_zero_line[128];
+
+namespace {
+
+typedef __attribute__((address_space(3))) void p3_lds_void;
+typedef __attribute__((address_space(1))) const void p3_gl_void;
+typedef _Float16 p3_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 p3_f16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t p3_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int P_TH = 8, P_TW = 16;            // output pixels per tile
+constexpr int P_HW = P_TW + 2;                // halo columns (even: row parity = column parity)
+constexpr int P_HR = (P_TH + 2) * P_HW;       // 180 halo rows
+constexpr int P_HP = (P_HR + 7) / 8;          // 23 DMA pieces of 8 rows (1 KiB)
+constexpr int P_HBYTES = P_HP * 1024;         // 23552 bytes per halo buffer (whole pieces)
+constexpr int P_WSLOT = 64 * 128;             // one weight tile: 64 rows of 128 bytes
+constexpr int P_NSLOT = 4;
+constexpr int P_LDS = 2 * P_HBYTES + P_NSLOT * P_WSLOT;   // 79872 bytes
+constexpr int P_WOFF = 2 * P_HBYTES;          // weight ring behind the two halo buffers
+constexpr int P_STG_ROW = 144;                // epilogue strip: 32 rows x 144 bytes per wave
+constexpr int P_STG = 32 * P_STG_ROW;
+static_assert(4 * P_STG <= P_HBYTES, "the epilogue strips alias one halo buffer");
+static_assert(P_LDS <= 81920, "two workgroups per CU");
+
+struct P3Args {
+    const char *x;            // f32s NHWC input
+    const char *w;            // f32s row-ordered weights [9][cout_pad][cin_pad], 4 bytes per element
+    const float *scale, *shift;
+    const char *residual;     // f32s or plain fp32 NHWC, or null
+    char *y;                  // f32s or plain fp32 NHWC
+    int H, W;
+    int in_pitchB, out_pitchB, res_pitchB;   // bytes per pixel
+    int cin_padB;             // bytes per weight row (cin_pad * 4)
+    int cout_pad;             // weight rows per tap
+    int ngroups;              // 32-channel groups of the output that exist (cout_pad / 32)
+    int nchunk, nblk;         // 32-channel K chunks; 64-channel output blocks
+    int tiles_x, tiles_y;
+    int items;                // B * tiles_y * tiles_x * nblk, output block fastest
+    int relu, out_plain, res_plain;
+    float res_mul;
+    uint32_t *range;
+    int stagger;
+};
+
+// vmcnt the loader waits for before the barrier of step t of a stage (steady state): everything
+// up to the weight tile of step g + 1 has landed, and (t == 8) the whole halo of the next stage.
+// Issue order per step: 8 weight pieces (tile g + 3), then the step's halo pieces
+// h(t) = {0, 4, 4, 4, 4, 4, 3, 0, 0}: allowed outstanding = h(t-2) + 8 + h(t-1).
+__device__ __forceinline__ void p3_wait_step(int t)
+{
+    switch (t) {
+    case 0: case 1: case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    }
+}
+
+__device__ __forceinline__ void p3_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// item -> (image, tile row, tile column, output block)
+struct P3Item { int b, ty0, tx0, nb; };
+__device__ __forceinline__ P3Item p3_decode(const P3Args &a, int item)
+{
+    P3Item it;
+    it.nb = item % a.nblk;
+    int t = item / a.nblk;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    it.b = t / a.tiles_y;
+    it.ty0 = ty * P_TH;
+    it.tx0 = tx * P_TW;
+    return it;
+}
+
+// RES: 0 = no residual, 1 = f32s residual, 2 = plain fp32 residual
+template <int RES, bool OUT_PLAIN>
+__global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
+{
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- this workgroup's items: XCD x = id % 8 owns a contiguous range, its workgroups take
+    // every (gridDim / 8)-th item of it (neighbouring tiles and the output blocks of one tile
+    // are in flight on one L2 at the same time)
+    const int nx = gridDim.x >> 3;                       // workgroups per XCD
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int per = (a.items + 7) >> 3;
+    const int lo = xcd * per, hi = min(lo + per, a.items);
+    const int first = lo + jx;
+    const int nit = first < hi ? (hi - first + nx - 1) / nx : 0;
+    if (nit == 0) return;
+    const int S = nit * a.nchunk;                         // stages of this workgroup
+
+    if (a.stagger && blockIdx.x >= 256) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)a.stagger * 256u) __builtin_amdgcn_s_sleep(32);
+    }
+
+    if (wave == 4) {
+        // =============================== LOADER ===============================
+        // halo pieces: piece k covers halo rows 8k .. 8k+7; lane = (row in piece, 16-byte slot s);
+        // slot s of row r receives source column s ^ key(r), key = (halo column >> 1) & 7
+        const int prow = lane >> 3, ps = lane & 7;
+        int poff[P_HP];          // byte offset of the lane's source inside the tile's input window, relative to pixel (ty0, tx0)
+        int pyx[P_HP];           // hy | hx << 8, or -1: row beyond the halo
+#pragma unroll
+        for (int k = 0; k < P_HP; ++k) {
+            const int r = 8 * k + prow;
+            const int hy = r / P_HW, hx = r - hy * P_HW;
+            const int col = ps ^ ((hx >> 1) & 7);
+            poff[k] = ((hy - 1) * a.W + (hx - 1)) * a.in_pitchB + col * 16;
+            pyx[k] = (r < P_HR) ? (hy | (hx << 8)) : -1;
+        }
+        const char *zero = reinterpret_cast<const char *>(cn_p3_zero_line) + ps * 16;
+
+        // weight pieces: piece p = rows 8p .. 8p+7 of the 64-row tile
+        int wrow[8];
+        unsigned wofs[8];        // per item: byte offset of the lane's source inside one tap's matrix
+#pragma unroll
+        for (int p = 0; p < 8; ++p) wrow[p] = 8 * p + prow;
+
+        // cursors: halo stage (item ordinal hk, chunk hc) and weight step (wk, wc, wt)
+        int hk = 0, hc = 0;
+        P3Item hit = p3_decode(a, first);
+        int wk = 0, wc = 0, wt = 0, wg = 0;
+        auto set_wofs = [&](int nb) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int n = wrow[p];
+                const int row = min(nb * 64 + n, a.cout_pad - 1);
+                wofs[p] = (unsigned)(row * a.cin_padB + ((ps ^ ((n >> 1) & 7)) << 4));
+            }
+        };
+        set_wofs(hit.nb);
+        const size_t tapB = (size_t)a.cout_pad * a.cin_padB;
+        auto issue_W = [&]() {   // weight tile of the cursor's step into ring slot wg & 3, then advance
+            if (wk >= nit) return;
+            const char *base = a.w + (size_t)wt * tapB + (size_t)wc * 128;
+            char *dst = smem + P_WOFF + (wg & (P_NSLOT - 1)) * P_WSLOT;
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                __builtin_amdgcn_global_load_lds((p3_gl_void *)(base + wofs[p]), (p3_lds_void *)(dst + p * 1024), 16, 0, 0);
+            ++wg;
+            if (++wt == 9) {
+                wt = 0;
+                if (++wc == a.nchunk) {
+                    wc = 0;
+                    ++wk;
+                    if (wk < nit && a.nblk > 1) set_wofs((first + wk * nx) % a.nblk);
+                }
+            }
+        };
+        // halo pieces [k0, k1) of the cursor's stage into buffer `buf`
+        const char *hbase = nullptr;   // address of pixel (ty0, tx0), chunk hc, of the cursor's item
+        auto set_hbase = [&]() {
+            hbase = a.x + ((size_t)(hit.b * a.H + hit.ty0) * a.W + hit.tx0) * a.in_pitchB + (size_t)hc * 128;
+        };
+        set_hbase();
+        auto issue_H = [&](auto K0, auto K1, int buf) {
+            constexpr int k0 = decltype(K0)::value, k1 = decltype(K1)::value;
+            char *dst = smem + buf * P_HBYTES;
+#pragma unroll
+            for (int k = k0; k < k1; ++k) {
+                const int hy = pyx[k] & 255, hx = pyx[k] >> 8;
+                const int iy = hit.ty0 - 1 + hy, ix = hit.tx0 - 1 + hx;
+                const bool ok = pyx[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const char *src = ok ? hbase + poff[k] : zero;
+                __builtin_amdgcn_global_load_lds((p3_gl_void *)src, (p3_lds_void *)(dst + k * 1024), 16, 0, 0);
+            }
+        };
+        auto advance_H = [&]() {   // cursor to the next stage
+            if (++hc == a.nchunk) {
+                hc = 0;
+                ++hk;
+                if (hk < nit) hit = p3_decode(a, first + hk * nx);
+            }
+            if (hk < nit) set_hbase();
+        };
+#define P3_IC(v) std::integral_constant<int, (v)>{}
+        // ---- prologue: halo of stage 0, weight tiles of steps 0, 1, 2
+        issue_H(P3_IC(0), P3_IC(P_HP), 0);
+        advance_H();
+        issue_W();
+        issue_W();
+        issue_W();
+        for (int s = 0;; ++s) {
+            const bool last = (s >= S - 1);   // no next stage: counts below do not hold, drain instead
+            if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else p3_wait_step(0);
+            p3_barrier();
+            if (s == S) break;
+            issue_W();
+            const int nbuf = (s + 1) & 1;
+#pragma unroll
+            for (int t = 1; t < 9; ++t) {
+                if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else p3_wait_step(t);
+                p3_barrier();
+                issue_W();
+                if (!last) {
+                    if (t == 1) issue_H(P3_IC(0), P3_IC(4), nbuf);
+                    if (t == 2) issue_H(P3_IC(4), P3_IC(8), nbuf);
+                    if (t == 3) issue_H(P3_IC(8), P3_IC(12), nbuf);
+                    if (t == 4) issue_H(P3_IC(12), P3_IC(16), nbuf);
+                    if (t == 5) issue_H(P3_IC(16), P3_IC(20), nbuf);
+                    if (t == 6) issue_H(P3_IC(20), P3_IC(P_HP), nbuf);
+                }
+            }
+            if (!last) advance_H();
+        }
+#undef P3_IC
+        return;
+    }
+
+    // =============================== CONSUMERS ===============================
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    // A fragment addresses (input pixels = the MFMA's B operand): block i = pixels 64 wm + 32 i + l31
+    // = tile rows 4 wm + 2 i + (l31 >> 4), column l31 & 15; tap (ky, kx) adds (ky * 18 + kx) rows
+    // (an immediate) and changes the swizzle key with kx only
+    const int px = l31 & 15;
+    int a0[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int row0 = (4 * wm + 2 * i + (l31 >> 4)) * P_HW + px;
+            const int key = ((px + kx) >> 1) & 7;
+            a0[i][kx] = row0 * 128 + (((lh ^ key) & 7) << 4);
+        }
+    // B fragment address (weights = the MFMA's A operand): row 32 wn + l31 of the tile
+    const int b0 = (32 * wn + l31) * 128 + (((lh ^ ((l31 >> 1) & 7)) & 7) << 4);
+
+    cn_f32x16 acc[2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    };
+    zero_acc();
+    float rng_out = 0.f;
+    cn_f32x4 resv[2][4];   // residual rows of the item (row layout), requested in its last stage
+
+    auto lds128 = [&](int off) { return *reinterpret_cast<const p3_f16x8 *>(smem + off); };
+
+    // one (tap, chunk) step: 12 fragment reads, 12 MFMAs
+    auto step = [&](auto T, int hb, int wb) {
+        constexpr int t = decltype(T)::value;
+        constexpr int ky = t / 3, kx = t % 3;
+        constexpr int tapoff = (ky * P_HW + kx) * 128;
+        // quarter q: 0 = high k 0-15, 1 = high k 16-31, 2 = low k 0-15, 3 = low k 16-31
+        p3_f16x8 xf[4][2], wf[4];
+        // the lane's row addresses pass through an opaque copy: otherwise the compiler keeps every
+        // (tap, quarter, ring slot) address variant of the unrolled stage in its own register (~70)
+        int ax[2] = {a0[0][kx], a0[1][kx]}, bx = b0;
+        asm volatile("" : "+v"(ax[0]), "+v"(ax[1]), "+v"(bx));
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            // (the operands of the first products first)
+            wf[kh] = lds128(wb + (bx ^ (kh << 5)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xf[2 + kh][i] = lds128(hb + tapoff + (ax[i] ^ ((kh << 5) | 64)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xf[kh][i] = lds128(hb + tapoff + (ax[i] ^ (kh << 5)));
+            wf[2 + kh] = lds128(wb + (bx ^ ((kh << 5) | 64)));
+        }
+        // every fragment read is issued before the first MFMA (cn_conv3x3.hip: a ds_read sunk behind
+        // an MFMA into that MFMA's operand registers can overwrite them before a queued MFMA reads them)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            // smallest terms first: w_hi * x_lo, w_lo * x_hi, then w_hi * x_hi
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kh], xf[2 + kh][i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[2 + kh], xf[kh][i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kh], xf[kh][i], acc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // pixel of the row-layout lane: block i, pass k -> row 8k + (lane >> 3) of the wave's block
+    const int rrow = lane >> 3, rcol = lane & 7;
+    auto row_pixel = [&](const P3Item &it, int i, int k, bool &ok) {
+        const int p = 64 * wm + 32 * i + 8 * k + rrow;
+        const int oy = it.ty0 + (p >> 4), ox = it.tx0 + (p & 15);
+        ok = oy < a.H && ox < a.W;
+        return (it.b * a.H + oy) * a.W + ox;
+    };
+    auto load_residual = [&](const P3Item &it) {
+        const int grp = 2 * it.nb + wn;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bool ok;
+                const int pix = row_pixel(it, i, k, ok);
+                const bool take = ok && grp < a.ngroups;
+                resv[i][k] = *reinterpret_cast<const cn_f32x4 *>(
+                    a.residual + (take ? (unsigned)pix * (unsigned)a.res_pitchB + (unsigned)(grp * 128 + rcol * 16) : 0u));
+            }
+    };
+
+    // epilogue of one item; `sb` = LDS offset of the (dead) halo buffer its strips alias
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+    auto epilogue = [&](const P3Item &it, int sb) {
+        const int grp = 2 * it.nb + wn;
+        if (grp >= a.ngroups) return;          // wave-uniform: this wave's 32 channels do not exist
+        const int stg = sb + wave * P_STG;
+        // scale / shift of the lane's channels 8g + 4 lh .. + 3 of the wave's group (one request
+        // burst ahead of everything else: its latency hides behind the residual strip writes)
+        cn_f32x4 sc[4], sh[4];
+        const unsigned cofs = (unsigned)(32 * grp + 4 * lh) * 4u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            sc[g] = *reinterpret_cast<const cn_f32x4 *>(reinterpret_cast<const char *>(a.scale) + (cofs + 32u * g));
+        if (a.shift) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                sh[g] = *reinterpret_cast<const cn_f32x4 *>(reinterpret_cast<const char *>(a.shift) + (cofs + 32u * g));
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sh[g] = cn_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int rowb = stg + l31 * P_STG_ROW + 8 * lh;    // + 16 g (+ 64): f32s pieces; plain: 2x
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (RES != 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<cn_f32x4 *>(smem + stg + (8 * k + rrow) * P_STG_ROW + rcol * 16) = resv[i][k];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                cn_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e] * sc[g][e] + sh[g][e];
+                if constexpr (RES == 2) {
+                    const cn_f32x4 r = *reinterpret_cast<const cn_f32x4 *>(smem + rowb + 8 * lh + 32 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(r[e], a.res_mul, v[e]);
+                } else if constexpr (RES == 1) {
+                    const cn_f32x4 r = cn_join4(*reinterpret_cast<const cn_f16x4v *>(smem + rowb + 16 * g),
+                                                *reinterpret_cast<const cn_f16x4v *>(smem + rowb + 64 + 16 * g));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(r[e], a.res_mul, v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_floor);
+                if constexpr (OUT_PLAIN) {
+                    *reinterpret_cast<cn_f32x4 *>(smem + rowb + 8 * lh + 32 * g) = v;
+                } else {
+                    cn_rng_upd4(rng_out, v);
+                    cn_f16x4v h4, l4;
+                    cn_split4(v, h4, l4);
+                    *reinterpret_cast<cn_f16x4v *>(smem + rowb + 16 * g) = h4;
+                    *reinterpret_cast<cn_f16x4v *>(smem + rowb + 64 + 16 * g) = l4;
+                }
+            }
+            // rows back in row layout: 8 lanes = one 128-byte output row
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bool ok;
+                const int pix = row_pixel(it, i, k, ok);
+                const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(smem + stg + (8 * k + rrow) * P_STG_ROW + rcol * 16);
+                if (ok)
+                    *reinterpret_cast<cn_f32x4 *>(a.y + ((unsigned)pix * (unsigned)a.out_pitchB + (unsigned)(grp * 128 + rcol * 16))) = v;
+            }
+        }
+    };
+
+    P3Item cur = p3_decode(a, first), prev = cur;
+    int k = 0, c = 0, g = 0;
+#define P3_IC(v) std::integral_constant<int, (v)>{}
+    for (int s = 0;; ++s) {
+        p3_barrier();
+        if (s > 0 && c == 0) {
+            // the previous item is complete: its last stage used buffer (s - 1) & 1, dead until the
+            // loader refills it after this step's successor barrier
+            epilogue(prev, ((s - 1) & 1) * P_HBYTES);
+            zero_acc();
+        }
+        if (s == S) break;
+        const int hb = (s & 1) * P_HBYTES;
+        const bool lastc = (c == a.nchunk - 1);
+        step(P3_IC(0), hb, P_WOFF + ((g + 0) & 3) * P_WSLOT);
+        p3_barrier(); step(P3_IC(1), hb, P_WOFF + ((g + 1) & 3) * P_WSLOT);
+        p3_barrier(); step(P3_IC(2), hb, P_WOFF + ((g + 2) & 3) * P_WSLOT);
+        p3_barrier(); step(P3_IC(3), hb, P_WOFF + ((g + 3) & 3) * P_WSLOT);
+        if constexpr (RES != 0) {
+            if (lastc) load_residual(cur);
+        }
+        p3_barrier(); step(P3_IC(4), hb, P_WOFF + ((g + 4) & 3) * P_WSLOT);
+        p3_barrier(); step(P3_IC(5), hb, P_WOFF + ((g + 5) & 3) * P_WSLOT);
+        p3_barrier(); step(P3_IC(6), hb, P_WOFF + ((g + 6) & 3) * P_WSLOT);
+        p3_barrier(); step(P3_IC(7), hb, P_WOFF + ((g + 7) & 3) * P_WSLOT);
+        p3_barrier(); step(P3_IC(8), hb, P_WOFF + ((g + 8) & 3) * P_WSLOT);
+        g += 9;
+        if (++c == a.nchunk) {
+            c = 0;
+            prev = cur;
+            ++k;
+            if (k < nit) cur = p3_decode(a, first + k * nx);
+        }
+    }
+#undef P3_IC
+    if constexpr (!OUT_PLAIN) {
+        if (a.range) cn_rng_commit(a.range, 0, rng_out);
+    }
+}
+
+}  // namespace
+
+// Does the persistent kernel take this layer?  f32s input (whole 128-byte groups per pixel), output
+// and residual as whole 32-channel groups (f32s, or plain fp32 at a pitch that is a multiple of 32).
+bool cn_conv3x3p_takes(int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch, int res_pitch,
+                       bool in_plain, bool has_res)
+{
+    if (!cn_tune_c3p || in_plain) return false;   // (the caller also guarantees a non-null scale)
+    if ((in_pitch & 31) || (out_pitch & 31) || (has_res && (res_pitch & 31))) return false;
+    if (Cout % 32) return false;
+    const long items = (long)B * cn_cdiv(H, P_TH) * cn_cdiv(W, P_TW) * cn_cdiv(Cout, 64);
+    // enough items that the persistent grid fills the chip (key 28 = 2: every shape, for tests)
+    if (cn_tune_c3p < 2 && items < 256) return false;
+    if ((long)B * H * W * (long)max(in_pitch, max(out_pitch, res_pitch)) * 4 >= (1L << 31)) return false;
+    (void)Cin;
+    return true;
+}
+
+int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale, const float *shift,
+                         const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
+                         int in_pitch, int out_pitch, int res_pitch, int relu, int out_plain, int res_plain,
+                         const cn_f32s_ctl *ctl, hipStream_t st)
+{
+    P3Args a = {};
+    a.x = (const char *)x; a.w = (const char *)w_packed; a.scale = scale; a.shift = shift;
+    a.residual = (const char *)residual; a.y = (char *)y;
+    a.H = H; a.W = W;
+    a.in_pitchB = in_pitch * 4; a.out_pitchB = out_pitch * 4; a.res_pitchB = res_pitch * 4;
+    const int cin_pad = (Cin + 31) / 32 * 32;
+    a.cin_padB = cin_pad * 4;
+    a.cout_pad = (Cout + 31) / 32 * 32;
+    a.ngroups = a.cout_pad / 32;
+    a.nchunk = cin_pad / 32;
+    a.nblk = cn_cdiv(Cout, 64);
+    a.tiles_x = cn_cdiv(W, P_TW);
+    a.tiles_y = cn_cdiv(H, P_TH);
+    a.items = B * a.tiles_y * a.tiles_x * a.nblk;
+    a.relu = relu; a.out_plain = out_plain; a.res_plain = res_plain;
+    a.res_mul = (ctl && ctl->res_mul != 0.f) ? ctl->res_mul : 1.f;
+    a.range = ctl ? ctl->range : nullptr;
+    a.stagger = cn_tune_c3p_stagger;
+    // two workgroups per CU, a multiple of 8 (one share per XCD), never more than one per item
+    int per_xcd = cn_cdiv(a.items, 8);
+    if (per_xcd > 64) per_xcd = 64;
+    const dim3 grid(8 * per_xcd), block(320);
+#define P3_LAUNCH(R, OP)                                                                   \
+    do {                                                                                   \
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<R, OP>), P_LDS);                               \
+        hipLaunchKernelGGL((conv3x3p_kernel<R, OP>), grid, block, P_LDS, st, a);            \
+    } while (0)
+    const int rmode = !residual ? 0 : (res_plain ? 2 : 1);
+    if (out_plain) {
+        if (rmode == 0) P3_LAUNCH(0, true); else if (rmode == 1) P3_LAUNCH(1, true); else P3_LAUNCH(2, true);
+    } else {
+        if (rmode == 0) P3_LAUNCH(0, false); else if (rmode == 1) P3_LAUNCH(1, false); else P3_LAUNCH(2, false);
+    }
+#undef P3_LAUNCH
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
