@@ -78,6 +78,10 @@ struct P3Args {
     float res_mul;
     uint32_t *range;
     int stagger;
+    // instrumented instantiation only (DBG = true; cn_conv3x3p_probe): ablation switches and cycle counters
+    int dbg;                  // 1: no MFMAs, 2: no fragment reads (and no MFMAs), 4: no weight DMA, 8: no halo DMA,
+                              // 16: no epilogue, 32: no output stores
+    unsigned long long *prof; // [workgroup][wave 5][8] cycle counters, or null
 };
 
 // vmcnt the loader waits for before the barrier of step t of a stage (steady state): everything
@@ -118,7 +122,7 @@ __device__ __forceinline__ P3Item p3_decode(const P3Args &a, int item)
 }
 
 // RES: 0 = no residual, 1 = f32s residual, 2 = plain fp32 residual
-template <int RES, bool OUT_PLAIN>
+template <int RES, bool OUT_PLAIN, bool DBG = false>
 __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
 {
     extern __shared__ __attribute__((aligned(128))) char smem[];
@@ -178,13 +182,18 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
         };
         set_wofs(hit.nb);
         const size_t tapB = (size_t)a.cout_pad * a.cin_padB;
+        unsigned long long pf_wait = 0, pf_bar = 0, pf_t0 = 0;
+        auto now = [&]() { return DBG ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
+        if (DBG) pf_t0 = now();
         auto issue_W = [&]() {   // weight tile of the cursor's step into ring slot wg & 3, then advance
             if (wk >= nit) return;
             const char *base = a.w + (size_t)wt * tapB + (size_t)wc * 128;
             char *dst = smem + P_WOFF + (wg & (P_NSLOT - 1)) * P_WSLOT;
+            if (!DBG || !(a.dbg & 4)) {
 #pragma unroll
             for (int p = 0; p < 8; ++p)
                 __builtin_amdgcn_global_load_lds((p3_gl_void *)(base + wofs[p]), (p3_lds_void *)(dst + p * 1024), 16, 0, 0);
+            }
             ++wg;
             if (++wt == 9) {
                 wt = 0;
@@ -204,6 +213,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
         auto issue_H = [&](auto K0, auto K1, int buf) {
             constexpr int k0 = decltype(K0)::value, k1 = decltype(K1)::value;
             char *dst = smem + buf * P_HBYTES;
+            if (DBG && (a.dbg & 8)) return;
 #pragma unroll
             for (int k = k0; k < k1; ++k) {
                 const int hy = pyx[k] & 255, hx = pyx[k] >> 8;
@@ -230,15 +240,21 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
         issue_W();
         for (int s = 0;; ++s) {
             const bool last = (s >= S - 1);   // no next stage: counts below do not hold, drain instead
+            unsigned long long c0 = now();
             if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else p3_wait_step(0);
+            unsigned long long c1 = now();
             p3_barrier();
+            if (DBG) { pf_wait += c1 - c0; pf_bar += now() - c1; }
             if (s == S) break;
             issue_W();
             const int nbuf = (s + 1) & 1;
 #pragma unroll
             for (int t = 1; t < 9; ++t) {
+                c0 = now();
                 if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else p3_wait_step(t);
+                c1 = now();
                 p3_barrier();
+                if (DBG) { pf_wait += c1 - c0; pf_bar += now() - c1; }
                 issue_W();
                 if (!last) {
                     if (t == 1) issue_H(P3_IC(0), P3_IC(4), nbuf);
@@ -252,6 +268,10 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
             if (!last) advance_H();
         }
 #undef P3_IC
+        if (DBG && a.prof && lane == 0) {
+            unsigned long long *o = a.prof + ((size_t)blockIdx.x * 5 + 4) * 8;
+            o[0] = now() - pf_t0; o[1] = pf_wait; o[2] = pf_bar; o[3] = (unsigned long long)S;
+        }
         return;
     }
 
@@ -283,7 +303,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
     };
     zero_acc();
     float rng_out = 0.f;
-    cn_f32x4 resv[2][4];   // residual rows of the item (row layout), requested in its last stage
+    cn_f32x4 resv[2][4];   // residual rows of the item (row layout), requested at its first step
 
     auto lds128 = [&](int off) { return *reinterpret_cast<const p3_f16x8 *>(smem + off); };
 
@@ -293,6 +313,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
         constexpr int ky = t / 3, kx = t % 3;
         constexpr int tapoff = (ky * P_HW + kx) * 128;
         // quarter q: 0 = high k 0-15, 1 = high k 16-31, 2 = low k 0-15, 3 = low k 16-31
+        if (DBG && (a.dbg & 2)) return;
         p3_f16x8 xf[4][2], wf[4];
         // the lane's row addresses pass through an opaque copy: otherwise the compiler keeps every
         // (tap, quarter, ring slot) address variant of the unrolled stage in its own register (~70)
@@ -311,6 +332,11 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
         // every fragment read is issued before the first MFMA (cn_conv3x3.hip: a ds_read sunk behind
         // an MFMA into that MFMA's operand registers can overwrite them before a queued MFMA reads them)
         __builtin_amdgcn_sched_barrier(0);
+        if (DBG && (a.dbg & 1)) {   // keep the fragments live
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" :: "v"(wf[q]), "v"(xf[q][0]), "v"(xf[q][1]));
+            return;
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
@@ -378,21 +404,32 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     *reinterpret_cast<cn_f32x4 *>(smem + stg + (8 * k + rrow) * P_STG_ROW + rcol * 16) = resv[i][k];
+                // (the strip is exchanged between lanes: the LDS serves a wave's accesses in order,
+                // the compiler must keep them in order too)
+                asm volatile("" ::: "memory");
+            }
+            // every residual piece of the wave is read before any output piece is written: with
+            // different formats on the two sides a lane's output bytes are other lanes' residual bytes
+            cn_f32x4 rr[4];
+            if constexpr (RES != 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (RES == 2)
+                        rr[g] = *reinterpret_cast<const cn_f32x4 *>(smem + rowb + 8 * lh + 32 * g);
+                    else
+                        rr[g] = cn_join4(*reinterpret_cast<const cn_f16x4v *>(smem + rowb + 16 * g),
+                                         *reinterpret_cast<const cn_f16x4v *>(smem + rowb + 64 + 16 * g));
+                }
+                asm volatile("" ::: "memory");
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 cn_f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e] * sc[g][e] + sh[g][e];
-                if constexpr (RES == 2) {
-                    const cn_f32x4 r = *reinterpret_cast<const cn_f32x4 *>(smem + rowb + 8 * lh + 32 * g);
+                if constexpr (RES != 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(r[e], a.res_mul, v[e]);
-                } else if constexpr (RES == 1) {
-                    const cn_f32x4 r = cn_join4(*reinterpret_cast<const cn_f16x4v *>(smem + rowb + 16 * g),
-                                                *reinterpret_cast<const cn_f16x4v *>(smem + rowb + 64 + 16 * g));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(r[e], a.res_mul, v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(rr[g][e], a.res_mul, v[e]);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_floor);
@@ -407,43 +444,56 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
                 }
             }
             // rows back in row layout: 8 lanes = one 128-byte output row
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 bool ok;
                 const int pix = row_pixel(it, i, k, ok);
                 const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(smem + stg + (8 * k + rrow) * P_STG_ROW + rcol * 16);
-                if (ok)
+                if (ok && !(DBG && (a.dbg & 32)))
                     *reinterpret_cast<cn_f32x4 *>(a.y + ((unsigned)pix * (unsigned)a.out_pitchB + (unsigned)(grp * 128 + rcol * 16))) = v;
             }
+            asm volatile("" ::: "memory");
         }
     };
 
     P3Item cur = p3_decode(a, first), prev = cur;
     int k = 0, c = 0, g = 0;
+    unsigned long long pf_bar = 0, pf_epi = 0, pf_t0 = 0;
+    auto now = [&]() { return DBG ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
+    if (DBG) pf_t0 = now();
+    auto bar = [&]() {
+        const unsigned long long c0 = now();
+        p3_barrier();
+        if (DBG) pf_bar += now() - c0;
+    };
 #define P3_IC(v) std::integral_constant<int, (v)>{}
     for (int s = 0;; ++s) {
-        p3_barrier();
+        bar();
         if (s > 0 && c == 0) {
             // the previous item is complete: its last stage used buffer (s - 1) & 1, dead until the
             // loader refills it after this step's successor barrier
-            epilogue(prev, ((s - 1) & 1) * P_HBYTES);
+            const unsigned long long c0 = now();
+            if (!(DBG && (a.dbg & 16))) epilogue(prev, ((s - 1) & 1) * P_HBYTES);
             zero_acc();
+            if (DBG) pf_epi += now() - c0;
         }
         if (s == S) break;
         const int hb = (s & 1) * P_HBYTES;
-        const bool lastc = (c == a.nchunk - 1);
-        step(P3_IC(0), hb, P_WOFF + ((g + 0) & 3) * P_WSLOT);
-        p3_barrier(); step(P3_IC(1), hb, P_WOFF + ((g + 1) & 3) * P_WSLOT);
-        p3_barrier(); step(P3_IC(2), hb, P_WOFF + ((g + 2) & 3) * P_WSLOT);
-        p3_barrier(); step(P3_IC(3), hb, P_WOFF + ((g + 3) & 3) * P_WSLOT);
+        // the item's residual rows: requested at its first step, used in its epilogue (a whole
+        // item of HBM latency hidden; the registers are free until then)
         if constexpr (RES != 0) {
-            if (lastc) load_residual(cur);
+            if (c == 0) load_residual(cur);
         }
-        p3_barrier(); step(P3_IC(4), hb, P_WOFF + ((g + 4) & 3) * P_WSLOT);
-        p3_barrier(); step(P3_IC(5), hb, P_WOFF + ((g + 5) & 3) * P_WSLOT);
-        p3_barrier(); step(P3_IC(6), hb, P_WOFF + ((g + 6) & 3) * P_WSLOT);
-        p3_barrier(); step(P3_IC(7), hb, P_WOFF + ((g + 7) & 3) * P_WSLOT);
-        p3_barrier(); step(P3_IC(8), hb, P_WOFF + ((g + 8) & 3) * P_WSLOT);
+        step(P3_IC(0), hb, P_WOFF + ((g + 0) & 3) * P_WSLOT);
+        bar(); step(P3_IC(1), hb, P_WOFF + ((g + 1) & 3) * P_WSLOT);
+        bar(); step(P3_IC(2), hb, P_WOFF + ((g + 2) & 3) * P_WSLOT);
+        bar(); step(P3_IC(3), hb, P_WOFF + ((g + 3) & 3) * P_WSLOT);
+        bar(); step(P3_IC(4), hb, P_WOFF + ((g + 4) & 3) * P_WSLOT);
+        bar(); step(P3_IC(5), hb, P_WOFF + ((g + 5) & 3) * P_WSLOT);
+        bar(); step(P3_IC(6), hb, P_WOFF + ((g + 6) & 3) * P_WSLOT);
+        bar(); step(P3_IC(7), hb, P_WOFF + ((g + 7) & 3) * P_WSLOT);
+        bar(); step(P3_IC(8), hb, P_WOFF + ((g + 8) & 3) * P_WSLOT);
         g += 9;
         if (++c == a.nchunk) {
             c = 0;
@@ -451,6 +501,10 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
             ++k;
             if (k < nit) cur = p3_decode(a, first + k * nx);
         }
+    }
+    if (DBG && a.prof && lane == 0) {
+        unsigned long long *o = a.prof + ((size_t)blockIdx.x * 5 + wave) * 8;
+        o[0] = now() - pf_t0; o[1] = pf_epi; o[2] = pf_bar; o[3] = (unsigned long long)S;
     }
 #undef P3_IC
     if constexpr (!OUT_PLAIN) {
@@ -474,6 +528,17 @@ bool cn_conv3x3p_takes(int B, int H, int W, int Cin, int Cout, int in_pitch, int
     if ((long)B * H * W * (long)max(in_pitch, max(out_pitch, res_pitch)) * 4 >= (1L << 31)) return false;
     (void)Cin;
     return true;
+}
+
+static int p3_probe_dbg = 0;
+static unsigned long long *p3_probe_prof = nullptr;
+// instrumented launches (tools/bench_c3p.py): dbg != 0 or prof != null route cn_conv3x3s1_persist to the
+// DBG instantiation (no residual, f32s output) with these switches / counters
+extern "C" int cn_conv3x3p_probe(int dbg, void *prof)
+{
+    p3_probe_dbg = dbg;
+    p3_probe_prof = (unsigned long long *)prof;
+    return CN_OK;
 }
 
 int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale, const float *shift,
@@ -509,6 +574,19 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
         hipLaunchKernelGGL((conv3x3p_kernel<R, OP>), grid, block, P_LDS, st, a);            \
     } while (0)
     const int rmode = !residual ? 0 : (res_plain ? 2 : 1);
+    if ((p3_probe_dbg || p3_probe_prof) && !out_plain && rmode < 2) {
+        a.dbg = p3_probe_dbg;
+        a.prof = p3_probe_prof;
+        if (rmode == 0) {
+            CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, true>), P_LDS);
+            hipLaunchKernelGGL((conv3x3p_kernel<0, false, true>), grid, block, P_LDS, st, a);
+        } else {
+            CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<1, false, true>), P_LDS);
+            hipLaunchKernelGGL((conv3x3p_kernel<1, false, true>), grid, block, P_LDS, st, a);
+        }
+        CN_CHECK_LAUNCH();
+        return CN_OK;
+    }
     if (out_plain) {
         if (rmode == 0) P3_LAUNCH(0, true); else if (rmode == 1) P3_LAUNCH(1, true); else P3_LAUNCH(2, true);
     } else {

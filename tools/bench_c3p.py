@@ -118,7 +118,7 @@ def check(case, nb=None, label=""):
                     float(case.range.view(torch.float32).max()))
     d01 = float((out[0][1] - out[2][1]).abs().max()) / rms
     # everything beyond the checked images must agree between the two kernels
-    ok = out[2][0] < 6e-6 and d01 < 6e-6
+    ok = out[2][0] < max(6e-6, 1.5 * out[0][0]) and d01 < max(6e-6, 1.5 * out[0][0])
     # pad channels of an f32s output must stay zero
     print("%-44s halo %.2e  persist %.2e  |halo-persist| %.2e  range %.4g / %.4g  %s" % (
         label, out[0][0], out[2][0], d01, out[0][2], out[2][2], "ok" if ok else "FAIL"))
@@ -175,3 +175,34 @@ for (ci, H, W, co) in SHAPES:
         del c
 lib.cn_set_tuning(28, 1)
 lib.cn_set_tuning(29, 0)
+
+# ---- where a launch spends its time: ablation switches and in-kernel cycle counters of the
+# instrumented instantiation (cn_conv3x3p_probe)
+lib.cn_conv3x3p_probe.argtypes = [ctypes.c_int, ctypes.c_void_p]
+NAMES = {0: "full", 1: "no MFMA", 2: "no frag reads / MFMA", 12: "no DMA", 16: "no epilogue", 32: "no stores",
+         28: "no DMA, no epilogue", 3 | 16: "barriers + DMA only", 31: "barriers only"}
+print("== probes (instrumented instantiation), B = 32")
+for (ci, H, W, co) in [(64, 128, 128, 64), (256, 32, 32, 256)]:
+    for res in (0, 1):
+        c = Case(32, ci, H, W, co, res=res)
+        fl = 2.0 * 32 * H * W * co * ci * 9
+        lib.cn_set_tuning(28, 1)
+        prof = torch.zeros((512, 5, 8), device=dev, dtype=torch.int64)
+        row = []
+        for dbg in (0, 1, 2, 12, 16, 32, 28, 19, 31):
+            lib.cn_conv3x3p_probe(dbg, prof.data_ptr())
+            ms = c.time(10)
+            row.append("%s %.4f" % (NAMES[dbg], ms))
+        print("%-20s res %d | %s" % (str((ci, H, W, co)), res, " | ".join(row)))
+        lib.cn_conv3x3p_probe(0, prof.data_ptr())
+        prof.zero_()
+        c.launch()
+        torch.cuda.synchronize()
+        pr = prof.cpu().double()
+        used = pr[:, 0, 3] > 0
+        cons, load = pr[used][:, :4], pr[used][:, 4]
+        print("   consumers: total %.0f cyc, epilogue %.0f, barrier wait %.0f, stages %.0f | loader: total %.0f, vmcnt wait %.0f, barrier wait %.0f  (cycles of the 100 MHz? counter: ratios matter)" % (
+            cons[..., 0].mean(), cons[..., 1].mean(), cons[..., 2].mean(), cons[..., 3].mean(),
+            load[:, 0].mean(), load[:, 1].mean(), load[:, 2].mean()))
+        lib.cn_conv3x3p_probe(0, None)
+        del c
