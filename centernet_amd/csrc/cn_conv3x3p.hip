@@ -33,7 +33,9 @@
 #include <type_traits>
 
 int cn_tune_c3p = 1;        // cn_set_tuning key 28: 0 = off, 1 = on for the shapes it takes
-int cn_tune_c3p_stagger = 0;  // cn_set_tuning key 29: start delay of the second resident workgroup, in units of 256 cycles
+int cn_tune_c3p_stagger = 64; // cn_set_tuning key 29: start delay of the second resident workgroup, in units of 256 cycles
+                              // (measured 0 ... 96: 48-64 is best on every trunk shape, +6 ... +13 % over none)
+int cn_tune_c3p_knobs = 0;    // cn_set_tuning key 30 (A/B): see P3Args.knobs
 
 // one 128-byte line of zeros: the DMA source of halo pixels outside the image
 __device__ __attribute__((aligned(128))) unsigned char cn_p3_zero_line[128];
@@ -53,8 +55,9 @@ constexpr int P_HP = (P_HR + 7) / 8;          // 23 DMA pieces of 8 rows (1 KiB)
 constexpr int P_HBYTES = P_HP * 1024;         // 23552 bytes per halo buffer (whole pieces)
 constexpr int P_WSLOT = 64 * 128;             // one weight tile: 64 rows of 128 bytes
 constexpr int P_NSLOT = 4;
-constexpr int P_LDS = 2 * P_HBYTES + P_NSLOT * P_WSLOT;   // 79872 bytes
 constexpr int P_WOFF = 2 * P_HBYTES;          // weight ring behind the two halo buffers
+constexpr int P_SSOFF = P_WOFF + P_NSLOT * P_WSLOT;       // per consumer wave: scale[32], shift[32] of its channels
+constexpr int P_LDS = P_SSOFF + 4 * 256;      // 80896 bytes
 constexpr int P_STG_ROW = 144;                // epilogue strip: 32 rows x 144 bytes per wave
 constexpr int P_STG = 32 * P_STG_ROW;
 static_assert(4 * P_STG <= P_HBYTES, "the epilogue strips alias one halo buffer");
@@ -78,23 +81,27 @@ struct P3Args {
     float res_mul;
     uint32_t *range;
     int stagger;
+    int knobs;                // A/B switches (cn_set_tuning key 30): 1 = no s_setprio around the MFMA block, 2 = loader at priority 3
     // instrumented instantiation only (DBG = true; cn_conv3x3p_probe): ablation switches and cycle counters
     int dbg;                  // 1: no MFMAs, 2: no fragment reads (and no MFMAs), 4: no weight DMA, 8: no halo DMA,
                               // 16: no epilogue, 32: no output stores
     unsigned long long *prof; // [workgroup][wave 5][8] cycle counters, or null
 };
 
-// vmcnt the loader waits for before the barrier of step t of a stage (steady state): everything
-// up to the weight tile of step g + 1 has landed, and (t == 8) the whole halo of the next stage.
+// vmcnt the loader waits for before the barrier of step t of a stage (steady state): the weight
+// tile of step g has landed (issued three steps earlier), and (t == 0) the whole halo of the stage.
 // Issue order per step: 8 weight pieces (tile g + 3), then the step's halo pieces
-// h(t) = {0, 4, 4, 4, 4, 4, 3, 0, 0}: allowed outstanding = h(t-2) + 8 + h(t-1).
+// h(t) = {0, 4, 4, 4, 4, 4, 3, 0, 0}: allowed outstanding = h(t-3) + 8 + h(t-2) + 8 + h(t-1)
+// (t == 0: the last halo pieces went out at t = 6, 16 weight pieces behind them).
 __device__ __forceinline__ void p3_wait_step(int t)
 {
     switch (t) {
-    case 0: case 1: case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 0: case 1: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
     }
 }
 
@@ -232,6 +239,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
             if (hk < nit) set_hbase();
         };
 #define P3_IC(v) std::integral_constant<int, (v)>{}
+        if (a.knobs & 2) __builtin_amdgcn_s_setprio(3);
         // ---- prologue: halo of stage 0, weight tiles of steps 0, 1, 2
         issue_H(P3_IC(0), P3_IC(P_HP), 0);
         advance_H();
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
             for (int q = 0; q < 4; ++q) asm volatile("" :: "v"(wf[q]), "v"(xf[q][0]), "v"(xf[q][1]));
             return;
         }
-        __builtin_amdgcn_s_setprio(1);
+        if (!(a.knobs & 1)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             // smallest terms first: w_hi * x_lo, w_lo * x_hi, then w_hi * x_hi
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
             for (int i = 0; i < 2; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kh], xf[kh][i], acc[i], 0, 0, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (!(a.knobs & 1)) __builtin_amdgcn_s_setprio(0);
     };
 
     // pixel of the row-layout lane: block i, pass k -> row 8k + (lane >> 3) of the wave's block
@@ -382,20 +390,13 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
         const int grp = 2 * it.nb + wn;
         if (grp >= a.ngroups) return;          // wave-uniform: this wave's 32 channels do not exist
         const int stg = sb + wave * P_STG;
-        // scale / shift of the lane's channels 8g + 4 lh .. + 3 of the wave's group (one request
-        // burst ahead of everything else: its latency hides behind the residual strip writes)
+        // scale / shift of the lane's channels 8g + 4 lh .. + 3 of the wave's group: from the wave's
+        // LDS stash (requested at the item's first step, stored two steps later)
         cn_f32x4 sc[4], sh[4];
-        const unsigned cofs = (unsigned)(32 * grp + 4 * lh) * 4u;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            sc[g] = *reinterpret_cast<const cn_f32x4 *>(reinterpret_cast<const char *>(a.scale) + (cofs + 32u * g));
-        if (a.shift) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                sh[g] = *reinterpret_cast<const cn_f32x4 *>(reinterpret_cast<const char *>(a.shift) + (cofs + 32u * g));
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) sh[g] = cn_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 4; ++g) {
+            sc[g] = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + wave * 256 + (8 * g + 4 * lh) * 4);
+            sh[g] = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + wave * 256 + 128 + (8 * g + 4 * lh) * 4);
         }
         const int rowb = stg + l31 * P_STG_ROW + 8 * lh;    // + 16 g (+ 64): f32s pieces; plain: 2x
 #pragma unroll
@@ -480,14 +481,25 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
         }
         if (s == S) break;
         const int hb = (s & 1) * P_HBYTES;
-        // the item's residual rows: requested at its first step, used in its epilogue (a whole
-        // item of HBM latency hidden; the registers are free until then)
-        if constexpr (RES != 0) {
-            if (c == 0) load_residual(cur);
+        // per item: this lane's scale (lanes 0-31) or shift (32-63) value of the wave's 32 channels,
+        // requested at the first step and parked in the wave's LDS stash two steps later; the
+        // residual rows, requested two steps in (behind the previous item's output stores, whose
+        // registers the address arithmetic would otherwise have to wait for) and used in the
+        // epilogue, a whole item later
+        float ssv = 0.f;
+        if (c == 0) {
+            const int grp = 2 * cur.nb + wn;
+            const float *src = lh ? a.shift : a.scale;
+            if (grp < a.ngroups && src) ssv = src[32 * grp + l31];
+            else ssv = lh ? 0.f : 1.f;
         }
         step(P3_IC(0), hb, P_WOFF + ((g + 0) & 3) * P_WSLOT);
         bar(); step(P3_IC(1), hb, P_WOFF + ((g + 1) & 3) * P_WSLOT);
         bar(); step(P3_IC(2), hb, P_WOFF + ((g + 2) & 3) * P_WSLOT);
+        if (c == 0) {
+            *reinterpret_cast<float *>(smem + P_SSOFF + wave * 256 + lane * 4) = ssv;
+            if constexpr (RES != 0) load_residual(cur);
+        }
         bar(); step(P3_IC(3), hb, P_WOFF + ((g + 3) & 3) * P_WSLOT);
         bar(); step(P3_IC(4), hb, P_WOFF + ((g + 4) & 3) * P_WSLOT);
         bar(); step(P3_IC(5), hb, P_WOFF + ((g + 5) & 3) * P_WSLOT);
@@ -564,6 +576,7 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
     a.res_mul = (ctl && ctl->res_mul != 0.f) ? ctl->res_mul : 1.f;
     a.range = ctl ? ctl->range : nullptr;
     a.stagger = cn_tune_c3p_stagger;
+    a.knobs = cn_tune_c3p_knobs;
     // two workgroups per CU, a multiple of 8 (one share per XCD), never more than one per item
     int per_xcd = cn_cdiv(a.items, 8);
     if (per_xcd > 64) per_xcd = 64;

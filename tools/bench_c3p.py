@@ -126,7 +126,6 @@ def check(case, nb=None, label=""):
 
 
 allok = True
-lib.cn_set_tuning(29, 0)
 print("== correctness (error relative to the rms of the fp64 reference)")
 CASES = [
     ("B2 64->64 @32x32", dict(B=2, ci=64, H=32, W=32, co=64)),
@@ -140,7 +139,7 @@ CASES = [
     ("B32 64->64 @128 res f32s", dict(B=32, ci=64, H=128, W=128, co=64, res=1)),
     ("B32 512->512 @16", dict(B=32, ci=512, H=16, W=16, co=512, res=1)),
 ]
-for label, kw in CASES:
+for label, kw in ([] if os.environ.get("SKIPCHECK") else CASES):
     c = Case(**kw)
     allok &= check(c, nb=2, label=label)
     # run-to-run bit equality of the persistent kernel
@@ -157,7 +156,8 @@ if os.environ.get("QUICK"):
 
 print("== timing, B = 32 (ms per launch, effective TFLOP/s)")
 SHAPES = [(64, 128, 128, 64), (128, 64, 64, 128), (256, 32, 32, 256), (512, 16, 16, 512)]
-stags = [int(v) for v in os.environ.get("STAG", "0").split(",")]
+stags = [int(v) for v in os.environ.get("STAG", "64").split(",")]
+knobs = [int(v) for v in os.environ.get("KNOBS", "0").split(",")]
 for (ci, H, W, co) in SHAPES:
     for res in (0, 1):
         c = Case(32, ci, H, W, co, res=res)
@@ -167,14 +167,17 @@ for (ci, H, W, co) in SHAPES:
         ms = c.time()
         row.append("halo %.4f ms %6.1f TF" % (ms, fl / ms / 1e9))
         for sg in stags:
-            lib.cn_set_tuning(28, 1)
-            lib.cn_set_tuning(29, sg)
-            ms = c.time()
-            row.append("persist(stag %d) %.4f ms %6.1f TF" % (sg, ms, fl / ms / 1e9))
+            for kn in knobs:
+                lib.cn_set_tuning(28, 1)
+                lib.cn_set_tuning(29, sg)
+                lib.cn_set_tuning(30, kn)
+                ms = c.time()
+                row.append("persist(stag %d knobs %d) %.4f ms %6.1f TF" % (sg, kn, ms, fl / ms / 1e9))
         print("%-22s res %d | %s" % (str((ci, H, W, co)), res, " | ".join(row)))
         del c
 lib.cn_set_tuning(28, 1)
-lib.cn_set_tuning(29, 0)
+lib.cn_set_tuning(29, 64)
+lib.cn_set_tuning(30, 0)
 
 # ---- where a launch spends its time: ablation switches and in-kernel cycle counters of the
 # instrumented instantiation (cn_conv3x3p_probe)
@@ -182,7 +185,7 @@ lib.cn_conv3x3p_probe.argtypes = [ctypes.c_int, ctypes.c_void_p]
 NAMES = {0: "full", 1: "no MFMA", 2: "no frag reads / MFMA", 12: "no DMA", 16: "no epilogue", 32: "no stores",
          28: "no DMA, no epilogue", 3 | 16: "barriers + DMA only", 31: "barriers only"}
 print("== probes (instrumented instantiation), B = 32")
-for (ci, H, W, co) in [(64, 128, 128, 64), (256, 32, 32, 256)]:
+for (ci, H, W, co) in ([(64, 128, 128, 64), (256, 32, 32, 256)] if os.environ.get("PROBE") else []):
     for res in (0, 1):
         c = Case(32, ci, H, W, co, res=res)
         fl = 2.0 * 32 * H * W * co * ci * 9
