@@ -14,8 +14,9 @@
 //     no ds_write, no VALU.  The LDS images are unpadded 128-byte rows, XOR-swizzled through the
 //     per-lane SOURCE address (the destination of an LDS-DMA is lane-linear) so that the
 //     ds_read_b128 fragment reads stay conflict-free;
-//   * the work is split by wave role: wave 4 of the 320-thread workgroup is the LOADER (issues all
-//     DMA pieces, owns every vmcnt wait), waves 0-3 are CONSUMERS (ds_read + MFMA + epilogue).
+//   * the work is split by wave role: waves 4 and 5 of the 384-thread workgroup are LOADERS (weight
+//     tiles / halos: they issue all DMA pieces and own every vmcnt wait), waves 0-3 are CONSUMERS
+//     (ds_read + MFMA + epilogue).
 //     Consumers never have a DMA in flight, so their compiler-managed waits for residual loads /
 //     output stores do not drain the pipeline, and the loader's issue stalls do not block MFMAs;
 //   * two such workgroups share a CU (79.9 KB of LDS, <= 168 registers): one's epilogue and
@@ -81,29 +82,12 @@ struct P3Args {
     float res_mul;
     uint32_t *range;
     int stagger;
-    int knobs;                // A/B switches (cn_set_tuning key 30): 1 = no s_setprio around the MFMA block, 2 = loader at priority 3
+    int knobs;                // A/B switches (cn_set_tuning key 30): 1 = s_setprio 1 around the consumers' MFMA block (measured: slower)
     // instrumented instantiation only (DBG = true; cn_conv3x3p_probe): ablation switches and cycle counters
     int dbg;                  // 1: no MFMAs, 2: no fragment reads (and no MFMAs), 4: no weight DMA, 8: no halo DMA,
                               // 16: no epilogue, 32: no output stores
     unsigned long long *prof; // [workgroup][wave 5][8] cycle counters, or null
 };
-
-// vmcnt the loader waits for before the barrier of step t of a stage (steady state): the weight
-// tile of step g has landed (issued three steps earlier), and (t == 0) the whole halo of the stage.
-// Issue order per step: 8 weight pieces (tile g + 3), then the step's halo pieces
-// h(t) = {0, 4, 4, 4, 4, 4, 3, 0, 0}: allowed outstanding = h(t-3) + 8 + h(t-2) + 8 + h(t-1)
-// (t == 0: the last halo pieces went out at t = 6, 16 weight pieces behind them).
-__device__ __forceinline__ void p3_wait_step(int t)
-{
-    switch (t) {
-    case 0: case 1: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
-    }
-}
 
 __device__ __forceinline__ void p3_barrier()
 {
@@ -130,7 +114,7 @@ __device__ __forceinline__ P3Item p3_decode(const P3Args &a, int item)
 
 // RES: 0 = no residual, 1 = f32s residual, 2 = plain fp32 residual
 template <int RES, bool OUT_PLAIN, bool DBG = false>
-__global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
+__global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
 {
     extern __shared__ __attribute__((aligned(128))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -152,132 +136,147 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
         while (__builtin_readcyclecounter() - t0 < (unsigned long long)a.stagger * 256u) __builtin_amdgcn_s_sleep(32);
     }
 
-    if (wave == 4) {
-        // =============================== LOADER ===============================
-        // halo pieces: piece k covers halo rows 8k .. 8k+7; lane = (row in piece, 16-byte slot s);
-        // slot s of row r receives source column s ^ key(r), key = (halo column >> 1) & 7
+    if (wave >= 4) {
+        // =============================== LOADERS ===============================
+        // wave 4 streams the weight tiles, wave 5 the halos: each owns one in-order DMA queue (its
+        // vmcnt), both join every barrier.  (One loader wave issuing all 12 pieces of a step was
+        // measured busy for ~900 cycles per step: more than the step's matrix work.)
         const int prow = lane >> 3, ps = lane & 7;
-        int poff[P_HP];          // byte offset of the lane's source inside the tile's input window, relative to pixel (ty0, tx0)
-        int pyx[P_HP];           // hy | hx << 8, or -1: row beyond the halo
-#pragma unroll
-        for (int k = 0; k < P_HP; ++k) {
-            const int r = 8 * k + prow;
-            const int hy = r / P_HW, hx = r - hy * P_HW;
-            const int col = ps ^ ((hx >> 1) & 7);
-            poff[k] = ((hy - 1) * a.W + (hx - 1)) * a.in_pitchB + col * 16;
-            pyx[k] = (r < P_HR) ? (hy | (hx << 8)) : -1;
-        }
-        const char *zero = reinterpret_cast<const char *>(cn_p3_zero_line) + ps * 16;
-
-        // weight pieces: piece p = rows 8p .. 8p+7 of the 64-row tile
-        int wrow[8];
-        unsigned wofs[8];        // per item: byte offset of the lane's source inside one tap's matrix
-#pragma unroll
-        for (int p = 0; p < 8; ++p) wrow[p] = 8 * p + prow;
-
-        // cursors: halo stage (item ordinal hk, chunk hc) and weight step (wk, wc, wt)
-        int hk = 0, hc = 0;
-        P3Item hit = p3_decode(a, first);
-        int wk = 0, wc = 0, wt = 0, wg = 0;
-        auto set_wofs = [&](int nb) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int n = wrow[p];
-                const int row = min(nb * 64 + n, a.cout_pad - 1);
-                wofs[p] = (unsigned)(row * a.cin_padB + ((ps ^ ((n >> 1) & 7)) << 4));
-            }
-        };
-        set_wofs(hit.nb);
-        const size_t tapB = (size_t)a.cout_pad * a.cin_padB;
         unsigned long long pf_wait = 0, pf_bar = 0, pf_t0 = 0;
         auto now = [&]() { return DBG ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
         if (DBG) pf_t0 = now();
-        auto issue_W = [&]() {   // weight tile of the cursor's step into ring slot wg & 3, then advance
-            if (wk >= nit) return;
-            const char *base = a.w + (size_t)wt * tapB + (size_t)wc * 128;
-            char *dst = smem + P_WOFF + (wg & (P_NSLOT - 1)) * P_WSLOT;
-            if (!DBG || !(a.dbg & 4)) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p)
-                __builtin_amdgcn_global_load_lds((p3_gl_void *)(base + wofs[p]), (p3_lds_void *)(dst + p * 1024), 16, 0, 0);
-            }
-            ++wg;
-            if (++wt == 9) {
-                wt = 0;
-                if (++wc == a.nchunk) {
-                    wc = 0;
-                    ++wk;
-                    if (wk < nit && a.nblk > 1) set_wofs((first + wk * nx) % a.nblk);
-                }
-            }
-        };
-        // halo pieces [k0, k1) of the cursor's stage into buffer `buf`
-        const char *hbase = nullptr;   // address of pixel (ty0, tx0), chunk hc, of the cursor's item
-        auto set_hbase = [&]() {
-            hbase = a.x + ((size_t)(hit.b * a.H + hit.ty0) * a.W + hit.tx0) * a.in_pitchB + (size_t)hc * 128;
-        };
-        set_hbase();
-        auto issue_H = [&](auto K0, auto K1, int buf) {
-            constexpr int k0 = decltype(K0)::value, k1 = decltype(K1)::value;
-            char *dst = smem + buf * P_HBYTES;
-            if (DBG && (a.dbg & 8)) return;
-#pragma unroll
-            for (int k = k0; k < k1; ++k) {
-                const int hy = pyx[k] & 255, hx = pyx[k] >> 8;
-                const int iy = hit.ty0 - 1 + hy, ix = hit.tx0 - 1 + hx;
-                const bool ok = pyx[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const char *src = ok ? hbase + poff[k] : zero;
-                __builtin_amdgcn_global_load_lds((p3_gl_void *)src, (p3_lds_void *)(dst + k * 1024), 16, 0, 0);
-            }
-        };
-        auto advance_H = [&]() {   // cursor to the next stage
-            if (++hc == a.nchunk) {
-                hc = 0;
-                ++hk;
-                if (hk < nit) hit = p3_decode(a, first + hk * nx);
-            }
-            if (hk < nit) set_hbase();
-        };
+        __builtin_amdgcn_s_setprio(3);
 #define P3_IC(v) std::integral_constant<int, (v)>{}
-        if (a.knobs & 2) __builtin_amdgcn_s_setprio(3);
-        // ---- prologue: halo of stage 0, weight tiles of steps 0, 1, 2
-        issue_H(P3_IC(0), P3_IC(P_HP), 0);
-        advance_H();
-        issue_W();
-        issue_W();
-        issue_W();
-        for (int s = 0;; ++s) {
-            const bool last = (s >= S - 1);   // no next stage: counts below do not hold, drain instead
-            unsigned long long c0 = now();
-            if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else p3_wait_step(0);
-            unsigned long long c1 = now();
-            p3_barrier();
-            if (DBG) { pf_wait += c1 - c0; pf_bar += now() - c1; }
-            if (s == S) break;
-            issue_W();
-            const int nbuf = (s + 1) & 1;
+        if (wave == 4) {
+            // ---- weight tiles: piece p = rows 8p .. 8p+7 of the 64-row tile of (tap, chunk);
+            // slot s of row n receives source column s ^ ((n >> 1) & 7)
+            unsigned wofs[8];        // per item: byte offset of the lane's source inside one tap's matrix
+            auto set_wofs = [&](int nb) {
 #pragma unroll
-            for (int t = 1; t < 9; ++t) {
-                c0 = now();
-                if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else p3_wait_step(t);
-                c1 = now();
-                p3_barrier();
-                if (DBG) { pf_wait += c1 - c0; pf_bar += now() - c1; }
-                issue_W();
-                if (!last) {
-                    if (t == 1) issue_H(P3_IC(0), P3_IC(4), nbuf);
-                    if (t == 2) issue_H(P3_IC(4), P3_IC(8), nbuf);
-                    if (t == 3) issue_H(P3_IC(8), P3_IC(12), nbuf);
-                    if (t == 4) issue_H(P3_IC(12), P3_IC(16), nbuf);
-                    if (t == 5) issue_H(P3_IC(16), P3_IC(20), nbuf);
-                    if (t == 6) issue_H(P3_IC(20), P3_IC(P_HP), nbuf);
+                for (int p = 0; p < 8; ++p) {
+                    const int n = 8 * p + prow;
+                    const int row = min(nb * 64 + n, a.cout_pad - 1);
+                    wofs[p] = (unsigned)(row * a.cin_padB + ((ps ^ ((n >> 1) & 7)) << 4));
                 }
+            };
+            set_wofs(first % a.nblk);
+            const size_t tapB = (size_t)a.cout_pad * a.cin_padB;
+            int wk = 0, wc = 0, wt = 0, wg = 0;
+            auto issue_W = [&]() {   // weight tile of the cursor's step into ring slot wg & 3, then advance
+                if (wk >= nit) return;
+                const char *base = a.w + (size_t)wt * tapB + (size_t)wc * 128;
+                char *dst = smem + P_WOFF + (wg & (P_NSLOT - 1)) * P_WSLOT;
+                if (!DBG || !(a.dbg & 4)) {
+#pragma unroll
+                    for (int p = 0; p < 8; ++p)
+                        __builtin_amdgcn_global_load_lds((p3_gl_void *)(base + wofs[p]), (p3_lds_void *)(dst + p * 1024), 16, 0, 0);
+                }
+                ++wg;
+                if (++wt == 9) {
+                    wt = 0;
+                    if (++wc == a.nchunk) {
+                        wc = 0;
+                        ++wk;
+                        if (wk < nit && a.nblk > 1) set_wofs((first + wk * nx) % a.nblk);
+                    }
+                }
+            };
+            // tiles of steps 0, 1, 2 up front; then tile g + 3 behind the barrier of step g (the
+            // barrier says every consumer is done with tile g - 1, whose slot it takes), and before
+            // that barrier tile g has landed: at most the two younger tiles (16 pieces) outstanding
+            issue_W();
+            issue_W();
+            issue_W();
+            for (int s = 0;; ++s) {
+                const bool last = (s >= S - 1);   // the stream ends: drain instead of counting
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const unsigned long long c0 = now();
+                    if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    const unsigned long long c1 = now();
+                    p3_barrier();
+                    if (DBG) { pf_wait += c1 - c0; pf_bar += now() - c1; }
+                    if (s == S) break;
+                    issue_W();
+                }
+                if (s == S) break;
             }
-            if (!last) advance_H();
+        } else {
+            // ---- halos: piece k covers halo rows 8k .. 8k+7; lane = (row in piece, 16-byte slot s);
+            // slot s of row r receives source column s ^ key(r), key = (halo column >> 1) & 7
+            int poff[P_HP];          // byte offset of the lane's source relative to pixel (ty0, tx0) of the tile
+            int pyx[P_HP];           // hy | hx << 8, or -1: row beyond the halo
+#pragma unroll
+            for (int k = 0; k < P_HP; ++k) {
+                const int r = 8 * k + prow;
+                const int hy = r / P_HW, hx = r - hy * P_HW;
+                const int col = ps ^ ((hx >> 1) & 7);
+                poff[k] = ((hy - 1) * a.W + (hx - 1)) * a.in_pitchB + col * 16;
+                pyx[k] = (r < P_HR) ? (hy | (hx << 8)) : -1;
+            }
+            const char *zero = reinterpret_cast<const char *>(cn_p3_zero_line) + ps * 16;
+            int hk = 0, hc = 0;       // cursor: the stage whose halo goes out next
+            P3Item hit = p3_decode(a, first);
+            const char *hbase = nullptr;   // address of pixel (ty0, tx0), chunk hc, of the cursor's item
+            auto set_hbase = [&]() {
+                hbase = a.x + ((size_t)(hit.b * a.H + hit.ty0) * a.W + hit.tx0) * a.in_pitchB + (size_t)hc * 128;
+            };
+            set_hbase();
+            auto issue_H = [&](auto K0, auto K1, int buf) {   // pieces [k0, k1) of the cursor's stage
+                constexpr int k0 = decltype(K0)::value, k1 = decltype(K1)::value;
+                char *dst = smem + buf * P_HBYTES;
+                if (DBG && (a.dbg & 8)) return;
+#pragma unroll
+                for (int k = k0; k < k1; ++k) {
+                    const int hy = pyx[k] & 255, hx = pyx[k] >> 8;
+                    const int iy = hit.ty0 - 1 + hy, ix = hit.tx0 - 1 + hx;
+                    const bool ok = pyx[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    const char *src = ok ? hbase + poff[k] : zero;
+                    __builtin_amdgcn_global_load_lds((p3_gl_void *)src, (p3_lds_void *)(dst + k * 1024), 16, 0, 0);
+                }
+            };
+            auto advance_H = [&]() {   // cursor to the next stage
+                if (++hc == a.nchunk) {
+                    hc = 0;
+                    ++hk;
+                    if (hk < nit) hit = p3_decode(a, first + hk * nx);
+                }
+                if (hk < nit) set_hbase();
+            };
+            // halo of stage 0 up front; the halo of stage s + 1 goes out during steps 1 .. 6 of stage
+            // s (the buffer it takes was read last in stage s - 1 and holds the epilogue strips of
+            // an item that ended there until the barrier of step 1) and is complete -- every older
+            // piece of this wave's queue -- before the first barrier of stage s + 1
+            issue_H(P3_IC(0), P3_IC(P_HP), 0);
+            advance_H();
+            for (int s = 0;; ++s) {
+                const bool last = (s >= S - 1);
+                const int nbuf = (s + 1) & 1;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const unsigned long long c0 = now();
+                    if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long c1 = now();
+                    p3_barrier();
+                    if (DBG) { pf_wait += c1 - c0; pf_bar += now() - c1; }
+                    if (s == S) break;
+                    if (!last) {
+                        if (t == 1) issue_H(P3_IC(0), P3_IC(4), nbuf);
+                        if (t == 2) issue_H(P3_IC(4), P3_IC(8), nbuf);
+                        if (t == 3) issue_H(P3_IC(8), P3_IC(12), nbuf);
+                        if (t == 4) issue_H(P3_IC(12), P3_IC(16), nbuf);
+                        if (t == 5) issue_H(P3_IC(16), P3_IC(20), nbuf);
+                        if (t == 6) issue_H(P3_IC(20), P3_IC(P_HP), nbuf);
+                    }
+                }
+                if (s == S) break;
+                if (!last) advance_H();
+            }
         }
 #undef P3_IC
         if (DBG && a.prof && lane == 0) {
-            unsigned long long *o = a.prof + ((size_t)blockIdx.x * 5 + 4) * 8;
+            unsigned long long *o = a.prof + ((size_t)blockIdx.x * 6 + wave) * 8;
             o[0] = now() - pf_t0; o[1] = pf_wait; o[2] = pf_bar; o[3] = (unsigned long long)S;
         }
         return;
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
             for (int q = 0; q < 4; ++q) asm volatile("" :: "v"(wf[q]), "v"(xf[q][0]), "v"(xf[q][1]));
             return;
         }
-        if (!(a.knobs & 1)) __builtin_amdgcn_s_setprio(1);
+        if (a.knobs & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             // smallest terms first: w_hi * x_lo, w_lo * x_hi, then w_hi * x_hi
@@ -359,7 +358,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
             for (int i = 0; i < 2; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kh], xf[kh][i], acc[i], 0, 0, 0);
         }
-        if (!(a.knobs & 1)) __builtin_amdgcn_s_setprio(0);
+        if (a.knobs & 1) __builtin_amdgcn_s_setprio(0);
     };
 
     // pixel of the row-layout lane: block i, pass k -> row 8k + (lane >> 3) of the wave's block
@@ -515,7 +514,7 @@ __global__ __launch_bounds__(320, 3) void conv3x3p_kernel(const P3Args a)
         }
     }
     if (DBG && a.prof && lane == 0) {
-        unsigned long long *o = a.prof + ((size_t)blockIdx.x * 5 + wave) * 8;
+        unsigned long long *o = a.prof + ((size_t)blockIdx.x * 6 + wave) * 8;
         o[0] = now() - pf_t0; o[1] = pf_epi; o[2] = pf_bar; o[3] = (unsigned long long)S;
     }
 #undef P3_IC
@@ -580,7 +579,7 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
     // two workgroups per CU, a multiple of 8 (one share per XCD), never more than one per item
     int per_xcd = cn_cdiv(a.items, 8);
     if (per_xcd > 64) per_xcd = 64;
-    const dim3 grid(8 * per_xcd), block(320);
+    const dim3 grid(8 * per_xcd), block(384);
 #define P3_LAUNCH(R, OP)                                                                   \
     do {                                                                                   \
         CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<R, OP>), P_LDS);                               \

@@ -190,7 +190,7 @@ for (ci, H, W, co) in ([(64, 128, 128, 64), (256, 32, 32, 256)] if os.environ.ge
         c = Case(32, ci, H, W, co, res=res)
         fl = 2.0 * 32 * H * W * co * ci * 9
         lib.cn_set_tuning(28, 1)
-        prof = torch.zeros((512, 5, 8), device=dev, dtype=torch.int64)
+        prof = torch.zeros((512, 6, 8), device=dev, dtype=torch.int64)
         row = []
         for dbg in (0, 1, 2, 12, 16, 32, 28, 19, 31):
             lib.cn_conv3x3p_probe(dbg, prof.data_ptr())
@@ -203,9 +203,9 @@ for (ci, H, W, co) in ([(64, 128, 128, 64), (256, 32, 32, 256)] if os.environ.ge
         torch.cuda.synchronize()
         pr = prof.cpu().double()
         used = pr[:, 0, 3] > 0
-        cons, load = pr[used][:, :4], pr[used][:, 4]
-        print("   consumers: total %.0f cyc, epilogue %.0f, barrier wait %.0f, stages %.0f | loader: total %.0f, vmcnt wait %.0f, barrier wait %.0f  (cycles of the 100 MHz? counter: ratios matter)" % (
+        cons, lw, lh = pr[used][:, :4], pr[used][:, 4], pr[used][:, 5]
+        print("   consumers: total %.0f cyc, epilogue %.0f, barrier wait %.0f, stages %.0f | weight loader: total %.0f, vmcnt wait %.0f, barrier wait %.0f | halo loader: vmcnt wait %.0f, barrier wait %.0f" % (
             cons[..., 0].mean(), cons[..., 1].mean(), cons[..., 2].mean(), cons[..., 3].mean(),
-            load[:, 0].mean(), load[:, 1].mean(), load[:, 2].mean()))
+            lw[:, 0].mean(), lw[:, 1].mean(), lw[:, 2].mean(), lh[:, 1].mean(), lh[:, 2].mean()))
         lib.cn_conv3x3p_probe(0, None)
         del c
