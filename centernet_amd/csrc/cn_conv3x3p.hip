@@ -72,6 +72,7 @@ struct P3Args {
     char *y;                  // f32s or plain fp32 NHWC
     int H, W;
     int in_pitchB, out_pitchB, res_pitchB;   // bytes per pixel
+    int res_bytes;            // size of the residual tensor (buffer loads)
     int cin_padB;             // bytes per weight row (cin_pad * 4)
     int cout_pad;             // weight rows per tap
     int ngroups;              // 32-channel groups of the output that exist (cout_pad / 32)
@@ -114,7 +115,7 @@ __device__ __forceinline__ P3Item p3_decode(const P3Args &a, int item)
 
 // RES: 0 = no residual, 1 = f32s residual, 2 = plain fp32 residual
 template <int RES, bool OUT_PLAIN, bool DBG = false>
-__global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
+__global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a)
 {
     extern __shared__ __attribute__((aligned(128))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,6 +132,8 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
     if (nit == 0) return;
     const int S = nit * a.nchunk;                         // stages of this workgroup
 
+    unsigned long long pf_rt0 = 0;     // 100 MHz wall clock at entry (instrumented instantiation)
+    if (DBG) pf_rt0 = __builtin_amdgcn_s_memrealtime();
     if (a.stagger && blockIdx.x >= 256) {
         const unsigned long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < (unsigned long long)a.stagger * 256u) __builtin_amdgcn_s_sleep(32);
@@ -278,28 +281,33 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
         if (DBG && a.prof && lane == 0) {
             unsigned long long *o = a.prof + ((size_t)blockIdx.x * 6 + wave) * 8;
             o[0] = now() - pf_t0; o[1] = pf_wait; o[2] = pf_bar; o[3] = (unsigned long long)S;
+            o[4] = pf_rt0; o[5] = __builtin_amdgcn_s_memrealtime();
         }
         return;
     }
 
     // =============================== CONSUMERS ===============================
-    const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    // A fragment addresses (input pixels = the MFMA's B operand): block i = pixels 64 wm + 32 i + l31
-    // = tile rows 4 wm + 2 i + (l31 >> 4), column l31 & 15; tap (ky, kx) adds (ky * 18 + kx) rows
-    // (an immediate) and changes the swizzle key with kx only
-    const int px = l31 & 15;
-    int a0[2][3];
+    // Fragment addresses of the lane.  A (input pixels = the MFMA's B operand): block i = pixels
+    // 64 wm + 32 i + l31 = tile rows 4 wm + 2 i + (l31 >> 4), column l31 & 15; tap (ky, kx) adds
+    // (ky * 18 + kx) rows (an immediate) and changes the swizzle key with kx only: one register
+    // for the row base of block 0 (block 1 = two tile rows = 2 * 18 halo rows further: an immediate),
+    // one for the three swizzle terms (8 bits each).  B (weights = the MFMA's A operand): row
+    // 32 wn + l31 of the tile.  They are recomputed per item from an opaque copy of the lane id
+    // so that nothing of them is live (or spilled and reloaded behind the output stores) across
+    // an epilogue.
+    int arow, aswz, b0;
+    auto lane_consts = [&]() {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int l31 = ln & 31, lh = ln >> 5, px = ln & 15;
+        arow = ((4 * wm + (l31 >> 4)) * P_HW + px) * 128;
+        aswz = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int row0 = (4 * wm + 2 * i + (l31 >> 4)) * P_HW + px;
-            const int key = ((px + kx) >> 1) & 7;
-            a0[i][kx] = row0 * 128 + (((lh ^ key) & 7) << 4);
-        }
-    // B fragment address (weights = the MFMA's A operand): row 32 wn + l31 of the tile
-    const int b0 = (32 * wn + l31) * 128 + (((lh ^ ((l31 >> 1) & 7)) & 7) << 4);
+        for (int kx = 0; kx < 3; ++kx) aswz |= (((lh ^ (((px + kx) >> 1) & 7)) & 7) << 4) << (8 * kx);
+        b0 = (32 * wn + l31) * 128 + (((lh ^ ((l31 >> 1) & 7)) & 7) << 4);
+    };
+    lane_consts();
 
     cn_f32x16 acc[2];
     auto zero_acc = [&]() {
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
     };
     zero_acc();
     float rng_out = 0.f;
-    cn_f32x4 resv[2][4];   // residual rows of the item (row layout), requested at its first step
+    cn_f32x4 resv[2][4];   // residual rows of the item (row layout), requested at the end of its last step
 
     auto lds128 = [&](int off) { return *reinterpret_cast<const p3_f16x8 *>(smem + off); };
 
@@ -324,16 +332,17 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
         p3_f16x8 xf[4][2], wf[4];
         // the lane's row addresses pass through an opaque copy: otherwise the compiler keeps every
         // (tap, quarter, ring slot) address variant of the unrolled stage in its own register (~70)
-        int ax[2] = {a0[0][kx], a0[1][kx]}, bx = b0;
-        asm volatile("" : "+v"(ax[0]), "+v"(ax[1]), "+v"(bx));
+        int ax = arow + ((aswz >> (8 * kx)) & 0xff), bx = b0;
+        asm volatile("" : "+v"(ax), "+v"(bx));
+        constexpr int blk1 = 2 * P_HW * 128;   // block 1 of the wave: two tile rows below block 0
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             // (the operands of the first products first)
             wf[kh] = lds128(wb + (bx ^ (kh << 5)));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) xf[2 + kh][i] = lds128(hb + tapoff + (ax[i] ^ ((kh << 5) | 64)));
+            for (int i = 0; i < 2; ++i) xf[2 + kh][i] = lds128(hb + tapoff + i * blk1 + (ax ^ ((kh << 5) | 64)));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) xf[kh][i] = lds128(hb + tapoff + (ax[i] ^ (kh << 5)));
+            for (int i = 0; i < 2; ++i) xf[kh][i] = lds128(hb + tapoff + i * blk1 + (ax ^ (kh << 5)));
             wf[2 + kh] = lds128(wb + (bx ^ ((kh << 5) | 64)));
         }
         // every fragment read is issued before the first MFMA (cn_conv3x3.hip: a ds_read sunk behind
@@ -362,24 +371,36 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
     };
 
     // pixel of the row-layout lane: block i, pass k -> row 8k + (lane >> 3) of the wave's block
-    const int rrow = lane >> 3, rcol = lane & 7;
-    auto row_pixel = [&](const P3Item &it, int i, int k, bool &ok) {
+    // (lane-derived indices of the epilogue and the residual request are recomputed from an opaque
+    // copy of the lane id where they are used: kept as loop invariants they cost ~20 registers)
+    auto opaque_lane = [&]() {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        return ln;
+    };
+    auto row_pixel = [&](const P3Item &it, int i, int k, int rrow, bool &ok) {
         const int p = 64 * wm + 32 * i + 8 * k + rrow;
         const int oy = it.ty0 + (p >> 4), ox = it.tx0 + (p & 15);
         ok = oy < a.H && ox < a.W;
         return (it.b * a.H + oy) * a.W + ox;
     };
+    // raw buffer descriptor of the residual tensor (dword 3: 32-bit data format, gfx9 family)
+    const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(a.residual ? a.residual : a.x), 0, a.res_bytes, 0x00020000);
     auto load_residual = [&](const P3Item &it) {
+        const int ln = opaque_lane();
+        const int rrow = ln >> 3, rcol = ln & 7;
         const int grp = 2 * it.nb + wn;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 bool ok;
-                const int pix = row_pixel(it, i, k, ok);
+                const int pix = row_pixel(it, i, k, rrow, ok);
                 const bool take = ok && grp < a.ngroups;
-                resv[i][k] = *reinterpret_cast<const cn_f32x4 *>(
-                    a.residual + (take ? (unsigned)pix * (unsigned)a.res_pitchB + (unsigned)(grp * 128 + rcol * 16) : 0u));
+                // (buffer form: SGPR descriptor + 32-bit lane offset, no 64-bit address registers)
+                const unsigned off = take ? (unsigned)pix * (unsigned)a.res_pitchB + (unsigned)(grp * 128 + rcol * 16) : 0u;
+                resv[i][k] = __builtin_bit_cast(cn_f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, off, 0, 0));
             }
     };
 
@@ -389,14 +410,10 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
         const int grp = 2 * it.nb + wn;
         if (grp >= a.ngroups) return;          // wave-uniform: this wave's 32 channels do not exist
         const int stg = sb + wave * P_STG;
+        const int ln = opaque_lane();
+        const int rrow = ln >> 3, rcol = ln & 7, l31 = ln & 31, lh = ln >> 5;
         // scale / shift of the lane's channels 8g + 4 lh .. + 3 of the wave's group: from the wave's
         // LDS stash (requested at the item's first step, stored two steps later)
-        cn_f32x4 sc[4], sh[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            sc[g] = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + wave * 256 + (8 * g + 4 * lh) * 4);
-            sh[g] = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + wave * 256 + 128 + (8 * g + 4 * lh) * 4);
-        }
         const int rowb = stg + l31 * P_STG_ROW + 8 * lh;    // + 16 g (+ 64): f32s pieces; plain: 2x
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -424,9 +441,11 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const cn_f32x4 sc = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + wave * 256 + (8 * g + 4 * lh) * 4);
+                const cn_f32x4 sh = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + wave * 256 + 128 + (8 * g + 4 * lh) * 4);
                 cn_f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e] * sc[g][e] + sh[g][e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e] * sc[e] + sh[e];
                 if constexpr (RES != 0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaf(rr[g][e], a.res_mul, v[e]);
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 bool ok;
-                const int pix = row_pixel(it, i, k, ok);
+                const int pix = row_pixel(it, i, k, rrow, ok);
                 const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(smem + stg + (8 * k + rrow) * P_STG_ROW + rcol * 16);
                 if (ok && !(DBG && (a.dbg & 32)))
                     *reinterpret_cast<cn_f32x4 *>(a.y + ((unsigned)pix * (unsigned)a.out_pitchB + (unsigned)(grp * 128 + rcol * 16))) = v;
@@ -476,35 +495,45 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
             const unsigned long long c0 = now();
             if (!(DBG && (a.dbg & 16))) epilogue(prev, ((s - 1) & 1) * P_HBYTES);
             zero_acc();
+            lane_consts();
             if (DBG) pf_epi += now() - c0;
         }
         if (s == S) break;
         const int hb = (s & 1) * P_HBYTES;
         // per item: this lane's scale (lanes 0-31) or shift (32-63) value of the wave's 32 channels,
-        // requested at the first step and parked in the wave's LDS stash two steps later; the
-        // residual rows, requested two steps in (behind the previous item's output stores, whose
-        // registers the address arithmetic would otherwise have to wait for) and used in the
-        // epilogue, a whole item later
+        // requested at the first step and parked in the wave's LDS stash two steps later
         float ssv = 0.f;
         if (c == 0) {
             const int grp = 2 * cur.nb + wn;
-            const float *src = lh ? a.shift : a.scale;
-            if (grp < a.ngroups && src) ssv = src[32 * grp + l31];
-            else ssv = lh ? 0.f : 1.f;
+            const int ln = opaque_lane();
+            const unsigned o = (unsigned)(32 * grp + (ln & 31)) * 4u;
+            float sv = 1.f, hv = 0.f;
+            if (grp < a.ngroups) {
+                sv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.scale) + o);
+                if (a.shift) hv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.shift) + o);
+            }
+            ssv = (ln >> 5) ? hv : sv;
         }
         step(P3_IC(0), hb, P_WOFF + ((g + 0) & 3) * P_WSLOT);
         bar(); step(P3_IC(1), hb, P_WOFF + ((g + 1) & 3) * P_WSLOT);
         bar(); step(P3_IC(2), hb, P_WOFF + ((g + 2) & 3) * P_WSLOT);
-        if (c == 0) {
-            *reinterpret_cast<float *>(smem + P_SSOFF + wave * 256 + lane * 4) = ssv;
-            if constexpr (RES != 0) load_residual(cur);
-        }
+        if (c == 0) *reinterpret_cast<float *>(smem + P_SSOFF + wave * 256 + lane * 4) = ssv;
         bar(); step(P3_IC(3), hb, P_WOFF + ((g + 3) & 3) * P_WSLOT);
         bar(); step(P3_IC(4), hb, P_WOFF + ((g + 4) & 3) * P_WSLOT);
         bar(); step(P3_IC(5), hb, P_WOFF + ((g + 5) & 3) * P_WSLOT);
         bar(); step(P3_IC(6), hb, P_WOFF + ((g + 6) & 3) * P_WSLOT);
         bar(); step(P3_IC(7), hb, P_WOFF + ((g + 7) & 3) * P_WSLOT);
         bar(); step(P3_IC(8), hb, P_WOFF + ((g + 8) & 3) * P_WSLOT);
+        // the item's residual rows: requested behind the matrix work of its last step (the fragment
+        // registers are free from here on; held over the whole item the 32 registers push the kernel
+        // past 128 -- and two 6-wave workgroups at 3 waves per SIMD leave the dispatcher no slack:
+        // measured, half of the second workgroups then start only when a first one has finished)
+        if constexpr (RES != 0) {
+            if (c == a.nchunk - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_residual(cur);
+            }
+        }
         g += 9;
         if (++c == a.nchunk) {
             c = 0;
@@ -516,6 +545,12 @@ __global__ __launch_bounds__(384, 3) void conv3x3p_kernel(const P3Args a)
     if (DBG && a.prof && lane == 0) {
         unsigned long long *o = a.prof + ((size_t)blockIdx.x * 6 + wave) * 8;
         o[0] = now() - pf_t0; o[1] = pf_epi; o[2] = pf_bar; o[3] = (unsigned long long)S;
+        o[4] = pf_rt0; o[5] = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        o[6] = xcc; o[7] = hwid;
     }
 #undef P3_IC
     if constexpr (!OUT_PLAIN) {
@@ -545,6 +580,25 @@ static int p3_probe_dbg = 0;
 static unsigned long long *p3_probe_prof = nullptr;
 // instrumented launches (tools/bench_c3p.py): dbg != 0 or prof != null route cn_conv3x3s1_persist to the
 // DBG instantiation (no residual, f32s output) with these switches / counters
+// workgroups of the given instantiation the runtime expects to be resident per CU
+extern "C" int cn_conv3x3p_occupancy(int res, int out_plain)
+{
+    int n = -1;
+    hipError_t e;
+#define P3_OCC(R, OP)                                                                             \
+    do {                                                                                          \
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<R, OP>), P_LDS);                                      \
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3x3p_kernel<R, OP>, 384, P_LDS);  \
+    } while (0)
+    if (out_plain) {
+        if (res == 0) P3_OCC(0, true); else if (res == 1) P3_OCC(1, true); else P3_OCC(2, true);
+    } else {
+        if (res == 0) P3_OCC(0, false); else if (res == 1) P3_OCC(1, false); else P3_OCC(2, false);
+    }
+#undef P3_OCC
+    return e == hipSuccess ? n : -(int)e;
+}
+
 extern "C" int cn_conv3x3p_probe(int dbg, void *prof)
 {
     p3_probe_dbg = dbg;
@@ -562,6 +616,7 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
     a.residual = (const char *)residual; a.y = (char *)y;
     a.H = H; a.W = W;
     a.in_pitchB = in_pitch * 4; a.out_pitchB = out_pitch * 4; a.res_pitchB = res_pitch * 4;
+    a.res_bytes = (int)((long)B * H * W * res_pitch * 4);   // < 2^31 (cn_conv3x3p_takes)
     const int cin_pad = (Cin + 31) / 32 * 32;
     a.cin_padB = cin_pad * 4;
     a.cout_pad = (Cout + 31) / 32 * 32;

@@ -207,5 +207,16 @@ for (ci, H, W, co) in ([(64, 128, 128, 64), (256, 32, 32, 256)] if os.environ.ge
         print("   consumers: total %.0f cyc, epilogue %.0f, barrier wait %.0f, stages %.0f | weight loader: total %.0f, vmcnt wait %.0f, barrier wait %.0f | halo loader: vmcnt wait %.0f, barrier wait %.0f" % (
             cons[..., 0].mean(), cons[..., 1].mean(), cons[..., 2].mean(), cons[..., 3].mean(),
             lw[:, 0].mean(), lw[:, 1].mean(), lw[:, 2].mean(), lh[:, 1].mean(), lh[:, 2].mean()))
+        # wall clock (100 MHz) of every workgroup: shader clock and how many workgroups run at a time
+        rt0, rt1 = pr[used][:, 0, 4], pr[used][:, 0, 5]
+        t0 = rt0.min()
+        span = float(rt1.max() - t0) / 100.0        # us
+        clk = (cons[:, 0, 0] / ((rt1 - rt0) * 10.0)).mean()   # cycles per ns
+        late = int((rt0 > rt1.min()).sum())
+        hw = pr[used][:, 0, 7].long()
+        cu_id = (pr[used][:, 0, 6].long() << 16) | (((hw >> 8) & 0xf) << 4) | ((hw >> 13) & 0x7) << 8 | ((hw >> 16) & 0x3) << 12
+        ncu = len(set(cu_id.tolist()))
+        print("   launch span %.1f us; shader clock %.2f GHz; workgroups started after the first one ended: %d of %d; start spread %.1f us; distinct (xcc, se, sh, cu) ids %d; occupancy API: %d / %d" % (
+            span, clk, late, int(used.sum()), float(rt0.max() - t0) / 100.0, ncu, lib.cn_conv3x3p_occupancy(0, 0), lib.cn_conv3x3p_occupancy(1, 0)))
         lib.cn_conv3x3p_probe(0, None)
         del c
