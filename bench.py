@@ -32,7 +32,7 @@ F16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARC
 # matrix-pipe ceiling in ALGORITHMIC (fp32-equivalent) FLOPs is a third of the fp16 peak
 F32S_MFMA_PEAK_TF = F16_MFMA_PEAK_TF / 3.0
 
-DECODE_LAUNCHES = {"ctdet": 6, "multi_pose": 4}   # kernels per decode call (cn_decode.hip)
+DECODE_LAUNCHES = {"ctdet": 6, "multi_pose": 5}   # kernels per decode call (cn_decode.hip)
 
 # BASELINE.json configs[1..4] (configs[0] is the reference's CPU plumbing case: cpu_baseline)
 CONFIGS = {
@@ -212,6 +212,54 @@ def precision_check(dev):
     return out
 
 
+def box_calibration(dev, target_ms=50.0):
+    """What THIS box delivers right now, measured just before the timed region: a register-only
+    v_mfma_f32_32x32x16_f16 loop on every SIMD (no memory traffic: the matrix pipe at the clock
+    the part holds under load) and a float4 copy of 512 MiB (twice the Infinity Cache; read +
+    write bytes over time), each sized to ~``target_ms`` from a short trial launch.  The headline
+    divided by these two says whether a change between runs is the code or the box."""
+    import torch
+    from centernet_amd import native
+    lib, st = native.lib(), native.stream_ptr
+    sink = torch.zeros(16, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def mfma(iters):
+        e0.record()
+        fl = lib.cn_calib_mfma_f16(native.ptr(sink), iters, st())
+        e1.record()
+        torch.cuda.synchronize()
+        assert fl > 0, "cn_calib_mfma_f16 failed"
+        return fl, e0.elapsed_time(e1)
+    mfma(200)                                   # lazy code load
+    fl, ms = mfma(2000)
+    iters = max(2000, int(2000 * target_ms / max(ms, 1e-3)))
+    fl, ms = mfma(iters)
+    out = {"mfma_f16_TFLOPs": fl / ms / 1e9, "mfma_ms": ms,
+           "mfma_frac_of_2500": fl / ms / 1e9 / F16_MFMA_PEAK_TF}
+    nbytes = 512 << 20
+    src = torch.empty(nbytes // 4, device=dev).normal_()
+    dst = torch.empty_like(src)
+
+    def copy(n):
+        e0.record()
+        for _ in range(n):
+            native.check(lib.cn_calib_copy(native.ptr(src), native.ptr(dst), nbytes, st()), "cn_calib_copy")
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    copy(2)
+    ms = copy(4)
+    n = max(4, int(4 * target_ms / max(ms, 1e-3)))
+    ms = copy(n)
+    out.update({"copy_TBs": 2.0 * nbytes * n / ms / 1e9, "copy_ms": ms,
+                "copy_frac_of_8TBs": 2.0 * nbytes * n / ms / 1e6 / HBM_PEAK_GBS,
+                "what": "register-only v_mfma_f32_32x32x16_f16 loop (1024 workgroups x 4 waves) and a float4 "
+                        "copy of 512 MiB (read + write bytes), ~%d ms each, right before the timed region" % target_ms})
+    del src, dst
+    return out
+
+
 def _time_images(fn, make_input, seconds):
     fn(make_input(0))   # warm-up
     t0 = time.time()
@@ -288,6 +336,26 @@ def _reference_cpu_res18(ref_src, res, seconds, cores):
     return {"value": done / dt, "unit": "img/s", "cores": cores, "kind": "reference",
             "sample": "%d images %dx%d batch 1 in %.1f s: reference msra_resnet res_18 (no DCN) + "
                       "models/decode.ctdet_decode, torch CPU" % (done, res, res, dt)}
+
+
+def cross_rank_agreement(per_rank, tol=1e-4):
+    """Detections of ONE shared batch from every rank against rank 0's.  (B, K, 6) rows are
+    [x1, y1, x2, y2, score, class]: the sorted scores must agree within ``tol`` (rank by rank --
+    robust against two near-tied rows swapping places) and rows must agree in place (same class,
+    boxes within 1e-2 px) except for such swaps; any other tensor: max |difference| <= tol."""
+    import torch
+    ref = per_rank[0]
+    out = {"ranks": len(per_rank), "tol": tol, "max_score_diff": 0.0, "rows_equal_in_place": 1.0, "ok": True}
+    for t in per_rank[1:]:
+        if ref.dim() == 3 and ref.shape[-1] >= 6:
+            ds = float((t[..., 4] - ref[..., 4]).abs().max())
+            same = ((t[..., 5] == ref[..., 5]) & ((t[..., :4] - ref[..., :4]).abs().amax(-1) <= 1e-2)).float().mean()
+            out["max_score_diff"] = max(out["max_score_diff"], ds)
+            out["rows_equal_in_place"] = min(out["rows_equal_in_place"], float(same))
+        else:
+            out["max_score_diff"] = max(out["max_score_diff"], float((t - ref).abs().max()))
+    out["ok"] = out["max_score_diff"] <= tol and out["rows_equal_in_place"] >= 0.98
+    return out
 
 
 class _StubEvent(object):
@@ -368,10 +436,18 @@ def main():
     if env_world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=env_world)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=env_world)
+        except Exception as e:
+            raise SystemExit(
+                "bench.py: rank %d/%d could not join the %s process group on %s (%s: %s). Check: one "
+                "visible GPU per rank (LOCAL_RANK=%d -> cuda:%d of %d), MASTER_ADDR=127.0.0.1 and a free "
+                "MASTER_PORT, HSA_ENABLE_IPC_MODE_LEGACY=0 (RCCL needs dmabuf IPC on this driver)."
+                % (rank, env_world, backend, dev, type(e).__name__, str(e)[:200], local_rank, dev_index,
+                   torch.cuda.device_count() if not stub else 0))
         world = dist.get_world_size()
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s); launch with "
@@ -396,9 +472,13 @@ def main():
             det = detector_factory[opt.task](opt)
     if rank == 0 and not stub:
         synth.fill_state_dict_(det.model, 317)
-    bcast_bytes = 0
+    bcast_bytes, bcast_ms = 0, None
     if world > 1:
+        sync()
+        tb = time.perf_counter()
         bcast_bytes = broadcast_weights(det.model, src=0)   # ONE flat RCCL broadcast, then none
+        sync()
+        bcast_ms = (time.perf_counter() - tb) * 1e3
     det.model.invalidate_plans()
     if a.fp16:
         det.model.half_compute()
@@ -413,6 +493,19 @@ def main():
     # f32s: the first forward calibrated the per-tensor exponents on this batch; a clamped value
     # here would mean the calibration is broken -- never time a run that is not range-clean
     assert det.range_ok(images), "f32s range check failed during warm-up"
+    agreement = None
+    if dist is not None:
+        # every rank calibrated its f32s exponents on ITS OWN images: one shared batch through all
+        # replicas must still give the same detections (scores within 1e-4) behind the broadcast
+        shared = synth.images(B, a.res, a.res, seed=99).to(dev)
+        mine = det.run_batch(shared).detach().float().contiguous().clone()
+        sync()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        agreement = cross_rank_agreement([g.cpu() for g in gathered])
+        assert agreement["ok"], "replicas disagree on a shared batch: %r" % (agreement,)
+        assert det.range_ok(shared), "f32s range check failed on the shared batch"
+    calib = box_calibration(dev) if (rank == 0 and not stub) else None
     if dist is not None:
         dist.barrier()
     sync()
@@ -438,11 +531,19 @@ def main():
     # inside the timed region: the (synchronising) look at the f32s range words of all K steps
     range_clean = det.range_ok()
     sync()
+    dt_own = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    per_rank_rate = None
     if dist is not None:
+        # every rank's own rate (its loop without the closing barrier), so that a straggler GPU
+        # shows in the one line; the headline uses the MAX time over ranks
+        mine = torch.tensor([B * a.steps / dt_own], device=dev, dtype=torch.float64)
+        rates = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rates, mine)
+        per_rank_rate = [round(float(r.item()), 1) for r in rates]
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -466,7 +567,30 @@ def main():
         fp32_leg = {"value": B * n_leg / leg_dt, "unit": "img/s (this rank)", "steps": n_leg,
                     "ms_per_step": leg_dt / n_leg * 1e3, "dtype": "f32"}
         det.model.fp32_mfma(None)
+    track_leg = None
+    if rank == 0 and not a.fp16 and not a.fp32_mfma and not a.no_fp32_leg and not stub:
+        # the same step with the range words compiled out of the plan (NULL range pointers: no
+        # running maxima, no per-wave atomics, no fold launch) against the tracked plan, back to
+        # back in this process: what "nothing saturates silently" costs on this box
+        def leg(n):
+            for _ in range(3):
+                det.run_batch(images)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                det.run_batch(images)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n * 1e3
+        n_leg = max(5, min(30, a.steps))
+        det.model.range_tracking(False)
+        off_ms = leg(n_leg)
+        det.model.range_tracking(True)
+        on_ms = leg(n_leg)
+        track_leg = {"value": B / off_ms * 1e3, "unit": "img/s (this rank)", "steps": n_leg, "ms_per_step": off_ms,
+                     "tracked_ms_per_step_same_loop": on_ms, "tracking_cost_frac": (on_ms - off_ms) / on_ms,
+                     "note": "untracked plans clamp silently: measurement only"}
     if rank == 0:
+        plan = det.model.plan_for(B, a.res, a.res, dev)     # (the legs above rebuilt the plans)
         # ---- per-kernel-class time from the HIP events recorded inside the timed region
         kinds = {}
         for pr in probes:
@@ -517,8 +641,18 @@ def main():
             else:
                 ach = s["bytes"] / sec / 1e9 if sec > 0 else 0.0
                 peak, unit = HBM_PEAK_GBS, "GB/s"
+            tr, alg = traffic(k), s["bytes"] / max(s["launches"], 1)
+            note = None
+            if tr is not None and tr < alg:
+                note = ("measured HBM bytes below the algorithmic count: " + (
+                    "the algorithmic figure charges every decode input map as read once (SURVEY 8d), "
+                    "but only the heat-maps are streamed -- wh / reg / hps / hp_offset are gathered at the "
+                    "K selected cells (a few 32-byte sectors each)" if k == "decode" else
+                    "consecutive launches hand small tensors and the weights over through L2 / the 256 MB "
+                    "Infinity Cache (written, not yet evicted, read again), so fewer bytes reach HBM than a "
+                    "per-launch count of inputs + outputs assumes"))
             return {"kernel": k, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                    "frac": ach / peak, "traffic": traffic(k),
+                    "frac": ach / peak, "traffic": tr, "traffic_note": note,
                     "algorithmic_bytes_per_launch": s["bytes"] / max(s["launches"], 1),
                     "avg_launch_ms": s["ms"] / max(s["launches"], 1),
                     "launches_per_step": s["launches"] // a.steps}
@@ -545,7 +679,13 @@ def main():
                        "gflop_per_image": plan.flops / B / 1e9},
             "world_size_seen": world,
             "backend": ("%s (RCCL over xGMI)" % backend if backend == "nccl" else backend) if dist is not None else None,
-            "weight_broadcast_bytes": bcast_bytes,
+            "weight_broadcast_bytes": bcast_bytes, "weight_broadcast_ms": bcast_ms,
+            "per_rank_img_s": per_rank_rate, "cross_rank_agreement": agreement,
+            "box_calibration": calib,
+            "headline_over_calibration": None if not calib else {
+                "img_s_per_mfma_TFLOPs": total_imgs / dt / world / calib["mfma_f16_TFLOPs"],
+                "img_s_per_copy_TBs": total_imgs / dt / world / calib["copy_TBs"]},
+            "range_tracking_off_leg": track_leg,
             "roofline": roof(dom, "mfma" if kinds[dom]["flops"] > 0 else "hbm"),
             "roofline_dcn_mfma": roof("dcn", "mfma") if "dcn" in kinds else None,
             "roofline_dcn_hbm": roof("dcn", "hbm") if "dcn" in kinds else None,

@@ -354,7 +354,7 @@ __global__ void range_fold_kernel(uint32_t *cur, uint32_t *hi, uint32_t *lo, uin
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
     if (threadIdx.x == 0) {
         hi[blockIdx.x] = max(hi[blockIdx.x], v);
-        lo[blockIdx.x] = min(lo[blockIdx.x], v);
+        if (v) lo[blockIdx.x] = min(lo[blockIdx.x], v);   // an all-zero forward is not a 'low' one (as in the digest)
         if (summary) {   // sticky two-word digest: largest value seen, smallest non-zero per-forward maximum
             atomicMax(&summary[0], v);
             if (v) atomicMin(&summary[1], v);
@@ -708,4 +708,68 @@ extern "C" int cn_soft_nms_f32(float *boxes, int n, int stride, float sigma, flo
         }
     }
     return N;
+}
+
+// ---- box calibration (bench.py "box_calibration"): what THIS box's matrix pipe and HBM deliver
+// right now, so that a headline can be read against the box it ran on.  Not on the product path.
+namespace {
+
+// register-only v_mfma_f32_32x32x16_f16 loop: 4 independent accumulators per wave, no memory
+__global__ __launch_bounds__(256) void calib_mfma_f16_kernel(float *sink, int iters)
+{
+    cn_f16x8v a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = (_Float16)(0.001f * (float)((threadIdx.x + i) & 7));
+        b[i] = (_Float16)(0.002f * (float)((threadIdx.x + 3 * i) & 7));
+    }
+    cn_f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+    if (s == 12345.678f) sink[0] = s;     // never true: keeps the accumulators live
+}
+
+__global__ __launch_bounds__(256) void calib_copy_kernel(const cn_f32x4 *__restrict__ src,
+                                                         cn_f32x4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = src[i];
+}
+
+}  // namespace
+
+extern "C" double cn_calib_mfma_f16(float *sink, int iters, void *stream)
+{
+    if (!sink || iters <= 0) return 0.0;
+    const int blocks = 256 * 4;            // 4 workgroups of 4 waves per CU: 4 waves per SIMD
+    hipLaunchKernelGGL(calib_mfma_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sink, iters);
+    if (hipGetLastError() != hipSuccess) return 0.0;
+    // FLOPs of the launch: waves x iters x 16 MFMAs x 2 * 32 * 32 * 16
+    return (double)blocks * 4.0 * (double)iters * 16.0 * 32768.0;
+}
+
+extern "C" int cn_calib_copy(const void *src, void *dst, size_t bytes, void *stream)
+{
+    if (!src || !dst) return CN_ERR_NULL;
+    if (!cn_aligned16(src) || !cn_aligned16(dst) || (bytes & 15)) return CN_ERR_ALIGN;
+    if (!bytes) return CN_OK;
+    hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream,
+                       (const cn_f32x4 *)src, (cn_f32x4 *)dst, bytes / 16);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
 }

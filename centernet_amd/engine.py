@@ -33,6 +33,8 @@ from .native import (ConvDesc, F32sCtl, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTY
 TOP_LOG2 = 10
 F16_MAX = 65504.0
 LOW_WATER = 2.0 ** -3      # a per-forward maximum below this (stored units) asks for re-calibration
+LOW_STEP = 6               # ... which lowers an exponent by at most this many binades at a time
+LOW_EVERY = 64             # ... and happens at most once per this many forwards
 F16_MAX_BITS = 0x477FE000  # float32 bit patterns of the two bounds (non-negative floats order like
 LOW_WATER_BITS = 0x3E000000  # unsigned integers: the range words are compared as bits)
 W_TOP_LOG2 = 14            # weight rows are pre-scaled to max |w| in [2^13, 2^14)
@@ -139,7 +141,7 @@ class PlanBuilder:
     RANGE_WORDS = 2 * 64 * 16   # CN_RANGE_WORDS: 2 sides x 64 slots x one word per 64-byte line
 
     def __init__(self, device, B, H, W, dtype=torch.float32, wcache=None, split=None, exps=None,
-                 calibrating=False):
+                 calibrating=False, track=None):
         assert dtype in (torch.float32, torch.float16)
         self.device = device
         # fp32 networks compute in f32s (three fp16 MFMAs per product, fp32-level accuracy, 5.3x
@@ -177,7 +179,12 @@ class PlanBuilder:
         self.range = None
         self.range_slots = []  # slot -> logical id of the launch, for messages
         self._pack_events = [] # completion of weight-pack kernels this plan depends on
-        self.track = self.split and os.environ.get("CN_RANGE", "1") != "0"
+        # range words at every split site (csrc/cn_common.h "Range"); ``track=False`` (or CN_RANGE=0)
+        # builds the plan WITHOUT them: values beyond the fp16 range are then clamped silently --
+        # measurement only (bench.py range_tracking_off_leg)
+        if track is None:
+            track = os.environ.get("CN_RANGE", "1") != "0"
+        self.track = self.split and bool(track)
 
     # ---- helpers -------------------------------------------------------------
     def _lid(self, lid=None, tag=""):
@@ -271,6 +278,14 @@ class PlanBuilder:
         return (kind, self.cdtype, str(self.device)) + tuple(
             (id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in sources)
 
+    def _wput(self, key, hit):
+        """Cache a packed weight; packed copies of OLDER versions of the same parameter objects
+        (in-place updates bump ``_version``) are dropped -- they can never be hit again."""
+        ids = tuple(e[0] for e in key[3:])
+        for k in [k for k in self.wcache if k[:3] == key[:3] and tuple(e[0] for e in k[3:]) == ids]:
+            del self.wcache[k]
+        self.wcache[key] = hit
+
     def _pack(self, w_oihw, sources=None, f32s=False, prescale=False):
         """Packed copy of a (Cout,Cin,KH,KW) weight.  ``sources``: the parameter tensors the
         weight was assembled from (defaults to the weight itself) -- the cache key.  The pack
@@ -304,7 +319,7 @@ class PlanBuilder:
             ev.record()
             hit = (wp, factor, ev)
             if cacheable:
-                self.wcache[key] = hit
+                self._wput(key, hit)
         self.keep += [hit[0], hit[1]]
         self._pack_events.append(hit[2])
         return (hit[0], hit[1]) if (f32s or prescale) else hit[0]
@@ -502,7 +517,7 @@ class PlanBuilder:
             ev.record()
             hit = (wp, factor, ev)
             if cacheable:
-                self.wcache[key] = hit
+                self._wput(key, hit)
         wp, factor, ev = hit
         self._pack_events.append(ev)
         flags = 0
@@ -963,6 +978,8 @@ class Plan:
         hi, lo = (int(v) & 0xffffffff for v in vals)
         if hi > F16_MAX_BITS:                     # beyond 65504, inf or NaN bit patterns
             return "overflow"
+        if getattr(self, "ignore_low", False):    # a re-calibration on 'low' changed nothing
+            return "ok"
         return "low" if lo < LOW_WATER_BITS else "ok"
 
     def range_status(self, reset=True):
@@ -985,6 +1002,8 @@ class Plan:
             return "overflow", over
         # per side: (largest, smallest) per-forward maximum.  smallest == +inf: no forward since
         # the last look; largest == 0: this side of the launch splits nothing (or only zeros)
+        if getattr(self, "ignore_low", False):
+            return "ok", []
         low = [r for r in rep if any(side[0] > 0.0 and side[1] < LOW_WATER for side in r[1:])]
         return ("low", low) if low else ("ok", [])
 
@@ -1025,15 +1044,29 @@ class PlannedModule(torch.nn.Module):
         """Compute on the plain fp32 matrix instruction (v_mfma_f32_32x32x2_f32, the round-1
         kernels) instead of f32s (three fp16 MFMAs per product): the A/B reference mode."""
         self.f32s = (not enable) if enable is not None else None
-        self.invalidate_plans()
+        self.drop_plans()        # exponents depend on weights and input only; packed weights are keyed by form
         return self
 
     def half_compute(self, enable=True):
         """fp16 activations/weights with fp32 accumulation (BASELINE configs[4]); parameters
         stay fp32 in the module, only the packed plan copies are fp16."""
         self.compute_dtype = torch.float16 if enable else torch.float32
-        self.invalidate_plans()
+        self.drop_plans()
         return self
+
+    range_tracking_on = True        # see .range_tracking()
+
+    def range_tracking(self, enable=True):
+        """f32s plans with (default) or without the range words at the split sites.  Without them
+        a value beyond the calibrated range is clamped SILENTLY: for measuring what the tracking
+        costs (bench.py ``range_tracking_off_leg``), never for results."""
+        self.range_tracking_on = bool(enable)
+        self.drop_plans()
+        return self
+
+    def drop_plans(self):
+        """Drop the launch lists only (mode switches): calibrated exponents and packed weights stay."""
+        self.__dict__["_plans"] = {}
 
     max_plans = int(os.environ.get("CN_PLAN_CACHE", "8"))   # LRU bound on cached input shapes
 
@@ -1086,13 +1119,25 @@ class PlannedModule(torch.nn.Module):
                 for l in grp:
                     exps[l] = e
         old = self.__dict__.get("_exps")
-        if merge and old:
+        if merge == "decay" and old:
+            # a tensor drifted BELOW its calibrated range: follow it down, but by at most LOW_STEP
+            # binades per re-calibration (a dark batch between bright ones must not throw the
+            # bright batches' head-room away), never up past the old value from here
+            for l, e in old.items():
+                exps[l] = max(exps.get(l, e), e - LOW_STEP)
+        elif merge and old:
             for l, e in old.items():
                 exps[l] = max(e, exps.get(l, e))
-        self.__dict__["_exps"] = exps
         self.__dict__["_absmax"] = amax
-        self.__dict__["_plans"] = {}      # plans bake the exponents into their epilogue constants
         self.__dict__["_calibrations"] = self.__dict__.get("_calibrations", 0) + 1
+        if old is not None and exps == old:
+            # nothing moved (e.g. a member of a concatenation that is small next to the group's
+            # largest, or a tensor that simply IS tiny): keep the plans, and stop asking
+            for plan in self.__dict__.get("_plans", {}).values():
+                plan.ignore_low = True
+            return exps
+        self.__dict__["_exps"] = exps
+        self.__dict__["_plans"] = {}      # plans bake the exponents into their epilogue constants
         return exps
 
     def plan_for(self, B, H, W, device):
@@ -1100,14 +1145,15 @@ class PlannedModule(torch.nn.Module):
         ``max_plans`` shapes -- --keep_res / multi-scale evaluation sees many (H, W) -- while the
         packed weights live in one per-module cache shared by all of them."""
         cache = self.__dict__.setdefault("_plans", {})
-        key = (B, H, W, str(device), self.compute_dtype, self.f32s)
+        key = (B, H, W, str(device), self.compute_dtype, self.f32s, self.range_tracking_on)
         plan = cache.pop(key, None)
         if plan is None:
             native.lib()  # raises if the HIP library is missing
             with torch.no_grad():
                 pb = PlanBuilder(device, B, H, W, dtype=self.compute_dtype,
                                  wcache=self.__dict__.setdefault("_wcache", {}), split=self.f32s,
-                                 exps=self.__dict__.get("_exps"))
+                                 exps=self.__dict__.get("_exps"),
+                                 track=None if self.range_tracking_on else False)
                 x = pb.set_input(3)
                 outs = self.describe(pb, x)
             plan = Plan(pb, outs)
@@ -1157,8 +1203,23 @@ class PlannedModule(torch.nn.Module):
                 self.__dict__["_recalibrate"] = "merge"
             return False
         if worst == "low":
-            self.__dict__["_recalibrate"] = "replace"
+            self._schedule_low()
         return True
+
+    def _schedule_low(self):
+        """A forward reported a tensor far below its calibrated range (results still within the
+        error bound).  Re-calibrate before the next forward -- at most once per LOW_EVERY forwards:
+        inputs that alternate between far-apart scales would otherwise pay a calibration pass and
+        a plan rebuild per forward."""
+        nf, at = self.__dict__.get("_nfwd", 0), self.__dict__.get("_low_cal_at")
+        if at is not None and nf - at < LOW_EVERY:
+            if not self.__dict__.get("_low_warned"):
+                self.__dict__["_low_warned"] = True
+                warnings.warn("f32s: activations keep falling below the calibrated range; "
+                              "re-calibration is limited to once per %d forwards" % LOW_EVERY)
+            return
+        self.__dict__["_low_cal_at"] = nf
+        self.__dict__["_recalibrate"] = "decay"
 
     def forward(self, x, borrow=False, events=None, event_after=None, check=None):
         """[{head: (B,C,H/4,W/4)}] like the reference modules (fresh tensors).  ``borrow`` /
@@ -1179,7 +1240,8 @@ class PlannedModule(torch.nn.Module):
             if self.__dict__.get("_exps") is None:
                 self.calibrate(x)
             elif pending:
-                self.calibrate(x, merge=(pending == "merge"))
+                self.calibrate(x, merge=True if pending == "merge" else pending)
+            self.__dict__["_nfwd"] = self.__dict__.get("_nfwd", 0) + 1
         if check is None:
             check = f32s and not borrow
         plan = self.plan_for(B, H, W, x.device)
@@ -1189,10 +1251,12 @@ class PlannedModule(torch.nn.Module):
             if st == "overflow":
                 self.calibrate(x, merge=True)
                 plan = self.plan_for(B, H, W, x.device)
+                if events is not None:
+                    del events[:]          # the markers of the invalid forward
                 out = plan.run(x, events=events, event_after=event_after, borrow=borrow)
                 st, bad = plan.range_status()
                 if st == "overflow":
                     raise RangeError("f32s forward still clamps after re-calibration: %r" % (bad[:3],))
             elif st == "low":
-                self.__dict__["_recalibrate"] = "replace"
+                self._schedule_low()
         return [out]

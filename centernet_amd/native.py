@@ -95,6 +95,10 @@ def _declare(lib):
     lib.cn_range_fold.argtypes = [vp, vp, vp, i, vp]
     lib.cn_range_fold_digest.restype = i
     lib.cn_range_fold_digest.argtypes = [vp, vp, vp, vp, i, vp]
+    lib.cn_calib_mfma_f16.restype = ctypes.c_double
+    lib.cn_calib_mfma_f16.argtypes = [vp, i, vp]
+    lib.cn_calib_copy.restype = i
+    lib.cn_calib_copy.argtypes = [vp, vp, sz, vp]
     lib.cn_maxpool_nhwc_scaled.restype = i
     lib.cn_maxpool_nhwc_scaled.argtypes = [vp, vp, i, i, i, i, i, i, i, i, f, vp]
     lib.cn_dcn_v2_forward_nhwc.restype = i

@@ -230,7 +230,7 @@ int cn_f32s_to_f32_scaled(const void *x, float *y, size_t npix, int C, int in_pi
 int cn_absmax_f32(const float *x, size_t npix, int C, int pitch, uint32_t *word, void *stream);
 /* end-of-forward bookkeeping of the range words of n_launches launches (cur: n_launches x
  * CN_RANGE_WORDS; hi, lo: n_launches x 2 sides): m = max over the slots, hi = max(hi, m),
- * lo = min(lo, m), slots = 0 -- the host reads hi / lo whenever it synchronises anyway (largest
+ * lo = min(lo, m) over the non-zero m, slots = 0 -- the host reads hi / lo whenever it synchronises anyway (largest
  * and smallest per-forward maximum since its last look) instead of after every forward */
 int cn_range_fold(uint32_t *cur, uint32_t *hi, uint32_t *lo, int n_launches, void *stream);
 /* The same, plus a sticky two-word digest for a cheap host check: summary[0] = max over all
@@ -239,6 +239,14 @@ int cn_range_fold(uint32_t *cur, uint32_t *hi, uint32_t *lo, int n_launches, voi
  * host reads 8 bytes per forward and walks the hi / lo tables only when the digest is out of bounds. */
 int cn_range_fold_digest(uint32_t *cur, uint32_t *hi, uint32_t *lo, uint32_t *summary,
                          int n_launches, void *stream);
+
+/* Box calibration (bench.py `box_calibration`; measurement aid, not on the product path; no
+ * reference counterpart).  cn_calib_mfma_f16: a register-only v_mfma_f32_32x32x16_f16 loop on
+ * every SIMD (1024 workgroups x 4 waves, `iters` x 16 instructions per wave); returns the FLOPs
+ * of the launch (0 on error) -- the caller times it with HIP events.  cn_calib_copy: a float4
+ * grid-stride copy of `bytes` (multiple of 16) from src to dst. */
+double cn_calib_mfma_f16(float *sink, int iters, void *stream);
+int cn_calib_copy(const void *src, void *dst, size_t bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * Dense convolution as an implicit GEMM on fp32 MFMA (no im2col buffer).

@@ -308,16 +308,20 @@ def test_f32s_nhwc_kernel_stress_offsets(dev):
         _check(_dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, False), want)
 
 
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("shape", [(512, 16, 256), (256, 32, 128), (128, 64, 64),     # resdcn_18
-                                   (64, 128, 64), (256, 32, 64)])                       # dla_34
-def test_f32s_nhwc_kernel_at_benchmark_batch(dev, shape):
+                                   (64, 128, 64), (128, 64, 128), (256, 32, 256),      # dla_34
+                                   (256, 32, 64)])
+def test_f32s_nhwc_kernel_at_benchmark_batch(dev, shape, form):
     """B = 32, the layer shapes of resdcn_18 and dla_34: the launch the benchmark
-    times, default tap split; images 0, 13 and 31 against the C oracle (the operator is per
+    times -- form 0 = the library's DEFAULT choice for the shape (the register-sampling window
+    kernel dcn_reg_kernel on these grids, K-split on the 16^2 map), form 1 = the global-gather
+    kernel -- default tap split; images 0, 13 and 31 against the C oracle (the operator is per
     image, dcn_v2_cuda.c:61)."""
     Cin, HW, Cout = shape
     B = 32
     x, off, mask, w, b = _case(B, Cin, HW, HW, Cout, 300 + Cin)
-    y = _dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, False)
+    y = _dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, False, form=form)
     for i in (0, 13, 31):
         want = cref.dcn_v2_forward(x[i:i + 1], off[i:i + 1], mask[i:i + 1], w, b)
         _check(y[i:i + 1], want)

@@ -475,14 +475,52 @@ def test_inputs_far_below_the_calibration_batch_schedule_a_recalibration(dev):
     _detect(m, x, dev)
     small = x * 2.0 ** -16
     out, _, _ = _detect(m, small, dev)      # valid (floor 2^-25 stored), but flagged 'low'
-    assert m.__dict__.get("_recalibrate") == "replace"
-    _detect(m, small, dev)                  # this forward re-calibrates first
-    assert m.__dict__["_calibrations"] == 2 and "_recalibrate" not in m.__dict__
+    assert m.__dict__.get("_recalibrate") == "decay"
+    e0 = dict(m.exponents)
+    import warnings
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        _detect(m, small, dev)              # this forward re-calibrates first: exponents follow the
+        e1 = dict(m.exponents)              # input down, by at most LOW_STEP binades at a time
+        assert m.__dict__["_calibrations"] == 2 and "_recalibrate" not in m.__dict__
+        from centernet_amd.engine import LOW_STEP, LOW_EVERY
+        assert e1["input"] == e0["input"] - LOW_STEP and all(e1[k] >= e0[k] - LOW_STEP for k in e0)
+        # still low, but re-calibration is rate-limited: the next forwards neither calibrate nor
+        # rebuild their plan, and say so once
+        plan = next(iter(m.__dict__["_plans"].values()))
+        for _ in range(3):
+            _detect(m, small, dev)
+        assert m.__dict__["_calibrations"] == 2 and next(iter(m.__dict__["_plans"].values())) is plan
+    assert sum("re-calibration is limited" in str(w.message) for w in rec) == 1
+    assert LOW_EVERY > 4
     from oracle import net_oracle
     ref = net_oracle.forward("res_18", m.state_dict(), small, list(heads))
     for h in heads:
         err = float((out[h].cpu() - ref[h]).abs().max()) / max(1.0, float(ref[h].abs().max()))
         assert err < 1e-4, (h, err)
+
+
+def test_recalibration_that_changes_nothing_keeps_the_plans(dev):
+    """A 'low' report whose re-calibration leaves every exponent where it was (a tensor that IS
+    tiny, a concatenation member next to a large one) must not rebuild plans forever."""
+    from centernet_amd.model import create_model
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    m = create_model("res_18", dict(heads), 64)
+    synth.fill_state_dict_(m, 317)
+    m = m.to(dev).eval()
+    x = synth.images(1, 128, 128, seed=5).to(dev)
+    with torch.no_grad():
+        m(x)
+        plan = next(iter(m.__dict__["_plans"].values()))
+        e0 = dict(m.exponents)
+        m.calibrate(x, merge="decay")           # same batch: nothing moves
+        assert dict(m.exponents) == e0
+        assert next(iter(m.__dict__["_plans"].values())) is plan and plan.ignore_low
+        # mode switches keep the calibration (exponents depend on weights and input only)
+        n = m.__dict__["_calibrations"]
+        m.fp32_mfma(True); m(x); m.fp32_mfma(None); m(x)
+        m.range_tracking(False); m(x); m.range_tracking(True); m(x)
+        assert m.__dict__["_calibrations"] == n and dict(m.exponents) == e0
 
 
 def test_detector_reruns_a_clamped_batch(dev):

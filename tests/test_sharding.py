@@ -156,7 +156,13 @@ def test_bench_rank_logic_end_to_end_two_ranks_gloo():
     assert r["n_gpus"] == 2 and r["world_size_seen"] == 2 and r["backend"] == "gloo"
     assert r["steps"] == 6 and r["warmup"] == 2 and r["scaling"] == "weak" and r["data"] == "stub"
     assert r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "image-sharded x2"
-    assert r["weight_broadcast_bytes"] == 4 * (64 * 64 + 64)
+    assert r["weight_broadcast_bytes"] == 4 * (64 * 64 + 64) and r["weight_broadcast_ms"] > 0
+    # one shared batch through every replica behind the broadcast: same results on every rank
+    assert r["cross_rank_agreement"]["ok"] and r["cross_rank_agreement"]["ranks"] == 2
+    assert r["cross_rank_agreement"]["max_score_diff"] <= 1e-4
+    # every rank's own rate is in the line (a straggler GPU is visible); the headline is the slowest's clock
+    assert len(r["per_rank_img_s"]) == 2 and all(v > 0 for v in r["per_rank_img_s"])
+    assert r["value"] <= sum(r["per_rank_img_s"]) * (1 + 1e-6)
     # whole-job rate = images of ALL ranks / the slowest rank's time
     assert abs(r["value"] - 8 * 6 / (r["ms_per_step"] * 6e-3)) <= 1e-6 * r["value"]
     assert r["metric"].startswith("images/sec whole-node") and r["higher_is_better"] is True
@@ -187,3 +193,25 @@ def test_bench_under_a_launcher_with_the_wrong_world_fails(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
     assert "--gpus 4 but the process group has 2" in (p.stderr + p.stdout)
+
+
+def test_cross_rank_agreement_rule():
+    """bench.cross_rank_agreement: replicas agree when scores are within 1e-4 and rows sit in
+    place; a class change, a moved box or a larger score difference is a disagreement."""
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    g = torch.Generator().manual_seed(0)
+    d = torch.rand((2, 10, 6), generator=g)
+    d[..., 5] = torch.randint(0, 80, (2, 10), generator=g).float()
+    ok = bench.cross_rank_agreement([d, d + 0, d + torch.tensor([0, 0, 0, 0, 5e-5, 0])])
+    assert ok["ok"] and ok["ranks"] == 3 and abs(ok["max_score_diff"] - 5e-5) < 1e-6
+    bad = d.clone(); bad[0, 0, 4] += 1e-3
+    assert not bench.cross_rank_agreement([d, bad])["ok"]
+    bad = d.clone(); bad[:, :, 5] += 1
+    assert not bench.cross_rank_agreement([d, bad])["ok"]
+    y = torch.rand((64, 64), generator=g)
+    assert bench.cross_rank_agreement([y, y.clone()])["ok"]
+    assert not bench.cross_rank_agreement([y, y + 1e-3])["ok"]
