@@ -38,6 +38,11 @@ int cn_tune_f32s_policy = 0;   // cn_set_tuning key 21 (A/B): bit 0 = 128-wide t
 
 bool cn_conv3x3p_takes(int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch, int res_pitch,
                        bool in_plain, bool has_res);
+bool cn_heads3x3p_takes(int B, int H, int W, int in_pitch, int head_conv, int n_heads, const cn_head_out *heads,
+                        bool in_plain);
+int cn_heads3x3p(const void *x, int B, int H, int W, int Cin, int in_pitch, const void *w1_packed,
+                 const float *scale1, const float *bias1, int n_heads, const cn_head_out *heads,
+                 const cn_f32s_ctl *ctl, hipStream_t st);
 int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale, const float *shift,
                          const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                          int in_pitch, int out_pitch, int res_pitch, int relu, int out_plain, int res_plain,
@@ -1364,6 +1369,10 @@ extern "C" int cn_heads3x3_1x1(const void *x, int B, int H, int W, int Cin, int 
         if (head_conv > HEAD_CONV && heads[h].cout > W2_ROWS) return CN_ERR_UNSUPPORTED;
     }
     hd.slices = head_conv / HEAD_CONV;
+    // f32s feature map, one 64-wide hidden layer per head: the persistent loader / consumer kernel
+    // (cn_conv3x3p.hip, hidden layer in registers)
+    if (f32s && cn_heads3x3p_takes(B, H, W, in_pitch, head_conv, n_heads, heads, (flags & CN_CONV_X_PLAIN) != 0))
+        return cn_heads3x3p(x, B, H, W, Cin, in_pitch, w1_packed, scale1, bias1, n_heads, heads, ctl, st);
     C3Args a = {};
     c3_set_ctl(a, ctl);
     a.x = x; a.w = w1_packed; a.scale = scale1; a.shift = bias1; a.residual = nullptr; a.y = nullptr;

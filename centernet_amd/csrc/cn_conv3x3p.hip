@@ -37,6 +37,7 @@ int cn_tune_c3p = 1;        // cn_set_tuning key 28: 0 = off, 1 = on for the sha
 int cn_tune_c3p_stagger = 64; // cn_set_tuning key 29: start delay of the second resident workgroup, in units of 256 cycles
                               // (measured 0 ... 96: 48-64 is best on every trunk shape, +6 ... +13 % over none)
 int cn_tune_c3p_knobs = 0;    // cn_set_tuning key 30 (A/B): see P3Args.knobs
+int cn_tune_c3p_heads = 1;    // cn_set_tuning key 31: the fused heads (hidden width 64) on this kernel; 0 = halo kernel
 
 // one 128-byte line of zeros: the DMA source of halo pixels outside the image
 __device__ __attribute__((aligned(128))) unsigned char cn_p3_zero_line[128];
@@ -58,7 +59,7 @@ constexpr int P_WSLOT = 64 * 128;             // one weight tile: 64 rows of 128
 constexpr int P_NSLOT = 4;
 constexpr int P_WOFF = 2 * P_HBYTES;          // weight ring behind the two halo buffers
 constexpr int P_SSOFF = P_WOFF + P_NSLOT * P_WSLOT;       // per consumer wave: scale[32], shift[32] of its channels
-constexpr int P_LDS = P_SSOFF + 4 * 256;      // 80896 bytes
+constexpr int P_LDS = P_SSOFF + 6 * 256;      // 81408 bytes (heads: scale[64] shift[64] oscale[96] bias2[96])
 constexpr int P_STG_ROW = 144;                // epilogue strip: 32 rows x 144 bytes per wave
 constexpr int P_STG = 32 * P_STG_ROW;
 static_assert(4 * P_STG <= P_HBYTES, "the epilogue strips alias one halo buffer");
@@ -84,7 +85,8 @@ struct P3Args {
     uint32_t *range;
     int stagger;
     int knobs;                // A/B switches (cn_set_tuning key 30): 1 = no s_setprio 1 around the consumers' MFMA block
-                              // (with the loaders at priority 3 the raised priority measured 3-5 % faster)
+                              // (with the loaders at priority 3 the raised priority measured 3-5 % faster);
+                              // 8 + 2 * n: residual requested n = 0 .. 3 steps before the item's last step ends
     // instrumented instantiation only (DBG = true; cn_conv3x3p_probe): ablation switches and cycle counters
     int dbg;                  // 1: no MFMAs, 2: no fragment reads (and no MFMAs), 4: no weight DMA, 8: no halo DMA,
                               // 16: no epilogue, 32: no output stores
@@ -97,6 +99,20 @@ __device__ __forceinline__ void p3_barrier()
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+
+// Fused detection heads (HEADS = true, cn_heads3x3_1x1 with a 64-wide hidden layer; resnet_dcn.py:
+// 155-177): output block nb of an item = head nb; its 64 hidden channels never leave the registers
+// of the consumer waves and go straight into the head's 1x1 convolution.
+constexpr int P_MAXH = 8;
+struct P3Heads {
+    const char *wf[P_MAXH];       // 1x1 matrix as MFMA-ready (high, low) fragments (cn_pack_head_w2_f32s)
+    const float *bias[P_MAXH];    // (cout) or null
+    const float *oscale[P_MAXH];  // (cout) or null: y = acc * oscale + bias
+    float *y[P_MAXH];             // (B, cout, H, W)
+    int cout[P_MAXH];             // <= 96
+};
+
+__device__ __forceinline__ void p3_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // item -> (image, tile row, tile column, output block)
 struct P3Item { int b, ty0, tx0, nb; };
@@ -115,9 +131,12 @@ __device__ __forceinline__ P3Item p3_decode(const P3Args &a, int item)
 }
 
 // RES: 0 = no residual, 1 = f32s residual, 2 = plain fp32 residual
-template <int RES, bool OUT_PLAIN, bool DBG = false>
-__global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a)
+template <int RES, bool OUT_PLAIN, bool DBG = false, bool HEADS = false>
+__global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const P3Heads hd)
 {
+    // residual rows requested this many steps before an item's last step ends (A/B: knobs bit 3 set -> bits 1-2)
+    const int RES_AT = (a.knobs & 8) ? ((a.knobs >> 1) & 3) : 2;
+    static_assert(!HEADS || (RES == 0 && !DBG), "fused heads: no residual, no probes");
     extern __shared__ __attribute__((aligned(128))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -284,6 +303,254 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a)
             o[0] = now() - pf_t0; o[1] = pf_wait; o[2] = pf_bar; o[3] = (unsigned long long)S;
             o[4] = pf_rt0; o[5] = __builtin_amdgcn_s_memrealtime();
         }
+        return;
+    }
+
+
+    if constexpr (HEADS) {
+        // =============================== CONSUMERS, fused heads ===============================
+        // Waves 4 x 1: wave w owns pixels 32 w .. 32 w + 31 of the tile (tile rows 2 w, 2 w + 1) and
+        // ALL 64 hidden channels of the item's head: acc[j] = D[hidden 32 j ..][pixel], so a lane
+        // holds four CONSECUTIVE hidden channels of its pixel per register group.  The epilogue turns
+        // them into relu(acc * scale + bias1), splits them and uses them directly as the B operand of
+        // the head's 1x1 GEMM out[cout][pixel] (K order of a 16-deep step s of block j: lane half h
+        // contributes hidden 32 j + 16 s + 4 h + {0..3} and 32 j + 16 s + 8 + 4 h + {0..3}; the 1x1
+        // matrix is read from global memory -- L1 / L2 resident, <= 24 KB per head -- in that order
+        // and split on the way).  No hidden tile in LDS, no barrier between the two GEMMs; lanes run
+        // along x of the NCHW map the decode consumes.
+        int arow, aswz, b0;
+        auto lane_consts = [&]() {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int l31 = ln & 31, lh = ln >> 5, px = ln & 15;
+            arow = ((2 * wave + (l31 >> 4)) * P_HW + px) * 128;
+            aswz = 0;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) aswz |= (((lh ^ (((px + kx) >> 1) & 7)) & 7) << 4) << (8 * kx);
+            b0 = l31 * 128 + (((lh ^ ((l31 >> 1) & 7)) & 7) << 4);
+        };
+        lane_consts();
+        cn_f32x16 acc[2];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        };
+        zero_acc();
+        float rng_out = 0.f;
+        auto lds128 = [&](int off) { return *reinterpret_cast<const p3_f16x8 *>(smem + off); };
+        auto step = [&](auto T, int hb, int wb) {
+            constexpr int t = decltype(T)::value;
+            constexpr int ky = t / 3, kx = t % 3;
+            constexpr int tapoff = (ky * P_HW + kx) * 128;
+            constexpr int blk1 = 32 * 128;         // weight rows 32 .. 63: hidden block 1
+            p3_f16x8 xf[4], wf[4][2];
+            int ax = arow + ((aswz >> (8 * kx)) & 0xff), bx = b0;
+            asm volatile("" : "+v"(ax), "+v"(bx));
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) wf[kh][j] = lds128(wb + j * blk1 + (bx ^ (kh << 5)));
+                xf[2 + kh] = lds128(hb + tapoff + (ax ^ ((kh << 5) | 64)));
+                xf[kh] = lds128(hb + tapoff + (ax ^ (kh << 5)));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) wf[2 + kh][j] = lds128(wb + j * blk1 + (bx ^ ((kh << 5) | 64)));
+            }
+            __builtin_amdgcn_sched_barrier(0);     // (operand hazard: every read before the first MFMA)
+            if (!(a.knobs & 1)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kh][j], xf[2 + kh], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[2 + kh][j], xf[kh], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kh][j], xf[kh], acc[j], 0, 0, 0);
+            }
+            if (!(a.knobs & 1)) __builtin_amdgcn_s_setprio(0);
+        };
+        const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+        const int HWp = a.H * a.W;
+        // 1x1 weights of one 32-row output block jb as ready-made A fragments (cn_pack_head_w2_f32s:
+        // [jb][hidden block j][step s2][high | low][lane] x 16 bytes: one coalesced 1 KiB line each)
+        auto load_w2 = [&](p3_f16x8 (&dst)[2][2], const char *wbase, int jb, int j, int ln) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+                    dst[s2][part] = *reinterpret_cast<const p3_f16x8 *>(
+                        wbase + ((((jb * 2 + j) * 2 + s2) * 2 + part) * 64 + ln) * 16);
+        };
+        // 1x1 fragments of the current output block, hidden block 0 / 1 (of output block 0: the first half
+        // is requested two steps before the item's main loop ends, the second between the two hidden
+        // blocks of the epilogue -- registers)
+        p3_f16x8 wfa[2][2], wfb[2][2];
+        auto epilogue = [&](const P3Item &it) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int l31 = ln & 31, lh = ln >> 5;
+            const int head = it.nb;
+            const int cout2 = hd.cout[head];
+            const char *w2 = hd.wf[head];
+            float *y2 = hd.y[head];
+            const int nblk2 = (cout2 + 31) >> 5;
+            // hidden layer -> (high, low) B fragments [hidden block j][step s2]
+            p3_f16x8 shi[2][2], slo[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_w2(wfb, w2, 0, 1, ln);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                cn_f16x4v hq[4], lq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = 32 * j + 8 * g + 4 * lh;
+                    const cn_f32x4 sc = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + n * 4);
+                    const cn_f32x4 sh = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + 256 + n * 4);
+                    cn_f32x4 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = fmaxf(acc[j][4 * g + e] * sc[e] + sh[e], relu_floor);
+                    cn_rng_upd4(rng_out, t);
+                    cn_split4(t, hq[g], lq[g]);
+                }
+                shi[j][0] = __builtin_shufflevector(hq[0], hq[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                shi[j][1] = __builtin_shufflevector(hq[2], hq[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                slo[j][0] = __builtin_shufflevector(lq[0], lq[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                slo[j][1] = __builtin_shufflevector(lq[2], lq[3], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            const int p = 32 * wave + l31;
+            const int oy = it.ty0 + (p >> 4), ox = it.tx0 + (p & 15);
+            const bool ok = oy < a.H && ox < a.W;
+            float *ypix = y2 + (size_t)it.b * cout2 * HWp + oy * a.W + ox;
+#pragma unroll 1
+            for (int jb = 0; jb < nblk2; ++jb) {
+                cn_f32x16 acc2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+                __builtin_amdgcn_sched_barrier(0);     // (operand hazard: fragments landed before the first MFMA)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfa[s2][1], shi[0][s2], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfa[s2][0], slo[0][s2], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfa[s2][0], shi[0][s2], acc2, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfb[s2][1], shi[1][s2], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfb[s2][0], slo[1][s2], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfb[s2][0], shi[1][s2], acc2, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // output scale / bias of the lane's rows from the LDS stash (rows beyond cout hold 1 / 0).
+                // Reading the first register group closes the MFMA chain -- only then are the fragment
+                // registers re-used for the next block's loads (they land under this block's stores)
+                const int co0 = jb * 32 + 4 * lh;
+                auto out_group = [&](int gq) {
+                    const cn_f32x4 os = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + 512 + (co0 + 8 * gq) * 4);
+                    const cn_f32x4 bs = *reinterpret_cast<const cn_f32x4 *>(smem + P_SSOFF + 896 + (co0 + 8 * gq) * 4);
+                    cn_f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc2[4 * gq + e] * os[e] + bs[e];
+                    return v;
+                };
+                auto store_group = [&](int gq, cn_f32x4 v) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = co0 + 8 * gq + e;
+                        if (ok && co < cout2) ypix[(size_t)co * HWp] = v[e];
+                    }
+                };
+                const cn_f32x4 v0 = out_group(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (jb + 1 < nblk2) {
+                    load_w2(wfa, w2, jb + 1, 0, ln);
+                    load_w2(wfb, w2, jb + 1, 1, ln);
+                }
+                store_group(0, v0);
+#pragma unroll
+                for (int gq = 1; gq < 4; ++gq) store_group(gq, out_group(gq));
+            }
+        };
+
+#define P3_IC(v) std::integral_constant<int, (v)>{}
+        int g = 0, sidx = 0;
+        // one stage = the nine taps of one 32-channel chunk.  LAST = the item's last chunk: its copy of
+        // the code requests the first 1x1 fragments two steps before the end (a separate copy so that
+        // their 32 registers are live over those two steps and the epilogue only)
+        auto stage = [&](auto LAST, int c, const P3Item &cur) {
+            constexpr bool last = decltype(LAST)::value;
+            p3_barrier();
+            const int hb = (sidx & 1) * P_HBYTES;
+            // per item: scale (prescale factor * exponents) and bias1 of the head's 64 hidden channels and
+            // the output scale / bias of its 1x1 rows, requested at the first step, parked in the
+            // (shared: every wave writes the same values) LDS stash two steps later
+            float sv = 1.f, hv = 0.f, ov[2] = {1.f, 1.f}, bv[2] = {0.f, 0.f};
+            if (c == 0) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const unsigned o = (unsigned)(64 * cur.nb + ln) * 4u;
+                if (a.scale) sv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.scale) + o);
+                if (a.shift) hv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.shift) + o);
+                const float *os2 = hd.oscale[cur.nb], *b2 = hd.bias[cur.nb];
+                const int cout2 = hd.cout[cur.nb];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int co = ln + 64 * u;     // rows that do not exist: 1 / 0
+                    if (co < cout2) {
+                        if (os2) ov[u] = os2[co];
+                        if (b2) bv[u] = b2[co];
+                    }
+                }
+            }
+            step(P3_IC(0), hb, P_WOFF + ((g + 0) & 3) * P_WSLOT);
+            p3_barrier(); step(P3_IC(1), hb, P_WOFF + ((g + 1) & 3) * P_WSLOT);
+            p3_barrier(); step(P3_IC(2), hb, P_WOFF + ((g + 2) & 3) * P_WSLOT);
+            if (c == 0) {
+                *reinterpret_cast<float *>(smem + P_SSOFF + lane * 4) = sv;
+                *reinterpret_cast<float *>(smem + P_SSOFF + 256 + lane * 4) = hv;
+                *reinterpret_cast<float *>(smem + P_SSOFF + 512 + lane * 4) = ov[0];
+                *reinterpret_cast<float *>(smem + P_SSOFF + 896 + lane * 4) = bv[0];
+                if (lane < 32) {
+                    *reinterpret_cast<float *>(smem + P_SSOFF + 512 + (64 + lane) * 4) = ov[1];
+                    *reinterpret_cast<float *>(smem + P_SSOFF + 896 + (64 + lane) * 4) = bv[1];
+                }
+            }
+            p3_barrier(); step(P3_IC(3), hb, P_WOFF + ((g + 3) & 3) * P_WSLOT);
+            p3_barrier(); step(P3_IC(4), hb, P_WOFF + ((g + 4) & 3) * P_WSLOT);
+            p3_barrier(); step(P3_IC(5), hb, P_WOFF + ((g + 5) & 3) * P_WSLOT);
+            p3_barrier(); step(P3_IC(6), hb, P_WOFF + ((g + 6) & 3) * P_WSLOT);
+            if constexpr (last) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                __builtin_amdgcn_sched_barrier(0);
+                load_w2(wfa, hd.wf[cur.nb], 0, 0, ln);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            p3_barrier(); step(P3_IC(7), hb, P_WOFF + ((g + 7) & 3) * P_WSLOT);
+            p3_barrier(); step(P3_IC(8), hb, P_WOFF + ((g + 8) & 3) * P_WSLOT);
+            g += 9;
+            ++sidx;
+        };
+        for (int k = 0; k < nit; ++k) {
+            const P3Item cur = p3_decode(a, first + k * nx);
+            for (int c = 0; c < a.nchunk - 1; ++c) stage(std::false_type{}, c, cur);
+            stage(std::true_type{}, a.nchunk - 1, cur);
+            // (the stash was written in this item's first stage, two barriers ago at least; nothing the
+            // epilogue reads is touched by the loaders)
+            if (a.nchunk == 1) p3_lds_fence();
+            epilogue(cur);
+            zero_acc();
+            lane_consts();
+        }
+        p3_barrier();
+#undef P3_IC
+        if (a.range) cn_rng_commit(a.range, 0, rng_out);
         return;
     }
 
@@ -522,19 +789,27 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a)
         bar(); step(P3_IC(3), hb, P_WOFF + ((g + 3) & 3) * P_WSLOT);
         bar(); step(P3_IC(4), hb, P_WOFF + ((g + 4) & 3) * P_WSLOT);
         bar(); step(P3_IC(5), hb, P_WOFF + ((g + 5) & 3) * P_WSLOT);
-        bar(); step(P3_IC(6), hb, P_WOFF + ((g + 6) & 3) * P_WSLOT);
-        bar(); step(P3_IC(7), hb, P_WOFF + ((g + 7) & 3) * P_WSLOT);
-        bar(); step(P3_IC(8), hb, P_WOFF + ((g + 8) & 3) * P_WSLOT);
-        // the item's residual rows: requested behind the matrix work of its last step (the fragment
-        // registers are free from here on; held over the whole item the 32 registers push the kernel
-        // past 128 -- and two 6-wave workgroups at 3 waves per SIMD leave the dispatcher no slack:
-        // measured, half of the second workgroups then start only when a first one has finished)
-        if constexpr (RES != 0) {
-            if (c == a.nchunk - 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                load_residual(cur);
+        // the item's residual rows: requested RES_AT steps before the end of its last stage (probe:
+        // requested behind the last step, the epilogue of a 64 -> 64 item waits ~3500 cycles for
+        // them).  Held over the whole item the 32 registers push the kernel past 128 -- and two
+        // 6-wave workgroups at 3 waves per SIMD leave the dispatcher no slack: measured, half of the
+        // second workgroups then start only when a first one has finished
+        auto maybe_residual = [&](int at) {
+            if constexpr (RES != 0) {
+                if (at == RES_AT && c == a.nchunk - 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_residual(cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        }
+        };
+        maybe_residual(3);
+        bar(); step(P3_IC(6), hb, P_WOFF + ((g + 6) & 3) * P_WSLOT);
+        maybe_residual(2);
+        bar(); step(P3_IC(7), hb, P_WOFF + ((g + 7) & 3) * P_WSLOT);
+        maybe_residual(1);
+        bar(); step(P3_IC(8), hb, P_WOFF + ((g + 8) & 3) * P_WSLOT);
+        maybe_residual(0);
         g += 9;
         if (++c == a.nchunk) {
             c = 0;
@@ -639,7 +914,7 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
 #define P3_LAUNCH(R, OP)                                                                   \
     do {                                                                                   \
         CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<R, OP>), P_LDS);                               \
-        hipLaunchKernelGGL((conv3x3p_kernel<R, OP>), grid, block, P_LDS, st, a);            \
+        hipLaunchKernelGGL((conv3x3p_kernel<R, OP>), grid, block, P_LDS, st, a, P3Heads{}); \
     } while (0)
     const int rmode = !residual ? 0 : (res_plain ? 2 : 1);
     if ((p3_probe_dbg || p3_probe_prof) && !out_plain && rmode < 2) {
@@ -647,10 +922,10 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
         a.prof = p3_probe_prof;
         if (rmode == 0) {
             CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, true>), P_LDS);
-            hipLaunchKernelGGL((conv3x3p_kernel<0, false, true>), grid, block, P_LDS, st, a);
+            hipLaunchKernelGGL((conv3x3p_kernel<0, false, true>), grid, block, P_LDS, st, a, P3Heads{});
         } else {
             CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<1, false, true>), P_LDS);
-            hipLaunchKernelGGL((conv3x3p_kernel<1, false, true>), grid, block, P_LDS, st, a);
+            hipLaunchKernelGGL((conv3x3p_kernel<1, false, true>), grid, block, P_LDS, st, a, P3Heads{});
         }
         CN_CHECK_LAUNCH();
         return CN_OK;
@@ -661,6 +936,100 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
         if (rmode == 0) P3_LAUNCH(0, false); else if (rmode == 1) P3_LAUNCH(1, false); else P3_LAUNCH(2, false);
     }
 #undef P3_LAUNCH
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+// The fused heads on the persistent kernel: f32s feature map (whole 128-byte groups per pixel), one
+// 64-wide hidden layer per head, every head <= 96 outputs, enough items to fill the chip.
+bool cn_heads3x3p_takes(int B, int H, int W, int in_pitch, int head_conv, int n_heads, const cn_head_out *heads,
+                        bool in_plain)
+{
+    if (!cn_tune_c3p || !cn_tune_c3p_heads || in_plain || head_conv != 64 || n_heads > P_MAXH) return false;
+    if (in_pitch & 31) return false;
+    for (int h = 0; h < n_heads; ++h)
+        if (heads[h].cout > 96 || !heads[h].w_frag || !cn_aligned16(heads[h].w_frag)) return false;
+    const long items = (long)B * cn_cdiv(H, P_TH) * cn_cdiv(W, P_TW) * n_heads;
+    if (cn_tune_c3p < 2 && items < 256) return false;
+    if ((long)B * H * W * (long)in_pitch * 4 >= (1L << 31)) return false;
+    for (int h = 0; h < n_heads; ++h)
+        if ((long)B * heads[h].cout * H * W >= (1L << 31)) return false;
+    return true;
+}
+
+int cn_heads3x3p(const void *x, int B, int H, int W, int Cin, int in_pitch, const void *w1_packed,
+                 const float *scale1, const float *bias1, int n_heads, const cn_head_out *heads,
+                 const cn_f32s_ctl *ctl, hipStream_t st)
+{
+    P3Args a = {};
+    P3Heads hd = {};
+    for (int h = 0; h < n_heads; ++h) {
+        hd.wf[h] = (const char *)heads[h].w_frag; hd.bias[h] = heads[h].bias; hd.oscale[h] = heads[h].oscale;
+        hd.y[h] = heads[h].y; hd.cout[h] = heads[h].cout;
+    }
+    a.x = (const char *)x; a.w = (const char *)w1_packed; a.scale = scale1; a.shift = bias1;
+    a.H = H; a.W = W;
+    a.in_pitchB = in_pitch * 4;
+    const int cin_pad = (Cin + 31) / 32 * 32;
+    a.cin_padB = cin_pad * 4;
+    a.cout_pad = 64 * n_heads;
+    a.ngroups = a.cout_pad / 32;
+    a.nchunk = cin_pad / 32;
+    a.nblk = n_heads;
+    a.tiles_x = cn_cdiv(W, P_TW);
+    a.tiles_y = cn_cdiv(H, P_TH);
+    a.items = B * a.tiles_y * a.tiles_x * a.nblk;
+    a.relu = 1;
+    a.res_mul = 1.f;
+    a.range = ctl ? ctl->range : nullptr;
+    a.stagger = cn_tune_c3p_stagger;
+    a.knobs = cn_tune_c3p_knobs;
+    int per_xcd = cn_cdiv(a.items, 8);
+    if (per_xcd > 64) per_xcd = 64;
+    const dim3 grid(8 * per_xcd), block(384);
+    CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, false, true>), P_LDS);
+    hipLaunchKernelGGL((conv3x3p_kernel<0, false, false, true>), grid, block, P_LDS, st, a, hd);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+// ---- 1x1 matrix of a head as MFMA-ready fragments for the kernel above
+namespace {
+__global__ void pack_head_w2_kernel(const float *__restrict__ w, char *__restrict__ out, int cout, int nblk2)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;      // (jb, j, s2, lane)
+    if (t >= nblk2 * 4 * 64) return;
+    const int ln = t & 63, s2 = (t >> 6) & 1, j = (t >> 7) & 1, jb = t >> 8;
+    const int l31 = ln & 31, lh = ln >> 5;
+    const int row = jb * 32 + l31;
+    _Float16 hi[8], lo[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        // K order of step s2 of hidden block j: lane half lh holds 32 j + 16 s2 + 4 lh + {0..3}, then + 8
+        const int k = 32 * j + 16 * s2 + 8 * (q >> 2) + 4 * lh + (q & 3);
+        const float v = row < cout ? w[(size_t)row * 64 + k] : 0.f;
+        const float c = fminf(fmaxf(v, -65504.0f), 65504.0f);
+        hi[q] = (_Float16)c;
+        lo[q] = (_Float16)(c - (float)hi[q]);
+    }
+    char *o = out + ((size_t)((jb * 2 + j) * 2 + s2) * 2 * 64 + ln) * 16;
+    *reinterpret_cast<p3_f16x8 *>(o) = *reinterpret_cast<const p3_f16x8 *>(hi);
+    *reinterpret_cast<p3_f16x8 *>(o + 64 * 16) = *reinterpret_cast<const p3_f16x8 *>(lo);
+}
+}  // namespace
+
+extern "C" size_t cn_packed_head_w2_bytes(int cout)
+{
+    return cout > 0 ? (size_t)((cout + 31) / 32) * 8192 : 0;
+}
+
+extern "C" int cn_pack_head_w2_f32s(const float *w, void *out, int cout, void *stream)
+{
+    if (!w || !out) return CN_ERR_NULL;
+    if (cout <= 0) return CN_ERR_SHAPE;
+    if (!cn_aligned16(out)) return CN_ERR_ALIGN;
+    const int nblk2 = (cout + 31) / 32;
+    hipLaunchKernelGGL(pack_head_w2_kernel, dim3(nblk2), dim3(256), 0, (hipStream_t)stream, w, (char *)out, cout, nblk2);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

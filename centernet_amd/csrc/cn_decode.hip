@@ -462,9 +462,16 @@ constexpr int GUNIT = 16;    // rows per half-wave unit
 __global__ __launch_bounds__(NT) void group_max_kernel(const float *__restrict__ heat, int H, int W,
                                                        int nrg, int ncb, int flags,
                                                        uint32_t *__restrict__ gpeak,
-                                                       uint32_t *__restrict__ gall)
+                                                       uint32_t *__restrict__ gall, int C,
+                                                       int32_t *__restrict__ counts,
+                                                       int32_t *__restrict__ done)
 {
     const int tid = threadIdx.x;
+    // the second launch's per-image candidate count and arrival counter start at zero (stream order)
+    if (tid == 0 && blockIdx.x % (unsigned)C == 0) {
+        counts[blockIdx.x / (unsigned)C] = 0;
+        done[blockIdx.x / (unsigned)C] = 0;
+    }
     const int lane = tid & (CN_WAVE - 1);
     const int hl = lane & 31;                 // lane inside the half-wave
     const int hw = tid >> 5;                  // half-wave of the workgroup (0..7)
@@ -541,75 +548,57 @@ __global__ __launch_bounds__(NT) void group_max_kernel(const float *__restrict__
     }
 }
 
-// phase 2: per image, the K-th largest group peak-maximum (exact).  thr[b] = its SCORE key (the
-// logistic applied when it is fused), rawthr[b] = a conservative lower bound, in raw units, of
-// every cell whose score can reach it; counts[b] = 0, or GCAP + 1 for a degenerate image (fewer
-// than K groups, or a non-positive threshold: zeros of suppressed cells would take part)
-__global__ __launch_bounds__(NT) void group_threshold_kernel(const uint32_t *__restrict__ gpeak, int ng,
-                                                             int K, int flags,
-                                                             uint32_t *__restrict__ thr,
-                                                             float *__restrict__ rawthr,
-                                                             int32_t *__restrict__ counts)
+// phase 2 (device function, run by EVERY plane's workgroup of the second launch -- the select over
+// an image's ~1 k group maxima is cheaper than a launch boundary and needs no inter-workgroup
+// wait): the K-th largest group peak-maximum of image b (exact).  Returns, to every thread, the
+// SCORE key of the threshold (the logistic applied when it is fused; <= KEY_ZERO = degenerate
+// image: fewer than K groups with a peak, or a non-positive threshold -- zeros of suppressed cells
+// would take part) and a conservative lower bound, in raw units, of every cell whose score can
+// reach it.
+__device__ __forceinline__ uint32_t image_threshold(const uint32_t *__restrict__ g, int ng, int K, int flags,
+                                                    SelShared &sh, float &rawthr)
 {
-    __shared__ SelShared sh;
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const uint32_t *g = gpeak + (size_t)b * ng;
-    if (ng < K) {
-        if (tid == 0) { thr[b] = 0; rawthr[b] = 0.f; counts[b] = GCAP + 1; }
-        return;
-    }
+    rawthr = 0.f;
+    if (ng < K) return 0u;
     auto for_each = [&](auto &&f) {
         for (int j = tid; j < ng; j += NT) f(((u64)g[j] << 32) | (u64)(0xFFFFFFFFu - (uint32_t)j), false);
     };
     u64 prefix, mask;
     radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
     collect_and_sort<NT>(for_each, prefix, mask, sh);
-    if (tid == 0) {
-        const uint32_t kraw = (uint32_t)(sh.sel[K - 1] >> 32);
-        if (kraw == 0u) {   // fewer than K groups hold a peak at all
-            thr[b] = 0; rawthr[b] = 0.f; counts[b] = GCAP + 1;
-            return;
-        }
-        const float raw = key2f(kraw);
-        const bool sig = (flags & 1) != 0;
-        const float score = sig ? sigmoidf_ref(raw) : raw;
-        const uint32_t t = f2key(score + 0.0f);
-        thr[b] = t;
-        // the device logistic is monotone only up to its last bit: admit a margin of raw values
-        // below the K-th one; the exact test in phase 3 sorts them out
-        rawthr[b] = sig ? raw - (1e-3f + 1e-3f * fabsf(raw)) : raw;
-        counts[b] = (t <= KEY_ZERO) ? GCAP + 1 : 0;
-    }
+    const uint32_t kraw = (uint32_t)(sh.sel[K - 1] >> 32);    // (collect_and_sort ends with a barrier)
+    if (kraw == 0u) return 0u;    // fewer than K groups hold a peak at all
+    const float raw = key2f(kraw);
+    const bool sig = (flags & 1) != 0;
+    const float score = sig ? sigmoidf_ref(raw) : raw;
+    // the device logistic is monotone only up to its last bit: admit a margin of raw values
+    // below the K-th one; the exact test in phase 3 sorts them out
+    rawthr = sig ? raw - (1e-3f + 1e-3f * fabsf(raw)) : raw;
+    return f2key(score + 0.0f);
 }
 
-// phase 3: exact evaluation of the cells that can reach the threshold.  One workgroup per (image,
-// class) plane; its eight half-waves share the plane's live groups (all-cell maximum >= the raw
-// threshold).  A half-wave re-reads its 8 x 128 group with the same rolling register window as
-// phase 1 (10 row loads, neighbours by shuffle), applies the logistic to the whole window and
+// phase 3 (device function): exact evaluation of the cells of ONE plane that can reach the
+// threshold.  The workgroup's eight half-waves share the plane's live groups (all-cell maximum >=
+// the raw threshold).  A half-wave re-reads its 8 x 128 group with the same rolling register window
+// as phase 1 (10 row loads, neighbours by shuffle), applies the logistic to the whole window and
 // runs the reference's test on the SCORES -- 3x3 maximum, exact equality (decode.py:9-15) -- in
 // registers; qualifying cells are counted per lane, placed by a half-wave prefix sum and ONE
 // atomic per group.  The threshold often falls INTO the noise floor of a real heat-map (a few
 // confident objects, K = 100): then most groups are live and this pass costs about what phase 1
 // does plus the logistics -- not nine dependent loads per cell over the threshold.
-__global__ __launch_bounds__(NT) void peak_collect_kernel(const float *__restrict__ heat, int C, int H,
-                                                          int W, int nrg, int ncb, int flags,
-                                                          const uint32_t *__restrict__ gall,
-                                                          const uint32_t *__restrict__ thr,
-                                                          const float *__restrict__ rawthr,
-                                                          u64 *__restrict__ keys,
-                                                          int32_t *__restrict__ counts)
+__device__ __forceinline__ void plane_collect(const float *__restrict__ heat, int C, int H, int W, int nrg,
+                                              int ncb, int flags, const uint32_t *__restrict__ gall,
+                                              uint32_t tkey, float rthr, u64 *__restrict__ keys,
+                                              int32_t *__restrict__ counts)
 {
     const int tid = threadIdx.x;
     const int lane = tid & (CN_WAVE - 1);
     const int hl = lane & 31, hw = tid >> 5;
     const size_t plane_id = blockIdx.x;
     const int b = (int)(plane_id / C), c = (int)(plane_id - (size_t)b * C);
-    const uint32_t tkey = thr[b];
-    if (tkey <= KEY_ZERO) return;   // degenerate image: served by the gated per-band select
     const bool sig = (flags & 1) != 0;
     const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;
-    const float rthr = rawthr[b];
     const uint32_t rkey = f2key(rthr + 0.0f);   // group maxima are RAW keys
     const float *plane = heat + plane_id * (size_t)H * W;
     const uint32_t base = (uint32_t)c * (uint32_t)(H * W);
@@ -748,54 +737,18 @@ struct KeySrc {
     int flags;                // bit 0 sigmoid, CN_DECODE_NO_PEAK_TEST
 };
 
-template <int MODE, bool KEYS = false>
-__global__ __launch_bounds__(NTM) void merge_topk_kernel(
-    const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int N,
-    int per_class, int H, int W, int K, int C, const float *__restrict__ wh,
-    const float *__restrict__ reg, int cat_spec_wh, float *__restrict__ dets, int det_dim,
-    int32_t *__restrict__ inds_out, float *__restrict__ out_scores,
-    const float *__restrict__ kps_map, int J, int32_t *__restrict__ cls_out, const KeySrc ks)
+// rows 0 .. K-1 of the sorted selection sh.sel -> outputs of group g (see merge_topk_kernel)
+template <int MODE>
+__device__ __forceinline__ void emit_rows(const SelShared &sh, int g, int H, int W, int K, int C,
+                                          const float *__restrict__ wh, const float *__restrict__ reg,
+                                          int cat_spec_wh, float *__restrict__ dets, int det_dim,
+                                          int32_t *__restrict__ inds_out, float *__restrict__ out_scores,
+                                          const float *__restrict__ kps_map, int J,
+                                          int32_t *__restrict__ cls_out)
 {
-    constexpr bool CTDET = (MODE != MODE_CHANNEL);  // group = image, class from position
-    static_assert(!KEYS || CTDET, "candidate keys are image-level");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    SelShared &sh = *reinterpret_cast<SelShared *>(smem);
+    constexpr bool CTDET = (MODE != MODE_CHANNEL);
     const int tid = threadIdx.x;
-    const int g = blockIdx.x;
     const int HW = H * W;
-    const float *cs = cand_score + (size_t)g * N;
-    const int32_t *ci = cand_idx + (size_t)g * N;
-
-    u64 prefix, mask;
-    if constexpr (KEYS) {
-        // usable candidate list: between K and GCAP keys; otherwise the gated per-band select
-        // (launched right behind this kernel) produces this image
-        const int cnt = ks.counts[g];
-        if (cnt < K || cnt > GCAP) return;
-        const u64 *kg = ks.keys + (size_t)g * GCAP;
-        auto for_each = [&](auto &&f) {
-            for (int j = tid; j < cnt; j += NTM) f(kg[j], false);
-        };
-        radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
-        collect_and_sort<NTM>(for_each, prefix, mask, sh);
-    } else {
-        if (CTDET && ks.counts) {   // gated: only the images the candidate list could not serve
-            const int cnt = ks.counts[g];
-            if (cnt >= K && cnt <= GCAP) return;
-        }
-        auto for_each = [&](auto &&f) {
-            for (int j = tid; j < N; j += NTM) {
-                const int32_t idx = ci[j];
-                if (idx < 0) continue;
-                const uint32_t kk = f2key(cs[j] + 0.0f);
-                const uint32_t fid = CTDET ? (uint32_t)((j / per_class) * HW + idx) : (uint32_t)idx;
-                f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - fid), kk == KEY_ZERO);
-            }
-        };
-        radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
-        collect_and_sort<NTM>(for_each, prefix, mask, sh);
-    }
-
     if (tid < K) {
         const u64 k = sh.sel[tid];
         const float score = key2f((uint32_t)(k >> 32));
@@ -844,6 +797,58 @@ __global__ __launch_bounds__(NTM) void merge_topk_kernel(
             inds_out[(size_t)g * K + tid] = (int32_t)fid;
         }
     }
+}
+
+template <int MODE, bool KEYS = false>
+__global__ __launch_bounds__(NTM) void merge_topk_kernel(
+    const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int N,
+    int per_class, int H, int W, int K, int C, const float *__restrict__ wh,
+    const float *__restrict__ reg, int cat_spec_wh, float *__restrict__ dets, int det_dim,
+    int32_t *__restrict__ inds_out, float *__restrict__ out_scores,
+    const float *__restrict__ kps_map, int J, int32_t *__restrict__ cls_out, const KeySrc ks)
+{
+    constexpr bool CTDET = (MODE != MODE_CHANNEL);  // group = image, class from position
+    static_assert(!KEYS || CTDET, "candidate keys are image-level");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SelShared &sh = *reinterpret_cast<SelShared *>(smem);
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x;
+    const int HW = H * W;
+    const float *cs = cand_score + (size_t)g * N;
+    const int32_t *ci = cand_idx + (size_t)g * N;
+
+    u64 prefix, mask;
+    if constexpr (KEYS) {
+        // usable candidate list: between K and GCAP keys; otherwise the gated per-band select
+        // (launched right behind this kernel) produces this image
+        const int cnt = ks.counts[g];
+        if (cnt < K || cnt > GCAP) return;
+        const u64 *kg = ks.keys + (size_t)g * GCAP;
+        auto for_each = [&](auto &&f) {
+            for (int j = tid; j < cnt; j += NTM) f(kg[j], false);
+        };
+        radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
+        collect_and_sort<NTM>(for_each, prefix, mask, sh);
+    } else {
+        if (CTDET && ks.counts) {   // gated: only the images the candidate list could not serve
+            const int cnt = ks.counts[g];
+            if (cnt >= K && cnt <= GCAP) return;
+        }
+        auto for_each = [&](auto &&f) {
+            for (int j = tid; j < N; j += NTM) {
+                const int32_t idx = ci[j];
+                if (idx < 0) continue;
+                const uint32_t kk = f2key(cs[j] + 0.0f);
+                const uint32_t fid = CTDET ? (uint32_t)((j / per_class) * HW + idx) : (uint32_t)idx;
+                f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - fid), kk == KEY_ZERO);
+            }
+        };
+        radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
+        collect_and_sort<NTM>(for_each, prefix, mask, sh);
+    }
+
+    emit_rows<MODE>(sh, g, H, W, K, C, wh, reg, cat_spec_wh, dets, det_dim, inds_out, out_scores, kps_map, J,
+                    cls_out);
 }
 
 struct BandPlan {

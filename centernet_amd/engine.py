@@ -836,7 +836,18 @@ class PlanBuilder:
                 last.bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
             t = torch.empty((x.B, co, x.H, x.W), device=self.device, dtype=torch.float32)
             outs[n] = Act(t, x.B, x.H, x.W, co, nchw=True, lid=lid + "/" + n)
-            self.keep += [w2, b2, t, osc]
+            wfrag = None
+            if use_s and hc == 64 and co <= 96:
+                # the same (prescaled) matrix as MFMA-ready (high, low) fragments: lets the library
+                # run the heads on its persistent kernel
+                wfrag = torch.empty(lib.cn_packed_head_w2_bytes(co), device=self.device, dtype=torch.uint8)
+                native.check(lib.cn_pack_head_w2_f32s(native.ptr(w2), native.ptr(wfrag), co,
+                                                      native.stream_ptr()), "cn_pack_head_w2_f32s")
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pack_events.append(ev)
+                arr[i].w_frag = wfrag.data_ptr()
+            self.keep += [w2, b2, t, osc, wfrag]
             arr[i].w = w2.data_ptr()
             arr[i].bias = b2.data_ptr() if b2 is not None else None
             arr[i].y = t.data_ptr()

@@ -48,7 +48,8 @@ class ConvDesc(ctypes.Structure):
 class HeadOut(ctypes.Structure):
     """Mirror of ``cn_head_out`` (include/centernet_amd.h)."""
     _fields_ = [("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p),
-                ("cout", ctypes.c_int), ("reserved", ctypes.c_int), ("oscale", ctypes.c_void_p)]
+                ("cout", ctypes.c_int), ("reserved", ctypes.c_int), ("oscale", ctypes.c_void_p),
+                ("w_frag", ctypes.c_void_p)]
 
 
 def build(force=False, verbose=False):
@@ -95,6 +96,10 @@ def _declare(lib):
     lib.cn_range_fold.argtypes = [vp, vp, vp, i, vp]
     lib.cn_range_fold_digest.restype = i
     lib.cn_range_fold_digest.argtypes = [vp, vp, vp, vp, i, vp]
+    lib.cn_packed_head_w2_bytes.restype = sz
+    lib.cn_packed_head_w2_bytes.argtypes = [i]
+    lib.cn_pack_head_w2_f32s.restype = i
+    lib.cn_pack_head_w2_f32s.argtypes = [vp, vp, i, vp]
     lib.cn_calib_mfma_f16.restype = ctypes.c_double
     lib.cn_calib_mfma_f16.argtypes = [vp, i, vp]
     lib.cn_calib_copy.restype = i

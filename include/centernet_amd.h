@@ -394,7 +394,13 @@ typedef struct cn_head_out {
     int reserved;
     const float *oscale; /* (cout) or NULL: y = acc * oscale + bias -- undoes a per-row pre-scale of w
                             and the exponent of the hidden tile (f32s; see cn_f32s_ctl) */
+    const void *w_frag;  /* optional (f32s, head_conv = 64, cout <= 96): the same matrix w as (high, low)
+                            fp16 fragments, cn_pack_head_w2_f32s -- with it the heads run on the
+                            persistent kernel (cn_conv3x3p.hip); NULL = the one-tile-per-workgroup kernel */
 } cn_head_out;
+/* w (cout, 64) row-major -> out (cn_packed_head_w2_bytes(cout) bytes, 16-byte aligned) */
+size_t cn_packed_head_w2_bytes(int cout);
+int cn_pack_head_w2_f32s(const float *w, void *out, int cout, void *stream);
 int cn_heads3x3_1x1_f32(const float *x, int B, int H, int W, int Cin, int in_pitch,
                         const float *w1_packed, const float *bias1, int head_conv, int n_heads,
                         const cn_head_out *heads, void *stream);

@@ -420,6 +420,66 @@ def test_fused_heads(dev, cfg, split):
             _check(outs[name].t.cpu(), ref[name])
 
 
+def _heads_case(Fc, hidden, heads, seed=0):
+    pairs = {}
+    for i, (name, classes) in enumerate(heads.items()):
+        c1 = torch.nn.Conv2d(Fc, hidden, 3, padding=1, bias=True)
+        c2 = torch.nn.Conv2d(hidden, classes, 1, bias=(name != "nobias"))
+        with torch.no_grad():
+            c1.weight.copy_(torch.from_numpy(synth.normal(tuple(c1.weight.shape), (2.0 / (Fc * 9)) ** 0.5, seed + 20 + i)))
+            c1.bias.copy_(torch.from_numpy(synth.normal((hidden,), 0.2, seed + 30 + i)))
+            c2.weight.copy_(torch.from_numpy(synth.normal(tuple(c2.weight.shape), 0.15, seed + 40 + i)))
+            if c2.bias is not None:
+                c2.bias.copy_(torch.from_numpy(synth.normal((classes,), 0.5, seed + 50 + i)))
+        pairs[name] = (c1, c2)
+    return pairs
+
+
+@pytest.mark.parametrize("forced", [2, 1])
+def test_fused_heads_on_the_persistent_kernel(dev, forced):
+    """cn_heads3x3_1x1 with a 64-wide hidden layer on the persistent loader / consumer kernel
+    (cn_conv3x3p.hip, HEADS: hidden layer in registers, 1x1 weights as packed fragments) against the
+    per-head Sequential(conv3x3, ReLU, conv1x1) of resnet_dcn.py:155-177 on torch CPU and against
+    the one-tile-per-workgroup kernel (cn_set_tuning key 31 = 0): edge tiles, Cin padding, one to
+    five heads, 1 .. 96 outputs, a head without bias; key 28 = 2 forces the kernel onto small
+    shapes, = 1 is the library's own routing (taken at the benchmark shape)."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder
+    lib = native.lib()
+    cases = [(2, 64, 32, 32, {"hm": 80, "wh": 2, "reg": 2}),
+             (1, 64, 20, 24, {"hm": 80, "wh": 2, "reg": 2}),          # edge tiles in both directions
+             (3, 96, 17, 40, {"hm": 33, "nobias": 96, "a": 1, "b": 64, "c": 5}),
+             (2, 32, 8, 16, {"hm": 3})] if forced == 2 else \
+            [(32, 64, 128, 128, {"hm": 80, "wh": 2, "reg": 2})]
+    assert lib.cn_set_tuning(28, forced) == 0
+    try:
+        for (B, Fc, H, W, heads) in cases:
+            pairs = _heads_case(Fc, 64, heads, seed=B + H)
+            x = torch.from_numpy(synth.normal((B, Fc, H, W), 1.0, 11)).relu_()
+            nref = min(B, 2)
+            ref = {n: pairs[n][1](F.relu(pairs[n][0](x[:nref]))) for n in heads}
+            got = {}
+            for key31 in (1, 0):
+                assert lib.cn_set_tuning(31, key31) == 0
+                pb = PlanBuilder(dev, B, H, W, split=True)
+                outs = pb.heads_from_convs(pb.packed(_nhwc_act(x, dev)), pairs)
+                assert len(pb.ops) == 2, "convert + one fused launch"
+                _run(pb)
+                got[key31] = {n: outs[n].t.clone() for n in heads}
+                if key31 == 1:      # run-to-run bit equality of the persistent kernel
+                    _run(pb)
+                    for n in heads:
+                        assert torch.equal(outs[n].t, got[1][n]), n
+            for n in heads:
+                _check(got[1][n][:nref].cpu(), ref[n])
+                # the two kernels sum in different orders: equal to fp32 rounding, every image
+                d = float((got[1][n] - got[0][n]).abs().max()) / max(1.0, float(got[0][n].abs().max()))
+                assert d < 2e-5, (n, d)
+    finally:
+        lib.cn_set_tuning(28, 1)
+        lib.cn_set_tuning(31, 1)
+
+
 @pytest.mark.parametrize("form", [0, 1, 2, 3])
 def test_fused_heads_hidden_layer_forms(dev, form):
     """cn_set_tuning key 26: the f32s fused heads with the hidden layer staged through LDS (0), kept

@@ -485,12 +485,14 @@ def test_inputs_far_below_the_calibration_batch_schedule_a_recalibration(dev):
         assert m.__dict__["_calibrations"] == 2 and "_recalibrate" not in m.__dict__
         from centernet_amd.engine import LOW_STEP, LOW_EVERY
         assert e1["input"] == e0["input"] - LOW_STEP and all(e1[k] >= e0[k] - LOW_STEP for k in e0)
-        # still low, but re-calibration is rate-limited: the next forwards neither calibrate nor
-        # rebuild their plan, and say so once
+        # (2^-16 down, LOW_STEP up again: inside the range now.)  An input that keeps falling is
+        # flagged again, but re-calibration is rate-limited: the next forwards neither calibrate
+        # nor rebuild their plan, and say so once
         plan = next(iter(m.__dict__["_plans"].values()))
         for _ in range(3):
-            _detect(m, small, dev)
+            _detect(m, small * 2.0 ** -12, dev)
         assert m.__dict__["_calibrations"] == 2 and next(iter(m.__dict__["_plans"].values())) is plan
+        assert "_recalibrate" not in m.__dict__
     assert sum("re-calibration is limited" in str(w.message) for w in rec) == 1
     assert LOW_EVERY > 4
     from oracle import net_oracle
