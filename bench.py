@@ -32,7 +32,7 @@ F16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARC
 # matrix-pipe ceiling in ALGORITHMIC (fp32-equivalent) FLOPs is a third of the fp16 peak
 F32S_MFMA_PEAK_TF = F16_MFMA_PEAK_TF / 3.0
 
-DECODE_LAUNCHES = {"ctdet": 6, "multi_pose": 5}   # kernels per decode call (cn_decode.hip)
+DECODE_LAUNCHES = {"ctdet": 2, "multi_pose": 5}   # kernels per decode call (cn_decode.hip)
 
 # BASELINE.json configs[1..4] (configs[0] is the reference's CPU plumbing case: cpu_baseline)
 CONFIGS = {

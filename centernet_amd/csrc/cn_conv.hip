@@ -1669,7 +1669,7 @@ extern "C" int cn_stem_f32s_supported(const cn_conv_desc *d)
     return (d->stride == 1 && d->Cout <= 16 && d->pad_h == 3 && (d->W & 3) == 0 && g_tune_stem16s) ? 1 : 0;
 }
 
-extern int cn_tune_c3p, cn_tune_c3p_stagger, cn_tune_c3p_knobs, cn_tune_c3p_heads;
+extern int cn_tune_c3p, cn_tune_c3p_stagger, cn_tune_c3p_knobs, cn_tune_c3p_heads, cn_tune_c3p_deconv;
 extern "C" int cn_set_tuning(int key, int value)
 {
     if (key == 28 && value >= 0 && value <= 7) {
@@ -1686,6 +1686,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 31 && (value == 0 || value == 1)) {
         cn_tune_c3p_heads = value;
+        return CN_OK;
+    }
+    if (key == 32 && (value == 0 || value == 1)) {
+        cn_tune_c3p_deconv = value;
         return CN_OK;
     }
     if (key == 20 && (value == 0 || value == 1)) {

@@ -43,6 +43,10 @@ bool cn_heads3x3p_takes(int B, int H, int W, int in_pitch, int head_conv, int n_
 int cn_heads3x3p(const void *x, int B, int H, int W, int Cin, int in_pitch, const void *w1_packed,
                  const float *scale1, const float *bias1, int n_heads, const cn_head_out *heads,
                  const cn_f32s_ctl *ctl, hipStream_t st);
+bool cn_deconv4x4s2p_takes(int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch, bool in_plain);
+int cn_deconv4x4s2_persist(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                           int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch, int relu,
+                           int out_plain, const cn_f32s_ctl *ctl, hipStream_t st);
 int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale, const float *shift,
                          const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                          int in_pitch, int out_pitch, int res_pitch, int relu, int out_plain, int res_plain,
@@ -1432,6 +1436,10 @@ int cn_deconv4x4s2_halo(const void *x, const void *w_packed, const float *scale,
     a.in_plain = (dtype_flags >> 8) & CN_CONV_X_PLAIN ? 1 : 0;
     a.out_plain = (dtype_flags >> 8) & CN_CONV_Y_PLAIN ? 1 : 0;
     const bool wide = W >= 32;
+    if ((dtype_flags & 255) == CN_DTYPE_F32S && vec_out && scale &&
+        cn_deconv4x4s2p_takes(B, H, W, Cin, Cout, in_pitch, out_pitch, a.in_plain != 0))
+        return cn_deconv4x4s2_persist(x, w_packed, scale, shift, y, B, H, W, Cin, Cout, in_pitch, out_pitch, relu,
+                                      a.out_plain, ctl, st);
     if ((dtype_flags & 255) == CN_DTYPE_F32S) {
         if (Cout > 64)
             return wide ? launch_c3<cn_f32s, 32, 128, 4, 2, false, 128, false, true>(a, st)

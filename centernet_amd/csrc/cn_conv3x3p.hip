@@ -38,6 +38,7 @@ int cn_tune_c3p_stagger = 64; // cn_set_tuning key 29: start delay of the second
                               // (measured 0 ... 96: 48-64 is best on every trunk shape, +6 ... +13 % over none)
 int cn_tune_c3p_knobs = 0;    // cn_set_tuning key 30 (A/B): see P3Args.knobs
 int cn_tune_c3p_heads = 1;    // cn_set_tuning key 31: the fused heads (hidden width 64) on this kernel; 0 = halo kernel
+int cn_tune_c3p_deconv = 1;   // cn_set_tuning key 32: ConvTranspose2d(4, 2, 1) in parity form on this kernel; 0 = halo kernel
 
 // one 128-byte line of zeros: the DMA source of halo pixels outside the image
 __device__ __attribute__((aligned(128))) unsigned char cn_p3_zero_line[128];
@@ -79,14 +80,16 @@ struct P3Args {
     int ngroups;              // 32-channel groups of the output that exist (cout_pad / 32)
     int nchunk, nblk;         // 32-channel K chunks; 64-channel output blocks
     int tiles_x, tiles_y;
-    int items;                // B * tiles_y * tiles_x * nblk, output block fastest
+    int items;                // B * tiles_y * tiles_x * npar * nblk, output block fastest, then parity
+    int npar;                 // 1; 4 = ConvTranspose2d(4, stride 2, pad 1) as four parity 2x2 convolutions over the
+                              // same halo: parity (py, px) = taps (t / 2 + py, t % 2 + px) of the 3x3 neighbourhood
+                              // with weights [parity][tap][cout_pad][cin_pad], output pixel (2 y + py, 2 x + px)
     int relu, out_plain, res_plain;
     float res_mul;
     uint32_t *range;
     int stagger;
     int knobs;                // A/B switches (cn_set_tuning key 30): 1 = no s_setprio 1 around the consumers' MFMA block
-                              // (with the loaders at priority 3 the raised priority measured 3-5 % faster);
-                              // 8 + 2 * n: residual requested n = 0 .. 3 steps before the item's last step ends
+                              // (with the loaders at priority 3 the raised priority measured 3-5 % faster)
     // instrumented instantiation only (DBG = true; cn_conv3x3p_probe): ablation switches and cycle counters
     int dbg;                  // 1: no MFMAs, 2: no fragment reads (and no MFMAs), 4: no weight DMA, 8: no halo DMA,
                               // 16: no epilogue, 32: no output stores
@@ -115,12 +118,14 @@ struct P3Heads {
 __device__ __forceinline__ void p3_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // item -> (image, tile row, tile column, output block)
-struct P3Item { int b, ty0, tx0, nb; };
+struct P3Item { int b, ty0, tx0, nb, par; };
 __device__ __forceinline__ P3Item p3_decode(const P3Args &a, int item)
 {
     P3Item it;
     it.nb = item % a.nblk;
     int t = item / a.nblk;
+    it.par = t % a.npar;
+    t /= a.npar;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
@@ -131,12 +136,15 @@ __device__ __forceinline__ P3Item p3_decode(const P3Args &a, int item)
 }
 
 // RES: 0 = no residual, 1 = f32s residual, 2 = plain fp32 residual
-template <int RES, bool OUT_PLAIN, bool DBG = false, bool HEADS = false>
+template <int RES, bool OUT_PLAIN, bool DBG = false, bool HEADS = false, int NTAP = 9>
 __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const P3Heads hd)
 {
-    // residual rows requested this many steps before an item's last step ends (A/B: knobs bit 3 set -> bits 1-2)
-    const int RES_AT = (a.knobs & 8) ? ((a.knobs >> 1) & 3) : 2;
+    // residual rows requested this many steps before an item's last step ends (0 .. 3 measured with
+    // interleaved medians at B = 32: no difference on any trunk shape, so the shortest live range)
+    constexpr int RES_AT = 0;
     static_assert(!HEADS || (RES == 0 && !DBG), "fused heads: no residual, no probes");
+    static_assert(NTAP == 9 || (NTAP == 4 && RES == 0 && !DBG && !HEADS), "4 taps: the transposed convolution's parity form");
+    constexpr bool DECONV = (NTAP == 4);
     extern __shared__ __attribute__((aligned(128))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -185,9 +193,11 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
             set_wofs(first % a.nblk);
             const size_t tapB = (size_t)a.cout_pad * a.cin_padB;
             int wk = 0, wc = 0, wt = 0, wg = 0;
+            // (transposed convolution: the item's parity selects its group of four tap matrices)
+            size_t wpar = DECONV ? (size_t)((first / a.nblk) % a.npar) * NTAP * tapB : 0;
             auto issue_W = [&]() {   // weight tile of the cursor's step into ring slot wg & 3, then advance
                 if (wk >= nit) return;
-                const char *base = a.w + (size_t)wt * tapB + (size_t)wc * 128;
+                const char *base = a.w + wpar + (size_t)wt * tapB + (size_t)wc * 128;
                 char *dst = smem + P_WOFF + (wg & (P_NSLOT - 1)) * P_WSLOT;
                 if (!DBG || !(a.dbg & 4)) {
 #pragma unroll
@@ -195,12 +205,13 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
                         __builtin_amdgcn_global_load_lds((p3_gl_void *)(base + wofs[p]), (p3_lds_void *)(dst + p * 1024), 16, 0, 0);
                 }
                 ++wg;
-                if (++wt == 9) {
+                if (++wt == NTAP) {
                     wt = 0;
                     if (++wc == a.nchunk) {
                         wc = 0;
                         ++wk;
                         if (wk < nit && a.nblk > 1) set_wofs((first + wk * nx) % a.nblk);
+                        if (DECONV && wk < nit) wpar = (size_t)(((first + wk * nx) / a.nblk) % a.npar) * NTAP * tapB;
                     }
                 }
             };
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
             for (int s = 0;; ++s) {
                 const bool last = (s >= S - 1);   // the stream ends: drain instead of counting
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
+                for (int t = 0; t < NTAP; ++t) {
                     const unsigned long long c0 = now();
                     if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
                 const bool last = (s >= S - 1);
                 const int nbuf = (s + 1) & 1;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
+                for (int t = 0; t < NTAP; ++t) {
                     const unsigned long long c0 = now();
                     if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned long long c1 = now();
@@ -285,12 +296,18 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
                     if (DBG) { pf_wait += c1 - c0; pf_bar += now() - c1; }
                     if (s == S) break;
                     if (!last) {
-                        if (t == 1) issue_H(P3_IC(0), P3_IC(4), nbuf);
-                        if (t == 2) issue_H(P3_IC(4), P3_IC(8), nbuf);
-                        if (t == 3) issue_H(P3_IC(8), P3_IC(12), nbuf);
-                        if (t == 4) issue_H(P3_IC(12), P3_IC(16), nbuf);
-                        if (t == 5) issue_H(P3_IC(16), P3_IC(20), nbuf);
-                        if (t == 6) issue_H(P3_IC(20), P3_IC(P_HP), nbuf);
+                        if constexpr (DECONV) {     // four steps per stage: the halo goes out behind steps 1 .. 3
+                            if (t == 1) issue_H(P3_IC(0), P3_IC(8), nbuf);
+                            if (t == 2) issue_H(P3_IC(8), P3_IC(16), nbuf);
+                            if (t == 3) issue_H(P3_IC(16), P3_IC(P_HP), nbuf);
+                        } else {
+                            if (t == 1) issue_H(P3_IC(0), P3_IC(4), nbuf);
+                            if (t == 2) issue_H(P3_IC(4), P3_IC(8), nbuf);
+                            if (t == 3) issue_H(P3_IC(8), P3_IC(12), nbuf);
+                            if (t == 4) issue_H(P3_IC(12), P3_IC(16), nbuf);
+                            if (t == 5) issue_H(P3_IC(16), P3_IC(20), nbuf);
+                            if (t == 6) issue_H(P3_IC(20), P3_IC(P_HP), nbuf);
+                        }
                     }
                 }
                 if (s == S) break;
@@ -590,27 +607,30 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
 
     auto lds128 = [&](int off) { return *reinterpret_cast<const p3_f16x8 *>(smem + off); };
 
-    // one (tap, chunk) step: 12 fragment reads, 12 MFMAs
+    // one (tap, chunk) step: 12 fragment reads, 12 MFMAs.  Tap t sits at (t / 3, t % 3) of the 3x3
+    // neighbourhood; in the parity form of the transposed convolution at (t / 2 + py, t % 2 + px)
+    int par_y = 0, par_x = 0;      // parity of the current item (DECONV)
     auto step = [&](auto T, int hb, int wb) {
         constexpr int t = decltype(T)::value;
-        constexpr int ky = t / 3, kx = t % 3;
-        constexpr int tapoff = (ky * P_HW + kx) * 128;
+        const int ky = DECONV ? t / 2 + par_y : t / 3, kx = DECONV ? t % 2 + par_x : t % 3;
+        const int tapoff = (ky * P_HW + kx) * 128;
         // quarter q: 0 = high k 0-15, 1 = high k 16-31, 2 = low k 0-15, 3 = low k 16-31
         if (DBG && (a.dbg & 2)) return;
         p3_f16x8 xf[4][2], wf[4];
         // the lane's row addresses pass through an opaque copy: otherwise the compiler keeps every
         // (tap, quarter, ring slot) address variant of the unrolled stage in its own register (~70)
-        int ax = arow + ((aswz >> (8 * kx)) & 0xff), bx = b0;
+        int ax = arow + ((aswz >> (8 * kx)) & 0xff) + (DECONV ? tapoff : 0), bx = b0;
         asm volatile("" : "+v"(ax), "+v"(bx));
+        const int tapimm = DECONV ? 0 : tapoff;   // (a compile-time immediate in the 9-tap form)
         constexpr int blk1 = 2 * P_HW * 128;   // block 1 of the wave: two tile rows below block 0
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             // (the operands of the first products first)
             wf[kh] = lds128(wb + (bx ^ (kh << 5)));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) xf[2 + kh][i] = lds128(hb + tapoff + i * blk1 + (ax ^ ((kh << 5) | 64)));
+            for (int i = 0; i < 2; ++i) xf[2 + kh][i] = lds128(hb + tapimm + i * blk1 + (ax ^ ((kh << 5) | 64)));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) xf[kh][i] = lds128(hb + tapoff + i * blk1 + (ax ^ (kh << 5)));
+            for (int i = 0; i < 2; ++i) xf[kh][i] = lds128(hb + tapimm + i * blk1 + (ax ^ (kh << 5)));
             wf[2 + kh] = lds128(wb + (bx ^ ((kh << 5) | 64)));
         }
         // every fragment read is issued before the first MFMA (cn_conv3x3.hip: a ds_read sunk behind
@@ -650,6 +670,8 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
         const int p = 64 * wm + 32 * i + 8 * k + rrow;
         const int oy = it.ty0 + (p >> 4), ox = it.tx0 + (p & 15);
         ok = oy < a.H && ox < a.W;
+        if constexpr (DECONV)     // output pixel (2 y + py, 2 x + px) of the (2 H, 2 W) map
+            return (it.b * 2 * a.H + 2 * oy + (it.par >> 1)) * 2 * a.W + 2 * ox + (it.par & 1);
         return (it.b * a.H + oy) * a.W + ox;
     };
     // raw buffer descriptor of the residual tensor (dword 3: 32-bit data format, gfx9 family)
@@ -745,6 +767,7 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
     };
 
     P3Item cur = p3_decode(a, first), prev = cur;
+    par_y = cur.par >> 1; par_x = cur.par & 1;
     int k = 0, c = 0, g = 0;
     unsigned long long pf_bar = 0, pf_epi = 0, pf_t0 = 0;
     auto now = [&]() { return DBG ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
@@ -787,6 +810,7 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
         bar(); step(P3_IC(2), hb, P_WOFF + ((g + 2) & 3) * P_WSLOT);
         if (c == 0) *reinterpret_cast<float *>(smem + P_SSOFF + wave * 256 + lane * 4) = ssv;
         bar(); step(P3_IC(3), hb, P_WOFF + ((g + 3) & 3) * P_WSLOT);
+        if constexpr (!DECONV) {
         bar(); step(P3_IC(4), hb, P_WOFF + ((g + 4) & 3) * P_WSLOT);
         bar(); step(P3_IC(5), hb, P_WOFF + ((g + 5) & 3) * P_WSLOT);
         // the item's residual rows: requested RES_AT steps before the end of its last stage (probe:
@@ -810,12 +834,14 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
         maybe_residual(1);
         bar(); step(P3_IC(8), hb, P_WOFF + ((g + 8) & 3) * P_WSLOT);
         maybe_residual(0);
-        g += 9;
+        }
+        g += NTAP;
         if (++c == a.nchunk) {
             c = 0;
             prev = cur;
             ++k;
             if (k < nit) cur = p3_decode(a, first + k * nx);
+            par_y = cur.par >> 1; par_x = cur.par & 1;
         }
     }
     if (DBG && a.prof && lane == 0) {
@@ -850,6 +876,57 @@ bool cn_conv3x3p_takes(int B, int H, int W, int Cin, int Cout, int in_pitch, int
     if ((long)B * H * W * (long)max(in_pitch, max(out_pitch, res_pitch)) * 4 >= (1L << 31)) return false;
     (void)Cin;
     return true;
+}
+
+// ConvTranspose2d(4, stride 2, pad 1) in parity form on the persistent kernel: f32s input, output as
+// whole 32-channel groups (f32s or plain), enough items to fill the chip
+bool cn_deconv4x4s2p_takes(int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch, bool in_plain)
+{
+    if (!cn_tune_c3p || !(cn_tune_c3p_deconv) || in_plain) return false;
+    if ((in_pitch & 31) || (out_pitch & 31) || (Cout % 32)) return false;
+    const long items = 4L * B * cn_cdiv(H, P_TH) * cn_cdiv(W, P_TW) * cn_cdiv(Cout, 64);
+    if (cn_tune_c3p < 2 && items < 256) return false;
+    if (4L * B * H * W * (long)max(in_pitch, out_pitch) * 4 >= (1L << 31)) return false;
+    (void)Cin;
+    return true;
+}
+
+int cn_deconv4x4s2_persist(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                           int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch, int relu,
+                           int out_plain, const cn_f32s_ctl *ctl, hipStream_t st)
+{
+    P3Args a = {};
+    a.x = (const char *)x; a.w = (const char *)w_packed; a.scale = scale; a.shift = shift;
+    a.y = (char *)y;
+    a.H = H; a.W = W;
+    a.in_pitchB = in_pitch * 4; a.out_pitchB = out_pitch * 4;
+    const int cin_pad = (Cin + 31) / 32 * 32;
+    a.cin_padB = cin_pad * 4;
+    a.cout_pad = (Cout + 31) / 32 * 32;
+    a.ngroups = a.cout_pad / 32;
+    a.nchunk = cin_pad / 32;
+    a.nblk = cn_cdiv(Cout, 64);
+    a.npar = 4;
+    a.tiles_x = cn_cdiv(W, P_TW);
+    a.tiles_y = cn_cdiv(H, P_TH);
+    a.items = B * a.tiles_y * a.tiles_x * a.npar * a.nblk;
+    a.relu = relu; a.out_plain = out_plain;
+    a.res_mul = 1.f;
+    a.range = ctl ? ctl->range : nullptr;
+    a.stagger = cn_tune_c3p_stagger;
+    a.knobs = cn_tune_c3p_knobs;
+    int per_xcd = cn_cdiv(a.items, 8);
+    if (per_xcd > 64) per_xcd = 64;
+    const dim3 grid(8 * per_xcd), block(384);
+    if (out_plain) {
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, true, false, false, 4>), P_LDS);
+        hipLaunchKernelGGL((conv3x3p_kernel<0, true, false, false, 4>), grid, block, P_LDS, st, a, P3Heads{});
+    } else {
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, false, false, 4>), P_LDS);
+        hipLaunchKernelGGL((conv3x3p_kernel<0, false, false, false, 4>), grid, block, P_LDS, st, a, P3Heads{});
+    }
+    CN_CHECK_LAUNCH();
+    return CN_OK;
 }
 
 static int p3_probe_dbg = 0;
@@ -899,6 +976,7 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
     a.ngroups = a.cout_pad / 32;
     a.nchunk = cin_pad / 32;
     a.nblk = cn_cdiv(Cout, 64);
+    a.npar = 1;
     a.tiles_x = cn_cdiv(W, P_TW);
     a.tiles_y = cn_cdiv(H, P_TH);
     a.items = B * a.tiles_y * a.tiles_x * a.nblk;
@@ -976,6 +1054,7 @@ int cn_heads3x3p(const void *x, int B, int H, int W, int Cin, int in_pitch, cons
     a.ngroups = a.cout_pad / 32;
     a.nchunk = cin_pad / 32;
     a.nblk = n_heads;
+    a.npar = 1;
     a.tiles_x = cn_cdiv(W, P_TW);
     a.tiles_y = cn_cdiv(H, P_TH);
     a.items = B * a.tiles_y * a.tiles_x * a.nblk;

@@ -223,15 +223,8 @@ constexpr int GATE_CAP = 4096;  // = GCAP below: candidate keys per image of the
 __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ heat, int C, int H,
                                                       int W, int K, int R, int apply_sigmoid,
                                                       float *__restrict__ cand_score,
-                                                      int32_t *__restrict__ cand_idx,
-                                                      const int32_t *__restrict__ gate)
+                                                      int32_t *__restrict__ cand_idx)
 {
-    // gate (image-level mode): this per-band select only runs for the images whose candidate
-    // list was unusable (counts outside [K, GCAP]: plateaus of equal scores, degenerate maps)
-    if (gate) {
-        const int cnt = gate[blockIdx.z];
-        if (cnt >= K && cnt <= GATE_CAP) return;
-    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SelShared &sh = *reinterpret_cast<SelShared *>(smem);
     float *tile = reinterpret_cast<float *>(smem + sizeof(SelShared));
@@ -428,26 +421,28 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------------------
 // Image-level top-K without a per-band select (ctdet / _topk: the K best peaks of ALL classes of
 // an image, decode.py:103-119).  Only ~K of the C*H*W cells matter, so the exact select runs on
-// a threshold-pruned candidate list instead of in every (class, band):
-//   phase 1  group_max_kernel: ONE streaming pass over the raw map (logits when the sigmoid is
-//            fused: the logistic is monotone, no transcendental per cell).  A GROUP is the set of
-//            cells a workgroup covers in one sweep of its 256 threads; per group it records the
-//            largest raw value of all cells and the largest raw value among the cells that pass
-//            the 3x3 peak test on RAW values (a raw peak is also a peak of the sigmoid values).
-//   phase 2  group_threshold_kernel: T_b = K-th largest group peak-maximum of image b (as a
-//            score).  At least K distinct peaks reach T_b, so every cell of the exact top-K has
-//            a peak value >= T_b -- ties at T_b included -- and nothing below can be in it.
-//   phase 3  peak_collect_kernel: only the groups whose all-cell maximum reaches T_b are
-//            looked at again (~10 % of them, L2 / Infinity-Cache resident); their cells above a
-//            conservative raw threshold get the EXACT treatment -- sigmoid, 3x3 equality test
-//            on sigmoid values (decode.py:9-15) -- and are appended to the image's candidate
-//            list as 64-bit keys (score, ~flat index).
-//   phase 4  merge_topk_kernel<MODE, true>: exact radix select + sort of the few hundred
-//            candidates, gather, box assembly.
+// a threshold-pruned candidate list instead of in every (class, band) -- in TWO launches:
+//   launch 1  group_max_kernel: ONE streaming pass over the raw map (logits when the sigmoid is
+//             fused: the logistic is monotone, no transcendental per cell).  A GROUP is 8 rows x 128
+//             columns of a plane; per group it records the largest raw value of all cells and the
+//             largest raw value among the cells that pass the 3x3 peak test on RAW values (a raw
+//             peak is also a peak of the sigmoid values).
+//   launch 2  collect_merge_kernel, one workgroup per plane:
+//             image_threshold: T_b = K-th largest group peak-maximum of image b (as a score),
+//               computed by every plane of the image from the same ~1 k keys (cheaper than a launch
+//               boundary, and no workgroup ever waits for another).  At least K distinct peaks reach
+//               T_b, so every cell of the exact top-K has a peak value >= T_b -- ties at T_b
+//               included -- and nothing below can be in it.
+//             plane_collect: only the groups whose all-cell maximum reaches T_b are looked at again
+//               (L2 / Infinity-Cache resident); their cells get the EXACT treatment -- sigmoid, 3x3
+//               equality test on sigmoid values (decode.py:9-15) -- and are appended to the image's
+//               candidate list as 64-bit keys (score, ~flat index).
+//             the image's LAST plane to arrive (one atomic counter per image): exact radix select +
+//               sort of the few hundred candidates, gather, box assembly.
 // Images whose list is unusable (T_b <= 0: fewer than K groups with a positive peak; constant
-// maps; plateaus of more than GCAP cells tying T_b) are served by the per-(class, band) select
-// of nms_topk_kernel, launched behind phase 4 and gated on the image's count: its workgroups
-// exit at once for every image the list did serve, so every input is handled exactly.
+// maps; plateaus of more than GCAP cells tying T_b) are handled by that last workgroup as well, from
+// an exact scan of every cell of the image: every input is handled exactly, in the same two
+// launches.
 // ---------------------------------------------------------------------------
 constexpr int GCAP = GATE_CAP;  // candidate keys per image
 
@@ -555,19 +550,85 @@ __global__ __launch_bounds__(NT) void group_max_kernel(const float *__restrict__
 // image: fewer than K groups with a peak, or a non-positive threshold -- zeros of suppressed cells
 // would take part) and a conservative lower bound, in raw units, of every cell whose score can
 // reach it.
+// the `need`-th largest of the 32-bit keys `for_each(f)` enumerates (f(key32)), exactly: three
+// digit passes (11, 11, 10 bits, msb first) over a histogram in LDS, no early exit, no sort
+template <int TB, class ForEach>
+__device__ __forceinline__ uint32_t kth_largest_key32(ForEach &&for_each, uint32_t need, SelShared &sh)
+{
+    constexpr int BPT = HBINS / TB;
+    const int tid = threadIdx.x;
+    const int lane = tid & (CN_WAVE - 1), wave = tid / CN_WAVE;
+    uint32_t prefix = 0, mask = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 21 : pass == 1 ? 10 : 0;
+        const uint32_t dmask = pass == 2 ? 1023u : 2047u;
+        for (int i = tid; i < HBINS; i += TB) sh.hist[i] = 0;
+        __syncthreads();
+        for_each([&](uint32_t k) {
+            if ((k & mask) == prefix) atomicAdd(&sh.hist[(k >> shift) & dmask], 1u);
+        });
+        __syncthreads();
+        uint32_t p = 0;
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) p += sh.hist[tid * BPT + j];
+        uint32_t s = p;
+#pragma unroll
+        for (int o = 1; o < CN_WAVE; o <<= 1) {
+            const uint32_t t = __shfl_down(s, o);
+            if (lane + o < CN_WAVE) s += t;
+        }
+        if (lane == 0) sh.wsum[wave] = s;
+        __syncthreads();
+        for (int w = wave + 1; w < TB / CN_WAVE; ++w) s += sh.wsum[w];
+        const uint32_t above = s - p;  // keys in strictly higher bins
+        if (above < need && s >= need) {
+            uint32_t run = above;
+            for (int j = BPT - 1; j >= 0; --j) {
+                const uint32_t h = sh.hist[tid * BPT + j];
+                if (run + h >= need) {
+                    sh.digit = tid * BPT + j;
+                    sh.need = need - run;
+                    break;
+                }
+                run += h;
+            }
+        }
+        __syncthreads();
+        prefix |= sh.digit << shift;
+        mask |= dmask << shift;
+        need = sh.need;
+        __syncthreads();       // (sh.digit / sh.need are rewritten by the next pass)
+    }
+    return prefix;
+}
+
 __device__ __forceinline__ uint32_t image_threshold(const uint32_t *__restrict__ g, int ng, int K, int flags,
                                                     SelShared &sh, float &rawthr)
 {
     const int tid = threadIdx.x;
     rawthr = 0.f;
     if (ng < K) return 0u;
-    auto for_each = [&](auto &&f) {
-        for (int j = tid; j < ng; j += NT) f(((u64)g[j] << 32) | (u64)(0xFFFFFFFFu - (uint32_t)j), false);
-    };
-    u64 prefix, mask;
-    radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
-    collect_and_sort<NT>(for_each, prefix, mask, sh);
-    const uint32_t kraw = (uint32_t)(sh.sel[K - 1] >> 32);    // (collect_and_sort ends with a barrier)
+    // the image's group maxima: fetched ONCE into registers (a select pass over global memory is a
+    // load round trip per pass: ~10 us per workgroup, and every plane's workgroup does this)
+    constexpr int RK = 8;
+    uint32_t kraw;
+    if (ng <= RK * NT) {
+        uint32_t kr[RK];
+#pragma unroll
+        for (int u = 0; u < RK; ++u) kr[u] = (tid + u * NT < ng) ? g[tid + u * NT] : 0u;
+        auto for_each = [&](auto &&f) {
+#pragma unroll
+            for (int u = 0; u < RK; ++u)
+                if (tid + u * NT < ng) f(kr[u]);
+        };
+        kraw = kth_largest_key32<NT>(for_each, (uint32_t)K, sh);
+    } else {
+        auto for_each = [&](auto &&f) {
+            for (int j = tid; j < ng; j += NT) f(g[j]);
+        };
+        kraw = kth_largest_key32<NT>(for_each, (uint32_t)K, sh);
+    }
     if (kraw == 0u) return 0u;    // fewer than K groups hold a peak at all
     const float raw = key2f(kraw);
     const bool sig = (flags & 1) != 0;
@@ -685,8 +746,11 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
             for (int e = 0; e < 4; ++e) {
                 if (tmask & (1u << ((r - 1) * 4 + e))) {
                     const uint32_t cell = (uint32_t)(y * W + x4 * 4 + e);
+                    // (device-scope store: read by the image's last workgroup, possibly on another XCD,
+                    // without any cache maintenance in between -- see collect_merge_kernel)
                     if (pos < GCAP)
-                        kimg[pos] = ((u64)cell_key(r, e) << 32) | (u64)(0xFFFFFFFFu - (base + cell));
+                        __hip_atomic_store(kimg + pos, ((u64)cell_key(r, e) << 32) | (u64)(0xFFFFFFFFu - (base + cell)),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ++pos;
                 }
             }
@@ -729,13 +793,6 @@ enum { MODE_CTDET = 0, MODE_CHANNEL = 1, MODE_POSE = 2, MODE_TOPK = 3 };
 
 constexpr int NTM = 1024;  // the merge runs one workgroup per image: make it a big one
 
-// image-level candidate keys (phase 3 above) and what the exact full-scan path needs
-struct KeySrc {
-    const u64 *keys;          // [B][GCAP]
-    const int32_t *counts;    // [B]; outside [K, GCAP]: the gated per-band select serves the image
-    const float *heat;        // (B, C, H, W) as passed to the decode
-    int flags;                // bit 0 sigmoid, CN_DECODE_NO_PEAK_TEST
-};
 
 // rows 0 .. K-1 of the sorted selection sh.sel -> outputs of group g (see merge_topk_kernel)
 template <int MODE>
@@ -799,16 +856,15 @@ __device__ __forceinline__ void emit_rows(const SelShared &sh, int g, int H, int
     }
 }
 
-template <int MODE, bool KEYS = false>
+template <int MODE>
 __global__ __launch_bounds__(NTM) void merge_topk_kernel(
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int N,
     int per_class, int H, int W, int K, int C, const float *__restrict__ wh,
     const float *__restrict__ reg, int cat_spec_wh, float *__restrict__ dets, int det_dim,
     int32_t *__restrict__ inds_out, float *__restrict__ out_scores,
-    const float *__restrict__ kps_map, int J, int32_t *__restrict__ cls_out, const KeySrc ks)
+    const float *__restrict__ kps_map, int J, int32_t *__restrict__ cls_out)
 {
     constexpr bool CTDET = (MODE != MODE_CHANNEL);  // group = image, class from position
-    static_assert(!KEYS || CTDET, "candidate keys are image-level");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SelShared &sh = *reinterpret_cast<SelShared *>(smem);
     const int tid = threadIdx.x;
@@ -818,37 +874,130 @@ __global__ __launch_bounds__(NTM) void merge_topk_kernel(
     const int32_t *ci = cand_idx + (size_t)g * N;
 
     u64 prefix, mask;
-    if constexpr (KEYS) {
-        // usable candidate list: between K and GCAP keys; otherwise the gated per-band select
-        // (launched right behind this kernel) produces this image
-        const int cnt = ks.counts[g];
-        if (cnt < K || cnt > GCAP) return;
-        const u64 *kg = ks.keys + (size_t)g * GCAP;
-        auto for_each = [&](auto &&f) {
-            for (int j = tid; j < cnt; j += NTM) f(kg[j], false);
-        };
-        radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
-        collect_and_sort<NTM>(for_each, prefix, mask, sh);
-    } else {
-        if (CTDET && ks.counts) {   // gated: only the images the candidate list could not serve
-            const int cnt = ks.counts[g];
-            if (cnt >= K && cnt <= GCAP) return;
+    auto for_each = [&](auto &&f) {
+        for (int j = tid; j < N; j += NTM) {
+            const int32_t idx = ci[j];
+            if (idx < 0) continue;
+            const uint32_t kk = f2key(cs[j] + 0.0f);
+            const uint32_t fid = CTDET ? (uint32_t)((j / per_class) * HW + idx) : (uint32_t)idx;
+            f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - fid), kk == KEY_ZERO);
         }
-        auto for_each = [&](auto &&f) {
-            for (int j = tid; j < N; j += NTM) {
-                const int32_t idx = ci[j];
-                if (idx < 0) continue;
-                const uint32_t kk = f2key(cs[j] + 0.0f);
-                const uint32_t fid = CTDET ? (uint32_t)((j / per_class) * HW + idx) : (uint32_t)idx;
-                f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - fid), kk == KEY_ZERO);
-            }
-        };
-        radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
-        collect_and_sort<NTM>(for_each, prefix, mask, sh);
-    }
-
+    };
+    radix_select<NTM>(for_each, (uint32_t)K, sh, prefix, mask);
+    collect_and_sort<NTM>(for_each, prefix, mask, sh);
     emit_rows<MODE>(sh, g, H, W, K, C, wh, reg, cat_spec_wh, dets, det_dim, inds_out, out_scores, kps_map, J,
                     cls_out);
+}
+
+// ---------------------------------------------------------------------------
+// Second (and last) launch of the image-level decode: one workgroup per (image, class) plane
+//   1. image_threshold  -- every plane of an image derives the same threshold from the group maxima
+//                          of launch 1 (no wait between workgroups);
+//   2. plane_collect    -- the plane's candidate keys;
+//   3. the LAST plane of an image to arrive (one atomic counter per image; nobody waits for anybody)
+//      selects and sorts the image's K best candidates and writes its detections.
+// Degenerate images (threshold <= 0: fewer than K groups with a positive peak; constant maps;
+// plateaus of more than GCAP cells tying the threshold) are served by the last arriver too, from an
+// exact scan of every cell of the image (sigmoid -> 3x3 equality test -> heat * keep, zeros of
+// suppressed cells included: decode.py:9-15,103-119) -- slow (milliseconds per such image), rare,
+// and bit-identical to the per-(class, band) select.
+// ---------------------------------------------------------------------------
+struct EmitArgs {
+    const float *wh, *reg;
+    int cat_spec_wh;
+    float *dets;
+    int det_dim;
+    int32_t *inds_out;
+    float *out_scores;
+    int32_t *cls_out;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(NT) void collect_merge_kernel(const float *__restrict__ heat, int C, int H,
+                                                           int W, int nrg, int ncb, int flags, int K,
+                                                           const uint32_t *__restrict__ gpeak,
+                                                           const uint32_t *__restrict__ gall,
+                                                           u64 *__restrict__ keys,
+                                                           int32_t *__restrict__ counts,
+                                                           int32_t *__restrict__ done, const EmitArgs ea)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SelShared &sh = *reinterpret_cast<SelShared *>(smem);
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    const int b = (int)(blockIdx.x / (unsigned)C);
+    const int ng = C * nrg * ncb;
+    float rthr;
+    const uint32_t tkey = image_threshold(gpeak + (size_t)b * ng, ng, K, flags, sh, rthr);
+    const bool degenerate = tkey <= KEY_ZERO;      // uniform over the image's workgroups
+    if (!degenerate) plane_collect(heat, C, H, W, nrg, ncb, flags, gall, tkey, rthr, keys, counts);
+    // ---- arrival.  What the image's last workgroup reads from the others -- candidate keys and their
+    // count -- is written with device-scope atomics (write-through to the coherence point) and read
+    // with device-scope loads: no __threadfence() on either side (on this part a device-scope release /
+    // acquire is a write-back / invalidate of the whole L2 of the XCD; 2560 workgroups doing that cost
+    // 0.18 ms).  Order: every wave waits for the acknowledgement of its stores, the workgroup
+    // meets, then ONE thread bumps the image's counter.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        s_last = (__hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == C - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    const int cnt = degenerate ? GCAP + 1
+                               : __hip_atomic_load(&counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 prefix, mask;
+    if (cnt >= K && cnt <= GCAP) {
+        // the candidate keys: fetched once into registers (GCAP / NT = 16 per thread), device-scope loads
+        const u64 *kg = keys + (size_t)b * GCAP;
+        constexpr int RK = GCAP / NT;
+        u64 kr[RK];
+#pragma unroll
+        for (int u = 0; u < RK; ++u)
+            kr[u] = (tid + u * NT < cnt) ? __hip_atomic_load(kg + tid + u * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : 0ull;
+        auto for_each = [&](auto &&f) {
+#pragma unroll
+            for (int u = 0; u < RK; ++u)
+                if (tid + u * NT < cnt) f(kr[u], false);
+        };
+        radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
+        collect_and_sort<NT>(for_each, prefix, mask, sh);
+    } else {
+        const bool sig = (flags & 1) != 0;
+        const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;
+        const int HW = H * W;
+        const float *img = heat + (size_t)b * C * HW;
+        auto for_each = [&](auto &&f) {
+            for (int e = tid; e < C * HW; e += NT) {
+                const int c = e / HW, r = e - c * HW;
+                const int y = r / W, x = r - y * W;
+                const float *pl = img + (size_t)c * HW;
+                auto sc = [&](int yy, int xx) {
+                    const float v = pl[yy * W + xx];
+                    return sig ? sigmoidf_ref(v) : v;
+                };
+                const float v = sc(y, x);
+                float m = v;
+                if (!nonms) {
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        const int yy = y + dy;
+                        if (yy < 0 || yy >= H) continue;
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int xx = x + dx;
+                            if (xx < 0 || xx >= W || (dy == 0 && dx == 0)) continue;
+                            m = fmaxf(m, sc(yy, xx));
+                        }
+                    }
+                }
+                const uint32_t kk = f2key(((m == v) ? v : 0.0f) + 0.0f);   // heat * keep, -0.0 -> +0.0
+                f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - (uint32_t)e), kk == KEY_ZERO);
+            }
+        };
+        radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
+        collect_and_sort<NT>(for_each, prefix, mask, sh);
+    }
+    emit_rows<MODE>(sh, b, H, W, K, C, ea.wh, ea.reg, ea.cat_spec_wh, ea.dets, ea.det_dim, ea.inds_out,
+                    ea.out_scores, (const float *)nullptr, 0, ea.cls_out);
 }
 
 struct BandPlan {
@@ -876,13 +1025,12 @@ bool make_band_plan(int B, int C, int H, int W, int K, BandPlan *bp)
 }
 
 int launch_nms_topk(const float *heat, int B, int C, int H, int W, int K, int apply_sigmoid,
-                    const BandPlan &bp, float *cand_score, int32_t *cand_idx, hipStream_t st,
-                    const int32_t *gate = nullptr)
+                    const BandPlan &bp, float *cand_score, int32_t *cand_idx, hipStream_t st)
 {
     dim3 grid(bp.nbands, C, B), block(NT);
     CN_SET_MAX_LDS_ONCE(nms_topk_kernel, 160 * 1024);
     hipLaunchKernelGGL(nms_topk_kernel, grid, block, bp.lds, st, heat, C, H, W, K, bp.R,
-                       apply_sigmoid, cand_score, cand_idx, gate);
+                       apply_sigmoid, cand_score, cand_idx);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -896,7 +1044,7 @@ namespace {
 struct ImgPlan {
     bool use;
     int nrg, ncb;                  // 8-row groups per plane, 128-column blocks per row
-    size_t gpeak, gall, thr, rawthr, counts, keys, total;   // byte offsets in the workspace
+    size_t gpeak, gall, counts, done, keys, total;   // byte offsets in the workspace
 };
 ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
 {
@@ -910,34 +1058,29 @@ ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
     const size_t ng = (size_t)B * C * p.nrg * p.ncb;
     p.gpeak = o;  o += cn_align_up(ng * 4, 256);
     p.gall = o;   o += cn_align_up(ng * 4, 256);
-    p.thr = o;    o += cn_align_up((size_t)B * 4, 256);
-    p.rawthr = o; o += cn_align_up((size_t)B * 4, 256);
     p.counts = o; o += cn_align_up((size_t)B * 4, 256);
+    p.done = o;   o += cn_align_up((size_t)B * 4, 256);
     p.keys = o;   o += cn_align_up((size_t)B * GCAP * 8, 256);
     p.total = o;
     return p;
 }
 
-// phases 1-3 (the merge launch follows in the caller: its epilogue differs per entry point)
-int launch_image_candidates(const float *heat, int B, int C, int H, int W, int K, int flags,
-                            const BandPlan &bp, const ImgPlan &ip, char *ws, hipStream_t st)
+// the image-level decode: TWO launches (group maxima; threshold + candidates + select + outputs)
+template <int MODE>
+int launch_image_topk(const float *heat, int B, int C, int H, int W, int K, int flags, const ImgPlan &ip,
+                      char *ws, const EmitArgs &ea, hipStream_t st)
 {
-    (void)bp;
     uint32_t *gpeak = (uint32_t *)(ws + ip.gpeak);
     uint32_t *gall = (uint32_t *)(ws + ip.gall);
-    uint32_t *thr = (uint32_t *)(ws + ip.thr);
-    float *rawthr = (float *)(ws + ip.rawthr);
     int32_t *counts = (int32_t *)(ws + ip.counts);
+    int32_t *done = (int32_t *)(ws + ip.done);
     u64 *keys = (u64 *)(ws + ip.keys);
     dim3 grid((unsigned)(B * C)), block(NT);
     hipLaunchKernelGGL(group_max_kernel, grid, block, 0, st, heat, H, W, ip.nrg, ip.ncb, flags, gpeak,
-                       gall);
+                       gall, C, counts, done);
     CN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(group_threshold_kernel, dim3(B), dim3(NT), 0, st, gpeak, C * ip.nrg * ip.ncb, K,
-                       flags, thr, rawthr, counts);
-    CN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(peak_collect_kernel, grid, block, 0, st, heat, C, H, W, ip.nrg, ip.ncb, flags,
-                       gall, thr, rawthr, keys, counts);
+    hipLaunchKernelGGL(collect_merge_kernel<MODE>, grid, block, sizeof(SelShared), st, heat, C, H, W,
+                       ip.nrg, ip.ncb, flags, K, gpeak, gall, keys, counts, done, ea);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -979,32 +1122,15 @@ extern "C" int cn_ctdet_decode_f32(const float *heat, const float *wh, const flo
     int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
     const ImgPlan ip = make_img_plan(B, C, H, W, K, bp);
     if (ip.use && !(apply_sigmoid & 2048)) {   // bit 11: force the per-band select (tests / A-B)
-        char *ws = (char *)workspace;
-        rc = launch_image_candidates(heat, B, C, H, W, K, apply_sigmoid, bp, ip, ws, st);
-        if (rc != CN_OK) return rc;
-        const KeySrc ks = {(const u64 *)(ws + ip.keys), (const int32_t *)(ws + ip.counts), heat,
-                           apply_sigmoid};
-        hipLaunchKernelGGL((merge_topk_kernel<MODE_CTDET, true>), dim3(B), dim3(NTM),
-                           sizeof(SelShared), st, cand_score, cand_idx, 0, 1, H, W, K, C, wh, reg,
-                           cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr, 0,
-                           (int32_t *)nullptr, ks);
-        CN_CHECK_LAUNCH();
-        // images whose candidate list was unusable (every workgroup of the others exits at once)
-        rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st, ks.counts);
-        if (rc != CN_OK) return rc;
-        hipLaunchKernelGGL(merge_topk_kernel<MODE_CTDET>, dim3(B), dim3(NTM), sizeof(SelShared), st,
-                           cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh,
-                           reg, cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr,
-                           0, (int32_t *)nullptr, ks);
-        CN_CHECK_LAUNCH();
-        return CN_OK;
+        const EmitArgs ea = {wh, reg, cat_spec_wh, dets, 6, inds, nullptr, nullptr};
+        return launch_image_topk<MODE_CTDET>(heat, B, C, H, W, K, apply_sigmoid, ip, (char *)workspace, ea, st);
     }
     rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
     if (rc != CN_OK) return rc;
     hipLaunchKernelGGL(merge_topk_kernel<MODE_CTDET>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg,
                        cat_spec_wh, dets, 6, inds, (float *)nullptr, (const float *)nullptr, 0,
-                       (int32_t *)nullptr, KeySrc{});
+                       (int32_t *)nullptr);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -1033,7 +1159,7 @@ extern "C" int cn_nms_topk_channel_f32(const float *heat, int B, int C, int H, i
     hipLaunchKernelGGL(merge_topk_kernel<MODE_CHANNEL>, dim3(B * C), dim3(NTM), sizeof(SelShared),
                        st, cand_score, cand_idx, bp.nbands * K, bp.nbands * K, H, W, K, C,
                        (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0, inds,
-                       scores, (const float *)nullptr, 0, (int32_t *)nullptr, KeySrc{});
+                       scores, (const float *)nullptr, 0, (int32_t *)nullptr);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -1163,8 +1289,7 @@ extern "C" int cn_multi_pose_decode_f32(const float *heat, const float *wh, cons
     if (rc != CN_OK) return rc;
     hipLaunchKernelGGL(merge_topk_kernel<MODE_POSE>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_s, cand_i, C * bp.nbands * K, bp.nbands * K, H, W, K, C, wh, reg, 0,
-                       dets, D, (int32_t *)nullptr, (float *)nullptr, kps, J, (int32_t *)nullptr,
-                       KeySrc{});
+                       dets, D, (int32_t *)nullptr, (float *)nullptr, kps, J, (int32_t *)nullptr);
     CN_CHECK_LAUNCH();
     if (!hm_hp) return CN_OK;
     // stage B: per-joint top-K of the keypoint heat-map
@@ -1178,7 +1303,7 @@ extern "C" int cn_multi_pose_decode_f32(const float *heat, const float *wh, cons
                            sizeof(SelShared), st, cand_s, cand_i, bph.nbands * K, bph.nbands * K, H,
                            W, K, J, (const float *)nullptr, (const float *)nullptr, 0,
                            (float *)nullptr, 0, hp_i, hp_s, (const float *)nullptr, 0,
-                           (int32_t *)nullptr, KeySrc{});
+                           (int32_t *)nullptr);
         CN_CHECK_LAUNCH();
     }
     // stage C
@@ -1263,31 +1388,15 @@ extern "C" int cn_topk_f32(const float *heat, int B, int C, int H, int W, int K,
     int32_t *cand_idx = (int32_t *)((char *)workspace + cn_align_up(n * sizeof(float), 256));
     const ImgPlan ip = make_img_plan(B, C, H, W, K, bp);
     if (ip.use && !(apply_sigmoid & 2048)) {
-        char *ws = (char *)workspace;
-        rc = launch_image_candidates(heat, B, C, H, W, K, apply_sigmoid, bp, ip, ws, st);
-        if (rc != CN_OK) return rc;
-        const KeySrc ks = {(const u64 *)(ws + ip.keys), (const int32_t *)(ws + ip.counts), heat,
-                           apply_sigmoid};
-        hipLaunchKernelGGL((merge_topk_kernel<MODE_TOPK, true>), dim3(B), dim3(NTM),
-                           sizeof(SelShared), st, cand_score, cand_idx, 0, 1, H, W, K, C,
-                           (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0,
-                           inds, scores, (const float *)nullptr, 0, clses, ks);
-        CN_CHECK_LAUNCH();
-        rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st, ks.counts);
-        if (rc != CN_OK) return rc;
-        hipLaunchKernelGGL(merge_topk_kernel<MODE_TOPK>, dim3(B), dim3(NTM), sizeof(SelShared), st,
-                           cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C,
-                           (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0,
-                           inds, scores, (const float *)nullptr, 0, clses, ks);
-        CN_CHECK_LAUNCH();
-        return CN_OK;
+        const EmitArgs ea = {nullptr, nullptr, 0, nullptr, 0, inds, scores, clses};
+        return launch_image_topk<MODE_TOPK>(heat, B, C, H, W, K, apply_sigmoid, ip, (char *)workspace, ea, st);
     }
     rc = launch_nms_topk(heat, B, C, H, W, K, apply_sigmoid, bp, cand_score, cand_idx, st);
     if (rc != CN_OK) return rc;
     hipLaunchKernelGGL(merge_topk_kernel<MODE_TOPK>, dim3(B), dim3(NTM), sizeof(SelShared), st,
                        cand_score, cand_idx, C * bp.nbands * K, bp.nbands * K, H, W, K, C,
                        (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, 0, inds,
-                       scores, (const float *)nullptr, 0, clses, KeySrc{});
+                       scores, (const float *)nullptr, 0, clses);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -299,6 +299,49 @@ def _deconv_case(dev, cfg, split=False):
         _check(y.t[..., :Cout].permute(0, 3, 1, 2).cpu(), ref)
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 64), (1, 256, 16, 16, 256), (1, 128, 9, 7, 64),
+                                 (2, 128, 37, 45, 96), (1, 96, 8, 40, 32), (32, 128, 64, 64, 64)])
+def test_conv_transpose_4x4_s2_on_the_persistent_kernel(dev, cfg):
+    """ConvTranspose2d(4, 2, 1) in parity form on the persistent loader / consumer kernel
+    (cn_conv3x3p.hip, NTAP = 4: item = (tile, parity, output block), four taps per stage): f32s input,
+    f32s and plain output, edge tiles, a half-empty output block (96 channels), Cin = 96 -- against
+    torch.conv_transpose2d on the CPU and the one-tile-per-workgroup kernel (key 32 = 0); run-to-run
+    bit equality.  key 28 = 2 forces the kernel onto shapes with few items; the last case is
+    resdcn_18's second up-sampling layer at the benchmark batch, on the library's own routing."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder
+    lib = native.lib()
+    B, Cin, H, W, Cout = cfg
+    nref = min(B, 2)
+    x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1)).relu_()
+    w = torch.from_numpy(synth.normal((Cin, Cout, 4, 4), (2.0 / (Cin * 4)) ** 0.5, 2))
+    bn = _bn(Cout, 3)
+    ref = F.relu(bn(F.conv_transpose2d(x[:nref], w, None, 2, 1, 0))).detach()
+    assert lib.cn_set_tuning(28, 2 if B < 32 else 1) == 0
+    try:
+        for out_plain in (False, True):
+            got = {}
+            for key32 in (1, 0):
+                assert lib.cn_set_tuning(32, key32) == 0
+                pb = PlanBuilder(dev, B, H, W, split=True)
+                y = pb.conv_transpose4x4s2(pb.packed(_nhwc_act(x, dev)), w, bn=bn, relu=True, out_plain=out_plain)
+                assert y.fmt == ("f32" if out_plain else "f32s")
+                _run(pb)
+                got[key32] = y.to_float().clone()
+                if key32 == 1:
+                    raw = y.t.clone()
+                    _run(pb)
+                    assert torch.equal(raw, y.t), "not deterministic run to run"
+                    if not out_plain and Cout % 32 == 0 and y.pitch > Cout:
+                        assert float(y.t[..., Cout:].abs().max()) == 0.0
+            _check(got[1][:nref].permute(0, 3, 1, 2).cpu(), ref)
+            d = float((got[1] - got[0]).abs().max()) / max(1.0, float(got[0].abs().max()))
+            assert d < 2e-5, d
+    finally:
+        lib.cn_set_tuning(28, 1)
+        lib.cn_set_tuning(32, 1)
+
+
 def test_heads_fused_nchw_outputs(dev):
     from centernet_amd.engine import PlanBuilder
     B, F_, H, W = 2, 64, 32, 32

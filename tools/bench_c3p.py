@@ -158,21 +158,25 @@ print("== timing, B = 32 (ms per launch, effective TFLOP/s)")
 SHAPES = [(64, 128, 128, 64), (128, 64, 64, 128), (256, 32, 32, 256), (512, 16, 16, 512)]
 stags = [int(v) for v in os.environ.get("STAG", "64").split(",")]
 knobs = [int(v) for v in os.environ.get("KNOBS", "0").split(",")]
+ROUNDS = int(os.environ.get("ROUNDS", "5"))
 for (ci, H, W, co) in SHAPES:
     for res in (0, 1):
         c = Case(32, ci, H, W, co, res=res)
         fl = 2.0 * 32 * H * W * co * ci * 9
-        row = []
-        lib.cn_set_tuning(28, 0)
-        ms = c.time()
-        row.append("halo %.4f ms %6.1f TF" % (ms, fl / ms / 1e9))
-        for sg in stags:
-            for kn in knobs:
-                lib.cn_set_tuning(28, 1)
+        # configurations are timed in interleaved rounds and reported by their median: the clock the part
+        # holds drifts by several per cent over a second, so back-to-back blocks favour whoever runs last
+        cfgs = [("halo", 0, 64, 0)] + [("persist(stag %d knobs %d)" % (sg, kn), 1, sg, kn) for sg in stags for kn in knobs]
+        times = {name: [] for name, *_ in cfgs}
+        for _ in range(ROUNDS):
+            for name, k28, sg, kn in cfgs:
+                lib.cn_set_tuning(28, k28)
                 lib.cn_set_tuning(29, sg)
                 lib.cn_set_tuning(30, kn)
-                ms = c.time()
-                row.append("persist(stag %d knobs %d) %.4f ms %6.1f TF" % (sg, kn, ms, fl / ms / 1e9))
+                times[name].append(c.time(10))
+        row = []
+        for name, *_ in cfgs:
+            ms = sorted(times[name])[len(times[name]) // 2]
+            row.append("%s %.4f ms %6.1f TF" % (name, ms, fl / ms / 1e9))
         print("%-22s res %d | %s" % (str((ci, H, W, co)), res, " | ".join(row)))
         del c
 lib.cn_set_tuning(28, 1)
