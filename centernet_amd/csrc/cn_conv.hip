@@ -928,6 +928,10 @@ int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, 
                        int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
                        float x_mul, uint32_t *range, int min_wgs, int variant, int dbg, float *partial,
                        size_t partial_bytes, int *ksplit_out, hipStream_t st);
+bool cn_conv3x3s2p_takes(int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch);
+int cn_conv3x3s2_persist(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                         int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch, int relu,
+                         int out_plain, const cn_f32s_ctl *ctl, hipStream_t st);
 int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
                  int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
@@ -1311,6 +1315,14 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
                             g_tune_setprio | ((g_tune_bm256 & 1) << 1) | ((g_tune_bm256 >> 1) << 3) | (g_tune_waves8 << 2) | (g_tune_occ4 << 7) |
                                 ((g_tune_dbgskip & 7) << 4) | ((g_tune_dbgskip >> 3) << 9), cls, d->dtype | (d->flags << 8),
                             &d->ctl, st);
+    // 3x3 / stride 2 / pad 1, f32s tensors on both sides: the persistent kernel's parity-plane form
+    if (!g_tune_nohalo && f32s && !(d->flags & (CN_CONV_X_PLAIN | CN_CONV_R_PLAIN)) && !residual && scale &&
+        a.vec_out && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad_h == 1 && d->pad_w == 1 && d->dil == 1 &&
+        d->oy_mul == 1 && d->ox_mul == 1 && d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho && d->OW == d->Wo &&
+        d->in_layout == CN_LAYOUT_NHWC && d->out_layout == CN_LAYOUT_NHWC &&
+        cn_conv3x3s2p_takes(d->B, d->H, d->W, d->Cin, d->Cout, d->in_pitch, d->out_pitch))
+        return cn_conv3x3s2_persist(x, w_packed, scale, shift, y, d->B, d->H, d->W, d->Cin, d->Cout, d->in_pitch,
+                                    d->out_pitch, d->relu, (d->flags & CN_CONV_Y_PLAIN) ? 1 : 0, &d->ctl, st);
     if (f32s) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_s<64, 128, 2, 2, A_DENSE, false>(a, st)
@@ -1669,7 +1681,7 @@ extern "C" int cn_stem_f32s_supported(const cn_conv_desc *d)
     return (d->stride == 1 && d->Cout <= 16 && d->pad_h == 3 && (d->W & 3) == 0 && g_tune_stem16s) ? 1 : 0;
 }
 
-extern int cn_tune_c3p, cn_tune_c3p_stagger, cn_tune_c3p_knobs, cn_tune_c3p_heads, cn_tune_c3p_deconv;
+extern int cn_tune_c3p, cn_tune_c3p_stagger, cn_tune_c3p_knobs, cn_tune_c3p_heads, cn_tune_c3p_deconv, cn_tune_c3p_s2;
 extern "C" int cn_set_tuning(int key, int value)
 {
     if (key == 28 && value >= 0 && value <= 7) {
@@ -1690,6 +1702,10 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 32 && (value == 0 || value == 1)) {
         cn_tune_c3p_deconv = value;
+        return CN_OK;
+    }
+    if (key == 33 && (value == 0 || value == 1)) {
+        cn_tune_c3p_s2 = value;
         return CN_OK;
     }
     if (key == 20 && (value == 0 || value == 1)) {

@@ -39,6 +39,7 @@ int cn_tune_c3p_stagger = 64; // cn_set_tuning key 29: start delay of the second
 int cn_tune_c3p_knobs = 0;    // cn_set_tuning key 30 (A/B): see P3Args.knobs
 int cn_tune_c3p_heads = 1;    // cn_set_tuning key 31: the fused heads (hidden width 64) on this kernel; 0 = halo kernel
 int cn_tune_c3p_deconv = 1;   // cn_set_tuning key 32: ConvTranspose2d(4, 2, 1) in parity form on this kernel; 0 = halo kernel
+int cn_tune_c3p_s2 = 1;       // cn_set_tuning key 33: 3x3 / stride 2 / pad 1 in parity-plane form on this kernel; 0 = implicit GEMM
 
 // one 128-byte line of zeros: the DMA source of halo pixels outside the image
 __device__ __attribute__((aligned(128))) unsigned char cn_p3_zero_line[128];
@@ -72,7 +73,8 @@ struct P3Args {
     const float *scale, *shift;
     const char *residual;     // f32s or plain fp32 NHWC, or null
     char *y;                  // f32s or plain fp32 NHWC
-    int H, W;
+    int H, W;                 // the map the tiles cover (= the output, in units of its parity classes for the transposed form)
+    int Hi, Wi;               // the input map (= H, W except for stride 2)
     int in_pitchB, out_pitchB, res_pitchB;   // bytes per pixel
     int res_bytes;            // size of the residual tensor (buffer loads)
     int cin_padB;             // bytes per weight row (cin_pad * 4)
@@ -136,9 +138,22 @@ __device__ __forceinline__ P3Item p3_decode(const P3Args &a, int item)
 }
 
 // RES: 0 = no residual, 1 = f32s residual, 2 = plain fp32 residual
-template <int RES, bool OUT_PLAIN, bool DBG = false, bool HEADS = false, int NTAP = 9>
+// Stride 2 (S2): the 3x3 / stride-2 / pad-1 convolution as four stride-1 convolutions over the input's
+// PARITY PLANES (p, q) = pixels (2 y + p, 2 x + q): plane (1, 1) carries the four corner taps, (0, 1) and
+// (1, 0) two edge taps each, (0, 0) the centre tap -- every tap at offset (0 | 1, 0 | 1) of the plane's
+// 10 x 18 halo around the output tile.  A chunk is four stages (one halo each) of 4, 2, 2 and 1 steps.
+__device__ constexpr int p3_s2_oy(int i) { return i == 0 || i == 1 || i == 6 ? 0 : 1; }   // halo row offset of step i
+__device__ constexpr int p3_s2_ox(int i) { return i == 0 || i == 2 || i == 4 ? 0 : 1; }   // halo column offset
+__device__ constexpr int p3_s2_buf(int i) { return (i >= 4 && i <= 5) || i == 8 ? 1 : 0; } // halo buffer = stage parity
+__device__ constexpr int p3_s2_tap(int i)     // weight matrix (ky * 3 + kx) of step i
+{
+    return i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 6 : i == 3 ? 8 : i == 4 ? 3 : i == 5 ? 5 : i == 6 ? 1 : i == 7 ? 7 : 4;
+}
+
+template <int RES, bool OUT_PLAIN, bool DBG = false, bool HEADS = false, int NTAP = 9, bool S2 = false>
 __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const P3Heads hd)
 {
+    static_assert(!S2 || (NTAP == 9 && RES == 0 && !DBG && !HEADS), "stride 2: nine taps, no residual");
     // residual rows requested this many steps before an item's last step ends (0 .. 3 measured with
     // interleaved medians at B = 32: no difference on any trunk shape, so the shortest live range)
     constexpr int RES_AT = 0;
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
             size_t wpar = DECONV ? (size_t)((first / a.nblk) % a.npar) * NTAP * tapB : 0;
             auto issue_W = [&]() {   // weight tile of the cursor's step into ring slot wg & 3, then advance
                 if (wk >= nit) return;
-                const char *base = a.w + wpar + (size_t)wt * tapB + (size_t)wc * 128;
+                const char *base = a.w + wpar + (size_t)(S2 ? p3_s2_tap(wt) : wt) * tapB + (size_t)wc * 128;
                 char *dst = smem + P_WOFF + (wg & (P_NSLOT - 1)) * P_WSLOT;
                 if (!DBG || !(a.dbg & 4)) {
 #pragma unroll
@@ -246,15 +261,23 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
                 const int r = 8 * k + prow;
                 const int hy = r / P_HW, hx = r - hy * P_HW;
                 const int col = ps ^ ((hx >> 1) & 7);
-                poff[k] = ((hy - 1) * a.W + (hx - 1)) * a.in_pitchB + col * 16;
+                poff[k] = (S2 ? 2 : 1) * ((hy - 1) * a.Wi + (hx - 1)) * a.in_pitchB + col * 16;
                 pyx[k] = (r < P_HR) ? (hy | (hx << 8)) : -1;
             }
             const char *zero = reinterpret_cast<const char *>(cn_p3_zero_line) + ps * 16;
-            int hk = 0, hc = 0;       // cursor: the stage whose halo goes out next
+            int hk = 0, hc = 0, hj = 0;   // cursor: the stage whose halo goes out next (hj: parity plane, S2)
+            int hp = S2 ? 1 : 0, hq = S2 ? 1 : 0;   // plane order: (1, 1), (0, 1), (1, 0), (0, 0)
             P3Item hit = p3_decode(a, first);
             const char *hbase = nullptr;   // address of pixel (ty0, tx0), chunk hc, of the cursor's item
             auto set_hbase = [&]() {
-                hbase = a.x + ((size_t)(hit.b * a.H + hit.ty0) * a.W + hit.tx0) * a.in_pitchB + (size_t)hc * 128;
+                if constexpr (S2) {
+                    hp = (hj == 0 || hj == 2) ? 1 : 0;
+                    hq = (hj == 0 || hj == 1) ? 1 : 0;
+                    hbase = a.x + ((size_t)(hit.b * a.Hi + 2 * hit.ty0 + hp) * a.Wi + 2 * hit.tx0 + hq) * a.in_pitchB +
+                            (size_t)hc * 128;
+                } else {
+                    hbase = a.x + ((size_t)(hit.b * a.Hi + hit.ty0) * a.Wi + hit.tx0) * a.in_pitchB + (size_t)hc * 128;
+                }
             };
             set_hbase();
             auto issue_H = [&](auto K0, auto K1, int buf) {   // pieces [k0, k1) of the cursor's stage
@@ -264,13 +287,19 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
 #pragma unroll
                 for (int k = k0; k < k1; ++k) {
                     const int hy = pyx[k] & 255, hx = pyx[k] >> 8;
-                    const int iy = hit.ty0 - 1 + hy, ix = hit.tx0 - 1 + hx;
-                    const bool ok = pyx[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    const int iy = S2 ? 2 * (hit.ty0 - 1 + hy) + hp : hit.ty0 - 1 + hy;
+                    const int ix = S2 ? 2 * (hit.tx0 - 1 + hx) + hq : hit.tx0 - 1 + hx;
+                    const bool ok = pyx[k] >= 0 && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
                     const char *src = ok ? hbase + poff[k] : zero;
                     __builtin_amdgcn_global_load_lds((p3_gl_void *)src, (p3_lds_void *)(dst + k * 1024), 16, 0, 0);
                 }
             };
             auto advance_H = [&]() {   // cursor to the next stage
+                if (S2 && ++hj < 4) {
+                    set_hbase();
+                    return;
+                }
+                hj = 0;
                 if (++hc == a.nchunk) {
                     hc = 0;
                     ++hk;
@@ -284,6 +313,45 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
             // piece of this wave's queue -- before the first barrier of stage s + 1
             issue_H(P3_IC(0), P3_IC(P_HP), 0);
             advance_H();
+            if constexpr (S2) {
+                // stages of 4, 2, 2, 1 steps.  The next stage's halo goes out behind the barriers of this
+                // stage: from its second step on in a chunk's first stage (an item's first stage: the
+                // buffer holds the previous item's epilogue strips until then), from its first step
+                // otherwise (every consumer has left the stage before it: its buffer is free)
+                const int ST = 4 * S;
+                bool done = false;
+                auto run_stage = [&](auto N, int s) {
+                    constexpr int n = decltype(N)::value;
+                    const bool last = (s >= ST - 1);
+                    const int nbuf = (s + 1) & 1;
+#pragma unroll
+                    for (int t = 0; t < n; ++t) {
+                        if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        p3_barrier();
+                        if (s == ST) { done = true; return; }
+                        if (!last) {
+                            if constexpr (n == 4) {
+                                if (t == 1) issue_H(P3_IC(0), P3_IC(8), nbuf);
+                                if (t == 2) issue_H(P3_IC(8), P3_IC(16), nbuf);
+                                if (t == 3) issue_H(P3_IC(16), P3_IC(P_HP), nbuf);
+                            } else if constexpr (n == 2) {
+                                if (t == 0) issue_H(P3_IC(0), P3_IC(12), nbuf);
+                                if (t == 1) issue_H(P3_IC(12), P3_IC(P_HP), nbuf);
+                            } else {
+                                issue_H(P3_IC(0), P3_IC(P_HP), nbuf);
+                            }
+                        }
+                    }
+                };
+                for (int s = 0;; ++s) {
+                    const int sj = s & 3;
+                    if (sj == 0) run_stage(P3_IC(4), s);
+                    else if (sj == 3) run_stage(P3_IC(1), s);
+                    else run_stage(P3_IC(2), s);
+                    if (done) break;
+                    if (s < ST - 1) advance_H();
+                }
+            } else
             for (int s = 0;; ++s) {
                 const bool last = (s >= S - 1);
                 const int nbuf = (s + 1) & 1;
@@ -612,7 +680,8 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
     int par_y = 0, par_x = 0;      // parity of the current item (DECONV)
     auto step = [&](auto T, int hb, int wb) {
         constexpr int t = decltype(T)::value;
-        const int ky = DECONV ? t / 2 + par_y : t / 3, kx = DECONV ? t % 2 + par_x : t % 3;
+        const int ky = S2 ? p3_s2_oy(t) : (DECONV ? t / 2 + par_y : t / 3);
+        const int kx = S2 ? p3_s2_ox(t) : (DECONV ? t % 2 + par_x : t % 3);
         const int tapoff = (ky * P_HW + kx) * 128;
         // quarter q: 0 = high k 0-15, 1 = high k 16-31, 2 = low k 0-15, 3 = low k 16-31
         if (DBG && (a.dbg & 2)) return;
@@ -784,13 +853,14 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
             // the previous item is complete: its last stage used buffer (s - 1) & 1, dead until the
             // loader refills it after this step's successor barrier
             const unsigned long long c0 = now();
-            if (!(DBG && (a.dbg & 16))) epilogue(prev, ((s - 1) & 1) * P_HBYTES);
+            if (!(DBG && (a.dbg & 16))) epilogue(prev, S2 ? P_HBYTES : ((s - 1) & 1) * P_HBYTES);
             zero_acc();
             lane_consts();
             if (DBG) pf_epi += now() - c0;
         }
         if (s == S) break;
-        const int hb = (s & 1) * P_HBYTES;
+        const int hb0 = (s & 1) * P_HBYTES;
+        auto HB = [&](int i) { return S2 ? p3_s2_buf(i) * P_HBYTES : hb0; };   // halo buffer of step i
         // per item: this lane's scale (lanes 0-31) or shift (32-63) value of the wave's 32 channels,
         // requested at the first step and parked in the wave's LDS stash two steps later
         float ssv = 0.f;
@@ -805,14 +875,14 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
             }
             ssv = (ln >> 5) ? hv : sv;
         }
-        step(P3_IC(0), hb, P_WOFF + ((g + 0) & 3) * P_WSLOT);
-        bar(); step(P3_IC(1), hb, P_WOFF + ((g + 1) & 3) * P_WSLOT);
-        bar(); step(P3_IC(2), hb, P_WOFF + ((g + 2) & 3) * P_WSLOT);
+        step(P3_IC(0), HB(0), P_WOFF + ((g + 0) & 3) * P_WSLOT);
+        bar(); step(P3_IC(1), HB(1), P_WOFF + ((g + 1) & 3) * P_WSLOT);
+        bar(); step(P3_IC(2), HB(2), P_WOFF + ((g + 2) & 3) * P_WSLOT);
         if (c == 0) *reinterpret_cast<float *>(smem + P_SSOFF + wave * 256 + lane * 4) = ssv;
-        bar(); step(P3_IC(3), hb, P_WOFF + ((g + 3) & 3) * P_WSLOT);
+        bar(); step(P3_IC(3), HB(3), P_WOFF + ((g + 3) & 3) * P_WSLOT);
         if constexpr (!DECONV) {
-        bar(); step(P3_IC(4), hb, P_WOFF + ((g + 4) & 3) * P_WSLOT);
-        bar(); step(P3_IC(5), hb, P_WOFF + ((g + 5) & 3) * P_WSLOT);
+        bar(); step(P3_IC(4), HB(4), P_WOFF + ((g + 4) & 3) * P_WSLOT);
+        bar(); step(P3_IC(5), HB(5), P_WOFF + ((g + 5) & 3) * P_WSLOT);
         // the item's residual rows: requested RES_AT steps before the end of its last stage (probe:
         // requested behind the last step, the epilogue of a 64 -> 64 item waits ~3500 cycles for
         // them).  Held over the whole item the 32 registers push the kernel past 128 -- and two
@@ -828,11 +898,11 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
             }
         };
         maybe_residual(3);
-        bar(); step(P3_IC(6), hb, P_WOFF + ((g + 6) & 3) * P_WSLOT);
+        bar(); step(P3_IC(6), HB(6), P_WOFF + ((g + 6) & 3) * P_WSLOT);
         maybe_residual(2);
-        bar(); step(P3_IC(7), hb, P_WOFF + ((g + 7) & 3) * P_WSLOT);
+        bar(); step(P3_IC(7), HB(7), P_WOFF + ((g + 7) & 3) * P_WSLOT);
         maybe_residual(1);
-        bar(); step(P3_IC(8), hb, P_WOFF + ((g + 8) & 3) * P_WSLOT);
+        bar(); step(P3_IC(8), HB(8), P_WOFF + ((g + 8) & 3) * P_WSLOT);
         maybe_residual(0);
         }
         g += NTAP;
@@ -899,6 +969,7 @@ int cn_deconv4x4s2_persist(const void *x, const void *w_packed, const float *sca
     a.x = (const char *)x; a.w = (const char *)w_packed; a.scale = scale; a.shift = shift;
     a.y = (char *)y;
     a.H = H; a.W = W;
+    a.Hi = H; a.Wi = W;
     a.in_pitchB = in_pitch * 4; a.out_pitchB = out_pitch * 4;
     const int cin_pad = (Cin + 31) / 32 * 32;
     a.cin_padB = cin_pad * 4;
@@ -924,6 +995,60 @@ int cn_deconv4x4s2_persist(const void *x, const void *w_packed, const float *sca
     } else {
         CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, false, false, 4>), P_LDS);
         hipLaunchKernelGGL((conv3x3p_kernel<0, false, false, false, 4>), grid, block, P_LDS, st, a, P3Heads{});
+    }
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+// 3x3 / stride 2 / pad 1 on the persistent kernel (parity-plane form): f32s tensors on both sides,
+// whole 32-channel output groups, no residual
+bool cn_conv3x3s2p_takes(int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch)
+{
+    if (!cn_tune_c3p || !cn_tune_c3p_s2) return false;
+    if ((in_pitch & 31) || (out_pitch & 31) || (Cout % 32)) return false;
+    const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
+    const long items = (long)B * cn_cdiv(Ho, P_TH) * cn_cdiv(Wo, P_TW) * cn_cdiv(Cout, 64);
+    if (cn_tune_c3p < 2 && items < 256) return false;
+    if ((long)B * Hi * Wi * (long)in_pitch * 4 >= (1L << 31) || (long)B * Ho * Wo * (long)out_pitch * 4 >= (1L << 31))
+        return false;
+    (void)Cin;
+    return true;
+}
+
+int cn_conv3x3s2_persist(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                         int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch, int relu,
+                         int out_plain, const cn_f32s_ctl *ctl, hipStream_t st)
+{
+    P3Args a = {};
+    a.x = (const char *)x; a.w = (const char *)w_packed; a.scale = scale; a.shift = shift;
+    a.y = (char *)y;
+    a.H = (Hi - 1) / 2 + 1; a.W = (Wi - 1) / 2 + 1;
+    a.Hi = Hi; a.Wi = Wi;
+    a.in_pitchB = in_pitch * 4; a.out_pitchB = out_pitch * 4;
+    const int cin_pad = (Cin + 31) / 32 * 32;
+    a.cin_padB = cin_pad * 4;
+    a.cout_pad = (Cout + 31) / 32 * 32;
+    a.ngroups = a.cout_pad / 32;
+    a.nchunk = cin_pad / 32;
+    a.nblk = cn_cdiv(Cout, 64);
+    a.npar = 1;
+    a.tiles_x = cn_cdiv(a.W, P_TW);
+    a.tiles_y = cn_cdiv(a.H, P_TH);
+    a.items = B * a.tiles_y * a.tiles_x * a.nblk;
+    a.relu = relu; a.out_plain = out_plain;
+    a.res_mul = 1.f;
+    a.range = ctl ? ctl->range : nullptr;
+    a.stagger = cn_tune_c3p_stagger;
+    a.knobs = cn_tune_c3p_knobs;
+    int per_xcd = cn_cdiv(a.items, 8);
+    if (per_xcd > 64) per_xcd = 64;
+    const dim3 grid(8 * per_xcd), block(384);
+    if (out_plain) {
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, true, false, false, 9, true>), P_LDS);
+        hipLaunchKernelGGL((conv3x3p_kernel<0, true, false, false, 9, true>), grid, block, P_LDS, st, a, P3Heads{});
+    } else {
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, false, false, 9, true>), P_LDS);
+        hipLaunchKernelGGL((conv3x3p_kernel<0, false, false, false, 9, true>), grid, block, P_LDS, st, a, P3Heads{});
     }
     CN_CHECK_LAUNCH();
     return CN_OK;
@@ -968,6 +1093,7 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
     a.x = (const char *)x; a.w = (const char *)w_packed; a.scale = scale; a.shift = shift;
     a.residual = (const char *)residual; a.y = (char *)y;
     a.H = H; a.W = W;
+    a.Hi = H; a.Wi = W;
     a.in_pitchB = in_pitch * 4; a.out_pitchB = out_pitch * 4; a.res_pitchB = res_pitch * 4;
     a.res_bytes = (int)((long)B * H * W * res_pitch * 4);   // < 2^31 (cn_conv3x3p_takes)
     const int cin_pad = (Cin + 31) / 32 * 32;
@@ -1047,6 +1173,7 @@ int cn_heads3x3p(const void *x, int B, int H, int W, int Cin, int in_pitch, cons
     }
     a.x = (const char *)x; a.w = (const char *)w1_packed; a.scale = scale1; a.shift = bias1;
     a.H = H; a.W = W;
+    a.Hi = H; a.Wi = W;
     a.in_pitchB = in_pitch * 4;
     const int cin_pad = (Cin + 31) / 32 * 32;
     a.cin_padB = cin_pad * 4;

@@ -342,6 +342,48 @@ def test_conv_transpose_4x4_s2_on_the_persistent_kernel(dev, cfg):
         lib.cn_set_tuning(32, 1)
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 32, 128), (1, 128, 16, 32, 256), (1, 96, 17, 23, 96),
+                                 (2, 64, 40, 24, 64), (3, 32, 9, 70, 32), (32, 64, 128, 128, 128)])
+def test_conv3x3_stride2_on_the_persistent_kernel(dev, cfg):
+    """3x3 / stride 2 / pad 1 (the first convolution of a down-sampling BasicBlock, resnet_dcn.py:38-67)
+    in parity-plane form on the persistent loader / consumer kernel (cn_conv3x3p.hip, S2: four stages of
+    4 / 2 / 2 / 1 taps per chunk over the input's parity planes): even and odd map sizes, edge tiles,
+    Cin = 96, a half-empty output block, f32s and plain output -- against torch.conv2d on the CPU and
+    the implicit-GEMM kernel (key 33 = 0); run-to-run bit equality.  The last case is resdcn_18's
+    layer2 entry at the benchmark batch on the library's own routing."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder
+    lib = native.lib()
+    B, Cin, H, W, Cout = cfg
+    nref = min(B, 2)
+    x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1)).relu_()
+    w = torch.from_numpy(synth.normal((Cout, Cin, 3, 3), (2.0 / (Cin * 9)) ** 0.5, 2))
+    bn = _bn(Cout, 3)
+    ref = F.relu(bn(F.conv2d(x[:nref], w, None, 2, 1))).detach()
+    assert lib.cn_set_tuning(28, 2 if B < 32 else 1) == 0
+    try:
+        for out_plain in (False, True):
+            got = {}
+            for key33 in (1, 0):
+                assert lib.cn_set_tuning(33, key33) == 0
+                pb = PlanBuilder(dev, B, H, W, split=True)
+                y = pb.conv(pb.packed(_nhwc_act(x, dev)), w, bn=bn, relu=True, stride=2, padding=1,
+                            out_plain=out_plain)
+                assert y.fmt == ("f32" if out_plain else "f32s") and (y.H, y.W) == tuple(ref.shape[2:])
+                _run(pb)
+                got[key33] = y.to_float().clone()
+                if key33 == 1:
+                    raw = y.t.clone()
+                    _run(pb)
+                    assert torch.equal(raw, y.t), "not deterministic run to run"
+            _check(got[1][:nref].permute(0, 3, 1, 2).cpu(), ref)
+            d = float((got[1] - got[0]).abs().max()) / max(1.0, float(got[0].abs().max()))
+            assert d < 2e-5, d
+    finally:
+        lib.cn_set_tuning(28, 1)
+        lib.cn_set_tuning(33, 1)
+
+
 def test_heads_fused_nchw_outputs(dev):
     from centernet_amd.engine import PlanBuilder
     B, F_, H, W = 2, 64, 32, 32
