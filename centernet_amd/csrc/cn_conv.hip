@@ -918,7 +918,7 @@ int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, 
 int cn_stem_pool_rows(int B, int Ho, int Wo, int Cout, int KH, int KW, int stride, int KP);
 int cn_stem_pool_f32s(const float *x, const float *w_packed, const float *scale, const float *shift,
                       float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
-                      int stride, int pad, int relu, int out_pitch, int KP, const cn_f32s_ctl *ctl,
+                      int stride, int pad, int relu, int out_pitch, int KP, int y_f32s, const cn_f32s_ctl *ctl,
                       hipStream_t st);
 int cn_dcn_window_f32(const float *x, const float *w_packed, const float *bias, const float *om,
                       int om_pitch, const float *scale, const float *shift, float *y, int B, int Cin,
@@ -1272,7 +1272,8 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
                 return CN_ERR_UNSUPPORTED;
             return cn_stem_pool_f32s((const float *)x, (const float *)w_packed, scale, shift,
                                      (float *)y, d->B, d->H, d->W, d->Ho, d->Wo, d->Cout, d->KH,
-                                     d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad, &d->ctl, st);
+                                     d->KW, d->stride, d->pad_h, d->relu, d->out_pitch, a.cin_pad,
+                                     (d->flags & CN_CONV_STEM_Y_F32S) ? 1 : 0, &d->ctl, st);
         }
         if (!g_tune_nostem && d->pad_h == d->pad_w && d->dil == 1 && d->oy_mul == 1 &&
             d->ox_mul == 1 && d->OH == d->Ho && d->OW == d->Wo) {

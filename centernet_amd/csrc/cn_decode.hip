@@ -207,7 +207,6 @@ __device__ __forceinline__ float sigmoidf_ref(float x)
 }
 
 constexpr int CAND_CAP = 4096;  // compacted positive peaks per band (uint16 tile offsets)
-constexpr int GATE_CAP = 4096;  // = GCAP below: candidate keys per image of the image-level mode
 
 // ---------------------------------------------------------------------------
 // kernel 1: per (image, class, row-band): sigmoid + 3x3 peak test + top-K
@@ -439,12 +438,12 @@ __global__ __launch_bounds__(NT) void nms_topk_kernel(const float *__restrict__ 
 //               candidate list as 64-bit keys (score, ~flat index).
 //             the image's LAST plane to arrive (one atomic counter per image): exact radix select +
 //               sort of the few hundred candidates, gather, box assembly.
-// Images whose list is unusable (T_b <= 0: fewer than K groups with a positive peak; constant
-// maps; plateaus of more than GCAP cells tying T_b) are handled by that last workgroup as well, from
-// an exact scan of every cell of the image: every input is handled exactly, in the same two
-// launches.
+// A plane hands on at most its own K best keys (exact select inside the plane when it holds more:
+// saturated plateaus), so the image's list of C * K keys cannot overflow; images with T_b <= 0 (fewer
+// than K groups with a positive peak; constant maps: zeros of suppressed cells take part) run that
+// per-plane select over all cells of every plane.  Every input is handled exactly by the same two
+// launches; both forms are bit-identical to the per-(class, band) select of round 1.
 // ---------------------------------------------------------------------------
-constexpr int GCAP = GATE_CAP;  // candidate keys per image
 
 // A GROUP = 8 rows x 128 columns of one (image, class) plane.  One half-wave owns a 16-row x
 // 128-column unit (two groups): lane l holds the 4-cell quad l of a row and walks down the
@@ -639,20 +638,32 @@ __device__ __forceinline__ uint32_t image_threshold(const uint32_t *__restrict__
     return f2key(score + 0.0f);
 }
 
-// phase 3 (device function): exact evaluation of the cells of ONE plane that can reach the
-// threshold.  The workgroup's eight half-waves share the plane's live groups (all-cell maximum >=
-// the raw threshold).  A half-wave re-reads its 8 x 128 group with the same rolling register window
-// as phase 1 (10 row loads, neighbours by shuffle), applies the logistic to the whole window and
-// runs the reference's test on the SCORES -- 3x3 maximum, exact equality (decode.py:9-15) -- in
-// registers; qualifying cells are counted per lane, placed by a half-wave prefix sum and ONE
-// atomic per group.  The threshold often falls INTO the noise floor of a real heat-map (a few
-// confident objects, K = 100): then most groups are live and this pass costs about what phase 1
-// does plus the logistics -- not nine dependent loads per cell over the threshold.
+// phase 3 (device function): the candidate keys of ONE plane.  The workgroup's eight half-waves share
+// the plane's live groups (all-cell maximum >= the raw threshold).  A half-wave re-reads its 8 x 128
+// group with the same rolling register window as phase 1 (10 row loads, neighbours by shuffle),
+// applies the logistic to the whole window and runs the reference's test on the SCORES -- 3x3
+// maximum, exact equality (decode.py:9-15) -- in registers; qualifying cells are counted per lane,
+// placed by a half-wave prefix sum into a list in LDS.  The threshold often falls INTO the noise floor
+// of a real heat-map (a few confident objects, K = 100): then most groups are live and this pass costs
+// about what phase 1 does plus the logistics -- not nine dependent loads per cell over the threshold.
+// A plane never has to hand on more than its own K best keys (the image's K best are among them), so
+// the image's list -- capacity C * K -- cannot overflow whatever the map holds:
+//   n <= K qualifying cells        -> all of them
+//   K < n <= PLCAP                 -> exact select of the K best from the LDS list
+//   n > PLCAP (saturated plateaus) -> exact select over the cells of the plane, keys recomputed per
+//                                     pass from global memory (slow: tens of microseconds; rare)
+// and a DEGENERATE image (threshold <= 0: fewer than K groups with a positive peak, constant maps --
+// zeros of suppressed cells take part in the top K) takes the last route for every plane with all
+// cells admitted: every input is handled exactly, by the same two launches.
+constexpr int PLCAP = 512;    // candidate keys of a plane kept in LDS
+
 __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, int C, int H, int W, int nrg,
-                                              int ncb, int flags, const uint32_t *__restrict__ gall,
-                                              uint32_t tkey, float rthr, u64 *__restrict__ keys,
-                                              int32_t *__restrict__ counts)
+                                              int ncb, int flags, int K, const uint32_t *__restrict__ gall,
+                                              uint32_t tkey, float rthr, SelShared &sh, u64 *__restrict__ keys,
+                                              int cap, int32_t *__restrict__ counts)
 {
+    __shared__ u64 pl_keys[PLCAP];
+    __shared__ int pl_cnt, pl_base;
     const int tid = threadIdx.x;
     const int lane = tid & (CN_WAVE - 1);
     const int hl = lane & 31, hw = tid >> 5;
@@ -660,12 +671,16 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
     const int b = (int)(plane_id / C), c = (int)(plane_id - (size_t)b * C);
     const bool sig = (flags & 1) != 0;
     const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;
+    const bool degenerate = tkey <= KEY_ZERO;
     const uint32_t rkey = f2key(rthr + 0.0f);   // group maxima are RAW keys
-    const float *plane = heat + plane_id * (size_t)H * W;
-    const uint32_t base = (uint32_t)c * (uint32_t)(H * W);
-    u64 *kimg = keys + (size_t)b * GCAP;
+    const int HW = H * W;
+    const float *plane = heat + plane_id * (size_t)HW;
+    const uint32_t base = (uint32_t)c * (uint32_t)HW;
+    u64 *kimg = keys + (size_t)b * cap;
     const int w4 = W >> 2;
     const float NEG_INF = -__builtin_huge_valf();
+    if (tid == 0) pl_cnt = 0;
+    __syncthreads();
 
     auto collect_group = [&](int g) {
         const int rg = g / ncb, cb = g - rg * ncb;
@@ -726,7 +741,7 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
                 tmask |= take ? (1u << ((r - 1) * 4 + e)) : 0u;
             }
         }
-        // half-wave inclusive prefix sum of the per-lane counts, one atomic for the group
+        // half-wave inclusive prefix sum of the per-lane counts, one LDS atomic for the group
         const int mine = __popc(tmask);
         int incl = mine;
 #pragma unroll
@@ -737,7 +752,7 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
         const int total = __shfl(incl, 31, 32);
         if (total == 0) return;
         int pos0 = 0;
-        if (hl == 31) pos0 = atomicAdd(&counts[b], total);
+        if (hl == 31) pos0 = atomicAdd(&pl_cnt, total);
         int pos = __shfl(pos0, 31, 32) + incl - mine;
 #pragma unroll
         for (int r = 1; r <= GROWS; ++r) {
@@ -746,40 +761,98 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
             for (int e = 0; e < 4; ++e) {
                 if (tmask & (1u << ((r - 1) * 4 + e))) {
                     const uint32_t cell = (uint32_t)(y * W + x4 * 4 + e);
-                    // (device-scope store: read by the image's last workgroup, possibly on another XCD,
-                    // without any cache maintenance in between -- see collect_merge_kernel)
-                    if (pos < GCAP)
-                        __hip_atomic_store(kimg + pos, ((u64)cell_key(r, e) << 32) | (u64)(0xFFFFFFFFu - (base + cell)),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (pos < PLCAP)
+                        pl_keys[pos] = ((u64)cell_key(r, e) << 32) | (u64)(0xFFFFFFFFu - (base + cell));
                     ++pos;
                 }
             }
         }
     };
-    const int ng = nrg * ncb;
-    // which groups can hold a qualifying cell: all group maxima are fetched at once (a chain of
-    // dependent loads here cost more than the whole streaming pass)
-    // and the live ones compacted into a list, so that the two halves of a wave always work on
-    // two groups at the same time
-    __shared__ u64 live[NT / 64];
-    __shared__ int glist[NT];
-    for (int g0 = 0; g0 < ng; g0 += NT) {
-        const int g = g0 + tid;
-        const bool q = g < ng && gall[plane_id * ng + g] >= rkey;
-        const u64 bal = __ballot(q);
-        if (lane == 0) live[tid >> 6] = bal;
-        __syncthreads();
-        int before = 0, nlive = 0;
+    if (!degenerate) {
+        const int ng = nrg * ncb;
+        // which groups can hold a qualifying cell: all group maxima are fetched at once (a chain of
+        // dependent loads here cost more than the whole streaming pass)
+        // and the live ones compacted into a list, so that the two halves of a wave always work on
+        // two groups at the same time
+        __shared__ u64 live[NT / 64];
+        __shared__ int glist[NT];
+        for (int g0 = 0; g0 < ng; g0 += NT) {
+            const int g = g0 + tid;
+            const bool q = g < ng && gall[plane_id * ng + g] >= rkey;
+            const u64 bal = __ballot(q);
+            if (lane == 0) live[tid >> 6] = bal;
+            __syncthreads();
+            int before = 0, nlive = 0;
 #pragma unroll
-        for (int w = 0; w < NT / 64; ++w) {
-            const int n = __popcll(live[w]);
-            if (w < (tid >> 6)) before += n;
-            nlive += n;
+            for (int w = 0; w < NT / 64; ++w) {
+                const int n = __popcll(live[w]);
+                if (w < (tid >> 6)) before += n;
+                nlive += n;
+            }
+            if (q) glist[before + __popcll(bal & ((1ull << lane) - 1ull))] = g;
+            __syncthreads();
+            for (int i = hw; i < nlive; i += NT / 32) collect_group(glist[i]);
+            __syncthreads();
         }
-        if (q) glist[before + __popcll(bal & ((1ull << lane) - 1ull))] = g;
+    }
+    // ---- hand the plane's keys on: at most its K best
+    const int n = degenerate ? PLCAP + 1 : pl_cnt;      // (uniform; the last loop round ended with a barrier)
+    int m;                                              // keys this plane emits
+    const u64 *src;
+    if (n <= K) {
+        m = n;
+        src = pl_keys;
+    } else {
+        m = min(K, HW);
+        u64 prefix, mask;
+        if (n <= PLCAP) {
+            auto for_each = [&](auto &&f) {
+                for (int j = tid; j < n; j += NT) f(pl_keys[j], false);
+            };
+            radix_select<NT>(for_each, (uint32_t)m, sh, prefix, mask);
+            collect_and_sort<NT>(for_each, prefix, mask, sh);
+        } else {
+            // every cell of the plane (degenerate image), or every cell that reaches the threshold (more
+            // of them than the LDS list holds): keys recomputed from global memory in every pass
+            auto for_each = [&](auto &&f) {
+                for (int e = tid; e < HW; e += NT) {
+                    const int y = e / W, x = e - y * W;
+                    auto sc = [&](int yy, int xx) {
+                        const float v = plane[yy * W + xx];
+                        return sig ? sigmoidf_ref(v) : v;
+                    };
+                    const float v = sc(y, x);
+                    float mx = v;
+                    if (!nonms) {
+                        for (int dy = -1; dy <= 1; ++dy) {
+                            const int yy = y + dy;
+                            if (yy < 0 || yy >= H) continue;
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                const int xx = x + dx;
+                                if (xx < 0 || xx >= W || (dy == 0 && dx == 0)) continue;
+                                mx = fmaxf(mx, sc(yy, xx));
+                            }
+                        }
+                    }
+                    const uint32_t kk = f2key(((mx == v) ? v : 0.0f) + 0.0f);   // heat * keep, -0.0 -> +0.0
+                    if (degenerate || kk >= tkey)
+                        f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - (base + (uint32_t)e)), kk == KEY_ZERO);
+                }
+            };
+            radix_select<NT>(for_each, (uint32_t)m, sh, prefix, mask);
+            collect_and_sort<NT>(for_each, prefix, mask, sh);
+        }
+        src = sh.sel;
+    }
+    if (m > 0) {
+        // one returning atomic per plane reserves its slice of the image's list; the keys go out as
+        // device-scope stores (read by the image's last workgroup, possibly on another XCD, without any
+        // cache maintenance in between -- see collect_merge_kernel)
+        if (tid == 0) pl_base = atomicAdd(&counts[b], m);
         __syncthreads();
-        for (int i = hw; i < nlive; i += NT / 32) collect_group(glist[i]);
-        __syncthreads();
+        const int o = pl_base;
+        for (int j = tid; j < m; j += NT)
+            if (o + j < cap) __hip_atomic_store(kimg + o + j, src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -896,11 +969,8 @@ __global__ __launch_bounds__(NTM) void merge_topk_kernel(
 //   2. plane_collect    -- the plane's candidate keys;
 //   3. the LAST plane of an image to arrive (one atomic counter per image; nobody waits for anybody)
 //      selects and sorts the image's K best candidates and writes its detections.
-// Degenerate images (threshold <= 0: fewer than K groups with a positive peak; constant maps;
-// plateaus of more than GCAP cells tying the threshold) are served by the last arriver too, from an
-// exact scan of every cell of the image (sigmoid -> 3x3 equality test -> heat * keep, zeros of
-// suppressed cells included: decode.py:9-15,103-119) -- slow (milliseconds per such image), rare,
-// and bit-identical to the per-(class, band) select.
+// Degenerate images and saturated plateaus are dealt with plane by plane in plane_collect (every
+// plane hands on at most its K best keys): the last arriver always finds between K and C * K keys.
 // ---------------------------------------------------------------------------
 struct EmitArgs {
     const float *wh, *reg;
@@ -917,7 +987,7 @@ __global__ __launch_bounds__(NT) void collect_merge_kernel(const float *__restri
                                                            int W, int nrg, int ncb, int flags, int K,
                                                            const uint32_t *__restrict__ gpeak,
                                                            const uint32_t *__restrict__ gall,
-                                                           u64 *__restrict__ keys,
+                                                           u64 *__restrict__ keys, int cap,
                                                            int32_t *__restrict__ counts,
                                                            int32_t *__restrict__ done, const EmitArgs ea)
 {
@@ -929,8 +999,7 @@ __global__ __launch_bounds__(NT) void collect_merge_kernel(const float *__restri
     const int ng = C * nrg * ncb;
     float rthr;
     const uint32_t tkey = image_threshold(gpeak + (size_t)b * ng, ng, K, flags, sh, rthr);
-    const bool degenerate = tkey <= KEY_ZERO;      // uniform over the image's workgroups
-    if (!degenerate) plane_collect(heat, C, H, W, nrg, ncb, flags, gall, tkey, rthr, keys, counts);
+    plane_collect(heat, C, H, W, nrg, ncb, flags, K, gall, tkey, rthr, sh, keys, cap, counts);
     // ---- arrival.  What the image's last workgroup reads from the others -- candidate keys and their
     // count -- is written with device-scope atomics (write-through to the coherence point) and read
     // with device-scope loads: no __threadfence() on either side (on this part a device-scope release /
@@ -943,13 +1012,14 @@ __global__ __launch_bounds__(NT) void collect_merge_kernel(const float *__restri
         s_last = (__hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == C - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    const int cnt = degenerate ? GCAP + 1
-                               : __hip_atomic_load(&counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every plane handed on its K best (or all it had): between K and C * K keys, the image's K best
+    // among them (fewer than K only when the whole image has fewer cells: excluded by the caller)
+    const int cnt = min(__hip_atomic_load(&counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cap);
+    const u64 *kg = keys + (size_t)b * cap;
     u64 prefix, mask;
-    if (cnt >= K && cnt <= GCAP) {
-        // the candidate keys: fetched once into registers (GCAP / NT = 16 per thread), device-scope loads
-        const u64 *kg = keys + (size_t)b * GCAP;
-        constexpr int RK = GCAP / NT;
+    constexpr int RK = 16;
+    if (cnt <= RK * NT) {
+        // fetched once into registers (16 per thread), device-scope loads
         u64 kr[RK];
 #pragma unroll
         for (int u = 0; u < RK; ++u)
@@ -958,39 +1028,15 @@ __global__ __launch_bounds__(NT) void collect_merge_kernel(const float *__restri
         auto for_each = [&](auto &&f) {
 #pragma unroll
             for (int u = 0; u < RK; ++u)
-                if (tid + u * NT < cnt) f(kr[u], false);
+                if (tid + u * NT < cnt) f(kr[u], (uint32_t)(kr[u] >> 32) == KEY_ZERO);
         };
         radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
         collect_and_sort<NT>(for_each, prefix, mask, sh);
     } else {
-        const bool sig = (flags & 1) != 0;
-        const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;
-        const int HW = H * W;
-        const float *img = heat + (size_t)b * C * HW;
         auto for_each = [&](auto &&f) {
-            for (int e = tid; e < C * HW; e += NT) {
-                const int c = e / HW, r = e - c * HW;
-                const int y = r / W, x = r - y * W;
-                const float *pl = img + (size_t)c * HW;
-                auto sc = [&](int yy, int xx) {
-                    const float v = pl[yy * W + xx];
-                    return sig ? sigmoidf_ref(v) : v;
-                };
-                const float v = sc(y, x);
-                float m = v;
-                if (!nonms) {
-                    for (int dy = -1; dy <= 1; ++dy) {
-                        const int yy = y + dy;
-                        if (yy < 0 || yy >= H) continue;
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const int xx = x + dx;
-                            if (xx < 0 || xx >= W || (dy == 0 && dx == 0)) continue;
-                            m = fmaxf(m, sc(yy, xx));
-                        }
-                    }
-                }
-                const uint32_t kk = f2key(((m == v) ? v : 0.0f) + 0.0f);   // heat * keep, -0.0 -> +0.0
-                f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - (uint32_t)e), kk == KEY_ZERO);
+            for (int j = tid; j < cnt; j += NT) {
+                const u64 k = __hip_atomic_load(kg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f(k, (uint32_t)(k >> 32) == KEY_ZERO);
             }
         };
         radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
@@ -1044,6 +1090,7 @@ namespace {
 struct ImgPlan {
     bool use;
     int nrg, ncb;                  // 8-row groups per plane, 128-column blocks per row
+    int cap;                       // candidate keys per image: every plane hands on at most its K best
     size_t gpeak, gall, counts, done, keys, total;   // byte offsets in the workspace
 };
 ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
@@ -1060,7 +1107,8 @@ ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
     p.gall = o;   o += cn_align_up(ng * 4, 256);
     p.counts = o; o += cn_align_up((size_t)B * 4, 256);
     p.done = o;   o += cn_align_up((size_t)B * 4, 256);
-    p.keys = o;   o += cn_align_up((size_t)B * GCAP * 8, 256);
+    p.cap = C * K;
+    p.keys = o;   o += cn_align_up((size_t)B * p.cap * 8, 256);
     p.total = o;
     return p;
 }
@@ -1080,7 +1128,7 @@ int launch_image_topk(const float *heat, int B, int C, int H, int W, int K, int 
                        gall, C, counts, done);
     CN_CHECK_LAUNCH();
     hipLaunchKernelGGL(collect_merge_kernel<MODE>, grid, block, sizeof(SelShared), st, heat, C, H, W,
-                       ip.nrg, ip.ncb, flags, K, gpeak, gall, keys, counts, done, ea);
+                       ip.nrg, ip.ncb, flags, K, gpeak, gall, keys, ip.cap, counts, done, ea);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -42,8 +42,9 @@ struct WarpArgs {
     double m[6];         // dst -> src (already inverted the way cv::warpAffine inverts it)
     int oh, ow;
     double mean[3], stdv[3];
-    float *out;          // (1|2, 3, oh, ow)
+    float *out;          // (1|2, 3, oh, ow) per image
     int flip;
+    size_t img_stride, out_stride;   // bytes / floats from one image of a batch to the next (blockIdx.z)
 };
 
 // four int16-range weights of a 1/32-pixel fraction pair (initInterTab2D, INTER_LINEAR, fixed point)
@@ -106,14 +107,16 @@ __global__ void warp_normalize_kernel(const WarpArgs a)
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= a.ow) return;
     int v[3];
-    warp_pixel<3>(a.img, a.H, a.W, (size_t)a.pitch, a.m, x, y, row_base(a.m, 1, 2, y), row_base(a.m, 4, 5, y), v);
+    const uint8_t *img = a.img + (size_t)blockIdx.z * a.img_stride;
+    float *out = a.out + (size_t)blockIdx.z * a.out_stride;
+    warp_pixel<3>(img, a.H, a.W, (size_t)a.pitch, a.m, x, y, row_base(a.m, 1, 2, y), row_base(a.m, 4, 5, y), v);
     const size_t plane = (size_t)a.oh * a.ow;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const double n = ((double)v[c] / 255.0 - a.mean[c]) / a.stdv[c];
         const float f = (float)n;
-        a.out[c * plane + (size_t)y * a.ow + x] = f;
-        if (a.flip) a.out[(3 + c) * plane + (size_t)y * a.ow + (a.ow - 1 - x)] = f;
+        out[c * plane + (size_t)y * a.ow + x] = f;
+        if (a.flip) out[(3 + c) * plane + (size_t)y * a.ow + (a.ow - 1 - x)] = f;
     }
 }
 
@@ -188,10 +191,21 @@ extern "C" int cn_warp_normalize_u8_f32(const uint8_t *image_hwc, int H, int W, 
                                         const float *mean3, const float *std3, int flip_concat,
                                         float *out_nchw, void *stream)
 {
+    return cn_warp_normalize_u8_f32_batch(image_hwc, 1, 0, H, W, pitch_bytes, dst_to_src_2x3, out_h, out_w,
+                                          mean3, std3, flip_concat, out_nchw, stream);
+}
+
+extern "C" int cn_warp_normalize_u8_f32_batch(const uint8_t *images_hwc, int N, size_t image_stride_bytes,
+                                              int H, int W, int pitch_bytes, const double *dst_to_src_2x3,
+                                              int out_h, int out_w, const float *mean3, const float *std3,
+                                              int flip_concat, float *out_nchw, void *stream)
+{
+    const uint8_t *image_hwc = images_hwc;
     if (!image_hwc || !dst_to_src_2x3 || !mean3 || !std3 || !out_nchw) return CN_ERR_NULL;
     if (H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0 || pitch_bytes < 3 * W || out_h > 65535 ||
-        H > 32767 || W > 32767)
+        H > 32767 || W > 32767 || N <= 0 || N > 65535)
         return CN_ERR_SHAPE;
+    if (N > 1 && image_stride_bytes < (size_t)pitch_bytes * (size_t)H) return CN_ERR_SHAPE;
     WarpArgs a = {};
     a.img = image_hwc; a.H = H; a.W = W; a.pitch = pitch_bytes; a.oh = out_h; a.ow = out_w;
     for (int i = 0; i < 6; ++i) a.m[i] = dst_to_src_2x3[i];
@@ -201,7 +215,9 @@ extern "C" int cn_warp_normalize_u8_f32(const uint8_t *image_hwc, int H, int W, 
         a.stdv[c] = (double)std3[c];
     }
     a.out = out_nchw; a.flip = flip_concat ? 1 : 0;
-    dim3 grid(cn_cdiv(out_w, 128), out_h);
+    a.img_stride = image_stride_bytes;
+    a.out_stride = (size_t)(a.flip ? 6 : 3) * out_h * out_w;
+    dim3 grid(cn_cdiv(out_w, 128), out_h, N);
     hipLaunchKernelGGL(warp_normalize_kernel, grid, dim3(128), 0, (hipStream_t)stream, a);
     CN_CHECK_LAUNCH();
     return CN_OK;
@@ -331,5 +347,72 @@ extern "C" int cn_resize_linear_u8_host(const uint8_t *img, int h_in, int w_in, 
     case 3: resize_host<3>(img, h_in, w_in, h_out, w_out, out); break;
     default: resize_host<4>(img, h_in, w_in, h_out, w_out, out); break;
     }
+    return CN_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// ctdet_post_process + the per-class split on the device (utils/post_process.py:83-100,
+// utils/image.py:19-24,63-66, detectors/ctdet.py:47-56), so that the host tail of a batch is one small
+// copy and 80 slices per image: for every image the K raw detections [x1, y1, x2, y2, score, class]
+// in output-grid units become rows [x1, y1, x2, y2, score] in source-frame pixels, grouped by class
+// (ascending; inside a class in their original, score-descending order: a stable sort), plus the
+// class boundaries.  Arithmetic as the reference's: float32 point -> float64 (t0*x + t1*y) + t2 ->
+// float32, then / scale in float32; rows whose class lies outside [0, num_classes) are dropped
+// (they match no `classes == j`).
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int PP_KMAX = 128;
+__global__ __launch_bounds__(PP_KMAX) void ctdet_post_kernel(const float *__restrict__ dets, int K, int num_classes,
+                                                             const double *__restrict__ to_source, int per_image,
+                                                             float scale, float *__restrict__ rows,
+                                                             int32_t *__restrict__ bounds)
+{
+    __shared__ int cls_s[PP_KMAX];
+    const int b = blockIdx.x, k = threadIdx.x;
+    const double *t = to_source + (per_image ? (size_t)b * 6 : 0);
+    float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int cls = num_classes;             // sorts behind every class
+    if (k < K) {
+        const float *d = dets + ((size_t)b * K + k) * 6;
+        const int c = (int)(long long)d[5];        // astype(np.int64): truncation
+        if (c >= 0 && c < num_classes) cls = c;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const double x = (double)d[2 * p], y = (double)d[2 * p + 1];
+            const double sx = (x * t[0] + y * t[1]) + t[2];
+            const double sy = (x * t[3] + y * t[4]) + t[5];
+            r[2 * p] = (float)sx / scale;
+            r[2 * p + 1] = (float)sy / scale;
+        }
+        r[4] = d[4];
+    }
+    cls_s[k] = cls;
+    __syncthreads();
+    if (k < K) {
+        int rank = 0;
+        for (int j = 0; j < K; ++j) rank += (cls_s[j] < cls || (cls_s[j] == cls && j < k)) ? 1 : 0;
+        float *o = rows + ((size_t)b * K + rank) * 5;
+#pragma unroll
+        for (int e = 0; e < 5; ++e) o[e] = r[e];
+    }
+    for (int c = k; c <= num_classes; c += PP_KMAX) {
+        int n = 0;
+        for (int j = 0; j < K; ++j) n += cls_s[j] < c ? 1 : 0;
+        bounds[(size_t)b * (num_classes + 1) + c] = n;
+    }
+}
+}  // namespace
+
+extern "C" int cn_ctdet_post_process_f32(const float *dets, int B, int K, int num_classes,
+                                         const double *to_source_2x3, int per_image, float scale,
+                                         float *rows, int32_t *bounds, void *stream)
+{
+    if (!dets || !to_source_2x3 || !rows || !bounds) return CN_ERR_NULL;
+    if (B <= 0 || K <= 0 || num_classes <= 0 || !(scale > 0.f)) return CN_ERR_SHAPE;
+    if (K > PP_KMAX) return CN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(ctdet_post_kernel, dim3(B), dim3(PP_KMAX), 0, (hipStream_t)stream, dets, K, num_classes,
+                       to_source_2x3, per_image ? 1 : 0, scale, rows, bounds);
+    CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -32,6 +32,7 @@ struct StemArgs {
     int H, W, Ho, Wo, Cout, KH, KW, stride, pad, relu, out_pitch, KP, tiles_per_image, cout_pad;
     float x_mul;      // f32s kernels: the image is multiplied by this (2^-e) before it is split
     uint32_t *range;  // f32s kernels: [1] receives max |x * x_mul| (cn_f32s_ctl), may be null
+    int y_f32s;       // stem + max-pool kernel: y is an f32s tensor (CN_CONV_STEM_Y_F32S), range side 0 = max |y|
 };
 
 template <int BN>
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
         }
         vmask = mk;
     };
-    float rng_in = 0.f;
+    float rng_in = 0.f, rng_out = 0.f;
     auto put = [&](int idx, float xr) {
         const float xs = xr * a.x_mul;
         cn_rng_upd1(rng_in, xs);
@@ -813,8 +814,16 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
                             const int pc = 2 * (2 * q + lh + 8 * i + 16 * wm) + h2;
-                            if (n < a.Cout)
-                                yb[(size_t)pc * a.out_pitch] = fmaxf(cur[t][(i * 4 + q) * 2 + h2], hp[i][q][h2]);
+                            if (n < a.Cout) {
+                                const float v = fmaxf(cur[t][(i * 4 + q) * 2 + h2], hp[i][q][h2]);
+                                if (a.y_f32s) {   // (high, low) halves of channel n: 32 lanes = 64 contiguous bytes each
+                                    cn_rng_upd1(rng_out, v);
+                                    cn_store1_f32s(a.y, (size_t)(b * PH + pr) * PW + (size_t)cb * (BM / 2) + pc,
+                                                   a.out_pitch, n, v);
+                                } else {
+                                    yb[(size_t)pc * a.out_pitch] = v;
+                                }
+                            }
                         }
             }
 #pragma unroll
@@ -831,7 +840,10 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
         par ^= 1;
         s = ns; y = ny; cb = ncb;
     }
-    if (a.range) cn_rng_commit(a.range, 1, rng_in);
+    if (a.range) {
+        cn_rng_commit(a.range, 1, rng_in);
+        if (a.y_f32s) cn_rng_commit(a.range, 0, rng_out);
+    }
 }
 
 template <int TPR>
@@ -1102,12 +1114,14 @@ int cn_stem_pool_rows(int B, int Ho, int Wo, int Cout, int KH, int KW, int strid
 
 int cn_stem_pool_f32s(const float *x, const float *w_packed, const float *scale, const float *shift,
                       float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
-                      int stride, int pad, int relu, int out_pitch, int KP, const cn_f32s_ctl *ctl,
+                      int stride, int pad, int relu, int out_pitch, int KP, int y_f32s, const cn_f32s_ctl *ctl,
                       hipStream_t st)
 {
     const int R = cn_stem_pool_rows(B, Ho, Wo, Cout, KH, KW, stride, KP);
     if (!R) return CN_ERR_UNSUPPORTED;
+    if (y_f32s && ((out_pitch & 31) || (((uintptr_t)y) & 127u))) return CN_ERR_ALIGN;
     StemArgs a;
+    a.y_f32s = y_f32s;
     a.x_mul = (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f;
     a.range = ctl ? ctl->range : nullptr;
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y;
@@ -1136,6 +1150,7 @@ int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, 
     if (persistent && KH == PKH && KW == PKW && Wo % BM == 0 && (stride == 1 || stride == 2) &&
         KP >= PKH * PKW * 3) {
         StemArgs a;
+        a.y_f32s = 0;
         a.x_mul = ctl_x_mul; a.range = ctl_range;
         a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y;
         a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = KH; a.KW = KW;
@@ -1175,6 +1190,7 @@ int cn_stem_conv_f32(const float *x, const float *w_packed, const float *scale, 
     }
     if ((long)3 * wy * (wx | 1) > WIN_MAX || wx > 2 * NT) return CN_ERR_UNSUPPORTED;
     StemArgs a;
+    a.y_f32s = 0;
     a.x_mul = 1.f; a.range = nullptr;   // fp32 kernel: nothing is split
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.y = y;
     a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = KH; a.KW = KW;

@@ -46,6 +46,117 @@ class _PhaseClock(object):
         return self.t
 
 
+class _FramePipe(object):
+    """Persistent resources of ``run_frames`` / ``run_frames_stream`` for one batch geometry
+    (B frames of (H, W, 3) uint8 at one test scale): ``depth`` sets of a pinned uint8 staging
+    buffer, its device copy and pinned result buffers, one copy stream, a few staging threads.
+
+    Per batch: the frames are copied into the pinned buffer by the staging threads (numpy releases
+    the GIL), go to the device as ONE asynchronous uint8 copy on the copy stream, and everything
+    else -- the batched device pre-process, network + decode (``run_batch``), the device tail
+    (``cn_ctdet_post_process_f32``: inverse affine + class grouping) and the copies of the rows /
+    class bounds / f32s range digest into pinned memory -- is enqueued on the launch stream
+    without a single host synchronisation.  The host waits for batch i - depth + 1 only when it
+    collects it, i.e. while later batches are on the device."""
+
+    def __init__(self, det, B, H, W, scale, depth):
+        import concurrent.futures
+        opt, dev = det.opt, det.opt.device
+        self.det, self.B, self.H, self.W, self.scale, self.depth = det, B, H, W, scale, depth
+        self.g = det.input_geometry(H, W, scale)
+        g = self.g
+        self.resize = (g.scaled_h, g.scaled_w) != (g.src_h, g.src_w)
+        self.meta = det._meta(g)
+        to_input = get_affine_transform(g.center, g.extent, 0, [g.inp_w, g.inp_h])
+        self.dst_to_src = (ctypes.c_double * 6)(*invert_affine(to_input).reshape(-1))
+        self.mean = (ctypes.c_float * 3)(*[float(v) for v in det.mean.reshape(-1)])
+        self.std = (ctypes.c_float * 3)(*[float(v) for v in det.std.reshape(-1)])
+        self.pinned_in = [torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self.np_in = [t.numpy() for t in self.pinned_in]
+        self.dev_in = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(depth)]
+        self.scaled = torch.empty((B, g.scaled_h, g.scaled_w, 3), dtype=torch.uint8, device=dev) \
+            if self.resize else None
+        self.batch = torch.empty((B, 3, g.inp_h, g.inp_w), device=dev, dtype=torch.float32)
+        self.copy_stream = torch.cuda.Stream()
+        self.ev_h2d = [torch.cuda.Event() for _ in range(depth)]
+        self.ev_pre = [torch.cuda.Event() for _ in range(depth)]
+        self.ev_done = [torch.cuda.Event() for _ in range(depth)]
+        self.used = [False] * depth
+        self.digest_host = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(depth)]
+        self.has_digest = [False] * depth
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=min(4, B))
+        self.tail = det._device_tail_alloc(self) if det._device_tail_alloc is not None else None
+        self.dets_host = None if self.tail is not None else [None] * depth
+
+    def _stage(self, slot, frames):
+        dst = self.np_in[slot]
+        n = len(frames)
+        step = -(-n // self.pool._max_workers)
+
+        def copy(lo):
+            for i in range(lo, min(lo + step, n)):
+                np.copyto(dst[i], frames[i])
+        list(self.pool.map(copy, range(0, n, step)))
+
+    def submit(self, i, frames):
+        det, lib, g, B = self.det, native.lib(), self.g, self.B
+        slot = i % self.depth
+        if self.used[slot]:
+            self.ev_h2d[slot].synchronize()      # the pinned buffer's previous upload has left it
+        self._stage(slot, frames)
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(self.copy_stream):
+            if self.used[slot]:
+                self.copy_stream.wait_event(self.ev_pre[slot])   # the device copy's previous reader is done
+            self.dev_in[slot].copy_(self.pinned_in[slot], non_blocking=True)
+            self.ev_h2d[slot].record(self.copy_stream)
+        self.used[slot] = True
+        cur.wait_event(self.ev_h2d[slot])
+        stream = native.stream_ptr()
+        src = self.dev_in[slot]
+        if self.resize:
+            for j in range(B):
+                native.check(lib.cn_resize_bilinear_u8(native.ptr(src[j]), g.src_h, g.src_w, g.src_w * 3,
+                                                       g.scaled_h, g.scaled_w, native.ptr(self.scaled[j]), stream),
+                             "cn_resize_bilinear_u8")
+            src = self.scaled
+        native.check(lib.cn_warp_normalize_u8_f32_batch(
+            native.ptr(src), B, g.scaled_h * g.scaled_w * 3, g.scaled_h, g.scaled_w, g.scaled_w * 3,
+            self.dst_to_src, g.inp_h, g.inp_w, self.mean, self.std, 0, native.ptr(self.batch), stream),
+            "cn_warp_normalize_u8_f32_batch")
+        self.ev_pre[slot].record()
+        dets = det.run_batch(self.batch)
+        plan = det.model.plan_for(B, g.inp_h, g.inp_w, self.batch.device)
+        rs = getattr(plan.b, "range_sum", None) if plan.b.range is not None else None
+        self.has_digest[slot] = rs is not None
+        if rs is not None:
+            self.digest_host[slot].copy_(rs, non_blocking=True)
+        if self.tail is not None:
+            det._device_tail_run(self, slot, dets)
+        else:
+            self.dets_host[slot] = torch.empty(dets.shape, dtype=dets.dtype).pin_memory() \
+                if self.dets_host[slot] is None else self.dets_host[slot]
+            self.dets_host[slot].copy_(dets, non_blocking=True)
+        self.ev_done[slot].record()
+
+    def collect(self, i, frames):
+        """Results of batch i (waits for it; later batches keep the device busy)."""
+        from ..engine import F16_MAX_BITS
+        det = self.det
+        slot = i % self.depth
+        self.ev_done[slot].synchronize()
+        if self.has_digest[slot] and (int(self.digest_host[slot][0]) & 0xffffffff) > F16_MAX_BITS:
+            # an f32s value was clamped somewhere up to this batch: results invalid.  Drain the
+            # device, let the module re-calibrate, and run this batch again synchronously.
+            torch.cuda.synchronize()
+            det.range_ok(None)
+            return det._run_frames_sync(frames, self.scale)
+        metas = [self.meta] * len(frames)
+        if self.tail is not None:
+            return det._device_tail_results(self, slot, len(frames))
+        return det.results_batch(self.dets_host[slot].numpy()[:len(frames)], metas, self.scale)
+
+
 class BaseDetector(object):
     def __init__(self, opt):
         if opt.gpus[0] < 0:
@@ -179,17 +290,12 @@ class BaseDetector(object):
         frames' metas -> what ``run(frame)['results']`` returns, per image."""
         raise NotImplementedError
 
-    def run_frames(self, frames):
-        """A list of (H, W, 3) uint8 BGR frames of one size -> list of per-image results, what
-        ``run(frame)['results']`` returns for each (single scale, no flip).  The reference's
-        test loop is batch_size = 1 (test.py:60-62); here the frames are uploaded as ONE uint8
-        copy, pre-processed on the device straight into one batch tensor, and the whole batch
-        goes through the network + decode once (``run_batch``); the host tail is vectorised."""
-        if len(self.scales) != 1 or self.opt.flip_test:
-            raise ValueError("run_frames is single-scale, no flip")
-        if len({tuple(f.shape) for f in frames}) != 1:
-            raise ValueError("run_frames needs frames of one size")
-        scale = self.scales[0]
+    # device tail of the frame pipeline: task classes that have one set the three hooks
+    _device_tail_alloc = None
+
+    def _run_frames_sync(self, frames, scale):
+        """One batch, synchronously, frame by frame through ``pre_process_device`` (the comparison
+        path of the pipeline, and its re-run path after an f32s re-calibration)."""
         uploaded = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).to(self.opt.device)
         g = self.input_geometry(uploaded.shape[1], uploaded.shape[2], scale)
         batch = torch.empty((len(frames), 3, g.inp_h, g.inp_w), device=self.opt.device,
@@ -202,6 +308,56 @@ class BaseDetector(object):
             if not self.range_ok(batch):
                 raise native.NativeError("f32s forward clamps values after re-calibration")
         return self.results_batch(dets, metas, scale)
+
+    def _pipe_for(self, frames, depth):
+        if len(self.scales) != 1 or self.opt.flip_test:
+            raise ValueError("run_frames is single-scale, no flip")
+        shapes = {tuple(f.shape) for f in frames}
+        if len(shapes) != 1:
+            raise ValueError("run_frames needs frames of one size")
+        (H, W, C), = shapes
+        if C != 3 or any(f.dtype != np.uint8 for f in frames):
+            raise ValueError("run_frames needs (H, W, 3) uint8 BGR frames")
+        key = (len(frames), H, W, self.scales[0], depth)
+        pipes = self.__dict__.setdefault("_pipes", {})
+        if key not in pipes:
+            if len(pipes) >= 4:
+                pipes.pop(next(iter(pipes)))
+            pipes[key] = _FramePipe(self, len(frames), H, W, self.scales[0], depth)
+        return pipes[key]
+
+    def run_frames(self, frames):
+        """A list of (H, W, 3) uint8 BGR frames of one size -> list of per-image results, what
+        ``run(frame)['results']`` returns for each (single scale, no flip).  The reference's
+        test loop is batch_size = 1 (test.py:60-62); here the frames are uploaded as ONE uint8
+        copy, pre-processed on the device in one launch straight into one batch tensor, the whole
+        batch goes through the network + decode once (``run_batch``) and, for ctdet, through the
+        device tail (inverse affine + class grouping); the host slices the result."""
+        pipe = self._pipe_for(frames, 1)
+        pipe.submit(0, frames)
+        return pipe.collect(0, frames)
+
+    def run_frames_stream(self, batches, depth=3):
+        """``run_frames`` over an iterable of batches (lists of frames, all batches of one size and
+        frame geometry), pipelined: while batch i is on the device the host stages batch i + 1
+        (pinned uint8 copy by a few threads, asynchronous upload on a copy stream) and builds the
+        result dictionaries of batch i - 1.  Yields the per-image results batch by batch, in order."""
+        pipe, pending = None, collections.deque()
+        n = 0
+        for frames in batches:
+            if pipe is None:
+                pipe = self._pipe_for(frames, depth)
+            elif (len(frames), ) + tuple(frames[0].shape) != (pipe.B, pipe.H, pipe.W, 3):
+                raise ValueError("run_frames_stream needs batches of one size and frame geometry")
+            if len(pending) == depth:
+                j, fr = pending.popleft()
+                yield pipe.collect(j, fr)
+            pipe.submit(n, frames)
+            pending.append((n, frames))
+            n += 1
+        while pending:
+            j, fr = pending.popleft()
+            yield pipe.collect(j, fr)
 
     def range_ok(self, images=None):
         """Synchronising look at the f32s range words of every forward since the last look

@@ -101,6 +101,45 @@ class CtdetDetector(BaseDetector):
             probe['dec_events'] = (e0, e1)
             return dets
 
+    # ---- device tail of the frame pipeline (base_detector._FramePipe)
+    def _device_tail_alloc(self, pipe):
+        """Buffers of cn_ctdet_post_process_f32 for one pipe, or None when the host tail has to
+        serve it (more detections than the kernel takes or than max_per_image keeps)."""
+        from ..image import get_affine_transform
+        K, nc, B, dev = self.opt.K, self.opt.num_classes, pipe.B, self.opt.device
+        if K > 128 or K > self.max_per_image:
+            return None
+        m = pipe.meta
+        to_source = get_affine_transform(m['c'], m['s'], 0, (m['out_width'], m['out_height']), inv=1)
+        t = {'to_source': torch.from_numpy(np.ascontiguousarray(to_source, np.float64).reshape(-1)).to(dev),
+             'rows': torch.empty((B, K, 5), device=dev, dtype=torch.float32),
+             'bounds': torch.empty((B, nc + 1), device=dev, dtype=torch.int32),
+             'rows_host': [torch.empty((B, K, 5), dtype=torch.float32).pin_memory() for _ in range(pipe.depth)],
+             'bounds_host': [torch.empty((B, nc + 1), dtype=torch.int32).pin_memory() for _ in range(pipe.depth)]}
+        return t
+
+    def _device_tail_run(self, pipe, slot, dets):
+        from .. import native
+        t, K, nc = pipe.tail, self.opt.K, self.opt.num_classes
+        dets = dets.contiguous()
+        native.check(native.lib().cn_ctdet_post_process_f32(
+            native.ptr(dets), pipe.B, K, nc, native.ptr(t['to_source']), 0, float(pipe.scale),
+            native.ptr(t['rows']), native.ptr(t['bounds']), native.stream_ptr()), "cn_ctdet_post_process_f32")
+        t['rows_host'][slot].copy_(t['rows'], non_blocking=True)
+        t['bounds_host'][slot].copy_(t['bounds'], non_blocking=True)
+
+    def _device_tail_results(self, pipe, slot, n):
+        """Per image ``{class: (n, 5) float32}`` -- the rows are already in source pixels and grouped
+        by class; what is left is 80 slices per image."""
+        t, nc = pipe.tail, self.opt.num_classes
+        rows = t['rows_host'][slot].numpy().copy()        # (the pinned buffer is reused by a later batch)
+        bounds = t['bounds_host'][slot].numpy().tolist()
+        out = []
+        for i in range(n):
+            r, bd = rows[i], bounds[i]
+            out.append({j + 1: r[bd[j]:bd[j + 1]] for j in range(nc)})
+        return out
+
     def results_batch(self, dets, metas, scale):
         """Host tail of ``run_frames``: (B, K, 6) host array -> per-image ``{class: (n, 5)}``."""
         return ctdet_results_batch(dets, metas, self.opt.num_classes, scale, self.max_per_image)

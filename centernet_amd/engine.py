@@ -23,7 +23,7 @@ import torch
 from . import native
 from .native import (ConvDesc, F32sCtl, LAYOUT_NCHW, LAYOUT_NHWC, DTYPE_F16, DTYPE_F32, DTYPE_F32S,
                      CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN, CONV_STEM_F32S,
-                     CONV_STEM_MAXPOOL)
+                     CONV_STEM_MAXPOOL, CONV_STEM_Y_F32S)
 
 # ---- f32s range policy (csrc/cn_common.h "Range") ------------------------------------------
 # A tensor of exponent e is stored as real * 2^-e.  e is chosen on a plain-fp32 calibration pass
@@ -414,7 +414,12 @@ class PlanBuilder:
                 t = torch.empty((x.B, co, Ho, Wo), device=self.device, dtype=torch.float32)
                 out = Act(t, x.B, Ho, Wo, co, nchw=True, lid=lid)
             elif fuse_pool:
-                out = self._new(x.B, Ho // 2, Wo // 2, co, lid=pool_lid)
+                # the pooled stem map goes to f32s layers (the first BasicBlock: conv + residual): written
+                # as an f32s tensor it lets them run on the persistent 3x3 kernel (CN_STEM_Y_F32S=0: plain)
+                y_s = stem_s and co % 32 == 0 and os.environ.get("CN_STEM_Y_F32S", "1") != "0"
+                out = self._new(x.B, Ho // 2, Wo // 2, co, fmt="f32s" if y_s else None, lid=pool_lid)
+                if y_s:
+                    flags |= CONV_STEM_Y_F32S
             else:
                 out = self._new(x.B, Ho, Wo, co,
                                 fmt="f32s" if (use_s and not out_plain) else None, lid=lid)
@@ -422,7 +427,7 @@ class PlanBuilder:
             out.lid, out.exp = lid, self._exp(lid)
         if use_s and out.fmt != "f32s":
             flags |= CONV_Y_PLAIN
-        assert use_s or out.fmt != "f32s"
+        assert use_s or stem_s or out.fmt != "f32s"
         if residual is not None and residual.pitch != out.pitch:
             # channel counts that are not a multiple of 32: an f32s tensor is padded to whole
             # groups, a plain one is not -- bring the residual to the output's format

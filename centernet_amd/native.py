@@ -23,6 +23,7 @@ DTYPE_F32 = 0
 DTYPE_F16 = 1
 DTYPE_F32S = 2        # fp32 values as fp16 (high, low) pairs: three fp16 MFMAs per product
 CONV_X_PLAIN, CONV_Y_PLAIN, CONV_R_PLAIN, CONV_STEM_F32S, CONV_STEM_MAXPOOL = 1, 2, 4, 8, 16
+CONV_STEM_Y_F32S = 32
 
 _lib = None
 
@@ -158,6 +159,12 @@ def _declare(lib):
     lib.cn_warp_normalize_u8_f32.argtypes = [vp, i, i, i, ctypes.POINTER(ctypes.c_double), i, i,
                                              ctypes.POINTER(ctypes.c_float),
                                              ctypes.POINTER(ctypes.c_float), i, vp, vp]
+    lib.cn_warp_normalize_u8_f32_batch.restype = i
+    lib.cn_warp_normalize_u8_f32_batch.argtypes = [vp, i, sz, i, i, i, ctypes.POINTER(ctypes.c_double), i, i,
+                                                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                                   i, vp, vp]
+    lib.cn_ctdet_post_process_f32.restype = i
+    lib.cn_ctdet_post_process_f32.argtypes = [vp, i, i, i, vp, i, ctypes.c_float, vp, vp, vp]
     lib.cn_resize_bilinear_u8.restype = i
     lib.cn_resize_bilinear_u8.argtypes = [vp, i, i, i, i, i, vp, vp]
     lib.cn_warp_affine_u8_host.restype = i

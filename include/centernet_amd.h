@@ -291,6 +291,10 @@ typedef struct cn_conv_desc {
  * Ho / Wo stay the convolution's output size, y is the pooled (B, Ho/2, Wo/2, out_pitch) tensor.
  * Only for shapes cn_stem_maxpool_supported() accepts, CN_ERR_UNSUPPORTED otherwise. */
 #define CN_CONV_STEM_MAXPOOL 16
+/* with CN_CONV_STEM_MAXPOOL: y (the pooled map) is written as an f32s tensor (out_pitch % 32 == 0,
+ * 128-byte aligned) holding y * 2^-e -- the exponent folded into scale / shift by the caller -- and
+ * side 0 of ctl.range receives max |y|: the consumers of the ResNet stem are f32s layers */
+#define CN_CONV_STEM_Y_F32S 32
 
 /* 1 when cn_conv2d accepts CN_CONV_STEM_MAXPOOL for this stem descriptor (7x7 / stride 2, 33..64
  * output channels, rows of 1..4 whole 128-pixel tiles, even Ho, batch * Ho large enough to fill
@@ -434,6 +438,22 @@ int cn_warp_normalize_u8_f32(const uint8_t *image_hwc, int H, int W, int pitch_b
                              const double *dst_to_src_2x3, int out_h, int out_w,
                              const float *mean3, const float *std3, int flip_concat,
                              float *out_nchw, void *stream);
+/* the same for N images of one geometry in ONE launch (frames of a video, a batch from the loader):
+ * images image_stride_bytes apart, outputs dense (N, 3 | 6, out_h, out_w) */
+int cn_warp_normalize_u8_f32_batch(const uint8_t *images_hwc, int N, size_t image_stride_bytes, int H, int W,
+                                   int pitch_bytes, const double *dst_to_src_2x3, int out_h, int out_w,
+                                   const float *mean3, const float *std3, int flip_concat,
+                                   float *out_nchw, void *stream);
+/* ctdet_post_process + the per-class split (utils/post_process.py:83-100, utils/image.py:19-24,63-66,
+ * detectors/ctdet.py:47-56) on the device.  dets (B, K, 6) raw detections in output-grid units (K <= 128);
+ * to_source_2x3: the float64 inverse map of get_affine_transform(c, s, 0, out_size, inv=1) -- one for
+ * all images (per_image = 0) or B of them on the device (per_image = 1; device pointer either way);
+ * rows (B, K, 5): [x1, y1, x2, y2, score] in source pixels / scale, grouped by class, inside a class
+ * in their original order; bounds (B, num_classes + 1): class j of image b = rows[b, bounds[b, j] :
+ * bounds[b, j + 1]] (rows with a class outside [0, num_classes) lie behind bounds[b, num_classes]).
+ * Bit-identical to the reference's float64 affine + float32 rounding. */
+int cn_ctdet_post_process_f32(const float *dets, int B, int K, int num_classes, const double *to_source_2x3,
+                              int per_image, float scale, float *rows, int32_t *bounds, void *stream);
 int cn_resize_bilinear_u8(const uint8_t *image_hwc, int H, int W, int pitch_bytes, int out_h,
                           int out_w, uint8_t *out_hwc, void *stream);
 

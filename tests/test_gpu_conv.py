@@ -165,22 +165,30 @@ def test_stem_with_fused_maxpool_equals_two_launches(dev, cfg, monkeypatch):
     w = torch.from_numpy(synth.normal((Cout, 3, 7, 7), (2.0 / 147) ** 0.5, 2))
     bn = _bn(Cout, 4)
 
-    def build(fuse):
+    def build(fuse, y_f32s="0"):
         monkeypatch.setenv("CN_FUSE_STEM_POOL", "1" if fuse else "0")
+        monkeypatch.setenv("CN_STEM_Y_F32S", y_f32s)
         pb = PlanBuilder(dev, B, H, W, split=True)
         y = pb.conv(pb.set_input(3), w, bn=bn, relu=True, stride=2, padding=3, pool=(3, 2, 1))
         pb.input.t = x.to(dev)
         _run(pb)
-        return y.t.clone(), len(pb.ops)
-    two, n2 = build(False)
-    one, n1 = build(True)
+        return y, len(pb.ops)
+    (two, n2), (one, n1) = build(False), build(True)
     assert n2 == 2
     assert n1 == (1 if expect_fused else 2), (n1, cfg)
-    assert one.shape == two.shape == (B, H // 4, W // 4, Cout)
-    assert torch.equal(one, two)
+    assert one.fmt == two.fmt == "f32" and one.t.shape == two.t.shape == (B, H // 4, W // 4, Cout)
+    assert torch.equal(one.t, two.t)
     nb = min(B, 2)
     ref = F.max_pool2d(F.relu(bn(F.conv2d(x[:nb], w, None, 2, 3))), 3, 2, 1).detach()
-    _check(one[:nb].permute(0, 3, 1, 2).cpu(), ref)
+    _check(one.t[:nb].permute(0, 3, 1, 2).cpu(), ref)
+    # the default form: the pooled map written as an f32s tensor (the consumers are f32s layers) --
+    # the same values, each as its fp16 (high, low) pair, pad channels of the last group zero
+    if expect_fused and Cout % 32 == 0:
+        ys, ns = build(True, "1")
+        assert ns == 1 and ys.fmt == "f32s"
+        h = one.t.half()
+        want = h.float() + (one.t - h.float()).half().float()
+        assert torch.equal(ys.to_float(), want)
 
 
 def test_stem_conv_nchw_input(dev):

@@ -215,6 +215,46 @@ def test_multi_pose_run_frames_equals_run(dev):
         assert np.abs(a - b).max() < 5e-3                      # pixels
 
 
+def test_run_frames_stream_equals_run_frames_and_the_host_tail(dev):
+    """run_frames_stream (pinned staging, asynchronous upload on a copy stream, batched device
+    pre-process, device tail cn_ctdet_post_process_f32, no host synchronisation between batches)
+    returns, batch by batch and in order, exactly what run_frames returns for each batch alone;
+    and the device tail is bit-identical to the host tail (ctdet_results_batch: the reference's
+    float64 affine + float32 rounding + per-class split, utils/post_process.py:83-100) on the same
+    raw detections -- including test scale 0.5 (the resize in front of the warp, boxes / scale)."""
+    import contextlib, sys
+    from centernet_amd.opts import opts
+    from centernet_amd.detectors.detector_factory import detector_factory
+    from centernet_amd.post_process import ctdet_results_batch
+    for scales in ("1", "0.5"):
+        with contextlib.redirect_stdout(sys.stderr):
+            opt = opts().init(["ctdet", "--arch", "resdcn_18", "--input_h", "128", "--input_w", "128",
+                               "--test_scales", scales])
+            det = detector_factory[opt.task](opt)
+        synth.fill_state_dict_(det.model, 317)
+        det.model.invalidate_plans()
+        rng = np.random.RandomState(7)
+        batches = [[rng.randint(0, 256, (100, 140, 3)).astype(np.uint8) for _ in range(4)] for _ in range(5)]
+        alone = [det.run_frames(b) for b in batches]
+        streamed = list(det.run_frames_stream(iter(batches), depth=2))
+        assert len(streamed) == len(batches)
+        for ra, rs in zip(alone, streamed):
+            assert len(ra) == len(rs) == 4
+            for a, b in zip(ra, rs):
+                for j in range(1, 81):
+                    assert a[j].dtype == np.float32 and np.array_equal(a[j], b[j]), j
+        # device tail vs host tail on the same raw detections
+        pipe = det._pipe_for(batches[0], 1)
+        assert pipe.tail is not None
+        pipe.submit(0, batches[0])
+        got = pipe.collect(0, batches[0])
+        raw = det.run_batch(pipe.batch).detach().cpu().numpy()
+        want = ctdet_results_batch(raw, [pipe.meta] * 4, det.opt.num_classes, pipe.scale, det.max_per_image)
+        for a, b in zip(got, want):
+            for j in range(1, 81):
+                assert a[j].shape == b[j].shape and np.array_equal(a[j].view(np.int32), b[j].view(np.int32)), j
+
+
 def test_run_frames_equals_run(dev):
     """run_frames (batched, device pre-process) == run() per frame (same kernels per image up to
     the batch-size dependent split-K summation order)."""

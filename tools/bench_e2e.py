@@ -34,3 +34,15 @@ for B in (8, 32):
     for _ in range(n): det.run_frames(fr)
     dt = (time.perf_counter() - t) / n
     print("%s run_frames(B=%d) %.2f ms/batch  %.0f img/s (uint8 H2D + device pre-process + net + decode + D2H + host post)" % (arch, B, dt * 1e3, B / dt))
+
+# pipelined form: batches staged / uploaded / collected around the device work (run_frames_stream)
+for B in (8, 32):
+    nb = 24
+    batches = [[frames[(i + j) % 32] for j in range(B)] for i in range(nb)]
+    for _ in det.run_frames_stream(iter(batches[:4])): pass
+    t = time.perf_counter()
+    n = sum(len(r) for r in det.run_frames_stream(iter(batches)))
+    dt = time.perf_counter() - t
+    print("%s run_frames_stream(B=%d) %.2f ms/batch  %.0f img/s (pinned staging by 4 threads + async uint8 H2D on a copy "
+          "stream + batched device pre-process + net + decode + device tail + D2H, pipelined 3 deep, %d batches)"
+          % (arch, B, dt / nb * 1e3, n / dt, nb))
