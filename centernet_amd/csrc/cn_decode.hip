@@ -650,12 +650,17 @@ __device__ __forceinline__ uint32_t image_threshold(const uint32_t *__restrict__
 // the image's list -- capacity C * K -- cannot overflow whatever the map holds:
 //   n <= K qualifying cells        -> all of them
 //   K < n <= PLCAP                 -> exact select of the K best from the LDS list
-//   n > PLCAP (saturated plateaus) -> exact select over the cells of the plane, keys recomputed per
-//                                     pass from global memory (slow: tens of microseconds; rare)
+//   n > PLCAP                      -> (class planes with a high bias hold most of an image's candidates)
+//                                     the plane raises ITS threshold to the K-th best of the PLCAP keys
+//                                     it did keep -- the plane's own K best all reach it -- and
+//                                     collects again; only if that changes nothing (a plateau of more
+//                                     than PLCAP equal scores)
+//                                  -> exact select over the cells of the plane, keys recomputed per
+//                                     pass from global memory (slow: hundreds of microseconds; rare)
 // and a DEGENERATE image (threshold <= 0: fewer than K groups with a positive peak, constant maps --
 // zeros of suppressed cells take part in the top K) takes the last route for every plane with all
 // cells admitted: every input is handled exactly, by the same two launches.
-constexpr int PLCAP = 512;    // candidate keys of a plane kept in LDS
+constexpr int PLCAP = 1024;   // candidate keys of a plane kept in LDS
 
 __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, int C, int H, int W, int nrg,
                                               int ncb, int flags, int K, const uint32_t *__restrict__ gall,
@@ -679,8 +684,7 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
     u64 *kimg = keys + (size_t)b * cap;
     const int w4 = W >> 2;
     const float NEG_INF = -__builtin_huge_valf();
-    if (tid == 0) pl_cnt = 0;
-    __syncthreads();
+    uint32_t tcur = tkey;          // the plane's current threshold (raised when its list overflows)
 
     auto collect_group = [&](int g) {
         const int rg = g / ncb, cb = g - rg * ncb;
@@ -737,7 +741,7 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
             const int y = y0 - 1 + r;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool take = col_ok && y < H && cell_key(r, e) >= tkey;
+                const bool take = col_ok && y < H && cell_key(r, e) >= tcur;
                 tmask |= take ? (1u << ((r - 1) * 4 + e)) : 0u;
             }
         }
@@ -768,7 +772,11 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
             }
         }
     };
-    if (!degenerate) {
+    bool plateau = false;
+    if (!degenerate)
+    for (int round = 0;; ++round) {
+        if (tid == 0) pl_cnt = 0;
+        __syncthreads();
         const int ng = nrg * ncb;
         // which groups can hold a qualifying cell: all group maxima are fetched at once (a chain of
         // dependent loads here cost more than the whole streaming pass)
@@ -794,9 +802,21 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
             for (int i = hw; i < nlive; i += NT / 32) collect_group(glist[i]);
             __syncthreads();
         }
+        if (pl_cnt <= PLCAP) break;            // (uniform: read behind the barrier)
+        // more qualifying cells than the list holds: raise the plane's threshold to the K-th best of the
+        // PLCAP keys that were kept (its own K best all reach that) and collect again
+        auto kept = [&](auto &&f) {
+            for (int j = tid; j < PLCAP; j += NT) f((uint32_t)(pl_keys[j] >> 32));
+        };
+        const uint32_t tnew = kth_largest_key32<NT>(kept, (uint32_t)K, sh);
+        if (tnew == tcur || round == 3) {      // a plateau of equal scores (or no progress): exact select below
+            plateau = true;
+            break;
+        }
+        tcur = tnew;
     }
     // ---- hand the plane's keys on: at most its K best
-    const int n = degenerate ? PLCAP + 1 : pl_cnt;      // (uniform; the last loop round ended with a barrier)
+    const int n = (degenerate || plateau) ? PLCAP + 1 : pl_cnt;      // (uniform; the last loop round ended with a barrier)
     int m;                                              // keys this plane emits
     const u64 *src;
     if (n <= K) {
@@ -835,7 +855,7 @@ __device__ __forceinline__ void plane_collect(const float *__restrict__ heat, in
                         }
                     }
                     const uint32_t kk = f2key(((mx == v) ? v : 0.0f) + 0.0f);   // heat * keep, -0.0 -> +0.0
-                    if (degenerate || kk >= tkey)
+                    if (degenerate || kk >= tcur)
                         f(((u64)kk << 32) | (u64)(0xFFFFFFFFu - (base + (uint32_t)e)), kk == KEY_ZERO);
                 }
             };

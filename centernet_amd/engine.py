@@ -137,7 +137,7 @@ def fold_bn(conv_bias, bn, cout, device):
 class PlanBuilder:
     """Records launches for one (B, H, W) input shape."""
 
-    RANGE_LAUNCHES = 256   # launches per plan that may split fp32 values (cn_f32s_ctl.range)
+    RANGE_LAUNCHES = 256   # launches per chunk of range words (cn_f32s_ctl.range); a plan takes as many chunks as it needs
     RANGE_WORDS = 2 * 64 * 16   # CN_RANGE_WORDS: 2 sides x 64 slots x one word per 64-byte line
 
     def __init__(self, device, B, H, W, dtype=torch.float32, wcache=None, split=None, exps=None,
@@ -177,6 +177,7 @@ class PlanBuilder:
         # range words of the launches that split values: [cur | hi | lo] x RANGE_WORDS, int32
         # views of float bit patterns (non-negative floats order like integers)
         self.range = None
+        self.range_chunks = [] # (cur, stat) tensors per RANGE_LAUNCHES launches
         self.range_slots = []  # slot -> logical id of the launch, for messages
         self._pack_events = [] # completion of weight-pack kernels this plan depends on
         # range words at every split site (csrc/cn_common.h "Range"); ``track=False`` (or CN_RANGE=0)
@@ -204,23 +205,24 @@ class PlanBuilder:
         c.x_mul, c.res_mul = float(x_mul), float(res_mul)
         c.range = None
         if self.track:
-            if self.range is None:
-                # cur: per launch CN_RANGE_WORDS; stat: [hi | lo] x (launch, side)
-                self.range = torch.zeros((self.RANGE_LAUNCHES, self.RANGE_WORDS), device=self.device,
-                                         dtype=torch.int32)
-                self.range_stat = torch.zeros((2, self.RANGE_LAUNCHES, 2), device=self.device,
-                                              dtype=torch.int32)
-                self.range_stat[1].fill_(0x7f800000)
-                # sticky digest of the tables (cn_range_fold_digest) + its pinned host mirror: what
-                # the per-forward check reads (8 bytes, no table walk)
-                self.range_sum = torch.tensor([0, 0x7f800000], device=self.device, dtype=torch.int32)
-                self.range_sum_host = torch.tensor([0, 0x7f800000], dtype=torch.int32).pin_memory()
-                self.range_sum_event = torch.cuda.Event()
             slot = len(self.range_slots)
-            if slot >= self.RANGE_LAUNCHES:
-                raise native.NativeError("too many f32s launches for the range table")
+            ci, si = divmod(slot, self.RANGE_LAUNCHES)
+            if ci == len(self.range_chunks):
+                # range words grow in chunks of RANGE_LAUNCHES launches -- cur: per launch CN_RANGE_WORDS;
+                # stat: [hi | lo] x (launch, side) -- folded chunk by chunk into ONE digest
+                cur = torch.zeros((self.RANGE_LAUNCHES, self.RANGE_WORDS), device=self.device, dtype=torch.int32)
+                stat = torch.zeros((2, self.RANGE_LAUNCHES, 2), device=self.device, dtype=torch.int32)
+                stat[1].fill_(0x7f800000)
+                self.range_chunks.append((cur, stat))
+                if self.range is None:
+                    self.range, self.range_stat = cur, stat
+                    # sticky digest of the tables (cn_range_fold_digest) + its pinned host mirror: what
+                    # the per-forward check reads (8 bytes, no table walk)
+                    self.range_sum = torch.tensor([0, 0x7f800000], device=self.device, dtype=torch.int32)
+                    self.range_sum_host = torch.tensor([0, 0x7f800000], dtype=torch.int32).pin_memory()
+                    self.range_sum_event = torch.cuda.Event()
             self.range_slots.append(lid)
-            c.range = self.range.data_ptr() + 4 * self.RANGE_WORDS * slot
+            c.range = self.range_chunks[ci][0].data_ptr() + 4 * self.RANGE_WORDS * si
         self.keep.append(c)
         return c
 
@@ -880,18 +882,33 @@ class PlanBuilder:
         """Close the launch list: one tiny launch folds this forward's range words into the
         running (largest, smallest) per-launch maxima the host reads at its next look."""
         if self.range is not None and self.range_slots:
-            lib, n = self.lib, len(self.range_slots)
-            cur = ctypes.c_void_p(self.range.data_ptr())
-            hi, lo = (ctypes.c_void_p(self.range_stat[i].data_ptr()) for i in range(2))
+            lib = self.lib
             dig = ctypes.c_void_p(self.range_sum.data_ptr())
+            left = len(self.range_slots)
+            for cur_t, stat_t in self.range_chunks:
+                n = min(left, self.RANGE_LAUNCHES)
+                left -= n
+                cur = ctypes.c_void_p(cur_t.data_ptr())
+                hi, lo = (ctypes.c_void_p(stat_t[i].data_ptr()) for i in range(2))
 
-            def run():
-                rc = lib.cn_range_fold_digest(cur, hi, lo, dig, n, native.stream_ptr())
-                if rc:
-                    native.check(rc, "cn_range_fold_digest")
-            self.ops.append(run)
-            self.meta.append(dict(kind="range", flops=0, bytes=0))
-            self.trace.append(("range", None))
+                def run(cur=cur, hi=hi, lo=lo, n=n):
+                    rc = lib.cn_range_fold_digest(cur, hi, lo, dig, n, native.stream_ptr())
+                    if rc:
+                        native.check(rc, "cn_range_fold_digest")
+                self.ops.append(run)
+                self.meta.append(dict(kind="range", flops=0, bytes=0))
+                self.trace.append(("range", None))
+
+    def range_reset(self):
+        """Forget what the range words have seen so far (tables and digest)."""
+        for cur_t, stat_t in self.range_chunks:
+            cur_t.zero_()
+            stat_t[0].zero_()
+            stat_t[1].fill_(0x7f800000)
+        if self.range is not None:
+            fresh = torch.tensor([0, 0x7f800000], dtype=torch.int32)
+            self.range_sum.copy_(fresh)
+            self.range_sum_host.copy_(fresh)
 
 
 class Plan:
@@ -970,10 +987,12 @@ class Plan:
         if b.range is None or not b.range_slots:
             return None
         n = len(b.range_slots)
-        host = b.range_stat[:, :n].cpu()            # synchronises with the launch stream
-        if reset:
-            b.range_stat[0, :n].zero_()
-            b.range_stat[1, :n].fill_(0x7f800000)
+        RL = b.RANGE_LAUNCHES
+        host = torch.cat([st[:, :min(RL, n - i * RL)] for i, (_, st) in enumerate(b.range_chunks)], dim=1).cpu()
+        if reset:                                   # (the .cpu() above synchronised with the launch stream)
+            for _, st in b.range_chunks:
+                st[0].zero_()
+                st[1].fill_(0x7f800000)
         hi = host[0].contiguous().view(torch.float32).tolist()
         lo = host[1].contiguous().view(torch.float32).tolist()
         return [(lid, (hi[i][0], lo[i][0]), (hi[i][1], lo[i][1])) for i, lid in enumerate(b.range_slots)]
@@ -1040,6 +1059,10 @@ class Plan:
             for op in self.b.ops:
                 op()
         self.graph = g
+        # the zero-image warm-up and capture runs above went through the range words: forget them
+        # (an all-zero forward must not read as a tensor far below its calibrated range)
+        torch.cuda.current_stream().synchronize()
+        self.b.range_reset()
         return self
 
 

@@ -525,6 +525,36 @@ def test_recalibration_that_changes_nothing_keeps_the_plans(dev):
         assert m.__dict__["_calibrations"] == n and dict(m.exponents) == e0
 
 
+def test_range_tables_grow_in_chunks(dev, monkeypatch):
+    """A plan takes as many chunks of range words as it has f32s launches (deep networks are not
+    capped by a fixed table): with 8 launches per chunk res_18 needs several, every launch still
+    reports its maxima, the digest still sees a clamped value, and a HIP-graph capture leaves the
+    words clean."""
+    from centernet_amd import engine
+    from centernet_amd.model import create_model
+    monkeypatch.setattr(engine.PlanBuilder, "RANGE_LAUNCHES", 8)
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    m = create_model("res_18", dict(heads), 64)
+    synth.fill_state_dict_(m, 317)
+    m = m.to(dev).eval()
+    x = synth.images(1, 128, 128, seed=5).to(dev)
+    with torch.no_grad():
+        m(x)
+        plan = next(iter(m.__dict__["_plans"].values()))
+        nslots = len(plan.b.range_slots)
+        assert nslots > 16 and len(plan.b.range_chunks) == -(-nslots // 8)
+        m(x, check=False)
+        rep = plan.range_report(reset=False)
+        assert len(rep) == nslots
+        assert all(max(r[1][0], r[2][0]) > 0.0 for r in rep), "a launch of a later chunk reported nothing"
+        n = m.__dict__["_calibrations"]
+        m(x * 1000.0)                       # clamps somewhere -> detected through the digest, re-calibrated, re-run
+        assert m.__dict__["_calibrations"] == n + 1
+        plan = m.plan_for(1, 128, 128, x.device).capture()
+        assert plan.range_status(reset=False)[0] == "ok"
+        assert int(plan.b.range_sum[0]) == 0, "capture warm-up must not leave anything in the digest"
+
+
 def test_detector_reruns_a_clamped_batch(dev):
     """detector.run() / process() look at the range words where the reference synchronises;
     run_frames() where it copies the detections to the host."""
