@@ -74,6 +74,8 @@ def pmc_traffic(tag):
     # class sums, a 2-in-36 overestimate with the profile command's 30 + 3 steps)
     def is_heads(k):
         base, targs = short(k)
+        if base == "conv3x3p_kernel":     # <RES, OUT_PLAIN, DBG, HEADS, NTAP, S2>: the fused heads of the persistent kernel
+            return len(targs) > 2 and targs[2] in ("true", 1)
         return base == "conv3x3s1_kernel" and len(targs) > 4 and targs[4] in ("true", 1)
     heads = {k: v.get("launches", 0) for k, v in raw.items() if isinstance(v, dict) and is_heads(k)}
     main = [n_ for k, n_ in heads.items() if "cn_f32s" in k] or [n_ for k, n_ in heads.items() if "DF16_" in k] \
@@ -93,7 +95,7 @@ def pmc_traffic(tag):
             c = "dcn"
         elif base.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_")):
             c = "conv"
-        elif base.startswith(("nms_topk", "merge_topk", "peak_", "group_", "pose_match", "decode_")):
+        elif base.startswith(("nms_topk", "merge_topk", "peak_", "group_", "pose_match", "decode_", "collect_merge")):
             c = "decode"
         elif base.startswith("maxpool"):
             c = "maxpool"

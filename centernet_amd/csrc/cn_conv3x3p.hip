@@ -94,7 +94,7 @@ struct P3Args {
                               // (with the loaders at priority 3 the raised priority measured 3-5 % faster)
     // instrumented instantiation only (DBG = true; cn_conv3x3p_probe): ablation switches and cycle counters
     int dbg;                  // 1: no MFMAs, 2: no fragment reads (and no MFMAs), 4: no weight DMA, 8: no halo DMA,
-                              // 16: no epilogue, 32: no output stores
+                              // 16: no epilogue, 32: no output stores, 64: half of the fragment reads
     unsigned long long *prof; // [workgroup][wave 5][8] cycle counters, or null
 };
 
@@ -692,6 +692,18 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
         asm volatile("" : "+v"(ax), "+v"(bx));
         const int tapimm = DECONV ? 0 : tapoff;   // (a compile-time immediate in the 9-tap form)
         constexpr int blk1 = 2 * P_HW * 128;   // block 1 of the wave: two tile rows below block 0
+        if (DBG && (a.dbg & 64)) {
+            // ablation: half of the fragment reads (the low parts re-use the high parts' registers)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                wf[kh] = lds128(wb + (bx ^ (kh << 5)));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) xf[kh][i] = lds128(hb + tapimm + i * blk1 + (ax ^ (kh << 5)));
+                wf[2 + kh] = wf[kh];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) xf[2 + kh][i] = xf[kh][i];
+            }
+        } else
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             // (the operands of the first products first)

@@ -187,7 +187,8 @@ lib.cn_set_tuning(30, 0)
 # instrumented instantiation (cn_conv3x3p_probe)
 lib.cn_conv3x3p_probe.argtypes = [ctypes.c_int, ctypes.c_void_p]
 NAMES = {0: "full", 1: "no MFMA", 2: "no frag reads / MFMA", 12: "no DMA", 16: "no epilogue", 32: "no stores",
-         28: "no DMA, no epilogue", 3 | 16: "barriers + DMA only", 31: "barriers only"}
+         28: "no DMA, no epilogue", 3 | 16: "barriers + DMA only", 31: "barriers only", 64: "half the frag reads",
+         64 | 16: "half the frag reads, no epilogue"}
 print("== probes (instrumented instantiation), B = 32")
 for (ci, H, W, co) in ([(64, 128, 128, 64), (256, 32, 32, 256)] if os.environ.get("PROBE") else []):
     for res in (0, 1):
@@ -196,7 +197,7 @@ for (ci, H, W, co) in ([(64, 128, 128, 64), (256, 32, 32, 256)] if os.environ.ge
         lib.cn_set_tuning(28, 1)
         prof = torch.zeros((512, 6, 8), device=dev, dtype=torch.int64)
         row = []
-        for dbg in (0, 1, 2, 12, 16, 32, 28, 19, 31):
+        for dbg in (0, 64, 0, 64, 64 | 16, 1, 2, 12, 16, 32, 28, 19, 31):
             lib.cn_conv3x3p_probe(dbg, prof.data_ptr())
             ms = c.time(10)
             row.append("%s %.4f" % (NAMES[dbg], ms))
