@@ -315,18 +315,21 @@ def test_stem_at_every_image_scale(dev, pool, scale):
     pb32.input.t = x.float().to(dev)
     _run(pb32)
     err32 = _rel(y32.t[:nb].permute(0, 3, 1, 2).cpu(), ref)
-    pb = PlanBuilder(dev, B, H, W, split=True, exps={"input": _exp(x)})
+    # (the fused stem + pool kernel writes its map as an f32s tensor with the exponent of "t1/pool")
+    pb = PlanBuilder(dev, B, H, W, split=True, exps={"input": _exp(x), "t1/pool": _exp(ref)})
     y = pb.conv(pb.set_input(3), w.float(), bn=bn, relu=True, stride=2, padding=3,
                 pool=(3, 2, 1) if pool else None)
     pb.input.t = x.float().to(dev)
-    assert len(pb.ops) == 1
+    assert len(pb.ops) == 1 and y.fmt == ("f32s" if pool else "f32")
     _run(pb)
-    err = _rel(y.t[:nb].permute(0, 3, 1, 2).cpu(), ref)
+    err = _rel(y.to_float()[:nb].permute(0, 3, 1, 2).cpu(), ref)
     _report(test="stem", pool=pool, scale=scale, f32s=err, fp32_mfma=err32)
     assert err <= _bar(err32), (err, err32)
     wd = _words(pb)["t1"]
     want = float(x.float().abs().max()) * 2.0 ** -_exp(x)
     assert abs(wd[1] - want) <= 1e-6 * want, (wd, want)
+    if pool:    # the output side of the launch is tracked too: max |y| in stored units
+        assert 2.0 ** 8 <= wd[0] < 2.0 ** 11, wd
 
 
 @pytest.mark.parametrize("scale", SCALES)
