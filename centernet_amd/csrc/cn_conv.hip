@@ -934,7 +934,7 @@ int cn_conv3x3s2_persist(const void *x, const void *w_packed, const float *scale
                          int out_plain, const cn_f32s_ctl *ctl, hipStream_t st);
 int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
-                 int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
+                 int in_pitch, int out_pitch, int res_pitch, int relu, int vec_out, int setprio, int bn_class,
                  int f16, const cn_f32s_ctl *ctl, hipStream_t st);
 int cn_conv3x3_c16(const float *x, const float *w_packed, const float *scale, const float *shift,
                    float *y, int B, int H, int W, int Ho, int Wo, int Cin, int Cout, int stride,
@@ -1193,6 +1193,30 @@ static int dense_ksplit(const cn_conv_desc *d, const IgemmArgs &a)
     return plan_ksplit(a.M, d->Cout, a.KT, bm, bn);
 }
 
+static bool is_3x3s1(const cn_conv_desc *d)
+{
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->dil == 1 &&
+           d->oy_mul == 1 && d->ox_mul == 1 && d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho &&
+           d->OW == d->Wo;
+}
+
+// (mirror of cn_conv2d's route to cn_conv3x3s1; the caller passes the workspace its query asked for,
+// so a layer that wants split-K gets it and stays on the implicit-GEMM kernel)
+extern "C" int cn_conv2d_res_pitch_supported(const cn_conv_desc *d)
+{
+    IgemmArgs a = {};
+    if (!d || conv_fill_args(d, &a) != CN_OK) return 0;
+    if (g_tune_nohalo || !is_3x3s1(d) || is_stem(d->Cin, d->in_layout) || d->out_layout != CN_LAYOUT_NHWC) return 0;
+    if (d->dtype == CN_DTYPE_F32 && d->Cin == 16 && d->Cout <= 32) return 0;     // cn_conv16.hip
+    if (d->dtype == CN_DTYPE_F32S && (d->flags & CN_CONV_X_PLAIN) && (d->flags & CN_CONV_Y_PLAIN) && d->Cin == 16 &&
+        d->Cout <= 32)
+        return 0;
+    a.in_plain = (d->flags & CN_CONV_X_PLAIN) ? 1 : 0;
+    a.out_plain = (d->flags & CN_CONV_Y_PLAIN) ? 1 : 0;
+    a.res_plain = (d->flags & CN_CONV_R_PLAIN) ? 1 : 0;
+    return dense_ksplit(d, a) > 1 ? 0 : 1;
+}
+
 extern "C" size_t cn_conv2d_workspace_bytes(const cn_conv_desc *d)
 {
     IgemmArgs a = {};
@@ -1308,11 +1332,13 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         if (rc != CN_ERR_UNSUPPORTED) return rc;
     }
     // 3x3 / stride 1 / pad 1: the LDS-halo kernel (cn_conv3x3.hip) unless split-K applies
-    if (!g_tune_nohalo && a.ksplit == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
-        d->pad_h == 1 && d->pad_w == 1 && d->dil == 1 && d->oy_mul == 1 && d->ox_mul == 1 &&
-        d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho && d->OW == d->Wo)
+    const int res_pitch = d->res_pitch > 0 ? d->res_pitch : d->out_pitch;
+    const bool to_halo = !g_tune_nohalo && a.ksplit == 1 && is_3x3s1(d);
+    // a residual at its own pixel pitch (channel slices of wider tensors): only the 3x3 / s1 kernels
+    if (residual && res_pitch != d->out_pitch && !to_halo) return CN_ERR_UNSUPPORTED;
+    if (to_halo)
         return cn_conv3x3s1(x, w_packed, scale, shift, residual, y, d->B, d->H, d->W, d->Cin,
-                            d->Cout, d->in_pitch, d->out_pitch, d->relu, a.vec_out,
+                            d->Cout, d->in_pitch, d->out_pitch, res_pitch, d->relu, a.vec_out,
                             g_tune_setprio | ((g_tune_bm256 & 1) << 1) | ((g_tune_bm256 >> 1) << 3) | (g_tune_waves8 << 2) | (g_tune_occ4 << 7) |
                                 ((g_tune_dbgskip & 7) << 4) | ((g_tune_dbgskip >> 3) << 9), cls, d->dtype | (d->flags << 8),
                             &d->ctl, st);

@@ -1296,9 +1296,10 @@ static void c3_set_ctl(C3Args &a, const cn_f32s_ctl *ctl)
 // f16: 0 = fp32 tensors, 1 = fp16 tensors (fp32 accumulate, scale/shift fp32)
 int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const float *shift,
                  const void *residual, void *y, int B, int H, int W, int Cin, int Cout,
-                 int in_pitch, int out_pitch, int relu, int vec_out, int setprio, int bn_class,
+                 int in_pitch, int out_pitch, int res_pitch, int relu, int vec_out, int setprio, int bn_class,
                  int f16, const cn_f32s_ctl *ctl, hipStream_t st)
 {
+    if (res_pitch <= 0) res_pitch = out_pitch;
     C3Args a = {};
     c3_set_ctl(a, ctl);
     a.bm256 = ((setprio >> 1) & 1) | ((setprio >> 2) & 2);  // bits 1 and 3 of the knob word: cn_set_tuning key 14
@@ -1309,7 +1310,7 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.in_pitch = in_pitch;
     a.out_pitch = out_pitch; a.relu = relu; a.vec_out = vec_out; a.setprio = setprio;
-    a.res_pitch = out_pitch;
+    a.res_pitch = res_pitch;
     // f16: the dtype code CN_DTYPE_F32 / F16 / F32S in the low byte, cn_conv_desc.flags above it
     a.in_plain = (f16 >> 8) & CN_CONV_X_PLAIN ? 1 : 0;
     a.out_plain = (f16 >> 8) & CN_CONV_Y_PLAIN ? 1 : 0;
@@ -1324,9 +1325,9 @@ int cn_conv3x3s1(const void *x, const void *w_packed, const float *scale, const 
     a.wfrag_off = (size_t)9 * a.cout_pad * a.cin_pad * 4;   // behind the row-ordered copy
     // f32s tensors on both sides: the persistent loader / consumer kernel (cn_conv3x3p.hip)
     if (f16 == CN_DTYPE_F32S && !a.dbg && vec_out && scale &&
-        cn_conv3x3p_takes(B, H, W, Cin, Cout, in_pitch, out_pitch, out_pitch, a.in_plain != 0, residual != nullptr))
+        cn_conv3x3p_takes(B, H, W, Cin, Cout, in_pitch, out_pitch, res_pitch, a.in_plain != 0, residual != nullptr))
         return cn_conv3x3s1_persist(x, w_packed, scale, shift, residual, y, B, H, W, Cin, Cout, in_pitch,
-                                    out_pitch, out_pitch, relu, a.out_plain, a.res_plain, ctl, st);
+                                    out_pitch, res_pitch, relu, a.out_plain, a.res_plain, ctl, st);
     if (f16 == CN_DTYPE_F32S) return c3_dispatch<cn_f32s>(a, bn_class, st);
     return f16 == CN_DTYPE_F16 ? c3_dispatch<_Float16>(a, bn_class, st) : c3_dispatch<float>(a, bn_class, st);
 }

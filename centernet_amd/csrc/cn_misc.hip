@@ -84,6 +84,46 @@ __global__ void maxpool_nhwc_kernel(const float *__restrict__ x, float *__restri
     }
 }
 
+// f32s in (pixel pitch in_pitch), f32s out (pixel pitch out_pitch: the output may be a channel slice of
+// a wider tensor, e.g. a concatenation buffer): y = split(max(window) * mul).  max commutes with the
+// join of a (high, low) pair and with a positive factor, so this is the plain max-pool of the values.
+__global__ void maxpool_nhwc_f32s_kernel(const void *__restrict__ x, void *__restrict__ y, int B, int H,
+                                         int W, int C, int in_pitch, int out_pitch, int Ho, int Wo, int k,
+                                         int s, int pad, float mul, uint32_t *range)
+{
+    const int c4n = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * c4n;
+    float rng = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float ninf = -__builtin_huge_valf();
+        cn_f32x4 m = {ninf, ninf, ninf, ninf};
+        for (int dy = 0; dy < k; ++dy) {
+            const int iy = oy * s - pad + dy;
+            if (iy < 0 || iy >= H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int ix = ox * s - pad + dx;
+                if (ix < 0 || ix >= W) continue;
+                const cn_f32x4 v = cn_load4_f32s(x, ((size_t)b * H + iy) * W + ix, in_pitch, c4 * 4);
+                m.x = fmaxf(m.x, v.x);
+                m.y = fmaxf(m.y, v.y);
+                m.z = fmaxf(m.z, v.z);
+                m.w = fmaxf(m.w, v.w);
+            }
+        }
+        m = m * mul;
+        cn_rng_upd4(rng, m);
+        cn_store4_f32s(y, ((size_t)b * Ho + oy) * Wo + ox, out_pitch, c4 * 4, m);
+    }
+    cn_rng_commit(range, 0, rng);
+}
+
 // offset (B,18,HW) + mask (B,9,HW) NCHW -> om (B,HW,32) NHWC
 __global__ void pack_offset_mask_kernel(const float *__restrict__ offset,
                                         const float *__restrict__ mask, float *__restrict__ om,
@@ -275,6 +315,25 @@ extern "C" int cn_maxpool_nhwc_scaled(const void *x, float *y, int B, int H, int
     const size_t total = (size_t)B * Ho * Wo * (C >> 2);
     hipLaunchKernelGGL(maxpool_nhwc_kernel<true>, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
                        (hipStream_t)stream, (const float *)x, y, B, H, W, C, Ho, Wo, k, s, pad, out_mul);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
+extern "C" int cn_maxpool_nhwc_f32s(const void *x, void *y, int B, int H, int W, int C, int in_pitch,
+                                    int out_pitch, int k, int s, int pad, float mul, uint32_t *range,
+                                    void *stream)
+{
+    if (mul == 0.f) mul = 1.f;
+    if (!x || !y) return CN_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || pad < 0 || in_pitch < C || out_pitch < C || !(mul > 0.f))
+        return CN_ERR_SHAPE;
+    if ((C & 31) || (in_pitch & 31) || (out_pitch & 31)) return CN_ERR_UNSUPPORTED;   // whole 32-channel groups
+    if ((((uintptr_t)x) & 127u) || (((uintptr_t)y) & 127u)) return CN_ERR_ALIGN;
+    const int Ho = (H + 2 * pad - k) / s + 1, Wo = (W + 2 * pad - k) / s + 1;
+    if (Ho <= 0 || Wo <= 0) return CN_ERR_SHAPE;
+    const size_t total = (size_t)B * Ho * Wo * (C >> 2);
+    hipLaunchKernelGGL(maxpool_nhwc_f32s_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, B, H, W, C, in_pitch, out_pitch, Ho, Wo, k, s, pad, mul, range);
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

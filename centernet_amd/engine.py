@@ -411,6 +411,7 @@ class PlanBuilder:
             if fuse_pool:
                 flags |= CONV_STEM_MAXPOOL
         pool_lid = lid + "/pool" if pool is not None else None
+        out_given = out is not None
         if out is None:
             if out_nchw:
                 t = torch.empty((x.B, co, Ho, Wo), device=self.device, dtype=torch.float32)
@@ -430,17 +431,41 @@ class PlanBuilder:
         if use_s and out.fmt != "f32s":
             flags |= CONV_Y_PLAIN
         assert use_s or stem_s or out.fmt != "f32s"
+        res_pitch = 0
         if residual is not None and residual.pitch != out.pitch:
-            # channel counts that are not a multiple of 32: an f32s tensor is padded to whole
-            # groups, a plain one is not -- bring the residual to the output's format
-            assert use_s
-            if out.fmt == "f32s":
-                residual = self.packed(residual)
-                flags &= ~CONV_R_PLAIN
+            sliced = out.pitch != (out.C if out.fmt != "f32s" else (out.C + 31) // 32 * 32) or \
+                residual.pitch != (residual.C if residual.fmt != "f32s" else (residual.C + 31) // 32 * 32)
+            if sliced:
+                # the output or the residual is a channel slice of a wider tensor (a concatenation
+                # buffer): the residual keeps its own pixel pitch where the library takes one
+                res_pitch = residual.pitch
             else:
-                residual = self.plain(residual)
-                flags |= CONV_R_PLAIN
-            assert residual.pitch == out.pitch
+                # channel counts that are not a multiple of 32: an f32s tensor is padded to whole
+                # groups, a plain one is not -- bring the residual to the output's format
+                assert use_s
+                if out.fmt == "f32s":
+                    residual = self.packed(residual)
+                    flags &= ~CONV_R_PLAIN
+                else:
+                    residual = self.plain(residual)
+                    flags |= CONV_R_PLAIN
+                assert residual.pitch == out.pitch
+        if res_pitch:
+            probe = ConvDesc(B=x.B, H=x.H, W=x.W, Cin=ci, Ho=Ho, Wo=Wo, Cout=co, KH=kh, KW=kw,
+                             stride=stride, pad_h=padding, pad_w=padding, dil=dilation,
+                             in_layout=LAYOUT_NCHW if x.nchw else LAYOUT_NHWC, in_pitch=x.pitch,
+                             out_layout=LAYOUT_NCHW if out.nchw else LAYOUT_NHWC, out_pitch=out.pitch,
+                             OH=Ho, OW=Wo, oy_mul=1, oy_add=0, ox_mul=1, ox_add=0, relu=int(relu),
+                             dtype=cd, flags=flags, res_pitch=res_pitch)
+            if not self.lib.cn_conv2d_res_pitch_supported(ctypes.byref(probe)):
+                # this layer's kernel wants the residual at the output's pitch: write a private tensor
+                # (the caller's concat copies it into the buffer)
+                assert out_given and residual.pitch == (residual.C if residual.fmt != "f32s"
+                                                        else (residual.C + 31) // 32 * 32), \
+                    "a residual slice needs a kernel that takes its pitch"
+                return self.conv(x, weight, bias=bias, bn=bn, relu=relu, residual=residual, stride=stride,
+                                 padding=padding, dilation=dilation, out_nchw=out_nchw, out=None,
+                                 wsources=wsources, out_plain=out_plain, pool=pool, lid=lid)
         # ---- exponents (csrc/cn_common.h "Range"): the matrix loop sees x * 2^-ex and
         # w / factor; the epilogue returns to the output's stored units
         ctl = None
@@ -464,6 +489,8 @@ class PlanBuilder:
                      dtype=cd, flags=flags)
         if ctl is not None:
             d.ctl = ctl
+        if res_pitch:
+            d.res_pitch = res_pitch
         fl = 2 * x.B * Ho * Wo * co * ci * kh * kw
         by = 4 * (x.B * x.H * x.W * ci + x.B * out.H * out.W * co * (2 if residual is not None else 1)
                   + co * ci * kh * kw)
@@ -561,20 +588,42 @@ class PlanBuilder:
         self.flops += fl
         return out
 
-    def maxpool(self, x, k, s, pad, lid=None):
+    def maxpool(self, x, k, s, pad, lid=None, out=None, to_s=False):
+        """MaxPool2d.  ``to_s`` / ``out``: an f32s input of whole groups stays f32s -- written into
+        ``out`` when given (a channel slice of a concatenation buffer) -- so that its consumers (a
+        projection, a Root's concatenation: pose_dla_dcn.py:206-221) read (high, low) pairs."""
         assert self.dtype == torch.float32, "max-pool is built for fp32 only"
         lid = self._lid(lid)
-        from_s = x.fmt == "f32s" and x.C % 32 == 0     # read (high, low) pairs, write plain floats
+        lib = self.lib
+        from_s = x.fmt == "f32s" and x.C % 32 == 0     # read (high, low) pairs
+        Ho, Wo = _out_size(x.H, k, s, pad), _out_size(x.W, k, s, pad)
+        if from_s and (to_s or (out is not None and out.fmt == "f32s")):
+            if out is None:
+                out = self._new(x.B, Ho, Wo, x.C, fmt="f32s", lid=lid)
+            else:
+                assert out.fmt == "f32s" and (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, x.C)
+                out.lid, out.exp = lid, self._exp(lid)
+            assert x.c_off % 32 == 0 and out.c_off % 32 == 0
+            mul = _pow2(x.exp - out.exp)
+            ctl = self._ctl(lid)
+
+            def run():
+                rc = lib.cn_maxpool_nhwc_f32s(x.ptr(), out.ptr(), x.B, x.H, x.W, x.C, x.pitch, out.pitch,
+                                              k, s, pad, mul, ctl.range, native.stream_ptr())
+                if rc:
+                    native.check(rc, "cn_maxpool_nhwc_f32s")
+            self.ops.append(run)
+            self.meta.append(dict(kind="maxpool", flops=0, bytes=4 * x.B * x.C * (x.H * x.W + Ho * Wo)))
+            self.trace.append(("maxpool", out))
+            return out
         if not from_s:
             x = self.plain(x)
-        Ho, Wo = _out_size(x.H, k, s, pad), _out_size(x.W, k, s, pad)
-        out = self._new(x.B, Ho, Wo, x.C, lid=lid)
-        lib = self.lib
+        private = self._new(x.B, Ho, Wo, x.C, lid=lid)
         assert x.pitch == x.C and x.c_off == 0
         mul = _pow2(x.exp) if from_s else 1.0
 
         def run():
-            rc = lib.cn_maxpool_nhwc_scaled(x.ptr(), out.ptr(), x.B, x.H, x.W, x.C, k, s, pad,
+            rc = lib.cn_maxpool_nhwc_scaled(x.ptr(), private.ptr(), x.B, x.H, x.W, x.C, k, s, pad,
                                             DTYPE_F32S if from_s else DTYPE_F32, mul,
                                             native.stream_ptr())
             if rc:
@@ -582,18 +631,36 @@ class PlanBuilder:
         self.ops.append(run)
         self.meta.append(dict(kind="maxpool", flops=0,
                               bytes=4 * x.B * x.C * (x.H * x.W + Ho * Wo)))
-        self.trace.append(("maxpool", out))
-        return out
+        self.trace.append(("maxpool", private))
+        return private
 
     def _emit_simple(self, fn, kind, out, nbytes):
         self.ops.append(fn)
         self.meta.append(dict(kind=kind, flops=0, bytes=nbytes))
         self.trace.append((kind, out))
 
-    def concat(self, acts):
+    def concat_buffer(self, B, H, W, widths):
+        """A concatenation buffer allocated BEFORE its members exist, and one Act per member to pass
+        as ``out=`` to the producing launch (conv / maxpool): members written in place need no copy.
+        f32s plans only, members of whole 32-channel groups; otherwise (None, None) -- ``concat``
+        then allocates and copies as before.  Pass the buffer to ``concat(acts, into=buf)``."""
+        if not self.split or any(w % 32 for w in widths) or os.environ.get("CN_CONCAT_INPLACE", "1") == "0":
+            return None, None
+        C = sum(widths)
+        buf = self._new(B, H, W, C, fmt="f32s")
+        slices, off = [], 0
+        for w in widths:
+            slices.append(Act(buf.t, B, H, W, w, pitch=C, c_off=off, fmt="f32s"))
+            off += w
+        return buf, slices
+
+    def concat(self, acts, into=None):
         """torch.cat(acts, 1) (Root.forward, pose_dla_dcn.py:159): channel-slice copies into
-        one NHWC buffer."""
+        one NHWC buffer; members that already live in their slice of ``into`` (``concat_buffer``)
+        are not copied."""
         lid = self._lid()
+        if into is not None:
+            return self._concat_into(acts, into, lid)
         # the inputs of a concatenation share one exponent (PlannedModule.calibrate gives the
         # whole group the exponent of its largest member)
         self.groups.append([lid] + [a.lid for a in acts])
@@ -624,6 +691,36 @@ class PlanBuilder:
             self._emit_simple(run, "copy", dst, 8 * npix * a.C)
             off += a.C
         return out
+
+    def _concat_into(self, acts, buf, lid):
+        self.groups.append([lid] + [a.lid for a in acts])
+        C = buf.pitch
+        assert buf.fmt == "f32s" and sum(a.C for a in acts) == C
+        exps = {a.exp for a in acts}
+        buf.lid = lid
+        buf.exp = acts[0].exp
+        lib, npix, off = self.lib, buf.B * buf.H * buf.W, 0
+        for a in acts:
+            assert (a.B, a.H, a.W) == (buf.B, buf.H, buf.W) and not a.nchw
+            in_place = a.t is buf.t and a.c_off == off and a.pitch == C and a.fmt == "f32s"
+            if not in_place:
+                src = a if (a.fmt == "f32s" and a.C % 32 == 0 and a.exp == buf.exp) else None
+                if src is None:
+                    # a member in another format or with another exponent: through plain floats
+                    p = self.plain(a)
+                    q = Act(p.t, p.B, p.H, p.W, p.C, p.pitch, p.c_off, fmt="f32", exp=buf.exp, lid=a.lid)
+                    src = self.packed(q)
+                dst = Act(buf.t, buf.B, buf.H, buf.W, a.C, pitch=C, c_off=off, fmt="f32s", exp=buf.exp, lid=a.lid)
+
+                def run(src=src, dst=dst):
+                    rc = lib.cn_copy_channels_f32(src.ptr(), src.pitch, dst.ptr(), C, npix, src.C,
+                                                  native.stream_ptr())
+                    if rc:
+                        native.check(rc, "cn_copy_channels_f32")
+                self._emit_simple(run, "copy", dst, 8 * npix * a.C)
+            off += a.C
+        assert len(exps) == 1 or not self.exps, "members of a concatenation share one exponent"
+        return buf
 
     def dw_deconv(self, x, weight, f, add=None):
         """Depthwise ConvTranspose2d(C, C, 2f, stride f, padding f//2, groups=C) + add

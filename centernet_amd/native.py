@@ -43,7 +43,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad_h", "pad_w",
         "dil", "in_layout", "in_pitch", "out_layout", "out_pitch", "OH", "OW", "oy_mul",
-        "oy_add", "ox_mul", "ox_add", "relu", "dtype", "flags")] + [("ctl", F32sCtl)]
+        "oy_add", "ox_mul", "ox_add", "relu", "dtype", "flags", "res_pitch")] + [("ctl", F32sCtl)]
 
 
 class HeadOut(ctypes.Structure):
@@ -105,6 +105,8 @@ def _declare(lib):
     lib.cn_calib_mfma_f16.argtypes = [vp, i, vp]
     lib.cn_calib_copy.restype = i
     lib.cn_calib_copy.argtypes = [vp, vp, sz, vp]
+    lib.cn_maxpool_nhwc_f32s.restype = i
+    lib.cn_maxpool_nhwc_f32s.argtypes = [vp, vp, i, i, i, i, i, i, i, i, i, f, vp, vp]
     lib.cn_maxpool_nhwc_scaled.restype = i
     lib.cn_maxpool_nhwc_scaled.argtypes = [vp, vp, i, i, i, i, i, i, i, i, f, vp]
     lib.cn_dcn_v2_forward_nhwc.restype = i
@@ -129,6 +131,8 @@ def _declare(lib):
     lib.cn_packed_conv_weight_elems.argtypes = [i] * 5
     lib.cn_pack_conv_weight.restype = i
     lib.cn_pack_conv_weight.argtypes = [vp, vp, i, i, i, i, i, vp]
+    lib.cn_conv2d_res_pitch_supported.restype = i
+    lib.cn_conv2d_res_pitch_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.cn_conv2d_workspace_bytes.restype = sz
     lib.cn_conv2d_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.cn_conv2d.restype = i

@@ -21,14 +21,15 @@ class BasicBlock(nn.Module):
         self.conv1, self.bn1 = conv(inplanes, planes, 3, stride, dilation=dilation), bn(planes)
         self.conv2, self.bn2 = conv(planes, planes, 3, dilation=dilation), bn(planes)
 
-    def describe(self, pb, x, residual=None):
-        # pose_dla_dcn.py:45-62
+    def describe(self, pb, x, residual=None, out=None):
+        # pose_dla_dcn.py:45-62.  ``out``: the block's result goes straight into this Act (a channel
+        # slice of the Root's concatenation buffer) where the kernel allows it
         if residual is None:
             residual = x
-        out = pb.conv(x, self.conv1.weight, bn=self.bn1, relu=True, stride=self.stride,
+        mid = pb.conv(x, self.conv1.weight, bn=self.bn1, relu=True, stride=self.stride,
                       padding=self.dilation, dilation=self.dilation)
-        return pb.conv(out, self.conv2.weight, bn=self.bn2, relu=True, residual=residual,
-                       padding=self.dilation, dilation=self.dilation)
+        return pb.conv(mid, self.conv2.weight, bn=self.bn2, relu=True, residual=residual,
+                       padding=self.dilation, dilation=self.dilation, out=out)
 
 
 class Root(nn.Module):
@@ -38,9 +39,10 @@ class Root(nn.Module):
         self.conv = conv(in_channels, out_channels, 1, pad=(kernel_size - 1) // 2)
         self.bn = bn(out_channels)
 
-    def describe(self, pb, *children, out_plain=False):
-        # pose_dla_dcn.py:157-165: conv1x1(cat(children)) + BN (+ children[0]) + ReLU
-        x = pb.concat(list(children))
+    def describe(self, pb, *children, out_plain=False, into=None):
+        # pose_dla_dcn.py:157-165: conv1x1(cat(children)) + BN (+ children[0]) + ReLU.  ``into``: the
+        # concatenation buffer the Tree allocated up front (members written in place are not copied)
+        x = pb.concat(list(children), into=into)
         return pb.conv(x, self.conv.weight, bn=self.bn, relu=True,
                        residual=children[0] if self.residual else None,
                        padding=self.conv.padding[0], out_plain=out_plain)
@@ -78,15 +80,28 @@ class Tree(nn.Module):
         # pose_dla_dcn.py:206-221.  ``out_plain``: the stage's result is written as plain floats
         # (it feeds the deformable layers and skip adds of the up-sampling pyramid)
         children = [] if children is None else children
-        bottom = pb.maxpool(x, self.stride, self.stride, 0) if self.downsample is not None else x
+        # a leaf tree knows its Root's concatenation (x2, x1, handed-down children, bottom) before any
+        # member exists: the buffer is allocated first and tree1 / tree2 / the max-pool write their
+        # results into their slices (Root.forward's torch.cat, pose_dla_dcn.py:159, without the copies)
+        buf = slots = None
+        if self.levels == 1 and self.downsample is not None:
+            oc = self.tree1.conv2.weight.shape[0]
+            widths = [oc, oc] + [c.C for c in children] + ([x.C] if self.level_root else [])
+            Ho, Wo = x.H // self.stride, x.W // self.stride
+            if x.H % self.stride == 0 and x.W % self.stride == 0:
+                buf, slots = pb.concat_buffer(x.B, Ho, Wo, widths)
+        pooled_out = slots[-1] if (slots is not None and self.level_root) else None
+        bottom = pb.maxpool(x, self.stride, self.stride, 0, out=pooled_out, to_s=True) \
+            if self.downsample is not None else x
         residual = pb.conv(bottom, self.project[0].weight, bn=self.project[1]) \
             if self.project is not None else bottom
         if self.level_root:
             children.append(bottom)
-        x1 = self.tree1.describe(pb, x, residual)
         if self.levels == 1:
-            x2 = self.tree2.describe(pb, x1)
-            return self.root.describe(pb, x2, x1, *children, out_plain=out_plain)
+            x1 = self.tree1.describe(pb, x, residual, out=slots[1] if slots is not None else None)
+            x2 = self.tree2.describe(pb, x1, out=slots[0] if slots is not None else None)
+            return self.root.describe(pb, x2, x1, *children, out_plain=out_plain, into=buf)
+        x1 = self.tree1.describe(pb, x, residual)
         children.append(x1)
         return self.tree2.describe(pb, x1, children=children, out_plain=out_plain)
 

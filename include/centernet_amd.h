@@ -276,8 +276,14 @@ typedef struct cn_conv_desc {
     int relu;
     int dtype;              /* CN_DTYPE_F32 / CN_DTYPE_F16 / CN_DTYPE_F32S (x, w, residual, NHWC y) */
     int flags;              /* CN_CONV_* bits, 0 by default */
+    int res_pitch;          /* pixel pitch of the residual in floats; 0 = out_pitch.  A pitch that differs
+                               from out_pitch (y or the residual is a channel slice of a wider tensor, e.g. a
+                               concatenation buffer: pose_dla_dcn.py:157-165) is taken by the 3x3 / stride 1
+                               / pad 1 layers only: ask cn_conv2d_res_pitch_supported() */
     cn_f32s_ctl ctl;        /* dtype = CN_DTYPE_F32S (and the CN_CONV_STEM_F32S stem): range control */
 } cn_conv_desc;
+/* 1 when cn_conv2d honours d->res_pitch != d->out_pitch for this descriptor (host-only) */
+int cn_conv2d_res_pitch_supported(const cn_conv_desc *d);
 /* dtype = CN_DTYPE_F32S only: x (and the residual) / y are plain fp32 NHWC tensors; the kernel
  * converts while staging / storing (e.g. the offset maps the deformable kernel reads). */
 #define CN_CONV_X_PLAIN 1
@@ -360,6 +366,12 @@ int cn_maxpool_nhwc(const void *x_nhwc, float *y_nhwc, int B, int H, int W, int 
 /* f32s input of exponent e: out_mul = 2^e brings the pooled values back to real units */
 int cn_maxpool_nhwc_scaled(const void *x_nhwc, float *y_nhwc, int B, int H, int W, int C, int k,
                            int s, int pad, int in_dtype, float out_mul, void *stream);
+/* f32s in (pixel pitch in_pitch), f32s out (pixel pitch out_pitch -- y may be a channel slice of a wider
+ * tensor, e.g. the concatenation buffer of pose_dla_dcn.py:157-165): y = split(max(window) * mul), mul a
+ * power of two (the ratio of the two tensors' exponents); range (CN_RANGE_WORDS words, may be NULL)
+ * side 0 receives max |y| */
+int cn_maxpool_nhwc_f32s(const void *x, void *y, int B, int H, int W, int C, int in_pitch, int out_pitch,
+                         int k, int s, int pad, float mul, uint32_t *range, void *stream);
 
 /* Depthwise ConvTranspose2d(C, C, kernel 2f, stride f, padding f/2, groups=C, bias=False)
  * -- the up-sampling of IDAUp (pose_dla_dcn.py:370-373) -- fused with the element-wise

@@ -392,6 +392,48 @@ def test_conv3x3_stride2_on_the_persistent_kernel(dev, cfg):
         lib.cn_set_tuning(33, 1)
 
 
+@pytest.mark.parametrize("persistent", [1, 0])
+def test_concat_members_written_in_place(dev, persistent):
+    """Root.forward's torch.cat (pose_dla_dcn.py:157-165) without copies: the concatenation buffer is
+    allocated first, a max-pool (f32s in, f32s out at the buffer's pitch: cn_maxpool_nhwc_f32s), a 3x3
+    block output with a residual at ANOTHER pixel pitch (cn_conv_desc.res_pitch) and a 3x3 layer whose
+    residual is its neighbour slice write their members in place; a fourth member is copied.  Against
+    torch on the CPU, and the launch list holds exactly one copy."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder
+    B, C, H, W = 8, 64, 64, 64      # (grids large enough that no layer wants split-K)
+    native.lib().cn_set_tuning(28, persistent)     # both 3x3 kernels take a residual pitch
+    x = torch.from_numpy(synth.normal((B, C, 2 * H, 2 * W), 1.0, 1)).relu_()
+    r = torch.from_numpy(synth.normal((B, C, H, W), 1.0, 2))
+    extra = torch.from_numpy(synth.normal((B, 32, H, W), 1.0, 3)).relu_()
+    w1 = torch.from_numpy(synth.normal((C, C, 3, 3), (2.0 / (C * 9)) ** 0.5, 4))
+    w2 = torch.from_numpy(synth.normal((C, C, 3, 3), (2.0 / (C * 9)) ** 0.5, 5))
+    bn1, bn2 = _bn(C, 6), _bn(C, 7)
+    bottom = F.max_pool2d(x, 2, 2)
+    x1 = F.relu(bn1(F.conv2d(bottom, w1, None, 1, 1)) + r)
+    x2 = F.relu(bn2(F.conv2d(x1, w2, None, 1, 1)) + x1)
+    ref = torch.cat([x2, x1, extra, bottom], 1).detach()
+    pb = PlanBuilder(dev, B, 2 * H, 2 * W, split=True)
+    xa = pb.packed(_nhwc_act(x, dev))
+    ra = pb.packed(_nhwc_act(r, dev))
+    ea = pb.packed(_nhwc_act(extra, dev))
+    n0 = len(pb.ops)
+    buf, slots = pb.concat_buffer(B, H, W, [C, C, 32, C])
+    assert buf is not None and buf.pitch == 3 * C + 32
+    pooled = pb.maxpool(xa, 2, 2, 0, out=slots[3])
+    a1 = pb.conv(pooled, w1, bn=bn1, relu=True, residual=ra, padding=1, out=slots[1])       # residual pitch 64, output pitch 224
+    a2 = pb.conv(a1, w2, bn=bn2, relu=True, residual=a1, padding=1, out=slots[0])
+    assert all(a.t is buf.t for a in (pooled, a1, a2))
+    cat = pb.concat([a2, a1, ea, pooled], into=buf)
+    kinds = [k for k, _ in pb.trace[n0:]]
+    assert kinds.count("copy") == 1 and kinds.count("maxpool") == 1 and kinds.count("convert") == 0, kinds
+    try:
+        _run(pb)
+    finally:
+        native.lib().cn_set_tuning(28, 1)
+    _check(cat.to_float().permute(0, 3, 1, 2).cpu(), ref)
+
+
 def test_heads_fused_nchw_outputs(dev):
     from centernet_amd.engine import PlanBuilder
     B, F_, H, W = 2, 64, 32, 32
