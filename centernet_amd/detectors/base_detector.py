@@ -145,6 +145,7 @@ class _FramePipe(object):
         det = self.det
         slot = i % self.depth
         self.ev_done[slot].synchronize()
+        det.__dict__["_unchecked"] = 0       # (the batch's range digest is looked at right here)
         if self.has_digest[slot] and (int(self.digest_host[slot][0]) & 0xffffffff) > F16_MAX_BITS:
             # an f32s value was clamped somewhere up to this batch: results invalid.  Drain the
             # device, let the module re-calibrate, and run this batch again synchronously.
@@ -359,10 +360,23 @@ class BaseDetector(object):
             j, fr = pending.popleft()
             yield pipe.collect(j, fr)
 
+    UNCHECKED_LIMIT = 4096     # run_batch forwards without a look at the range words before a warning
+
+    def _note_unchecked_forward(self):
+        """``run_batch`` does not look at the f32s range words (it never synchronises): the caller
+        owes a ``range_ok()`` where it consumes results.  A caller that never pays gets told, once."""
+        n = self.__dict__.get("_unchecked", 0) + 1
+        self.__dict__["_unchecked"] = n
+        if n == self.UNCHECKED_LIMIT and self.model.uses_f32s():
+            import warnings
+            warnings.warn("%d run_batch() forwards without a range_ok() look: a clamped f32s value "
+                          "would go unnoticed (call detector.range_ok() where results are consumed)" % n)
+
     def range_ok(self, images=None):
         """Synchronising look at the f32s range words of every forward since the last look
         (``PlannedModule.range_ok``): False = a value was clamped, those results are invalid and
         the network has been re-calibrated (on ``images`` when given) -- run the batch again."""
+        self.__dict__["_unchecked"] = 0
         return self.model.range_ok(images)
 
     def run(self, image_or_path_or_tensor, meta=None):

@@ -84,6 +84,7 @@ class CtdetDetector(BaseDetector):
         ``probe``: optional dict for measurement (bench.py): ``event_after`` (set of launch
         indices) in, ``net_events`` (HIP events at those launch boundaries) and ``dec_events``
         (before / after the decode) out."""
+        self._note_unchecked_forward()
         with torch.no_grad():
             if probe is None:
                 out = self.model(images, borrow=True)[-1]

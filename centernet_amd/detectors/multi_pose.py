@@ -64,6 +64,7 @@ class MultiPoseDetector(BaseDetector):
     def run_batch(self, images, probe=None):
         """New surface (as CtdetDetector.run_batch): a device-resident, normalised batch ->
         raw (B,K,40) detections in output-grid units; sigmoids fused into the decode kernels."""
+        self._note_unchecked_forward()
         with torch.no_grad():
             ev = None
             if probe is not None:

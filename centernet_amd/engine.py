@@ -178,6 +178,7 @@ class PlanBuilder:
         # views of float bit patterns (non-negative floats order like integers)
         self.range = None
         self.range_chunks = [] # (cur, stat) tensors per RANGE_LAUNCHES launches
+        self._plain_cache = {} # (storage, slice) -> plain copy of an f32s activation (PlanBuilder.plain)
         self.range_slots = []  # slot -> logical id of the launch, for messages
         self._pack_events = [] # completion of weight-pack kernels this plan depends on
         # range words at every split site (csrc/cn_common.h "Range"); ``track=False`` (or CN_RANGE=0)
@@ -243,6 +244,11 @@ class PlanBuilder:
         if x is None or x.fmt != "f32s":
             return x
         assert x.c_off % 32 == 0      # a slice starts on a 32-channel group
+        # (activations are written once: the plain copy of a tensor serves every later reader)
+        key = (id(x.t), x.c_off, x.C)
+        hit = self._plain_cache.get(key)
+        if hit is not None and hit[0] is x.t:
+            return hit[1]
         out = self._new(x.B, x.H, x.W, x.C, fmt="f32", lid=x.lid)
         out.exp = x.exp
         lib, npix = self.lib, x.B * x.H * x.W
@@ -254,6 +260,7 @@ class PlanBuilder:
             if rc:
                 native.check(rc, "cn_f32s_to_f32")
         self._emit_simple(run, "convert", out, 8 * npix * x.C)
+        self._plain_cache[key] = (x.t, out)
         return out
 
     def packed(self, x):

@@ -6,6 +6,8 @@ DLAUp (:390-413), DLASeg (:427-482).  State-dict names follow that file
 (base.level2.tree1.conv1.weight, dla_up.ida_0.proj_1.conv.conv_offset_mask.bias,
 ida_up.node_2.actf.0.running_var, hm.0.weight, ...).
 """
+import os
+
 import numpy as np
 from torch import nn
 
@@ -146,9 +148,10 @@ class DLA(nn.Module):
                     x = pb.conv(x, c.weight, bn=mods[j + 1], relu=True, stride=c.stride[0],
                                 padding=c.padding[0], dilation=c.dilation[0])
             else:
-                # stage outputs feed the deformable layers / skip adds of the pyramid: plain floats
-                # (+1 % on dla_34 against converting them afterwards, same box)
-                x = level.describe(pb, x, out_plain=True)
+                # stage outputs feed the next stage (3x3 / s2, max-pool, projection: f32s readers) AND
+                # the deformable layers / skip adds of the pyramid (plain readers): CN_DLA_LEVEL_PLAIN=1
+                # writes them plain (round 3), the default f32s with ONE plain copy for the pyramid
+                x = level.describe(pb, x, out_plain=os.environ.get("CN_DLA_LEVEL_PLAIN", "0") == "1")
             y.append(x)
         return y
 

@@ -255,6 +255,30 @@ def test_run_frames_stream_equals_run_frames_and_the_host_tail(dev):
                 assert a[j].shape == b[j].shape and np.array_equal(a[j].view(np.int32), b[j].view(np.int32)), j
 
 
+def test_run_batch_without_a_range_look_is_reported(dev):
+    """run_batch never synchronises, so it cannot look at the f32s range words itself: a caller
+    that keeps calling it without range_ok() is warned (once per limit); a look resets the count."""
+    import contextlib, sys, warnings
+    from centernet_amd.opts import opts
+    from centernet_amd.detectors.detector_factory import detector_factory
+    with contextlib.redirect_stdout(sys.stderr):
+        opt = opts().init(["ctdet", "--arch", "res_18", "--input_h", "128", "--input_w", "128"])
+        det = detector_factory[opt.task](opt)
+    synth.fill_state_dict_(det.model, 317)
+    det.model.invalidate_plans()
+    det.UNCHECKED_LIMIT = 3
+    x = synth.images(2, 128, 128, seed=1).to(dev)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        det.run_batch(x); det.run_batch(x)
+        assert not [w for w in rec if "range_ok" in str(w.message)]
+        assert det.range_ok()
+        det.run_batch(x); det.run_batch(x)
+        assert not [w for w in rec if "range_ok" in str(w.message)]
+        det.run_batch(x)
+        assert len([w for w in rec if "range_ok" in str(w.message)]) == 1
+
+
 def test_run_frames_equals_run(dev):
     """run_frames (batched, device pre-process) == run() per frame (same kernels per image up to
     the batch-size dependent split-K summation order)."""
