@@ -1,7 +1,12 @@
-// cn_conv3x3p.hip -- persistent, loader / consumer specialised 3x3 / stride-1 / pad-1 convolution
-// in f32s arithmetic (fp32 values as fp16 (high, low) pairs, cn_common.h): the trunk convolutions
-// of every backbone (resnet_dcn.py:38-67 BasicBlock, pose_dla_dcn.py:31-62, large_hourglass.py:48-74)
-// when input and output are f32s tensors.
+// cn_conv3x3p.hip -- persistent, loader / consumer specialised 3x3 convolution family in f32s arithmetic
+// (fp32 values as fp16 (high, low) pairs, cn_common.h), for layers whose input is an f32s tensor:
+//   * 3x3 / stride 1 / pad 1 (+BN, ReLU, residual): the trunk convolutions of every backbone
+//     (resnet_dcn.py:38-67 BasicBlock, pose_dla_dcn.py:31-62, large_hourglass.py:48-74);
+//   * 3x3 / stride 2 / pad 1 (the first convolution of a down-sampling block) as four stride-1
+//     convolutions over the input's parity planes (template S2);
+//   * ConvTranspose2d(4, 2, 1) (resnet_dcn.py:228-235) as four parity 2x2 convolutions (NTAP = 4);
+//   * the detection heads conv3x3 -> ReLU -> conv1x1 with a 64-wide hidden layer, all heads in one
+//     launch, hidden layer in registers (resnet_dcn.py:155-177; template HEADS).
 //
 // Why a third 3x3 kernel.  Probes of the one-tile-per-workgroup halo kernel (cn_conv3x3.hip,
 // DESIGN.md section 3.1b) show a tile's life as prologue (address set-up, first halo + weight
