@@ -103,6 +103,16 @@ __device__ __forceinline__ void cn_rng_upd4(float &m, cn_f32x4 v)
                         __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
 }
 __device__ __forceinline__ void cn_rng_upd1(float &m, float v) { m = __builtin_fmaxf(m, __builtin_fabsf(v)); }
+// the same, NaN-sticky: for the sites where USER data enters (the network input in the stem kernels,
+// the plain -> f32s converter).  fmaxf drops a NaN and the clamp in front of the split turns it into
+// -65504, so a NaN image would give finite garbage where the reference propagates NaN; here it makes
+// the range word read +inf: the forward is reported as invalid and the re-calibration that follows
+// refuses non-finite activations loudly.  (Inside the network values stay finite: every split site
+// clamps, so a NaN cannot be produced from finite inputs and weights.)
+__device__ __forceinline__ void cn_rng_upd1_in(float &m, float v)
+{
+    m = (v == v) ? __builtin_fmaxf(m, __builtin_fabsf(v)) : __builtin_inff();
+}
 // wave-wide maximum of non-negative floats, returned (uniform) as a bit pattern: integer max
 // over the bit patterns -- four DPP steps inside each row of 16 lanes, then the four rows
 // through SGPRs.  ~12 instructions, no LDS traffic (a __shfl_xor ladder is six dependent

@@ -363,7 +363,8 @@ __global__ void f32_to_f32s_kernel(const float *__restrict__ x, void *__restrict
             for (int e = 0; e < 4 && n + e < C; ++e) v[e] = x[p * in_pitch + n + e];
         }
         v = v * mul;
-        cn_rng_upd4(rng, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cn_rng_upd1_in(rng, v[e]);    // (user data may enter here: NaN-sticky)
         cn_store4_f32s(y, p, out_pitch, n, v);   // channels past C inside the group: zeros
     }
     cn_rng_commit(range, 1, rng);

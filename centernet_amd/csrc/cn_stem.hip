@@ -488,7 +488,7 @@ __global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a,
     float rng_in = 0.f;
     auto put = [&](int idx, float xr) {
         const float xs = xr * a.x_mul;
-        cn_rng_upd1(rng_in, xs);
+        cn_rng_upd1_in(rng_in, xs);
         const float x = __builtin_fminf(__builtin_fmaxf(xs, -65504.0f), 65504.0f);
         const _Float16 hi = (_Float16)x;
         winH[idx] = hi;
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
     float rng_in = 0.f, rng_out = 0.f;
     auto put = [&](int idx, float xr) {
         const float xs = xr * a.x_mul;
-        cn_rng_upd1(rng_in, xs);
+        cn_rng_upd1_in(rng_in, xs);
         const float x = __builtin_fminf(__builtin_fmaxf(xs, -65504.0f), 65504.0f);
         const _Float16 hi = (_Float16)x;
         winH[idx] = hi;
@@ -969,7 +969,8 @@ __global__ __launch_bounds__(NT, 2) void stem16s_kernel(const StemArgs a, int to
             if (i < 21 * S16_PAIRS) {
                 const int row = i / S16_PAIRS, pp = i - row * S16_PAIRS;
                 const float s0 = v0[st][u] * x_mul, s1 = v1[st][u] * x_mul, sm = vm[st][u] * x_mul;   // real -> stored units
-                rng_in = fmaxf(rng_in, fmaxf(fabsf(s0), fabsf(s1)));
+                cn_rng_upd1_in(rng_in, s0);
+                cn_rng_upd1_in(rng_in, s1);
                 const float c0 = fminf(fmaxf(s0, -65504.f), 65504.f), c1 = fminf(fmaxf(s1, -65504.f), 65504.f);
                 const float cm = fminf(fmaxf(sm, -65504.f), 65504.f);
                 uint32_t he, le, ho, lo;

@@ -558,6 +558,37 @@ def test_range_tables_grow_in_chunks(dev, monkeypatch):
         assert int(plan.b.range_sum[0]) == 0, "capture warm-up must not leave anything in the digest"
 
 
+def test_a_nan_in_the_image_is_reported_not_clamped_away(dev):
+    """fmaxf drops a NaN and the clamp in front of a split would turn it into -65504: finite garbage
+    where the reference propagates NaN.  The sites where user data enters (the stem kernels, the
+    plain -> f32s converter) make the range word read +inf instead: the forward is invalid, and the
+    re-calibration that follows refuses the batch loudly."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder
+    from centernet_amd.model import create_model
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    m = create_model("res_18", dict(heads), 64)
+    synth.fill_state_dict_(m, 317)
+    m = m.to(dev).eval()
+    x = synth.images(1, 128, 256, seed=5).to(dev)
+    with torch.no_grad():
+        m(x)
+        bad = x.clone()
+        bad[0, 1, 17, 33] = float("nan")
+        with pytest.raises(native.NativeError, match="non-finite"):
+            m(bad)
+    # the converter
+    pb = PlanBuilder(dev, 1, 8, 8, split=True)
+    t = torch.ones((1, 32, 8, 8))
+    t[0, 3, 2, 2] = float("nan")
+    pb.packed(_act(t, dev, pb, "x"))
+    for op in pb.ops:
+        op()
+    torch.cuda.synchronize()
+    w = pb.range[0].view(torch.float32).reshape(2, 64, 16)[1, :, 0]
+    assert bool(torch.isinf(w).any())
+
+
 def test_detector_reruns_a_clamped_batch(dev):
     """detector.run() / process() look at the range words where the reference synchronises;
     run_frames() where it copies the detections to the host."""
