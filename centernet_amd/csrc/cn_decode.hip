@@ -1512,7 +1512,7 @@ extern "C" int cn_ddd_decode_f32(const float *heat, const float *rot, const floa
 }
 
 // ---------------------------------------------------------------------------
-// exct_decode (models/decode.py:273-424), aggr_weight == 0: ExtremeNet-style grouping of the
+// exct_decode (models/decode.py:273-424; aggr_weight > 0: cn_exct_aggregate_f32 in front): ExtremeNet-style grouping of the
 // K best top / left / bottom / right extreme points into boxes.
 //   stage A  cn_topk_f32 x4 (_nms + _topk of the four extreme-point heat-maps)
 //   stage B  exct_score_kernel: the K^4 candidate scores (decode.py:316-366), written once
@@ -1667,6 +1667,64 @@ __global__ __launch_bounds__(NTM) void exct_select_kernel(
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------
+// Edge aggregation of exct_decode (models/decode.py:17-90, aggr_weight > 0): along a row (_h_aggregate)
+// or a column (_v_aggregate) of every plane, from both ends, a running sum that continues while the
+// values do not fall -- ret[i] = heat[i] + ret[i-1] * (heat[i] >= heat[i-1]) -- minus the value itself;
+// out = (w * first + w * second) + heat in the reference's order of float32 operations.  One thread per
+// line, two sequential passes (the recurrence is serial by definition; the maps are small).
+// ---------------------------------------------------------------------------
+namespace {
+__global__ void exct_aggregate_kernel(const float *__restrict__ heat, float *__restrict__ out, int planes,
+                                      int H, int W, int horizontal, float w)
+{
+    const int nline = horizontal ? H : W, len = horizontal ? W : H;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)planes * nline) return;
+    const int plane = (int)(t / nline), line = (int)(t - (long)plane * nline);
+    const size_t base = (size_t)plane * H * W + (horizontal ? (size_t)line * W : (size_t)line);
+    const size_t step = horizontal ? 1 : (size_t)W;
+    // first pass (from the start: _left / _top): out holds ret - heat
+    float prev_h = heat[base], prev_r = prev_h;
+    out[base] = add_rn(prev_r, -prev_h);
+    for (int i = 1; i < len; ++i) {
+        const float h = heat[base + i * step];
+        const float r = add_rn(h, mul_rn(prev_r, (h >= prev_h) ? 1.0f : 0.0f));
+        out[base + i * step] = add_rn(r, -h);
+        prev_h = h;
+        prev_r = r;
+    }
+    // second pass (from the end: _right / _bottom) and the combination
+    prev_h = heat[base + (size_t)(len - 1) * step];
+    prev_r = prev_h;
+    {
+        const size_t o = base + (size_t)(len - 1) * step;
+        out[o] = add_rn(add_rn(mul_rn(w, out[o]), mul_rn(w, add_rn(prev_r, -prev_h))), prev_h);
+    }
+    for (int i = len - 2; i >= 0; --i) {
+        const size_t o = base + i * step;
+        const float h = heat[o];
+        const float r = add_rn(h, mul_rn(prev_r, (h >= prev_h) ? 1.0f : 0.0f));
+        out[o] = add_rn(add_rn(mul_rn(w, out[o]), mul_rn(w, add_rn(r, -h))), h);
+        prev_h = h;
+        prev_r = r;
+    }
+}
+}  // namespace
+
+extern "C" int cn_exct_aggregate_f32(const float *heat, float *out, int B, int C, int H, int W,
+                                     int horizontal, float aggr_weight, void *stream)
+{
+    if (!heat || !out) return CN_ERR_NULL;
+    if (heat == out) return CN_ERR_UNSUPPORTED;      // two passes read the input
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CN_ERR_SHAPE;
+    const long lines = (long)B * C * (horizontal ? H : W);
+    hipLaunchKernelGGL(exct_aggregate_kernel, dim3((unsigned)((lines + 63) / 64)), dim3(64), 0,
+                       (hipStream_t)stream, heat, out, B * C, H, W, horizontal ? 1 : 0, aggr_weight);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
 
 extern "C" size_t cn_exct_decode_workspace_bytes(int B, int C, int H, int W, int K)
 {

@@ -190,13 +190,23 @@ def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=Non
                 r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, aggr_weight=0.0,
                 num_dets=1000):
     """decode.py:273-424 -> (B, num_dets, 14).  Heat-maps post-sigmoid (values <= 1).
-    ``aggr_weight > 0`` (edge aggregation, decode.py:17-90) is not built."""
-    if aggr_weight > 0:
-        raise native.NativeError("exct_decode: aggr_weight > 0 (edge aggregation) is not built")
+    ``aggr_weight > 0``: the edge aggregation of decode.py:17-90,136-140 runs in front
+    (``cn_exct_aggregate_f32``: rows of t / b, columns of l / r)."""
     t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr, l_regr, b_regr, r_regr = _prep(
         t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr, l_regr, b_regr, r_regr)
     lib = native.lib()
     B, C, H, W = t_heat.shape
+    if aggr_weight > 0:
+        for name, t in (("l_heat", l_heat), ("b_heat", b_heat), ("r_heat", r_heat)):
+            _expect(name, t, B, C, H, W, t_heat.device)
+        agg = []
+        for t, horizontal in ((t_heat, 1), (l_heat, 0), (b_heat, 1), (r_heat, 0)):
+            o = torch.empty_like(t)
+            native.check(lib.cn_exct_aggregate_f32(native.ptr(t), native.ptr(o), B, C, H, W, horizontal,
+                                                   float(aggr_weight), native.stream_ptr()),
+                         "cn_exct_aggregate_f32")
+            agg.append(o)
+        t_heat, l_heat, b_heat, r_heat = agg
     for name, t in (("l_heat", l_heat), ("b_heat", b_heat), ("r_heat", r_heat), ("ct_heat", ct_heat)):
         _expect(name, t, B, C, H, W, t_heat.device)
     for name, t in (("t_regr", t_regr), ("l_regr", l_regr), ("b_regr", b_regr), ("r_regr", r_regr)):

@@ -262,11 +262,20 @@ class BaseDetector(object):
     def merge_outputs(self, detections):
         raise NotImplementedError
 
+    def _no_debugger(self):
+        # the reference's Debugger (utils/debugger.py: cv2 / matplotlib windows) is outside the hot
+        # path and not built: --debug >= 1 runs the detector as --debug 0 does and says so once
+        if not self.__dict__.get("_debug_warned"):
+            self.__dict__["_debug_warned"] = True
+            import warnings
+            warnings.warn("--debug %d: visual debugging is not part of centernet_amd; results are "
+                          "computed and returned as with --debug 0" % self.opt.debug)
+
     def debug(self, debugger, images, dets, output, scale=1):
-        raise NotImplementedError("visual debugging (cv2/matplotlib) is outside the hot path")
+        self._no_debugger()
 
     def show_results(self, debugger, image, results):
-        raise NotImplementedError("visual debugging (cv2/matplotlib) is outside the hot path")
+        self._no_debugger()
 
     # ------------------------------------------------------------------ run
     @staticmethod

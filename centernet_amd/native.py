@@ -199,6 +199,8 @@ def _declare(lib):
     lib.cn_ddd_decode_f32.argtypes = [vp] * 6 + [i] * 6 + [vp, vp, sz, vp]
     lib.cn_exct_decode_workspace_bytes.restype = sz
     lib.cn_exct_decode_workspace_bytes.argtypes = [i] * 5
+    lib.cn_exct_aggregate_f32.restype = i
+    lib.cn_exct_aggregate_f32.argtypes = [vp, vp, i, i, i, i, i, ctypes.c_float, vp]
     lib.cn_exct_decode_f32.restype = i
     lib.cn_exct_decode_f32.argtypes = [vp] * 9 + [i] * 5 + [ctypes.c_float, ctypes.c_float, i, i,
                                                         vp, vp, sz, vp]

@@ -553,6 +553,12 @@ int cn_ddd_decode_f32(const float *heat, const float *rot, const float *depth, c
                       int apply_sigmoid, float *dets, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* Edge aggregation in front of exct_decode when aggr_weight > 0 (models/decode.py:17-90, :136-140):
+ * out = _h_aggregate(heat, aggr_weight) (horizontal = 1: t_heat, b_heat) or _v_aggregate (horizontal =
+ * 0: l_heat, r_heat); heat, out (B, C, H, W), out != heat.  Bit-identical to the reference's float32
+ * arithmetic. */
+int cn_exct_aggregate_f32(const float *heat, float *out, int B, int C, int H, int W, int horizontal,
+                          float aggr_weight, void *stream);
 /* exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr.., K=40, scores_thresh=0.1,
  *             center_thresh=0.1, aggr_weight=0.0, num_dets=1000)   (models/decode.py:273-424)
  * for aggr_weight == 0: dets (B, num_dets, 14) = [l_x, t_y, r_x, b_y, score, t_x, t_y, l_x, l_y,

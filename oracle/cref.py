@@ -208,12 +208,45 @@ def ddd_decode(heat, rot, depth, dim, wh=None, reg=None, K=40):
     return np.concatenate(parts, axis=2).astype(np.float32)
 
 
+def _edge_aggregate(heat, axis, weight):
+    """models/decode.py:17-77: along ``axis`` (3 = x: _h_aggregate, 2 = y: _v_aggregate), from both
+    ends, a running sum that continues while the values do not fall -- ret[i] = heat[i] + ret[i-1] *
+    (heat[i] >= heat[i-1]) -- minus the value itself; result weight*first + weight*second + heat,
+    float32, in the reference's order of operations."""
+    f32 = np.float32
+    h = np.moveaxis(np.ascontiguousarray(heat, f32), axis, 0)      # (N, ...)
+    n = h.shape[0]
+    fwd = h.copy()
+    for i in range(1, n):                                          # _left / _top
+        fwd[i] = fwd[i] + fwd[i - 1] * (h[i] >= h[i - 1]).astype(f32)
+    bwd = h.copy()
+    for i in range(n - 2, -1, -1):                                 # _right / _bottom
+        bwd[i] = bwd[i] + bwd[i + 1] * (h[i] >= h[i + 1]).astype(f32)
+    w = f32(weight)
+    out = (w * (fwd - h) + w * (bwd - h)) + h
+    return np.ascontiguousarray(np.moveaxis(out, 0, axis), f32)
+
+
+def h_aggregate(heat, aggr_weight=0.1):
+    """_h_aggregate (models/decode.py:71-73)."""
+    return _edge_aggregate(heat, 3, aggr_weight)
+
+
+def v_aggregate(heat, aggr_weight=0.1):
+    """_v_aggregate (models/decode.py:75-77)."""
+    return _edge_aggregate(heat, 2, aggr_weight)
+
+
 def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=None, b_regr=None,
-                r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, num_dets=1000):
-    """models/decode.py:273-424 with aggr_weight = 0, statement by statement in float32 numpy.
-    Ties of the final top-k are ordered by candidate index (torch leaves that unspecified)."""
+                r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, num_dets=1000, aggr_weight=0.0):
+    """models/decode.py:273-424, statement by statement in float32 numpy (aggr_weight > 0: the edge
+    aggregation of :136-140 in front).  Ties of the final top-k are ordered by candidate index (torch
+    leaves that unspecified)."""
     f32 = np.float32
     B, C, H, W = t_heat.shape
+    if aggr_weight > 0:                                              # :136-140
+        t_heat, b_heat = h_aggregate(t_heat, aggr_weight), h_aggregate(b_heat, aggr_weight)
+        l_heat, r_heat = v_aggregate(l_heat, aggr_weight), v_aggregate(r_heat, aggr_weight)
     tops = [topk(np.minimum(nms(h), f32(1.0)), K) for h in (t_heat, l_heat, b_heat, r_heat)]  # :297-310
 
     def ax(v, e):  # (B,K) -> broadcast along axis e of (B,K,K,K,K)

@@ -23,6 +23,13 @@ EXCT_CASES = {
 }
 
 
+# edge aggregation (decode.py:17-90, aggr_weight > 0): name -> (base case, aggr_weight)
+AGGR_CASES = {
+    "exct_aggr": ("exct_small", 0.1),
+    "exct_aggr_k40": ("exct_k40", 0.25),
+}
+
+
 def exct_inputs(name):
     B, C, H, W, K, num_dets, use_regr = EXCT_CASES[name]
     seed = 3000 + sum(map(ord, name))
@@ -60,6 +67,24 @@ def main():
         with torch.no_grad():
             dets = ref_decode.exct_decode(*[t(h) for h in heats], *[t(r) for r in regs], K=K,
                                           num_dets=num_dets)
+        out[name + "/dets"] = dets.numpy()
+        print(name, dets.shape, "valid:", int((dets[..., 4] > 0).sum()))
+    for name, (base, w) in AGGR_CASES.items():
+        heats, regs, K, num_dets = exct_inputs(base)
+        with torch.no_grad():
+            # decode.py:136-140 by the reference's own functions, then the rest of exct_decode.  (Called
+            # in one piece with aggr_weight > 0 the reference fails under torch >= 1.x: _v_aggregate
+            # returns a transposed view and _topk's .view() needs contiguous memory; the reference's
+            # pinned torch 0.4.1 produced contiguous results there.  The .contiguous() is the only
+            # difference.)
+            agg = [ref_decode._h_aggregate(t(heats[0]), aggr_weight=w).contiguous(),
+                   ref_decode._v_aggregate(t(heats[1]), aggr_weight=w).contiguous(),
+                   ref_decode._h_aggregate(t(heats[2]), aggr_weight=w).contiguous(),
+                   ref_decode._v_aggregate(t(heats[3]), aggr_weight=w).contiguous()]
+            dets = ref_decode.exct_decode(*agg, t(heats[4]), *[t(r) for r in regs], K=K,
+                                          num_dets=num_dets, aggr_weight=0.0)
+            out[name + "/h_aggr"] = agg[0].numpy()
+            out[name + "/v_aggr"] = agg[1].numpy()
         out[name + "/dets"] = dets.numpy()
         print(name, dets.shape, "valid:", int((dets[..., 4] > 0).sum()))
     np.savez_compressed(os.path.join(HERE, "exct_golden.npz"), **out)

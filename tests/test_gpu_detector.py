@@ -279,6 +279,31 @@ def test_run_batch_without_a_range_look_is_reported(dev):
         assert len([w for w in rec if "range_ok" in str(w.message)]) == 1
 
 
+def test_debug_levels_run_like_debug_0(dev):
+    """--debug 1 / 2 (base_detector.py:85-87,127-141: Debugger windows) are outside the hot path: the
+    detector runs as with --debug 0, returns the same results, and says once that nothing is drawn."""
+    import contextlib, sys, warnings
+    from centernet_amd.opts import opts
+    from centernet_amd.detectors.detector_factory import detector_factory
+    rng = np.random.RandomState(3)
+    frame = rng.randint(0, 256, (100, 140, 3)).astype(np.uint8)
+    res = {}
+    for dbg in (0, 2):
+        with contextlib.redirect_stdout(sys.stderr):
+            opt = opts().init(["ctdet", "--arch", "res_18", "--input_h", "128", "--input_w", "128",
+                               "--debug", str(dbg)])
+            det = detector_factory[opt.task](opt)
+        synth.fill_state_dict_(det.model, 317)
+        det.model.invalidate_plans()
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            res[dbg] = det.run(frame)['results']
+            det.run(frame)
+        assert len([w for w in rec if "visual debugging" in str(w.message)]) == (1 if dbg else 0)
+    for j in range(1, 81):
+        assert np.array_equal(res[0][j], res[2][j])
+
+
 def test_run_frames_equals_run(dev):
     """run_frames (batched, device pre-process) == run() per frame (same kernels per image up to
     the batch-size dependent split-K summation order)."""

@@ -35,5 +35,25 @@ def test_exct_decode_partial_regr_and_errors(dev):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     with pytest.raises(RuntimeError):
         D.exct_decode(*[_t(h, dev) for h in heats], K=K, num_dets=K ** 4 + 1)
-    with pytest.raises(native.NativeError):
-        D.exct_decode(*[_t(h, dev) for h in heats], K=K, num_dets=10, aggr_weight=0.1)
+
+
+@pytest.mark.parametrize("name", sorted(GEN.AGGR_CASES))
+def test_exct_decode_with_edge_aggregation(dev, name):
+    """aggr_weight > 0 (models/decode.py:17-90,136-140): cn_exct_aggregate_f32 bit-identical to the
+    reference's _h_aggregate / _v_aggregate, the decode behind it to the reference's rows and, bit for
+    bit, to the oracle."""
+    base, w = GEN.AGGR_CASES[name]
+    heats, regs, K, num_dets = GEN.exct_inputs(base)
+    lib = native.lib()
+    B, C, H, W = heats[0].shape
+    for which, horizontal, key in ((0, 1, "/h_aggr"), (1, 0, "/v_aggr")):
+        x = _t(heats[which], dev)
+        o = torch.empty_like(x)
+        native.check(lib.cn_exct_aggregate_f32(native.ptr(x), native.ptr(o), B, C, H, W, horizontal, w,
+                                               native.stream_ptr()), "cn_exct_aggregate_f32")
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), GOLD[name + key].view(np.uint32))
+    dets = D.exct_decode(*[_t(h, dev) for h in heats], *[_t(r, dev) for r in regs], K=K,
+                         num_dets=num_dets, aggr_weight=w).cpu().numpy()
+    assert_same(dets, GOLD[name + "/dets"])
+    ref = cref.exct_decode(*heats, *regs, K=K, num_dets=num_dets, aggr_weight=w)
+    assert np.array_equal(dets.view(np.uint32), ref.view(np.uint32))

@@ -59,3 +59,15 @@ def test_oracle_exct_decode(name):
     ref = GOLD[name + "/dets"]
     assert int((ref[..., 4] > 0).sum()) > 0, "golden must contain valid groupings"
     assert_same(dets, ref)
+
+
+@pytest.mark.parametrize("name", sorted(GEN.AGGR_CASES))
+def test_oracle_edge_aggregation_and_decode(name):
+    """aggr_weight > 0 (models/decode.py:17-90,136-140): the oracle's _h / _v aggregates are
+    bit-identical to the reference's, and exct_decode behind them matches the reference's rows."""
+    base, w = GEN.AGGR_CASES[name]
+    heats, regs, K, num_dets = GEN.exct_inputs(base)
+    assert np.array_equal(cref.h_aggregate(heats[0], w).view(np.uint32), GOLD[name + "/h_aggr"].view(np.uint32))
+    assert np.array_equal(cref.v_aggregate(heats[1], w).view(np.uint32), GOLD[name + "/v_aggr"].view(np.uint32))
+    dets = cref.exct_decode(*heats, *regs, K=K, num_dets=num_dets, aggr_weight=w)
+    assert_same(dets, GOLD[name + "/dets"])
