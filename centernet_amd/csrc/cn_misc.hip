@@ -770,6 +770,49 @@ extern "C" int cn_soft_nms_f32(float *boxes, int n, int stride, float sigma, flo
     return N;
 }
 
+// ---- flip-test averaging (detectors/ctdet.py:34-37, multi_pose.py:44-55, models/utils.py:28-50): image 1
+// of the pair is the mirrored frame; out[c, y, x] = (f(x0[c, y, x]) + sign[c] * f(x1[src[c], y, W-1-x])) / 2
+// with f = the logistic when asked (then written back in place: the reference's sigmoid_()), src = the
+// left / right joint permutation, sign = -1 for the x components of joint offsets
+namespace {
+__global__ void flip_average_kernel(float *__restrict__ x, float *__restrict__ out, int C, int H, int W,
+                                    const int32_t *__restrict__ src, const float *__restrict__ sign,
+                                    int apply_sigmoid)
+{
+    const size_t total = (size_t)C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        size_t r = i / W;
+        const int y = (int)(r % H);
+        const int c = (int)(r / H);
+        const int cs = src ? src[c] : c;
+        const size_t j = total + ((size_t)cs * H + y) * W + (W - 1 - xx);
+        float a = x[i], b = x[j];
+        if (apply_sigmoid) {
+            a = 1.0f / (1.0f + __expf(-a));
+            b = 1.0f / (1.0f + __expf(-b));
+            x[i] = a;
+            x[j] = b;
+        }
+        if (sign) b = b * sign[c];
+        out[i] = (a + b) / 2.0f;
+    }
+}
+}  // namespace
+
+extern "C" int cn_flip_average_f32(float *x_pair, float *out, int C, int H, int W, const int32_t *chan_src,
+                                   const float *chan_sign, int apply_sigmoid, void *stream)
+{
+    if (!x_pair || !out) return CN_ERR_NULL;
+    if (C <= 0 || H <= 0 || W <= 0) return CN_ERR_SHAPE;
+    const size_t total = (size_t)C * H * W;
+    hipLaunchKernelGGL(flip_average_kernel, dim3(blocks_for(total, 256, 65535)), dim3(256), 0,
+                       (hipStream_t)stream, x_pair, out, C, H, W, chan_src, chan_sign, apply_sigmoid ? 1 : 0);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
+
 // ---- box calibration (bench.py "box_calibration"): what THIS box's matrix pipe and HBM deliver
 // right now, so that a headline can be read against the box it ran on.  Not on the product path.
 namespace {

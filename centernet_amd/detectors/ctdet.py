@@ -8,7 +8,7 @@ import torch
 
 from ..decode import ctdet_decode
 from ..post_process import ctdet_results_batch
-from ..utils import flip_tensor
+from ..utils import flip_average
 from .base_detector import BaseDetector
 
 
@@ -32,9 +32,8 @@ class CtdetDetector(BaseDetector):
             reg = output['reg'] if self.opt.reg_offset else None
             logits = not self.opt.flip_test
             if self.opt.flip_test:
-                hm = hm.sigmoid_()
-                hm = (hm[0:1] + flip_tensor(hm[1:2])) / 2
-                wh = (wh[0:1] + flip_tensor(wh[1:2])) / 2
+                hm = flip_average(hm, sigmoid=True)      # (sigmoid_() of both images in place, as ctdet.py:31)
+                wh = flip_average(wh)
                 reg = None if reg is None else reg[0:1]
             torch.cuda.synchronize()
             forward_time = time.time()

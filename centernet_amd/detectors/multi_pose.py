@@ -8,14 +8,10 @@ import torch
 
 from ..decode import multi_pose_decode
 from ..post_process import multi_pose_post_process
-from ..utils import flip_tensor, flip_lr, flip_lr_off
+from ..utils import flip_average
 from .base_detector import BaseDetector
 
 ROW = 39  # [x1, y1, x2, y2, score, 17 x (x, y)]
-
-
-def _mean_with_mirror(first, mirrored):
-    return (first + mirrored) / 2
 
 
 class MultiPoseDetector(BaseDetector):
@@ -36,11 +32,11 @@ class MultiPoseDetector(BaseDetector):
     def _average_flip(self, hm, wh, hps, reg, hm_hp, hp_offset):
         """Flip-test (multi_pose.py:44-55): image 1 of the batch is the mirrored frame; maps are
         averaged after un-mirroring, offsets of the un-mirrored frame are kept."""
-        hm = _mean_with_mirror(hm[0:1], flip_tensor(hm[1:2]))
-        wh = _mean_with_mirror(wh[0:1], flip_tensor(wh[1:2]))
-        hps = _mean_with_mirror(hps[0:1], flip_lr_off(hps[1:2], self.flip_idx))
+        hm = flip_average(hm)
+        wh = flip_average(wh)
+        hps = flip_average(hps, self.flip_idx, offsets=True)
         if hm_hp is not None:
-            hm_hp = _mean_with_mirror(hm_hp[0:1], flip_lr(hm_hp[1:2], self.flip_idx))
+            hm_hp = flip_average(hm_hp, self.flip_idx)
         reg = None if reg is None else reg[0:1]
         hp_offset = None if hp_offset is None else hp_offset[0:1]
         return hm, wh, hps, reg, hm_hp, hp_offset

@@ -101,6 +101,8 @@ def _declare(lib):
     lib.cn_packed_head_w2_bytes.argtypes = [i]
     lib.cn_pack_head_w2_f32s.restype = i
     lib.cn_pack_head_w2_f32s.argtypes = [vp, vp, i, vp]
+    lib.cn_flip_average_f32.restype = i
+    lib.cn_flip_average_f32.argtypes = [vp, vp, i, i, i, vp, vp, i, vp]
     lib.cn_calib_mfma_f16.restype = ctypes.c_double
     lib.cn_calib_mfma_f16.argtypes = [vp, i, vp]
     lib.cn_calib_copy.restype = i

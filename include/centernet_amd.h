@@ -240,6 +240,14 @@ int cn_range_fold(uint32_t *cur, uint32_t *hi, uint32_t *lo, int n_launches, voi
 int cn_range_fold_digest(uint32_t *cur, uint32_t *hi, uint32_t *lo, uint32_t *summary,
                          int n_launches, void *stream);
 
+/* Flip-test averaging (detectors/ctdet.py:34-37, detectors/multi_pose.py:44-55, models/utils.py:28-50).
+ * x_pair (2, C, H, W): image 1 is the horizontally mirrored frame; out (1, C, H, W) =
+ * (f(x0[c, y, x]) + sign[c] * f(x1[src[c], y, W-1-x])) / 2.  chan_src (C) = left / right joint permutation
+ * (flip_lr / flip_lr_off), NULL = identity; chan_sign (C), NULL = +1 (-1 on the x components of joint
+ * offsets); apply_sigmoid: f = logistic, written back to x_pair in place (the reference's sigmoid_()),
+ * chan_src must then be a permutation. */
+int cn_flip_average_f32(float *x_pair, float *out, int C, int H, int W, const int32_t *chan_src,
+                        const float *chan_sign, int apply_sigmoid, void *stream);
 /* Box calibration (bench.py `box_calibration`; measurement aid, not on the product path; no
  * reference counterpart).  cn_calib_mfma_f16: a register-only v_mfma_f32_32x32x16_f16 loop on
  * every SIMD (1024 workgroups x 4 waves, `iters` x 16 instructions per wave); returns the FLOPs

@@ -304,6 +304,34 @@ def test_debug_levels_run_like_debug_0(dev):
         assert np.array_equal(res[0][j], res[2][j])
 
 
+def test_flip_average_kernel_equals_the_reference_formulas(dev):
+    """cn_flip_average_f32 against (a + flip(b)) / 2 with flip = flip_tensor / flip_lr / flip_lr_off of
+    models/utils.py:28-50 (written out with torch ops on the CPU): bit-identical without the logistic,
+    within 1e-6 with it (in place on both images, as hm.sigmoid_() does)."""
+    from centernet_amd.utils import flip_average
+    g = torch.Generator().manual_seed(3)
+    flip_idx = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+    perm = list(range(17))
+    for a, b in flip_idx:
+        perm[a], perm[b] = perm[b], perm[a]
+    hm = torch.randn((2, 80, 24, 40), generator=g)
+    want = (hm[0:1] + torch.flip(hm[1:2], [3])) / 2
+    assert torch.equal(flip_average(hm.to(dev)).cpu(), want)
+    hp = torch.randn((2, 17, 24, 40), generator=g)
+    want = (hp[0:1] + torch.flip(hp[1:2], [3])[:, perm]) / 2
+    assert torch.equal(flip_average(hp.to(dev), flip_idx).cpu(), want)
+    off = torch.randn((2, 34, 24, 40), generator=g)
+    f = torch.flip(off[1:2], [3]).reshape(1, 17, 2, 24, 40).clone()
+    f[:, :, 0] *= -1
+    want = (off[0:1] + f[:, perm].reshape(1, 34, 24, 40)) / 2
+    assert torch.equal(flip_average(off.to(dev), flip_idx, offsets=True).cpu(), want)
+    d = hm.to(dev)
+    got = flip_average(d, sigmoid=True).cpu()
+    s = hm.sigmoid()
+    assert float((got - (s[0:1] + torch.flip(s[1:2], [3])) / 2).abs().max()) < 1e-6
+    assert float((d.cpu() - s).abs().max()) < 1e-6            # both images now hold scores
+
+
 def test_run_frames_equals_run(dev):
     """run_frames (batched, device pre-process) == run() per frame (same kernels per image up to
     the batch-size dependent split-K summation order)."""
