@@ -202,8 +202,11 @@ __device__ __forceinline__ void collect_and_sort(ForEach &&for_each, u64 prefix,
 
 __device__ __forceinline__ float sigmoidf_ref(float x)
 {
-    // 1 / (1 + exp(-x)) (detectors/ctdet.py:31): v_exp_f32 + v_rcp_f32, ~1e-7 of torch's value
-    return __frcp_rn(1.0f + __expf(-x));
+    // 1 / (1 + exp(-x)) (detectors/ctdet.py:31): v_exp_f32 + v_rcp_f32 (1 ulp each), within 2e-7 of
+    // torch's value.  The reciprocal is the hardware approximation, not the IEEE division (11
+    // instructions per cell, the largest single item of the one-launch decode); every decode form
+    // uses this one definition, so the forms stay bit-identical among themselves.
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
 constexpr int CAND_CAP = 4096;  // compacted positive peaks per band (uint16 tile offsets)
@@ -1066,6 +1069,256 @@ __global__ __launch_bounds__(NT) void collect_merge_kernel(const float *__restri
                     ea.out_scores, (const float *)nullptr, 0, ea.cls_out);
 }
 
+// ---------------------------------------------------------------------------
+// ONE-launch form of the image-level decode (round 4): planes of at most 128 x 128 cells -- the
+// ctdet map of a 512 x 512 input and everything smaller.  The heat-map is read exactly ONCE: a
+// workgroup owns one (image, class) plane and holds it in REGISTERS -- half-wave u keeps rows
+// 16u .. 16u+15 (+ one halo row above and below, from L2), lane l the 4-cell quad l of every row --
+// so the logistic, the 3x3 peak test on the scores (decode.py:9-15) and every later look at a cell
+// are register work; horizontal neighbours come from the adjacent lanes by shuffle.  Then
+//   1. every lane takes the largest key of its 64 cells; T0 = the K-th largest of the 256 lane
+//      maxima (exact: three digit passes over 256 values).  At least K cells of the plane reach T0,
+//      so nothing below it can be among the plane's -- or the image's -- K best.  T0 is folded into
+//      the image's FLOOR (a device-scope atomic maximum): planes that start later skip every cell
+//      below the best T0 published so far (a few dozen planes of an image are in flight at any time;
+//      the rest hand on next to nothing);
+//   2. the cells that reach max(T0, floor) go into a list in LDS (typically ~1.2 K of them); up to
+//      OP_PE keys are handed on as they are, a longer list goes through the exact select of the
+//      plane's K best, and a list that overflows LDS (plateaus, tiny or constant maps: T0 useless)
+//      through the same select over the register cells, zeros of suppressed cells included;
+//   3. arrival / last-arriver select exactly as in collect_merge_kernel.  The last arriver leaves
+//      the image's three state words (list length, arrival counter, floor) at zero.
+// Every input is handled exactly inside this launch; results are bit-identical to the two-launch
+// and the per-band forms (tests/test_gpu_decode.py).
+// ---------------------------------------------------------------------------
+constexpr int OP_PE = 256;        // keys a plane hands on without selecting (>= KMAX)
+static_assert(OP_PE >= KMAX && OP_PE <= PLCAP, "plane emit cap");
+
+template <int MODE>
+__global__ __launch_bounds__(NT, 3) void plane_select_merge_kernel(const float *__restrict__ heat, int C, int H,
+                                                                   int W, int flags, int K, u64 *__restrict__ keys,
+                                                                   int cap, int32_t *__restrict__ counts,
+                                                                   int32_t *__restrict__ done,
+                                                                   uint32_t *__restrict__ floorv, const EmitArgs ea)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SelShared &sh = *reinterpret_cast<SelShared *>(smem);
+    __shared__ u64 pl_keys[PLCAP];
+    __shared__ int pl_cnt, pl_base, s_last;
+    __shared__ uint32_t s_floor;
+    const int tid = threadIdx.x;
+    const int lane = tid & (CN_WAVE - 1);
+    const int hl = lane & 31, hw = tid >> 5;
+    const size_t plane_id = blockIdx.x;
+    const int b = (int)(plane_id / (unsigned)C), c = (int)(plane_id - (size_t)b * C);
+    const bool sig = (flags & 1) != 0;
+    const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;
+    const int HW = H * W;
+    const float *plane = heat + plane_id * (size_t)HW;
+    const uint32_t base = (uint32_t)c * (uint32_t)HW;
+    const int w4 = W >> 2;
+    const float NEG_INF = -__builtin_huge_valf();
+    // the image's floor so far: requested first, lands under the map loads
+    uint32_t fl = 0u;
+    if (tid == 0) fl = __hip_atomic_load(&floorv[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- the plane into registers: rows y0-1 .. y0+16 of this half-wave, all loads issued up front
+    const int y0 = hw * GUNIT;
+    const bool col_ok = hl < w4;
+    const int nv = col_ok ? min(max(H - y0, 0), GUNIT) : 0;      // valid rows of this lane's 16
+    // (branch-free: rows / quads outside the map read a clamped address and are replaced below)
+    cn_f32x4 rowv[GUNIT + 2];
+    {
+        const uint32_t xoff = col_ok ? (uint32_t)hl * 4u : 0u;
+#pragma unroll
+        for (int r = 0; r < GUNIT + 2; ++r) {
+            const int yc = min(max(y0 - 1 + r, 0), H - 1);
+            rowv[r] = *reinterpret_cast<const cn_f32x4 *>(plane + ((uint32_t)yc * (uint32_t)W + xoff));
+        }
+    }
+    // (selections below are written as bit masks: left as ?: the compiler wraps every transcendental
+    // and every shuffle fix-up in its own branch)
+    const uint32_t NINF = 0xff800000u;
+    auto sel = [](uint32_t msk, float a, float bfl) -> float {   // msk ? a : b, bitwise
+        return __uint_as_float((__float_as_uint(a) & msk) | (__float_as_uint(bfl) & ~msk));
+    };
+    // scores of a window row; cells outside the map stay -inf (the peak test's padding, decode.py:12)
+    auto score_row = [&](int r) {
+        const int y = y0 - 1 + r;
+        const uint32_t in_map = (col_ok && y >= 0 && y < H) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = rowv[r][e];
+            rowv[r][e] = sel(in_map, sig ? sigmoidf_ref(x) : x, __uint_as_float(NINF));
+        }
+    };
+    // horizontal 3-max of a row (neighbour quads by shuffle inside the half-wave)
+    const uint32_t has_l = (hl != 0 && col_ok) ? 0xffffffffu : 0u;
+    const uint32_t has_r = (hl != 31 && col_ok) ? 0xffffffffu : 0u;
+    auto hrow = [&](int r) -> cn_f32x4 {
+        const float l = sel(has_l, __shfl_up(rowv[r].w, 1, 32), __uint_as_float(NINF));
+        const float rr = sel(has_r, __shfl_down(rowv[r].x, 1, 32), __uint_as_float(NINF));
+        cn_f32x4 h;
+        h.x = fmaxf(fmaxf(l, rowv[r].x), rowv[r].y);
+        h.y = fmaxf(fmaxf(rowv[r].x, rowv[r].y), rowv[r].z);
+        h.z = fmaxf(fmaxf(rowv[r].y, rowv[r].z), rowv[r].w);
+        h.w = fmaxf(fmaxf(rowv[r].z, rowv[r].w), rr);
+        return h;
+    };
+    // the 64 cells of this lane as keys of heat * keep (decode.py:14; -0.0 -> +0.0); cell i = row
+    // y0 + (i >> 2), column 4 hl + (i & 3).  Cells outside the map get key 0, which no threshold
+    // admits (thresholds are >= 1; a cell of the map has key 0 only for one NaN pattern).  A row's
+    // registers die as soon as the row below it has been combined.
+    uint32_t kreg[GUNIT * 4];
+    {
+        score_row(0);
+        score_row(1);
+        cn_f32x4 h0 = hrow(0), h1 = hrow(1);
+#pragma unroll
+        for (int r = 1; r <= GUNIT; ++r) {
+            score_row(r + 1);
+            const cn_f32x4 h2 = hrow(r + 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = rowv[r][e];
+                const float m = fmaxf(fmaxf(h0[e], h1[e]), h2[e]);
+                const uint32_t k = f2key(((nonms || m == v) ? v : 0.0f) + 0.0f);
+                kreg[(r - 1) * 4 + e] = (r - 1 < nv) ? k : 0u;
+            }
+            h0 = h1;
+            h1 = h2;
+        }
+    }
+    auto key64 = [&](int i) -> u64 {
+        const uint32_t cell = (uint32_t)((y0 + (i >> 2)) * W + hl * 4 + (i & 3));
+        return ((u64)kreg[i] << 32) | (u64)(0xFFFFFFFFu - (base + cell));
+    };
+
+    // ---- 1. T0 = K-th largest lane maximum (0: fewer than K lanes hold a cell -- small maps: every
+    // cell of the map is admitted)
+    uint32_t lmax = 0u;
+#pragma unroll
+    for (int i = 0; i < GUNIT * 4; ++i) lmax = max(lmax, kreg[i]);
+    auto lanes = [&](auto &&f) { f(lmax); };
+    const uint32_t T0 = kth_largest_key32<NT>(lanes, (uint32_t)K, sh);
+    if (tid == 0) {
+        s_floor = fl;
+        pl_cnt = 0;
+        if (T0 > fl) __hip_atomic_fetch_max(&floorv[b], T0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const uint32_t thr = max(max(T0, s_floor), 1u);
+
+    // ---- 2. cells that reach thr -> LDS list (half-wave prefix sums, one LDS atomic per half-wave)
+    uint32_t m0 = 0u, m1 = 0u;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        m0 |= (kreg[i] >= thr) ? (1u << i) : 0u;
+        m1 |= (kreg[i + 32] >= thr) ? (1u << i) : 0u;
+    }
+    {
+        const int mine = __popc(m0) + __popc(m1);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int t = __shfl_up(incl, o, 32);
+            if (hl >= o) incl += t;
+        }
+        const int total = __shfl(incl, 31, 32);
+        int pos0 = 0;
+        if (hl == 31 && total) pos0 = atomicAdd(&pl_cnt, total);
+        int pos = __shfl(pos0, 31, 32) + incl - mine;
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                if ((i < 32 ? m0 >> i : m1 >> (i - 32)) & 1u) {
+                    if (pos < PLCAP) pl_keys[pos] = key64(i);
+                    ++pos;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = pl_cnt;                    // (uniform)
+    int m;
+    const u64 *src;
+    if (n <= OP_PE) {
+        m = n;
+        src = pl_keys;
+    } else {
+        m = K;                               // n > OP_PE >= K cells reach thr: the plane's K best are among them
+        u64 prefix, mask;
+        if (n <= PLCAP) {
+            auto for_each = [&](auto &&f) {
+                for (int j = tid; j < n; j += NT) f(pl_keys[j], false);
+            };
+            radix_select<NT>(for_each, (uint32_t)m, sh, prefix, mask);
+            collect_and_sort<NT>(for_each, prefix, mask, sh);
+        } else {
+            auto for_each = [&](auto &&f) {
+#pragma unroll
+                for (int i = 0; i < GUNIT * 4; ++i)
+                    if (kreg[i] >= thr) f(key64(i), kreg[i] == KEY_ZERO);
+            };
+            radix_select<NT>(for_each, (uint32_t)m, sh, prefix, mask);
+            collect_and_sort<NT>(for_each, prefix, mask, sh);
+        }
+        src = sh.sel;
+    }
+    u64 *kimg = keys + (size_t)b * cap;
+    if (m > 0) {
+        if (tid == 0) pl_base = atomicAdd(&counts[b], m);
+        __syncthreads();
+        const int o = pl_base;
+        for (int j = tid; j < m; j += NT)
+            if (o + j < cap) __hip_atomic_store(kimg + o + j, src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- 3. arrival (see collect_merge_kernel for the memory-ordering argument)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        s_last = (__hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == C - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    const int cnt = min(__hip_atomic_load(&counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cap);
+    u64 prefix, mask;
+    constexpr int RK = 16;
+    if (cnt <= RK * NT) {
+        u64 kr[RK];
+#pragma unroll
+        for (int u = 0; u < RK; ++u)
+            kr[u] = (tid + u * NT < cnt) ? __hip_atomic_load(kimg + tid + u * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : 0ull;
+        auto for_each = [&](auto &&f) {
+#pragma unroll
+            for (int u = 0; u < RK; ++u)
+                if (tid + u * NT < cnt) f(kr[u], (uint32_t)(kr[u] >> 32) == KEY_ZERO);
+        };
+        radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
+        collect_and_sort<NT>(for_each, prefix, mask, sh);
+    } else {
+        auto for_each = [&](auto &&f) {
+            for (int j = tid; j < cnt; j += NT) {
+                const u64 k = __hip_atomic_load(kimg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f(k, (uint32_t)(k >> 32) == KEY_ZERO);
+            }
+        };
+        radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
+        collect_and_sort<NT>(for_each, prefix, mask, sh);
+    }
+    emit_rows<MODE>(sh, b, H, W, K, C, ea.wh, ea.reg, ea.cat_spec_wh, ea.dets, ea.det_dim, ea.inds_out,
+                    ea.out_scores, (const float *)nullptr, 0, ea.cls_out);
+    // the image's state words go back to zero: the next call on this workspace needs no fill
+    // (device-scope stores: the words of other images share these cache lines and are being updated
+    // by atomics from other XCDs)
+    if (tid == 0) {
+        __hip_atomic_store(&counts[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&done[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&floorv[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 struct BandPlan {
     int R;       // rows per band
     int nbands;
@@ -1109,9 +1362,11 @@ namespace {
 // single-class maps such as the pose centre map keep the per-band select)
 struct ImgPlan {
     bool use;
+    bool one_pass;                 // planes of <= 128 x 128 cells: plane_select_merge_kernel (ONE launch)
     int nrg, ncb;                  // 8-row groups per plane, 128-column blocks per row
     int cap;                       // candidate keys per image: every plane hands on at most its K best
-    size_t gpeak, gall, counts, done, keys, total;   // byte offsets in the workspace
+    size_t gpeak, gall, counts, done, floorv, keys, total;   // byte offsets in the workspace
+    size_t state_bytes;            // counts | done | floorv: contiguous, zero between calls of the one-launch form
 };
 ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
 {
@@ -1122,12 +1377,15 @@ ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
     p.ncb = cn_cdiv(W, 128);
     // enough groups per image for a meaningful threshold; rows of whole quads
     p.use = (W & 3) == 0 && (long)C * p.nrg * p.ncb >= 4L * K;
+    p.one_pass = p.use && H <= 8 * GUNIT && W <= 128;
     const size_t ng = (size_t)B * C * p.nrg * p.ncb;
     p.gpeak = o;  o += cn_align_up(ng * 4, 256);
     p.gall = o;   o += cn_align_up(ng * 4, 256);
     p.counts = o; o += cn_align_up((size_t)B * 4, 256);
     p.done = o;   o += cn_align_up((size_t)B * 4, 256);
-    p.cap = C * K;
+    p.floorv = o; o += cn_align_up((size_t)B * 4, 256);
+    p.state_bytes = o - p.counts;
+    p.cap = C * (p.one_pass ? OP_PE : K);
     p.keys = o;   o += cn_align_up((size_t)B * p.cap * 8, 256);
     p.total = o;
     return p;
@@ -1144,6 +1402,18 @@ int launch_image_topk(const float *heat, int B, int C, int H, int W, int K, int 
     int32_t *done = (int32_t *)(ws + ip.done);
     u64 *keys = (u64 *)(ws + ip.keys);
     dim3 grid((unsigned)(B * C)), block(NT);
+    if (ip.one_pass && !(flags & CN_DECODE_TWO_LAUNCHES)) {
+        // ONE launch.  The image state words (list length, arrival counter, floor) must be zero on
+        // entry and are left at zero by the kernel: a caller that keeps the workspace to itself says
+        // so (CN_DECODE_STATE_CLEAN) after zeroing it once; anyone else pays a 3 x 128-byte fill.
+        if (!(flags & CN_DECODE_STATE_CLEAN)) {
+            if (hipMemsetAsync(ws + ip.counts, 0, ip.state_bytes, st) != hipSuccess) return CN_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(plane_select_merge_kernel<MODE>, grid, block, sizeof(SelShared), st, heat, C, H, W,
+                           flags, K, keys, ip.cap, counts, done, (uint32_t *)(ws + ip.floorv), ea);
+        CN_CHECK_LAUNCH();
+        return CN_OK;
+    }
     hipLaunchKernelGGL(group_max_kernel, grid, block, 0, st, heat, H, W, ip.nrg, ip.ncb, flags, gpeak,
                        gall, C, counts, done);
     CN_CHECK_LAUNCH();

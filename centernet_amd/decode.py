@@ -24,6 +24,25 @@ def _workspace(nbytes, device):
     return ws
 
 
+_STATE_CLEAN = 4096    # CN_DECODE_STATE_CLEAN: the workspace's image state words are zero (see below)
+_own_ws = {}
+
+
+def _own_workspace(entry, nbytes, device, shape):
+    """A workspace that only `entry` with this shape on this stream ever touches, zeroed once: the
+    one-launch image-level decode keeps three state words per image in it, needs them zero on entry
+    and leaves them zero on exit (include/centernet_amd.h, CN_DECODE_STATE_CLEAN) -- so the call is
+    ONE kernel launch, without the fill the library otherwise puts in front."""
+    key = (str(device), entry, torch.cuda.current_stream(device).cuda_stream) + tuple(shape)
+    ws = _own_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if len(_own_ws) >= 32:
+            _own_ws.clear()
+        ws = torch.zeros(max(int(nbytes), 256), device=device, dtype=torch.uint8)
+        _own_ws[key] = ws
+    return ws
+
+
 def _prep(*ts):
     out = []
     for t in ts:
@@ -62,9 +81,14 @@ def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=Fal
     dets = torch.empty((B, K, 6), device=heat.device, dtype=torch.float32)
     inds = torch.empty((B, K), device=heat.device, dtype=torch.int32)
     nbytes = lib.cn_ctdet_decode_workspace_bytes(B, C, H, W, K)
-    ws = _workspace(nbytes, heat.device)
+    flags = int(bool(apply_sigmoid)) | int(_debug_flags)
+    if _debug_flags:
+        ws = _workspace(nbytes, heat.device)
+    else:
+        ws = _own_workspace("ctdet", nbytes, heat.device, (B, C, H, W, K))
+        flags |= _STATE_CLEAN
     rc = lib.cn_ctdet_decode_f32(native.ptr(heat), native.ptr(wh), native.ptr(reg), B, C, H, W, K,
-                                 int(bool(cat_spec_wh)), int(bool(apply_sigmoid)) | int(_debug_flags),
+                                 int(bool(cat_spec_wh)), flags,
                                  native.ptr(dets), native.ptr(inds), native.ptr(ws), ws.numel(),
                                  native.stream_ptr())
     native.check(rc, "cn_ctdet_decode_f32")

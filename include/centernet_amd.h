@@ -532,6 +532,18 @@ int cn_ctdet_decode_f32(const float *heat, const float *wh, const float *reg,
  * cell, i.e. the plain _topk_channel / _topk without the _nms in front. */
 #define CN_DECODE_SIGMOID 1
 #define CN_DECODE_NO_PEAK_TEST 512
+/* Image-level top-K (cn_ctdet_decode_f32, cn_topk_f32) on planes of <= 128 x 128 cells is ONE kernel
+ * launch that reads the heat-map once.  Its per-image state words live in the workspace, must be
+ * zero on entry and are left at zero on exit; by default the call zeroes them itself (one small
+ * fill in front of the kernel).  CN_DECODE_STATE_CLEAN: the caller owns this workspace exclusively,
+ * zeroed it once after allocation (all of it) and has used it for nothing but calls of the same
+ * entry point with the same (B, C, H, W, K) since -- the fill is skipped.
+ * CN_DECODE_TWO_LAUNCHES selects the two-launch form (group maxima + threshold-pruned collect, the
+ * form for larger planes) and 2048 the per-(class, band) select, for comparison; all forms are
+ * bit-identical. */
+#define CN_DECODE_STATE_CLEAN 4096
+#define CN_DECODE_TWO_LAUNCHES 8192
+#define CN_DECODE_PER_BAND 2048
 
 /* _nms + _topk_channel (models/decode.py:9-15, 92-101) as one kernel: per
  * (b,c) plane the K best peaks; scores (B,C,K) desc, inds (B,C,K) int32. */

@@ -278,3 +278,85 @@ def test_image_level_select_degenerate_maps(dev):
         d, i = ctdet_decode(_gpu(heat, dev), _gpu(wh, dev), None, K=K, return_inds=True)
         assert np.array_equal(i.cpu().numpy(), ref_inds)
         assert np.array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("shape", [(4, 80, 128, 128, 100), (2, 100, 64, 64, 50), (2, 24, 112, 96, 40),
+                                   (3, 30, 40, 128, 20), (1, 80, 128, 128, 128)])
+@pytest.mark.parametrize("sig", [False, True])
+def test_one_launch_form_equals_the_other_forms(dev, shape, sig):
+    """Planes of <= 128 x 128 cells take the ONE-launch form (plane in registers, lane-maximum
+    threshold, image floor, last-arriver select).  It must be bit-identical to the two-launch form
+    (flag 8192) and the per-band select (2048), with the library's own fill of the state words
+    (debug-flag calls share a scratch workspace) and without it (the default call owns a zeroed
+    workspace, CN_DECODE_STATE_CLEAN); post-sigmoid input also against the oracle."""
+    from centernet_amd.decode import ctdet_decode
+    B, C, H, W, K = shape
+    heat = synth.heatmap((B, C, H, W), 131 + C + H)
+    if sig:
+        heat = np.log(np.clip(heat, 1e-6, 1 - 1e-6) / (1 - np.clip(heat, 1e-6, 1 - 1e-6))).astype(np.float32)
+    wh = synth.uniform((B, 2, H, W), 0, 40, 5)
+    reg = synth.uniform((B, 2, H, W), 0, 1, 6)
+    args = (_gpu(heat, dev), _gpu(wh, dev), _gpu(reg, dev))
+    a, ia = ctdet_decode(*args, K=K, apply_sigmoid=sig, return_inds=True)                       # one launch, clean state
+    f, i_f = ctdet_decode(*args, K=K, apply_sigmoid=sig, return_inds=True, _debug_flags=16384)   # one launch + fill
+    t, it = ctdet_decode(*args, K=K, apply_sigmoid=sig, return_inds=True, _debug_flags=8192)
+    p, ip_ = ctdet_decode(*args, K=K, apply_sigmoid=sig, return_inds=True, _debug_flags=2048)
+    for d, i in ((f, i_f), (t, it), (p, ip_)):
+        assert torch.equal(ia, i) and torch.equal(a, d)
+    if not sig:
+        ref, ref_inds = cref.ctdet_decode(heat, wh, reg, K=K, return_inds=True)
+        assert np.array_equal(ia.cpu().numpy(), ref_inds)
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_one_launch_form_leaves_its_state_clean(dev):
+    """Back-to-back calls on the SAME owned workspace (no fill in between) with different data,
+    a degenerate map among them: every call equals the oracle, i.e. the last arriver of every image
+    left list length, arrival counter and floor at zero."""
+    from centernet_amd.decode import ctdet_decode
+    B, C, H, W, K = 3, 40, 128, 128, 100
+    wh = synth.uniform((B, 2, H, W), 0, 40, 5)
+    maps = [synth.heatmap((B, C, H, W), 7), np.full((B, C, H, W), 0.5, np.float32),
+            synth.heatmap((B, C, H, W), 8), np.zeros((B, C, H, W), np.float32), synth.heatmap((B, C, H, W), 9)]
+    for rep in range(2):
+        for heat in maps:
+            ref, ref_inds = cref.ctdet_decode(heat, wh, None, K=K, return_inds=True)
+            d, i = ctdet_decode(_gpu(heat, dev), _gpu(wh, dev), None, K=K, return_inds=True)
+            assert np.array_equal(i.cpu().numpy(), ref_inds)
+            assert np.array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_one_launch_form_plateaus_and_sparse_planes(dev):
+    """Inputs on which the lane-maximum threshold is useless: saturated blocks (thousands of cells
+    tie at the top score: the plane's list overflows LDS -> exact select over the register cells),
+    planes with a handful of peaks (zeros of suppressed cells take part), a single hot plane."""
+    from centernet_amd.decode import ctdet_decode
+    B, C, H, W, K = 2, 80, 128, 128, 100
+    wh = synth.uniform((B, 2, H, W), 0, 40, 5)
+    reg = synth.uniform((B, 2, H, W), 0, 1, 6)
+    sat = synth.heatmap((B, C, H, W), 41)
+    sat[:, ::7, 20:90, 30:100] = 0.99                 # 4900 tied cells in every 7th plane
+    sparse = np.zeros((B, C, H, W), np.float32)
+    for i in range(30):
+        sparse[i % B, (11 * i) % C, (17 * i) % H, (29 * i) % W] = 0.2 + 0.02 * i
+    hot = synth.heatmap((B, C, H, W), 42) * 1e-3
+    hot[:, 5] = synth.heatmap((B, H, W), 43)
+    for heat in (sat, sparse, hot.astype(np.float32)):
+        ref, ref_inds = cref.ctdet_decode(heat, wh, reg, K=K, return_inds=True)
+        for flags in (0, 16384):
+            d, i = ctdet_decode(_gpu(heat, dev), _gpu(wh, dev), _gpu(reg, dev), K=K, return_inds=True,
+                                _debug_flags=flags)
+            assert np.array_equal(i.cpu().numpy(), ref_inds)
+            assert np.array_equal(d.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_topk_plain_function_takes_the_one_launch_form(dev):
+    """_topk without the _nms in front on negative and positive values (every cell ranks), through
+    cn_topk_f32's one-launch form, vs the C oracle."""
+    from centernet_amd.decode import _topk
+    B, C, H, W, K = 2, 40, 128, 128, 50
+    scores = synth.normal((B, C, H, W), 1.0, 23)
+    ts, ti, tc, ty, tx = cref.topk(scores, K)
+    s, i, c, ys, xs = _topk(_gpu(scores, dev), K=K, nms=False)
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), ts.view(np.uint32))
+    assert np.array_equal(i.cpu().numpy(), ti) and np.array_equal(c.cpu().numpy(), tc)
