@@ -554,6 +554,44 @@ __global__ __launch_bounds__(NT) void group_max_kernel(const float *__restrict__
 // reach it.
 // the `need`-th largest of the 32-bit keys `for_each(f)` enumerates (f(key32)), exactly: three
 // digit passes (11, 11, 10 bits, msb first) over a histogram in LDS, no early exit, no sort
+// The bin of sh.hist that holds the `need`-th largest element (bins counted from the top): sh.digit =
+// that bin, sh.need = the rank still to find inside it, sh.bincount = elements in that bin and above.
+// All threads call it behind a barrier that closes the histogram; it ends with a barrier.
+template <int TB>
+__device__ __forceinline__ void suffix_bin(uint32_t need, SelShared &sh)
+{
+    constexpr int BPT = HBINS / TB;
+    const int tid = threadIdx.x;
+    const int lane = tid & (CN_WAVE - 1), wave = tid / CN_WAVE;
+    uint32_t p = 0;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) p += sh.hist[tid * BPT + j];
+    uint32_t s = p;
+#pragma unroll
+    for (int o = 1; o < CN_WAVE; o <<= 1) {
+        const uint32_t t = __shfl_down(s, o);
+        if (lane + o < CN_WAVE) s += t;
+    }
+    if (lane == 0) sh.wsum[wave] = s;
+    __syncthreads();
+    for (int w = wave + 1; w < TB / CN_WAVE; ++w) s += sh.wsum[w];
+    const uint32_t above = s - p;  // elements in strictly higher bins
+    if (above < need && s >= need) {
+        uint32_t run = above;
+        for (int j = BPT - 1; j >= 0; --j) {
+            const uint32_t h = sh.hist[tid * BPT + j];
+            if (run + h >= need) {
+                sh.digit = tid * BPT + j;
+                sh.need = need - run;
+                sh.bincount = run + h;
+                break;
+            }
+            run += h;
+        }
+    }
+    __syncthreads();
+}
+
 template <int TB, class ForEach>
 __device__ __forceinline__ uint32_t kth_largest_key32(ForEach &&for_each, uint32_t need, SelShared &sh)
 {
@@ -1072,70 +1110,193 @@ __global__ __launch_bounds__(NT) void collect_merge_kernel(const float *__restri
 // ---------------------------------------------------------------------------
 // ONE-launch form of the image-level decode (round 4): planes of at most 128 x 128 cells -- the
 // ctdet map of a 512 x 512 input and everything smaller.  The heat-map is read exactly ONCE: a
-// workgroup owns one (image, class) plane and holds it in REGISTERS -- half-wave u keeps rows
-// 16u .. 16u+15 (+ one halo row above and below, from L2), lane l the 4-cell quad l of every row --
-// so the logistic, the 3x3 peak test on the scores (decode.py:9-15) and every later look at a cell
-// are register work; horizontal neighbours come from the adjacent lanes by shuffle.  Then
-//   1. every lane takes the largest key of its 64 cells; T0 = the K-th largest of the 256 lane
-//      maxima (exact: three digit passes over 256 values).  At least K cells of the plane reach T0,
-//      so nothing below it can be among the plane's -- or the image's -- K best.  T0 is folded into
-//      the image's FLOOR (a device-scope atomic maximum): planes that start later skip every cell
-//      below the best T0 published so far (a few dozen planes of an image are in flight at any time;
-//      the rest hand on next to nothing);
-//   2. the cells that reach max(T0, floor) go into a list in LDS (typically ~1.2 K of them); up to
-//      OP_PE keys are handed on as they are, a longer list goes through the exact select of the
-//      plane's K best, and a list that overflows LDS (plateaus, tiny or constant maps: T0 useless)
-//      through the same select over the register cells, zeros of suppressed cells included;
-//   3. arrival / last-arriver select exactly as in collect_merge_kernel.  The last arriver leaves
-//      the image's three state words (list length, arrival counter, floor) at zero.
+// workgroup of eight waves owns one (image, class) plane and holds it in REGISTERS -- half-wave u
+// keeps rows 8u .. 8u+7 (+ one halo row above and below, from L2), lane l the 4-cell quad l of every
+// row -- so the logistic, the 3x3 peak test on the scores (decode.py:9-15) and every later look at a
+// cell are register work; horizontal neighbours come from the adjacent lanes by shuffle.  Then
+//   1. every lane takes the largest key of its 32 cells; T0 = the K-th largest of the 512 lane maxima
+//      to OP_TBITS bits (ONE wave, the maxima in its registers, a binary search on wave ballots: no
+//      histogram, no barrier inside).  At least K cells of the plane reach T0, so nothing below it
+//      can be among the plane's -- or the image's -- K best.  T0 is folded into the image's FLOOR (a
+//      device-scope atomic maximum): planes that start later skip every cell below the best T0
+//      published so far.  Workgroups run class-major (all images' plane 0, then plane 1, ...): an
+//      image's planes are spread over the launch and most of them find a floor;
+//   2. the cells that reach max(T0, floor) go into a list in LDS; up to OP_PE keys go as they are
+//      into the plane's OWN slot of the image's key buffer (no position to fetch from a counter: one
+//      device-scope round trip less), a longer list goes through the exact select of the plane's K
+//      best, and a list that overflows LDS (plateaus, tiny or constant maps: T0 useless) through the
+//      same select over the register cells, zeros of suppressed cells included;
+//   3. arrival as in collect_merge_kernel; the last arriver reads the planes' key counts, keeps the
+//      keys that reach the image's FINAL floor (a few hundred: in LDS), selects and sorts the K best
+//      and writes the detections.  It leaves the image's state words (arrival counter, floor) at zero.
 // Every input is handled exactly inside this launch; results are bit-identical to the two-launch
 // and the per-band forms (tests/test_gpu_decode.py).
 // ---------------------------------------------------------------------------
-constexpr int OP_PE = 256;        // keys a plane hands on without selecting (>= KMAX)
+constexpr int OP_NT = 512;        // threads (8 waves)
+constexpr int OP_ROWS = 8;        // rows a half-wave owns
+constexpr int OP_CELLS = OP_ROWS * 4;
+constexpr int OP_PE = 256;        // key slots of a plane in the image's buffer (>= KMAX)
+constexpr int OP_RK = 40;         // key slots per thread the last arriver keeps in registers (80 planes)
+constexpr int OP_CMAX = 1024;     // classes (the planes' key counts sit in LDS)
+constexpr int OP_TBITS = 16;      // leading key bits T0 is resolved to
 static_assert(OP_PE >= KMAX && OP_PE <= PLCAP, "plane emit cap");
+static_assert((OP_PE & (OP_PE - 1)) == 0 && OP_NT * 4 % OP_PE == 0, "slot arithmetic");
+
+#ifdef CN_ABLATE_DECODE       // variant builds only (tools/build_variant.sh): leave after stage (flags >> 16) & 15
+#define PSM_STAGE_EXIT(n, keep)                                                         \
+    if (((flags >> 16) & 15) == (n)) {                                                  \
+        if ((keep) == 0xdeadbeefu) floorv[b] = 1u;                                      \
+        return;                                                                         \
+    }
+#else
+#define PSM_STAGE_EXIT(n, keep)
+#endif
+
+// The image's last arriver of plane_select_merge_kernel (its own function, not inlined: 80 registers of
+// keys must not weigh on the allocation of the plane part every workgroup runs).
+template <int MODE>
+__device__ __attribute__((noinline)) void psm_last_arriver(SelShared &sh, int32_t *s_pc, uint32_t *s_kmax_p, int b,
+                                                           int C, int H, int W, int K,
+                                                           const u64 *__restrict__ keys,
+                                                           const int32_t *__restrict__ pcount,
+                                                           const uint32_t *__restrict__ floorv, const EmitArgs ea)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & (CN_WAVE - 1);
+    uint32_t &s_kmax = *s_kmax_p;
+    // every plane's floor update precedes its arrival: this is the image's final floor, and the
+    // image's K best all reach it (the plane that set it has K cells there and handed them on)
+    const uint32_t F = max(__hip_atomic_load(&floorv[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 1u);
+    for (int p = tid; p < C; p += OP_NT)
+        s_pc[p] = __hip_atomic_load(&pcount[(size_t)b * C + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) s_kmax = 0u;
+    for (int i = tid; i < HBINS; i += OP_NT) sh.hist[i] = 0;
+    __syncthreads();
+    const u64 *kimg = keys + (size_t)b * C * OP_PE;
+    const int slots = C * OP_PE;
+    u64 prefix, mask;
+    if (slots <= OP_NT * OP_RK) {
+        // Every key of the image in registers, ONE round trip to the coherence point.  Then a LINEAR
+        // histogram of the score keys over [F, largest key] (2048 bins: order-preserving integers, so
+        // the bin that holds the K-th largest is exact) leaves the keys of that bin and above -- K plus
+        // a few -- which are sorted as they are; a plateau that fills the bin goes through the digit
+        // select.
+        u64 kr[OP_RK];
+#pragma unroll
+        for (int u = 0; u < OP_RK; ++u) {
+            const int i = tid + u * OP_NT;
+            const bool ok = i < slots && (i & (OP_PE - 1)) < s_pc[min(i, slots - 1) / OP_PE];
+            kr[u] = ok ? __hip_atomic_load(kimg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+        uint32_t mx = 0u;
+#pragma unroll
+        for (int u = 0; u < OP_RK; ++u) {
+            const uint32_t sk = (uint32_t)(kr[u] >> 32);
+            if (sk < F) kr[u] = 0ull;                            // (and the empty slots: key 0)
+            else mx = max(mx, sk);
+        }
+#pragma unroll
+        for (int o = CN_WAVE / 2; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        if (lane == 0 && mx) atomicMax(&s_kmax, mx);
+        __syncthreads();
+        const uint32_t range = max(s_kmax, F) - F;
+        const int shift = max(0, 21 - __clz((int)(range | 1u)));      // (range >> shift) < 2048
+#pragma unroll
+        for (int u = 0; u < OP_RK; ++u)
+            if (kr[u]) atomicAdd(&sh.hist[((uint32_t)(kr[u] >> 32) - F) >> shift], 1u);
+        __syncthreads();
+        suffix_bin<OP_NT>((uint32_t)K, sh);                      // sh.digit: the bin, sh.bincount: keys in it and above
+        const uint32_t F1 = F + (sh.digit << shift);
+        const uint32_t kept = sh.bincount;
+        auto for_each = [&](auto &&f) {
+#pragma unroll
+            for (int u = 0; u < OP_RK; ++u) {
+                const uint32_t sk = (uint32_t)(kr[u] >> 32);
+                if (sk >= F1) f(kr[u], sk == KEY_ZERO);
+            }
+        };
+        if (kept <= (uint32_t)KMAX) {
+            collect_and_sort<OP_NT>(for_each, 0ull, 0ull, sh);   // all of them
+        } else {
+            radix_select<OP_NT>(for_each, (uint32_t)K, sh, prefix, mask);
+            collect_and_sort<OP_NT>(for_each, prefix, mask, sh);
+        }
+    } else {                                 // (more planes than the registers take: straight from the slots)
+        auto for_each = [&](auto &&f) {
+            for (int i = tid; i < slots; i += OP_NT) {
+                if ((i & (OP_PE - 1)) < s_pc[i / OP_PE]) {
+                    const u64 k = __hip_atomic_load(kimg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(k >> 32) >= F) f(k, (uint32_t)(k >> 32) == KEY_ZERO);
+                }
+            }
+        };
+        radix_select<OP_NT>(for_each, (uint32_t)K, sh, prefix, mask);
+        collect_and_sort<OP_NT>(for_each, prefix, mask, sh);
+    }
+    emit_rows<MODE>(sh, b, H, W, K, C, ea.wh, ea.reg, ea.cat_spec_wh, ea.dets, ea.det_dim, ea.inds_out,
+                    ea.out_scores, (const float *)nullptr, 0, ea.cls_out);
+}
 
 template <int MODE>
-__global__ __launch_bounds__(NT, 3) void plane_select_merge_kernel(const float *__restrict__ heat, int C, int H,
-                                                                   int W, int flags, int K, u64 *__restrict__ keys,
-                                                                   int cap, int32_t *__restrict__ counts,
-                                                                   int32_t *__restrict__ done,
-                                                                   uint32_t *__restrict__ floorv, const EmitArgs ea)
+__global__ __launch_bounds__(OP_NT, 4) void plane_select_merge_kernel(const float *__restrict__ heat, int B, int C,
+                                                                      int H, int W, int flags, int K,
+                                                                      u64 *__restrict__ keys,
+                                                                      int32_t *__restrict__ pcount,
+                                                                      int32_t *__restrict__ done,
+                                                                      uint32_t *__restrict__ floorv, const EmitArgs ea)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SelShared &sh = *reinterpret_cast<SelShared *>(smem);
-    __shared__ u64 pl_keys[PLCAP];
-    __shared__ int pl_cnt, pl_base, s_last;
-    __shared__ uint32_t s_floor;
+    __shared__ u64 kbuf[PLCAP];             // the plane's list
+    __shared__ uint32_t s_lmax[OP_NT / 2];
+    __shared__ int32_t s_pc[OP_CMAX];
+    __shared__ int pl_cnt, s_last;
+    __shared__ uint32_t s_thr, s_kmax;
     const int tid = threadIdx.x;
     const int lane = tid & (CN_WAVE - 1);
     const int hl = lane & 31, hw = tid >> 5;
-    const size_t plane_id = blockIdx.x;
-    const int b = (int)(plane_id / (unsigned)C), c = (int)(plane_id - (size_t)b * C);
+    int b, c;
+    if (flags & CN_DECODE_IMAGE_MAJOR) {
+        b = (int)(blockIdx.x / (unsigned)C);
+        c = (int)blockIdx.x - b * C;
+    } else {
+        c = (int)(blockIdx.x / (unsigned)B);
+        b = (int)blockIdx.x - c * B;
+    }
+    const size_t plane_id = (size_t)b * C + c;
     const bool sig = (flags & 1) != 0;
     const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;
     const int HW = H * W;
     const float *plane = heat + plane_id * (size_t)HW;
     const uint32_t base = (uint32_t)c * (uint32_t)HW;
     const int w4 = W >> 2;
-    const float NEG_INF = -__builtin_huge_valf();
     // the image's floor so far: requested first, lands under the map loads
     uint32_t fl = 0u;
     if (tid == 0) fl = __hip_atomic_load(&floorv[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-    // ---- the plane into registers: rows y0-1 .. y0+16 of this half-wave, all loads issued up front
-    const int y0 = hw * GUNIT;
+    // ---- the plane into registers: rows y0-1 .. y0+8 of this half-wave, all loads issued up front
+    const int y0 = hw * OP_ROWS;
     const bool col_ok = hl < w4;
-    const int nv = col_ok ? min(max(H - y0, 0), GUNIT) : 0;      // valid rows of this lane's 16
+    const int nv = col_ok ? min(max(H - y0, 0), OP_ROWS) : 0;    // valid rows of this lane's 8
     // (branch-free: rows / quads outside the map read a clamped address and are replaced below)
-    cn_f32x4 rowv[GUNIT + 2];
+    cn_f32x4 rowv[OP_ROWS + 2];
     {
         const uint32_t xoff = col_ok ? (uint32_t)hl * 4u : 0u;
 #pragma unroll
-        for (int r = 0; r < GUNIT + 2; ++r) {
+        for (int r = 0; r < OP_ROWS + 2; ++r) {
             const int yc = min(max(y0 - 1 + r, 0), H - 1);
             rowv[r] = *reinterpret_cast<const cn_f32x4 *>(plane + ((uint32_t)yc * (uint32_t)W + xoff));
         }
     }
+#ifdef CN_ABLATE_DECODE
+    if (((flags >> 16) & 15) == 1) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < OP_ROWS + 2; ++r) acc += rowv[r].x + rowv[r].y + rowv[r].z + rowv[r].w;
+        if (acc == 123.456f) floorv[b] = 1u;
+        return;
+    }
+#endif
     // (selections below are written as bit masks: left as ?: the compiler wraps every transcendental
     // and every shuffle fix-up in its own branch)
     const uint32_t NINF = 0xff800000u;
@@ -1165,17 +1326,17 @@ __global__ __launch_bounds__(NT, 3) void plane_select_merge_kernel(const float *
         h.w = fmaxf(fmaxf(rowv[r].z, rowv[r].w), rr);
         return h;
     };
-    // the 64 cells of this lane as keys of heat * keep (decode.py:14; -0.0 -> +0.0); cell i = row
+    // the 32 cells of this lane as keys of heat * keep (decode.py:14; -0.0 -> +0.0); cell i = row
     // y0 + (i >> 2), column 4 hl + (i & 3).  Cells outside the map get key 0, which no threshold
     // admits (thresholds are >= 1; a cell of the map has key 0 only for one NaN pattern).  A row's
     // registers die as soon as the row below it has been combined.
-    uint32_t kreg[GUNIT * 4];
+    uint32_t kreg[OP_CELLS];
     {
         score_row(0);
         score_row(1);
         cn_f32x4 h0 = hrow(0), h1 = hrow(1);
 #pragma unroll
-        for (int r = 1; r <= GUNIT; ++r) {
+        for (int r = 1; r <= OP_ROWS; ++r) {
             score_row(r + 1);
             const cn_f32x4 h2 = hrow(r + 1);
 #pragma unroll
@@ -1194,30 +1355,49 @@ __global__ __launch_bounds__(NT, 3) void plane_select_merge_kernel(const float *
         return ((u64)kreg[i] << 32) | (u64)(0xFFFFFFFFu - (base + cell));
     };
 
-    // ---- 1. T0 = K-th largest lane maximum (0: fewer than K lanes hold a cell -- small maps: every
-    // cell of the map is admitted)
+    // ---- 1. T0 = K-th largest lane maximum, to OP_TBITS bits (0: fewer than K lanes hold a cell --
+    // small maps: every cell of the map is admitted)
     uint32_t lmax = 0u;
 #pragma unroll
-    for (int i = 0; i < GUNIT * 4; ++i) lmax = max(lmax, kreg[i]);
-    auto lanes = [&](auto &&f) { f(lmax); };
-    const uint32_t T0 = kth_largest_key32<NT>(lanes, (uint32_t)K, sh);
-    if (tid == 0) {
-        s_floor = fl;
-        pl_cnt = 0;
-        if (T0 > fl) __hip_atomic_fetch_max(&floorv[b], T0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < OP_CELLS; ++i) lmax = max(lmax, kreg[i]);
+    PSM_STAGE_EXIT(2, lmax)
+    // (a lane and its partner in the other half-wave count as one: 256 values, each the key of one cell)
+    const uint32_t pmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, 32));
+    if (lane < 32) s_lmax[(tid >> 6) * 32 + lane] = pmax;
+    if (tid == 0) pl_cnt = 0;
+    __syncthreads();
+    if (tid < CN_WAVE) {
+        // ONE wave searches while seven wait: it goes first on its SIMD
+        __builtin_amdgcn_s_setprio(3);
+        constexpr int NV = OP_NT / 2 / CN_WAVE;
+        uint32_t v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = s_lmax[lane + j * CN_WAVE];
+        uint32_t T0 = 0u;
+#pragma unroll
+        for (int bit = 31; bit >= 32 - OP_TBITS; --bit) {
+            const uint32_t cand = T0 | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) cnt += __popcll(__ballot(v[j] >= cand));
+            if (cnt >= K) T0 = cand;
+        }
+        if (tid == 0) {
+            s_thr = max(max(T0, fl), 1u);
+            if (T0 > fl) __hip_atomic_fetch_max(&floorv[b], T0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
-    const uint32_t thr = max(max(T0, s_floor), 1u);
+    const uint32_t thr = s_thr;
+    PSM_STAGE_EXIT(3, thr)
 
     // ---- 2. cells that reach thr -> LDS list (half-wave prefix sums, one LDS atomic per half-wave)
-    uint32_t m0 = 0u, m1 = 0u;
+    uint32_t m0 = 0u;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        m0 |= (kreg[i] >= thr) ? (1u << i) : 0u;
-        m1 |= (kreg[i + 32] >= thr) ? (1u << i) : 0u;
-    }
+    for (int i = 0; i < OP_CELLS; ++i) m0 |= (kreg[i] >= thr) ? (1u << i) : 0u;
     {
-        const int mine = __popc(m0) + __popc(m1);
+        const int mine = __popc(m0);
         int incl = mine;
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {
@@ -1230,9 +1410,9 @@ __global__ __launch_bounds__(NT, 3) void plane_select_merge_kernel(const float *
         int pos = __shfl(pos0, 31, 32) + incl - mine;
         if (mine) {
 #pragma unroll
-            for (int i = 0; i < 64; ++i) {
-                if ((i < 32 ? m0 >> i : m1 >> (i - 32)) & 1u) {
-                    if (pos < PLCAP) pl_keys[pos] = key64(i);
+            for (int i = 0; i < OP_CELLS; ++i) {
+                if ((m0 >> i) & 1u) {
+                    if (pos < PLCAP) kbuf[pos] = key64(i);
                     ++pos;
                 }
             }
@@ -1240,39 +1420,37 @@ __global__ __launch_bounds__(NT, 3) void plane_select_merge_kernel(const float *
     }
     __syncthreads();
     const int n = pl_cnt;                    // (uniform)
+    PSM_STAGE_EXIT(4, (uint32_t)n)
     int m;
     const u64 *src;
     if (n <= OP_PE) {
         m = n;
-        src = pl_keys;
+        src = kbuf;
     } else {
         m = K;                               // n > OP_PE >= K cells reach thr: the plane's K best are among them
         u64 prefix, mask;
         if (n <= PLCAP) {
             auto for_each = [&](auto &&f) {
-                for (int j = tid; j < n; j += NT) f(pl_keys[j], false);
+                for (int j = tid; j < n; j += OP_NT) f(kbuf[j], false);
             };
-            radix_select<NT>(for_each, (uint32_t)m, sh, prefix, mask);
-            collect_and_sort<NT>(for_each, prefix, mask, sh);
+            radix_select<OP_NT>(for_each, (uint32_t)m, sh, prefix, mask);
+            collect_and_sort<OP_NT>(for_each, prefix, mask, sh);
         } else {
             auto for_each = [&](auto &&f) {
 #pragma unroll
-                for (int i = 0; i < GUNIT * 4; ++i)
+                for (int i = 0; i < OP_CELLS; ++i)
                     if (kreg[i] >= thr) f(key64(i), kreg[i] == KEY_ZERO);
             };
-            radix_select<NT>(for_each, (uint32_t)m, sh, prefix, mask);
-            collect_and_sort<NT>(for_each, prefix, mask, sh);
+            radix_select<OP_NT>(for_each, (uint32_t)m, sh, prefix, mask);
+            collect_and_sort<OP_NT>(for_each, prefix, mask, sh);
         }
         src = sh.sel;
     }
-    u64 *kimg = keys + (size_t)b * cap;
-    if (m > 0) {
-        if (tid == 0) pl_base = atomicAdd(&counts[b], m);
-        __syncthreads();
-        const int o = pl_base;
-        for (int j = tid; j < m; j += NT)
-            if (o + j < cap) __hip_atomic_store(kimg + o + j, src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // the plane's own slot: nothing to fetch before the stores can go
+    u64 *kslot = keys + plane_id * OP_PE;
+    for (int j = tid; j < m; j += OP_NT) __hip_atomic_store(kslot + j, src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&pcount[plane_id], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PSM_STAGE_EXIT(5, (uint32_t)m)
 
     // ---- 3. arrival (see collect_merge_kernel for the memory-ordering argument)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1281,43 +1459,17 @@ __global__ __launch_bounds__(NT, 3) void plane_select_merge_kernel(const float *
         s_last = (__hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == C - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    const int cnt = min(__hip_atomic_load(&counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cap);
-    u64 prefix, mask;
-    constexpr int RK = 16;
-    if (cnt <= RK * NT) {
-        u64 kr[RK];
-#pragma unroll
-        for (int u = 0; u < RK; ++u)
-            kr[u] = (tid + u * NT < cnt) ? __hip_atomic_load(kimg + tid + u * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                         : 0ull;
-        auto for_each = [&](auto &&f) {
-#pragma unroll
-            for (int u = 0; u < RK; ++u)
-                if (tid + u * NT < cnt) f(kr[u], (uint32_t)(kr[u] >> 32) == KEY_ZERO);
-        };
-        radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
-        collect_and_sort<NT>(for_each, prefix, mask, sh);
-    } else {
-        auto for_each = [&](auto &&f) {
-            for (int j = tid; j < cnt; j += NT) {
-                const u64 k = __hip_atomic_load(kimg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                f(k, (uint32_t)(k >> 32) == KEY_ZERO);
-            }
-        };
-        radix_select<NT>(for_each, (uint32_t)K, sh, prefix, mask);
-        collect_and_sort<NT>(for_each, prefix, mask, sh);
-    }
-    emit_rows<MODE>(sh, b, H, W, K, C, ea.wh, ea.reg, ea.cat_spec_wh, ea.dets, ea.det_dim, ea.inds_out,
-                    ea.out_scores, (const float *)nullptr, 0, ea.cls_out);
+    PSM_STAGE_EXIT(6, (uint32_t)m)
+    psm_last_arriver<MODE>(sh, s_pc, &s_kmax, b, C, H, W, K, keys, pcount, floorv, ea);
     // the image's state words go back to zero: the next call on this workspace needs no fill
     // (device-scope stores: the words of other images share these cache lines and are being updated
     // by atomics from other XCDs)
     if (tid == 0) {
-        __hip_atomic_store(&counts[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&done[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&floorv[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+
 
 struct BandPlan {
     int R;       // rows per band
@@ -1365,7 +1517,7 @@ struct ImgPlan {
     bool one_pass;                 // planes of <= 128 x 128 cells: plane_select_merge_kernel (ONE launch)
     int nrg, ncb;                  // 8-row groups per plane, 128-column blocks per row
     int cap;                       // candidate keys per image: every plane hands on at most its K best
-    size_t gpeak, gall, counts, done, floorv, keys, total;   // byte offsets in the workspace
+    size_t gpeak, gall, counts, done, floorv, pcount, keys, total;   // byte offsets in the workspace
     size_t state_bytes;            // counts | done | floorv: contiguous, zero between calls of the one-launch form
 };
 ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
@@ -1377,7 +1529,7 @@ ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
     p.ncb = cn_cdiv(W, 128);
     // enough groups per image for a meaningful threshold; rows of whole quads
     p.use = (W & 3) == 0 && (long)C * p.nrg * p.ncb >= 4L * K;
-    p.one_pass = p.use && H <= 8 * GUNIT && W <= 128;
+    p.one_pass = p.use && H <= (OP_NT / 32) * OP_ROWS && W <= 128 && C <= OP_CMAX;
     const size_t ng = (size_t)B * C * p.nrg * p.ncb;
     p.gpeak = o;  o += cn_align_up(ng * 4, 256);
     p.gall = o;   o += cn_align_up(ng * 4, 256);
@@ -1385,6 +1537,7 @@ ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
     p.done = o;   o += cn_align_up((size_t)B * 4, 256);
     p.floorv = o; o += cn_align_up((size_t)B * 4, 256);
     p.state_bytes = o - p.counts;
+    p.pcount = o; o += cn_align_up((size_t)B * C * 4, 256);   // keys in every plane's slot (one-launch form)
     p.cap = C * (p.one_pass ? OP_PE : K);
     p.keys = o;   o += cn_align_up((size_t)B * p.cap * 8, 256);
     p.total = o;
@@ -1403,14 +1556,15 @@ int launch_image_topk(const float *heat, int B, int C, int H, int W, int K, int 
     u64 *keys = (u64 *)(ws + ip.keys);
     dim3 grid((unsigned)(B * C)), block(NT);
     if (ip.one_pass && !(flags & CN_DECODE_TWO_LAUNCHES)) {
-        // ONE launch.  The image state words (list length, arrival counter, floor) must be zero on
-        // entry and are left at zero by the kernel: a caller that keeps the workspace to itself says
-        // so (CN_DECODE_STATE_CLEAN) after zeroing it once; anyone else pays a 3 x 128-byte fill.
+        // ONE launch.  The image state words (arrival counter, floor) must be zero on entry and are
+        // left at zero by the kernel: a caller that keeps the workspace to itself says so
+        // (CN_DECODE_STATE_CLEAN) after zeroing it once; anyone else pays a small fill.
         if (!(flags & CN_DECODE_STATE_CLEAN)) {
             if (hipMemsetAsync(ws + ip.counts, 0, ip.state_bytes, st) != hipSuccess) return CN_ERR_LAUNCH;
         }
-        hipLaunchKernelGGL(plane_select_merge_kernel<MODE>, grid, block, sizeof(SelShared), st, heat, C, H, W,
-                           flags, K, keys, ip.cap, counts, done, (uint32_t *)(ws + ip.floorv), ea);
+        hipLaunchKernelGGL(plane_select_merge_kernel<MODE>, grid, dim3(OP_NT), sizeof(SelShared), st, heat, B, C,
+                           H, W, flags, K, keys, (int32_t *)(ws + ip.pcount), done, (uint32_t *)(ws + ip.floorv),
+                           ea);
         CN_CHECK_LAUNCH();
         return CN_OK;
     }

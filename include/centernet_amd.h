@@ -544,6 +544,9 @@ int cn_ctdet_decode_f32(const float *heat, const float *wh, const float *reg,
 #define CN_DECODE_STATE_CLEAN 4096
 #define CN_DECODE_TWO_LAUNCHES 8192
 #define CN_DECODE_PER_BAND 2048
+/* (A/B only) the one-launch form walks its (image, class) planes image by image instead of class by
+ * class -- same results, the image floor finds less to prune. */
+#define CN_DECODE_IMAGE_MAJOR 32768
 
 /* _nms + _topk_channel (models/decode.py:9-15, 92-101) as one kernel: per
  * (b,c) plane the K best peaks; scores (B,C,K) desc, inds (B,C,K) int32. */

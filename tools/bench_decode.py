@@ -85,6 +85,7 @@ check_forms()
 for name, flags, w in (("one launch, owned workspace (default product path)", 1 | 4096, zws),
                        ("one launch + state fill (any caller)", 1, ws),
                        ("one launch, post-sigmoid in", 4096, zws),
+                       ("one launch, planes image by image (flag 32768)", 1 | 32768, ws),
                        ("two launches (flag 8192; round-4 first form)", 1 | 8192, ws),
                        ("per-band select of round 1 (flag 2048)", 1 | 2048, ws)):
     ws_cur = w
