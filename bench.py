@@ -32,7 +32,9 @@ F16_MFMA_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARC
 # matrix-pipe ceiling in ALGORITHMIC (fp32-equivalent) FLOPs is a third of the fp16 peak
 F32S_MFMA_PEAK_TF = F16_MFMA_PEAK_TF / 3.0
 
-DECODE_LAUNCHES = {"ctdet": 2, "multi_pose": 5}   # kernels per decode call (cn_decode.hip)
+# kernels per decode call (cn_decode.hip): ctdet maps of <= 128 x 128 cells (a 512 x 512 input) take the
+# one-launch form plane_select_merge_kernel, larger ones group_max + collect_merge
+DECODE_LAUNCHES = {"ctdet": 1, "ctdet_large": 2, "multi_pose": 5}
 
 # BASELINE.json configs[1..4] (configs[0] is the reference's CPU plumbing case: cpu_baseline)
 CONFIGS = {
@@ -95,7 +97,8 @@ def pmc_traffic(tag):
             c = "dcn"
         elif base.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_")):
             c = "conv"
-        elif base.startswith(("nms_topk", "merge_topk", "peak_", "group_", "pose_match", "decode_", "collect_merge")):
+        elif base.startswith(("nms_topk", "merge_topk", "peak_", "group_", "pose_match", "decode_", "collect_merge",
+                              "plane_select_merge")):
             c = "decode"
         elif base.startswith("maxpool"):
             c = "maxpool"
@@ -619,7 +622,8 @@ def main():
         else:                   # hm 1 + wh 2 + hps 34 + reg 2 + hm_hp 17 + hp_offset 2, (K,40)
             dec_bytes = B * ((1 + 2 + 34 + 2 + 17 + 2) * Ho * Ho * 4 + opt.K * 40 * 4)
         kinds["decode"] = {"ms": dec_ms, "flops": 0, "bytes": dec_bytes * a.steps,
-                           "launches": DECODE_LAUNCHES[a.task] * a.steps}
+                           "launches": DECODE_LAUNCHES["ctdet_large" if a.task == "ctdet" and Ho > 128
+                                                       else a.task] * a.steps}
         dom = max(kinds, key=lambda k: kinds[k]["ms"])
         standard = (a.res == 512 and not a.tune and not a.fp32_mfma and
                     all(getattr(a, k) == v for k, v in CONFIGS[a.config].items()))

@@ -1709,6 +1709,7 @@ extern "C" int cn_stem_f32s_supported(const cn_conv_desc *d)
 }
 
 extern int cn_tune_c3p, cn_tune_c3p_stagger, cn_tune_c3p_knobs, cn_tune_c3p_heads, cn_tune_c3p_deconv, cn_tune_c3p_s2;
+extern int cn_tune_dcn_wgs, cn_tune_dcn_bn64;   // cn_dcn2.hip
 extern "C" int cn_set_tuning(int key, int value)
 {
     if (key == 28 && value >= 0 && value <= 7) {
@@ -1733,6 +1734,14 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 33 && (value == 0 || value == 1)) {
         cn_tune_c3p_s2 = value;
+        return CN_OK;
+    }
+    if (key == 34 && value >= 1 && value <= 4096) {
+        cn_tune_dcn_wgs = value;
+        return CN_OK;
+    }
+    if (key == 35 && value >= 0 && value <= 4096) {
+        cn_tune_dcn_bn64 = value;
         return CN_OK;
     }
     if (key == 20 && (value == 0 || value == 1)) {

@@ -35,6 +35,9 @@
 // Epilogue as everywhere: y = relu?((acc + bias) * scale + shift), plain fp32 or f32s, range words.
 #include "cn_common.h"
 
+int cn_tune_dcn_wgs = 256;     // cn_set_tuning key 34: the register-sampling form splits K until a launch has this many workgroups
+int cn_tune_dcn_bn64 = 0;      // cn_set_tuning key 35: 64-wide N tiles for Cout > 64 when 128-wide ones give fewer workgroups than this
+
 namespace {
 
 constexpr int NT = 512;        // 8 waves
@@ -830,21 +833,23 @@ int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, 
     if (H > 32767 || W > 32767 || (out_pitch & 3) || !cn_aligned16(y) || !cn_aligned16(x)) return CN_ERR_UNSUPPORTED;
     if ((om_pitch & 1) || (((uintptr_t)om) & 7u)) return CN_ERR_UNSUPPORTED;   // (offset pairs are 8-byte loads)
     if ((size_t)B * H * W * Cin * 4 >= ((size_t)1 << 32)) return CN_ERR_UNSUPPORTED;   // 32-bit byte offsets
-    const int bn = Cout > 64 ? 128 : 64;
     const int tsx = variant == 0 ? R_TX : TS;
+    int bn = Cout > 64 ? 128 : 64;
+    if (variant == 0 && bn == 128 && (long)B * (H / TS) * (W / tsx) * cn_cdiv(Cout, 128) < cn_tune_dcn_bn64) bn = 64;
     const long wgs = (long)B * (H / TS) * (W / tsx) * cn_cdiv(Cout, bn);
     // Too few tiles for the chip but a deep K (512 -> 256 @ 16^2): split the 32-channel chunks over
     // 2 / 4 / 8 workgroups per tile -- raw fp32 partial sums in the caller's workspace, summed in a
     // fixed order by splitk_reduce_kernel (deterministic) -- when that yields >= 256 workgroups
     int ksplit = 1;
-    if (wgs < min_wgs) {
+    if (wgs < cn_tune_dcn_wgs || wgs < min_wgs) {
+        // the smallest split that reaches the workgroup target, else the deepest one that fits
         const int nchunk = (Cin + 31) / 32;
         const int cout_pad = (Cout + 31) / 32 * 32;
-        for (int s2 = 2; s2 <= 8 && variant == 0 && partial && ksplit == 1; s2 *= 2)
-            if (nchunk % s2 == 0 && nchunk / s2 >= 2 && wgs * s2 >= 256 &&
+        for (int s2 = 2; s2 <= 8 && variant == 0 && partial && wgs * ksplit < cn_tune_dcn_wgs; s2 *= 2)
+            if (nchunk % s2 == 0 && nchunk / s2 >= 2 &&
                 (size_t)s2 * B * H * W * cout_pad * sizeof(float) <= partial_bytes)
                 ksplit = s2;
-        if (ksplit == 1) return CN_ERR_UNSUPPORTED;
+        if (wgs * ksplit < 256 && wgs < min_wgs) return CN_ERR_UNSUPPORTED;   // (the tap-split gather form serves these)
     }
     Dcn2Args a = {};
     a.x = x; a.w = w_packed; a.bias = bias; a.scale = scale; a.shift = shift; a.om = om; a.y = y;

@@ -1237,8 +1237,11 @@ __device__ __attribute__((noinline)) void psm_last_arriver(SelShared &sh, int32_
                     ea.out_scores, (const float *)nullptr, 0, ea.cls_out);
 }
 
+#ifndef CN_PSM_WAVES
+#define CN_PSM_WAVES 4        // waves per SIMD the register budget is cut for (two workgroups per CU)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(OP_NT, 4) void plane_select_merge_kernel(const float *__restrict__ heat, int B, int C,
+__global__ __launch_bounds__(OP_NT, CN_PSM_WAVES) void plane_select_merge_kernel(const float *__restrict__ heat, int B, int C,
                                                                       int H, int W, int flags, int K,
                                                                       u64 *__restrict__ keys,
                                                                       int32_t *__restrict__ pcount,
