@@ -854,7 +854,44 @@ __global__ __launch_bounds__(256) void calib_copy_kernel(const cn_f32x4 *__restr
         dst[i] = src[i];
 }
 
+// ONE lane walks a chain of dependent loads (chain[i] = index of the next element), then a chain of
+// dependent device-scope atomic additions on one word: out[0], out[1] = ticks of the constant 100 MHz
+// clock (s_memrealtime) each took, out[2] = a value that depends on every step.  What bandwidth and the
+// matrix loop do not show: the latency of this box's memory system, which the kernels with round trips
+// on their critical path (arrival counters, barrier-paced DMA) are sensitive to.
+__global__ __launch_bounds__(64) void calib_latency_kernel(const uint32_t *__restrict__ chain, uint32_t start,
+                                                           int steps, uint32_t *atom, unsigned long long *out)
+{
+    if (threadIdx.x != 0) return;
+    uint32_t i = start;
+    const unsigned long long t0 = wall_clock64();
+    for (int s = 0; s < steps; ++s) {
+        asm volatile("" : "+v"(i));            // a vector load (L1 -> L2 -> Infinity Cache -> HBM), not the scalar cache
+        i = chain[i];
+    }
+    asm volatile("" : "+v"(i));
+    const unsigned long long t1 = wall_clock64();
+    uint32_t v = i & 1u;
+    for (int s = 0; s < steps; ++s)
+        v = __hip_atomic_fetch_add(atom, (v >> 31) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" : "+v"(v));
+    const unsigned long long t2 = wall_clock64();
+    out[0] = t1 - t0;
+    out[1] = t2 - t1;
+    out[2] = (unsigned long long)i + v;
+}
+
 }  // namespace
+
+extern "C" int cn_calib_latency(const uint32_t *chain, uint32_t start, int steps, uint32_t *atom,
+                                unsigned long long *out, void *stream)
+{
+    if (!chain || !atom || !out) return CN_ERR_NULL;
+    if (steps <= 0) return CN_ERR_SHAPE;
+    hipLaunchKernelGGL(calib_latency_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, chain, start, steps, atom, out);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
 
 extern "C" double cn_calib_mfma_f16(float *sink, int iters, void *stream)
 {

@@ -255,6 +255,12 @@ int cn_flip_average_f32(float *x_pair, float *out, int C, int H, int W, const in
  * grid-stride copy of `bytes` (multiple of 16) from src to dst. */
 double cn_calib_mfma_f16(float *sink, int iters, void *stream);
 int cn_calib_copy(const void *src, void *dst, size_t bytes, void *stream);
+/* cn_calib_latency: ONE lane walks `steps` dependent loads through `chain` (chain[i] = index of the
+ * next element; the caller lays the walk out: a buffer beyond the caches for the HBM latency, a small
+ * one for L2), then `steps` dependent device-scope atomic additions on *atom.  out[0], out[1]: ticks of
+ * the constant 100 MHz clock each chain took; out[2]: sink. */
+int cn_calib_latency(const uint32_t *chain, uint32_t start, int steps, uint32_t *atom,
+                     unsigned long long *out, void *stream);
 
 /* ------------------------------------------------------------------------
  * Dense convolution as an implicit GEMM on fp32 MFMA (no im2col buffer).
