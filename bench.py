@@ -266,21 +266,23 @@ def box_calibration(dev, target_ms=50.0):
     # 256 KiB (L2), dependent device-scope atomics -- ONE lane, 4096 steps each
     steps = 4096
 
-    def walk(n_elems, stride):
+    def walk(n_elems, stride, fresh=False):
         chain = torch.arange(n_elems, device=dev, dtype=torch.int32) + stride
         chain = torch.where(chain >= n_elems, chain - n_elems, chain).contiguous()
         atom = torch.zeros(64, device=dev, dtype=torch.int32)
         res = torch.zeros(4, device=dev, dtype=torch.int64)
         best = None
         for _ in range(3):
-            native.check(lib.cn_calib_latency(native.ptr(chain), 0, steps, native.ptr(atom), native.ptr(res),
-                                              st()), "cn_calib_latency")
+            # (fresh: every repeat walks lines no earlier walk touched -- a repeat of the same walk
+            # would find its 4096 lines in L2)
+            native.check(lib.cn_calib_latency(native.ptr(chain), 32 * _ if fresh else 0, steps, native.ptr(atom),
+                                              native.ptr(res), st()), "cn_calib_latency")
             torch.cuda.synchronize()
             r = res.cpu().tolist()
             cur = (r[0] * 10.0 / steps, r[1] * 10.0 / steps)      # 100 MHz ticks -> ns per step
             best = cur if best is None else (min(best[0], cur[0]), min(best[1], cur[1]))
         return best
-    hbm_ns, atomic_ns = walk((1 << 30) // 4, 4099 * 64 + 32)    # a new 128-byte line 1 MiB away, every step, over 1 GiB
+    hbm_ns, atomic_ns = walk((1 << 30) // 4, 4099 * 64 + 32, fresh=True)   # a new 128-byte line 1 MiB away, every step, over 1 GiB
     l2_ns, _ = walk((1 << 20) // 4, 37 * 32)                     # 1 MiB: beyond L1, inside the XCD's 4 MiB L2
     l1_ns, _ = walk((8 << 10) // 4, 5 * 32)                      # 8 KiB: L1
     out.update({"latency_ns": {"hbm_dependent_load": hbm_ns, "l2_dependent_load": l2_ns, "l1_dependent_load": l1_ns,
