@@ -582,6 +582,27 @@ def main():
 
     if not range_clean:
         raise SystemExit("bench.py: an f32s forward clamped a value inside the timed region")
+    clock = None
+    if rank == 0 and not stub:
+        # the shader clock the step leaves the part at (a few more untimed steps, the probe enqueued right
+        # behind them) and the clock after half a second of rest: what power management does to THIS box
+        # under THIS kernel mix -- the register-only matrix loop of box_calibration does not pull it down
+        from centernet_amd import native
+        lib = native.lib()
+        cres = torch.zeros(4, device=dev, dtype=torch.int64)
+
+        def core_mhz():
+            native.check(lib.cn_calib_clock(native.ptr(cres), 3000, native.stream_ptr()), "cn_calib_clock")
+            torch.cuda.synchronize()
+            c, t = cres.cpu().tolist()[:2]
+            return 100.0 * c / max(t, 1)
+        for _ in range(5):
+            det.run_batch(images)
+        loaded = core_mhz()
+        time.sleep(0.5)
+        rested = core_mhz()
+        clock = {"core_MHz_behind_the_step": loaded, "core_MHz_after_500ms_rest": rested,
+                 "what": "s_memtime cycles over 30 us of the constant 100 MHz clock, one lane"}
     fp32_leg = None
     if rank == 0 and not a.fp16 and not a.fp32_mfma and not a.no_fp32_leg and not stub:
         # the same step on the plain fp32 matrix instruction (v_mfma_f32_32x32x2_f32), a few
@@ -719,6 +740,7 @@ def main():
                 "img_s_per_mfma_TFLOPs": total_imgs / dt / world / calib["mfma_f16_TFLOPs"],
                 "img_s_per_copy_TBs": total_imgs / dt / world / calib["copy_TBs"]},
             "range_tracking_off_leg": track_leg,
+            "clock_under_load": clock,
             "roofline": roof(dom, "mfma" if kinds[dom]["flops"] > 0 else "hbm"),
             "roofline_dcn_mfma": roof("dcn", "mfma") if "dcn" in kinds else None,
             "roofline_dcn_hbm": roof("dcn", "hbm") if "dcn" in kinds else None,

@@ -881,7 +881,32 @@ __global__ __launch_bounds__(64) void calib_latency_kernel(const uint32_t *__res
     out[2] = (unsigned long long)i + v;
 }
 
+// The shader clock right now: one lane counts core cycles (s_memtime) over `ticks` ticks of the constant
+// 100 MHz clock (s_memrealtime).  out[0] = core cycles, out[1] = 100 MHz ticks.  Launched right behind
+// a loaded stretch it reads the clock the power management left the part at -- which the register-only
+// matrix loop above does not pull down the way the real kernel mix does.
+__global__ __launch_bounds__(64) void calib_clock_kernel(unsigned long long *out, int ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long c0 = clock64();
+    unsigned long long t1 = t0;
+    while ((long long)(t1 - t0) < (long long)ticks) t1 = wall_clock64();
+    const unsigned long long c1 = clock64();
+    out[0] = c1 - c0;
+    out[1] = t1 - t0;
+}
+
 }  // namespace
+
+extern "C" int cn_calib_clock(unsigned long long *out, int ticks, void *stream)
+{
+    if (!out) return CN_ERR_NULL;
+    if (ticks <= 0 || ticks > 100000000) return CN_ERR_SHAPE;
+    hipLaunchKernelGGL(calib_clock_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, ticks);
+    CN_CHECK_LAUNCH();
+    return CN_OK;
+}
 
 extern "C" int cn_calib_latency(const uint32_t *chain, uint32_t start, int steps, uint32_t *atom,
                                 unsigned long long *out, void *stream)

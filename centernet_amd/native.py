@@ -107,6 +107,8 @@ def _declare(lib):
     lib.cn_calib_mfma_f16.argtypes = [vp, i, vp]
     lib.cn_calib_copy.restype = i
     lib.cn_calib_copy.argtypes = [vp, vp, sz, vp]
+    lib.cn_calib_clock.restype = i
+    lib.cn_calib_clock.argtypes = [vp, i, vp]
     lib.cn_calib_latency.restype = i
     lib.cn_calib_latency.argtypes = [vp, ctypes.c_uint32, i, vp, vp, vp]
     lib.cn_maxpool_nhwc_f32s.restype = i

@@ -261,6 +261,10 @@ int cn_calib_copy(const void *src, void *dst, size_t bytes, void *stream);
  * the constant 100 MHz clock each chain took; out[2]: sink. */
 int cn_calib_latency(const uint32_t *chain, uint32_t start, int steps, uint32_t *atom,
                      unsigned long long *out, void *stream);
+/* cn_calib_clock: one lane counts shader-core cycles over `ticks` ticks of the constant 100 MHz clock:
+ * out[0] = core cycles, out[1] = ticks -- the core clock at the moment the launch runs (enqueue it right
+ * behind the work whose clock is asked for). */
+int cn_calib_clock(unsigned long long *out, int ticks, void *stream);
 
 /* ------------------------------------------------------------------------
  * Dense convolution as an implicit GEMM on fp32 MFMA (no im2col buffer).
