@@ -16,6 +16,7 @@ timed loop.  Images shard over ranks (weak scaling, no collective in the loop); 
 broadcasts the flat weight buffer once at start-up over RCCL.  Prints ONE JSON line (rank 0).
 """
 import argparse
+import ctypes
 import glob
 import json
 import os
@@ -584,25 +585,36 @@ def main():
         raise SystemExit("bench.py: an f32s forward clamped a value inside the timed region")
     clock = None
     if rank == 0 and not stub:
-        # the shader clock the step leaves the part at (a few more untimed steps, the probe enqueued right
-        # behind them) and the clock after half a second of rest: what power management does to THIS box
-        # under THIS kernel mix -- the register-only matrix loop of box_calibration does not pull it down
+        # the shader clock WHILE the step runs: one spinning lane on a side stream counts core cycles
+        # (s_memtime) against the constant 100 MHz clock for about two steps, with untimed steps of the
+        # same loop on the launch stream around it -- and the same probe on the resting part.  What power
+        # management does to THIS box under THIS kernel mix; the register-only matrix loop of
+        # box_calibration does not pull the clock down the way the real mix does.
         from centernet_amd import native
         lib = native.lib()
         cres = torch.zeros(4, device=dev, dtype=torch.int64)
+        side = torch.cuda.Stream(device=dev)
+        step_ticks = max(3000, int(2.0 * dt / a.steps * 1e8))      # two steps, in 10 ns ticks
 
-        def core_mhz():
-            native.check(lib.cn_calib_clock(native.ptr(cres), 3000, native.stream_ptr()), "cn_calib_clock")
-            torch.cuda.synchronize()
-            c, t = cres.cpu().tolist()[:2]
-            return 100.0 * c / max(t, 1)
+        def probe(ticks, stream):
+            native.check(lib.cn_calib_clock(native.ptr(cres), ticks, ctypes.c_void_p(stream.cuda_stream)),
+                         "cn_calib_clock")
+        for _ in range(3):
+            det.run_batch(images)
+        probe(step_ticks, side)                 # (no event between the streams: the probe starts now)
         for _ in range(5):
             det.run_batch(images)
-        loaded = core_mhz()
+        torch.cuda.synchronize()
+        c, t = cres.cpu().tolist()[:2]
+        loaded = 100.0 * c / max(t, 1)
         time.sleep(0.5)
-        rested = core_mhz()
-        clock = {"core_MHz_behind_the_step": loaded, "core_MHz_after_500ms_rest": rested,
-                 "what": "s_memtime cycles over 30 us of the constant 100 MHz clock, one lane"}
+        probe(3000, torch.cuda.current_stream(dev))
+        torch.cuda.synchronize()
+        c, t = cres.cpu().tolist()[:2]
+        rested = 100.0 * c / max(t, 1)
+        clock = {"core_MHz_while_the_step_runs": loaded, "core_MHz_at_rest": rested,
+                 "what": "s_memtime cycles of one spinning lane over two steps (side stream, steps running "
+                         "on the launch stream) / over 30 us after 0.5 s of rest, against the constant 100 MHz clock"}
     fp32_leg = None
     if rank == 0 and not a.fp16 and not a.fp32_mfma and not a.no_fp32_leg and not stub:
         # the same step on the plain fp32 matrix instruction (v_mfma_f32_32x32x2_f32), a few
