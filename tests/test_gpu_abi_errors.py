@@ -103,3 +103,29 @@ def test_python_layer_raises_on_cpu_tensors():
     from centernet_amd.decode import ctdet_decode
     with pytest.raises(native.NativeError):
         ctdet_decode(torch.rand(1, 2, 8, 8), torch.rand(1, 2, 8, 8))
+
+
+def test_box_calibration_probes(dev):
+    """The measurement aids of bench.py's box_calibration / clock_under_load (no reference counterpart):
+    the dependent-load walk and the device-scope atomic chain report plausible times and follow the
+    chain they are given; the clock probe reads a core clock of a few GHz; error codes for bad arguments."""
+    lib = native.lib()
+    st, p = native.stream_ptr(), native.ptr
+    n, stride, steps = 4096, 5 * 32, 512
+    chain = (torch.arange(n, device=dev, dtype=torch.int32) + stride) % n
+    atom = torch.zeros(64, device=dev, dtype=torch.int32)
+    out = torch.zeros(4, device=dev, dtype=torch.int64)
+    assert lib.cn_calib_latency(p(chain), 0, steps, p(atom), p(out), st) == OK
+    torch.cuda.synchronize()
+    t_load, t_atom, sink = out.cpu().tolist()[:3]
+    assert 0 < t_load * 10.0 / steps < 5000 and 0 < t_atom * 10.0 / steps < 20000      # ns per step
+    assert int(atom[0]) == steps                                  # one addition of 1 per step
+    # the walk ends where `steps` hops of the chain lead (the sink adds the last fetched atomic value)
+    assert sink == (steps * stride) % n + (steps - 1)
+    assert lib.cn_calib_latency(None, 0, steps, p(atom), p(out), st) == NULL
+    assert lib.cn_calib_latency(p(chain), 0, 0, p(atom), p(out), st) == SHAPE
+    assert lib.cn_calib_clock(p(out), 2000, st) == OK
+    torch.cuda.synchronize()
+    cyc, ticks = out.cpu().tolist()[:2]
+    assert ticks >= 2000 and 300.0 < 100.0 * cyc / ticks < 5000.0     # MHz
+    assert lib.cn_calib_clock(None, 2000, st) == NULL and lib.cn_calib_clock(p(out), 0, st) == SHAPE
