@@ -1748,7 +1748,7 @@ extern "C" int cn_set_tuning(int key, int value)
         cn_tune_f32s_lds_weights = value;
         return CN_OK;
     }
-    if (key == 21 && value >= 0 && value <= 7) {
+    if (key == 21 && value >= 0 && value <= 15) {
         cn_tune_f32s_policy = value;
         return CN_OK;
     }
