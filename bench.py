@@ -612,7 +612,26 @@ def main():
         torch.cuda.synchronize()
         c, t = cres.cpu().tolist()[:2]
         rested = 100.0 * c / max(t, 1)
+        # the same for the memory system: the dependent-load walk over 1 GiB and the device-scope atomic
+        # chain of box_calibration, on the side stream WHILE steps run (fresh lines; ~2 ms of one lane)
+        n_el = (1 << 30) // 4
+        chain = torch.arange(n_el, device=dev, dtype=torch.int32) + (4099 * 64 + 32)
+        chain = torch.where(chain >= n_el, chain - n_el, chain).contiguous()
+        atom = torch.zeros(64, device=dev, dtype=torch.int32)
+        lres = torch.zeros(4, device=dev, dtype=torch.int64)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            det.run_batch(images)
+        native.check(lib.cn_calib_latency(native.ptr(chain), 32 * 7, 4096, native.ptr(atom), native.ptr(lres),
+                                          ctypes.c_void_p(side.cuda_stream)), "cn_calib_latency")
+        for _ in range(5):
+            det.run_batch(images)
+        torch.cuda.synchronize()
+        lr = lres.cpu().tolist()
+        del chain
         clock = {"core_MHz_while_the_step_runs": loaded, "core_MHz_at_rest": rested,
+                 "hbm_dependent_load_ns_while_the_step_runs": lr[0] * 10.0 / 4096,
+                 "device_scope_atomic_ns_while_the_step_runs": lr[1] * 10.0 / 4096,
                  "what": "s_memtime cycles of one spinning lane over two steps (side stream, steps running "
                          "on the launch stream) / over 30 us after 0.5 s of rest, against the constant 100 MHz clock"}
     fp32_leg = None
