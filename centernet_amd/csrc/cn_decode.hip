@@ -1262,6 +1262,20 @@ __global__ __launch_bounds__(OP_NT, CN_PSM_WAVES) void plane_select_merge_kernel
     if (flags & CN_DECODE_IMAGE_MAJOR) {
         b = (int)(blockIdx.x / (unsigned)C);
         c = (int)blockIdx.x - b * C;
+    } else if (flags & CN_DECODE_BLOCK_MAJOR) {
+        // (A/B) class-major in blocks of eight classes: eight consecutive workgroups read 512 KB of ONE
+        // image back to back (one or two translations instead of eight), an image's planes still spread
+        // over the launch; the classes beyond the last whole block come last, image by image
+        const int full = C & ~7, pid = (int)blockIdx.x;
+        if (pid < B * full) {
+            const int chi = pid / (B * 8), r = pid - chi * (B * 8);
+            b = r >> 3;
+            c = chi * 8 + (r & 7);
+        } else {
+            const int t = C - full, q = pid - B * full;
+            b = q / t;
+            c = full + (q - b * t);
+        }
     } else {
         c = (int)(blockIdx.x / (unsigned)B);
         b = (int)blockIdx.x - c * B;

@@ -557,6 +557,8 @@ int cn_ctdet_decode_f32(const float *heat, const float *wh, const float *reg,
 /* (A/B only) the one-launch form walks its (image, class) planes image by image instead of class by
  * class -- same results, the image floor finds less to prune. */
 #define CN_DECODE_IMAGE_MAJOR 32768
+/* (A/B only) class-major in blocks of eight classes: neighbouring workgroups read neighbouring planes. */
+#define CN_DECODE_BLOCK_MAJOR 131072
 
 /* _nms + _topk_channel (models/decode.py:9-15, 92-101) as one kernel: per
  * (b,c) plane the K best peaks; scores (B,C,K) desc, inds (B,C,K) int32. */
