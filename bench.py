@@ -181,6 +181,9 @@ def parse(argv=None):
     p.add_argument("--cpu-seconds", type=float, default=15.0,
                    help="bound of the CPU-baseline sample (seconds of CPU work)")
     p.add_argument("--per-op", action="store_true", help="print per-launch timings to stderr")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="skip the short runs of BASELINE configs[2..4] behind the headline loop")
+    p.add_argument("--secondary-steps", type=int, default=10)
     a = p.parse_args(argv)
     cfg = CONFIGS[a.config]
     for k, v in cfg.items():
@@ -369,6 +372,81 @@ def _reference_cpu_res18(ref_src, res, seconds, cores):
     return {"value": done / dt, "unit": "img/s", "cores": cores, "kind": "reference",
             "sample": "%d images %dx%d batch 1 in %.1f s: reference msra_resnet res_18 (no DCN) + "
                       "models/decode.ctdet_decode, torch CPU" % (done, res, res, dt)}
+
+
+def secondary_config(cfg_id, res, steps, dev):
+    """BASELINE configs[2..4] in the driver-timed line: the SAME step as the headline (det.run_batch on a
+    device-resident batch, range words read inside the timed region) for a few steps on a fresh detector;
+    value, ms_per_step and the per-class roofline fractions from HIP events at the class boundaries."""
+    import contextlib
+    import torch
+    from centernet_amd import synth
+    from centernet_amd.opts import opts
+    from centernet_amd.detectors import detector_factory
+    c = CONFIGS[cfg_id]
+    opt = opts().init([c["task"], "--arch", c["arch"], "--input_res", str(res)])
+    with contextlib.redirect_stdout(sys.stderr):
+        det = detector_factory[opt.task](opt)
+    synth.fill_state_dict_(det.model, 317)
+    det.model.invalidate_plans()
+    if c["fp16"]:
+        det.model.half_compute()
+    B = c["batch"]
+    images = synth.images(B, res, res, seed=100).to(dev)
+    for _ in range(3):
+        det.run_batch(images)
+    torch.cuda.synchronize()
+    if not c["fp16"]:
+        assert det.range_ok(images), "f32s range check failed during warm-up (config %d)" % cfg_id
+    plan = det.model.plan_for(B, res, res, dev)
+    metas = plan.b.meta
+    nops = len(metas)
+    bounds = [i for i in range(nops) if i == nops - 1 or metas[i]["kind"] != metas[i + 1]["kind"]]
+    seg_first = [0] + [b + 1 for b in bounds[:-1]]
+    probes = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        probe = {"event_after": set(bounds)}
+        det.run_batch(images, probe=probe)
+        probes.append(probe)
+    clean = det.range_ok() if not c["fp16"] else True
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kinds = {}
+    for pr in probes:
+        evs = pr["net_events"]
+        for si, (first, last) in enumerate(zip(seg_first, bounds)):
+            k = kinds.setdefault(metas[first]["kind"], {"ms": 0.0, "flops": 0, "launches": 0})
+            k["ms"] += evs[si].elapsed_time(evs[si + 1])
+            for m in metas[first:last + 1]:
+                k["flops"] += m["flops"]; k["launches"] += 1
+    dec_ms = sum(pr["dec_events"][0].elapsed_time(pr["dec_events"][1]) for pr in probes)
+    Ho = res // 4
+    if c["task"] == "ctdet":
+        dec_bytes = B * (opt.num_classes * Ho * Ho * 4 + 2 * 2 * Ho * Ho * 4 + opt.K * 6 * 4)
+    else:
+        dec_bytes = B * ((1 + 2 + 34 + 2 + 17 + 2) * Ho * Ho * 4 + opt.K * 40 * 4)
+    peak = F16_MFMA_PEAK_TF if c["fp16"] else F32S_MFMA_PEAK_TF
+    classes = {}
+    for k, v in kinds.items():
+        sec = v["ms"] * 1e-3
+        if v["flops"] > 0 and sec > 0:
+            classes[k] = {"bound": "mfma", "achieved_TFLOPs": v["flops"] / sec / 1e12,
+                          "frac": v["flops"] / sec / 1e12 / peak, "launches_per_step": v["launches"] // steps,
+                          "time_share": round(v["ms"] / (dt * 1e3), 4)}
+        else:
+            classes[k] = {"bound": "hbm", "launches_per_step": v["launches"] // steps,
+                          "time_share": round(v["ms"] / (dt * 1e3), 4)}
+    classes["decode"] = {"bound": "hbm", "achieved_GBs": dec_bytes * steps / (dec_ms * 1e-3) / 1e9 if dec_ms else 0.0,
+                         "frac": (dec_bytes * steps / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dec_ms else 0.0,
+                         "launches_per_step": DECODE_LAUNCHES[c["task"]], "time_share": round(dec_ms / (dt * 1e3), 4)}
+    out = {"config": "%s %s %dx%d, batch %d (BASELINE configs[%d])" % (c["task"], c["arch"], res, res, B, cfg_id),
+           "value": B * steps / dt, "unit": "img/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "dtype": "f16" if c["fp16"] else "f32s", "peak_TFLOPs": peak, "range_clean": bool(clean),
+           "gflop_per_image": plan.flops / B / 1e9, "classes": classes}
+    del det, plan, images
+    torch.cuda.empty_cache()
+    return out
 
 
 def cross_rank_agreement(per_rank, tol=1e-4):
@@ -793,6 +871,15 @@ def main():
                           "split site max-es |value| into range words, read inside the timed region"},
             "time_share": {k: round(v["ms"] / (dt * 1e3), 4) for k, v in kinds.items()},
         }
+        if world == 1 and standard and a.config == 1 and not a.no_secondary and not stub:
+            # BASELINE configs[2..4], a few steps each, behind the headline loop (never inside it)
+            sec = {}
+            for cid in (2, 3, 4):
+                try:
+                    sec["configs[%d]" % cid] = secondary_config(cid, a.res, a.secondary_steps, dev)
+                except Exception as e:      # a secondary leg must never cost the headline line
+                    sec["configs[%d]" % cid] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            res["secondary_configs"] = sec
         if world == 1 and not a.no_cpu_baseline and not stub:
             sd = {k: v.detach().cpu() for k, v in det.model.state_dict().items()}
             res["cpu_baseline"] = cpu_baseline(a.task, a.arch, sd, list(opt.heads), a.res,

@@ -92,6 +92,16 @@ __device__ __forceinline__ void cn_split4(cn_f32x4 v, cn_f16x4v &hi, cn_f16x4v &
     hi = __builtin_bit_cast(cn_f16x4v, u32x2{h[0], h[1]});
     lo = __builtin_bit_cast(cn_f16x4v, u32x2{l[0], l[1]});
 }
+// The logistic of the detectors (hm.sigmoid_(), detectors/ctdet.py:31, multi_pose.py:33-35): ONE definition
+// for every kernel that applies it (all decode forms, the flip-test average), so that the paths stay
+// bit-identical among themselves: 1 / (1 + exp(-x)) as v_exp_f32 + v_rcp_f32 (1 ulp each), within 2e-7
+// of torch's value.  The reciprocal is the hardware approximation, not the IEEE division (11 instructions
+// per cell, the largest single item of the one-launch decode).
+__device__ __forceinline__ float sigmoidf_ref(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+
 // ---- range words: running max |v| of everything a launch split, as float bit patterns
 // (non-negative floats order like unsigned integers).  One conditional atomic per wave, spread
 // over CN_RANGE_SLOTS words in separate 64-byte lines per side: the waves of a launch finish in

@@ -1,10 +1,10 @@
 // cn_dcn2.hip -- fused modulated deformable convolution (DCNv2) forward, f32s arithmetic, with
-// the input staged as an LDS WINDOW.  Two kernels:
-//   dcn_reg_kernel  (the product kernel, second half of this file): every lane samples its own
-//                   MFMA operand from the window; no A tile, no per-step barrier;
-//   dcn_win_kernel  (first half; kept for comparison, cn_set_tuning key 23 = 3): sampling waves
-//                   write an A tile that multiplying waves consume -- correct, but slower than
-//                   the global-gather form on every shape (see the note above dcn_reg_kernel).
+// the input staged as an LDS WINDOW: dcn_reg_kernel -- every lane samples its own MFMA operand from
+// the window; no A tile, no per-step barrier.  (Round 5: the team form in cn_dcn3.hip is built on
+// this one for four waves per SIMD; this kernel stays for 128-wide output tiles.  The first window
+// design -- sampling waves writing an A tile that multiplying waves consume, dcn_win_kernel -- was
+// slower than the global-gather form on every shape, 70-97 against 100-155 TFLOP/s at B = 32, and
+// was removed in round 5; DESIGN.md section 3.2 keeps the A/B.)
 //
 // Replaces: DCN.forward -> DCNv2Function.forward -> dcn_v2_cuda_forward
 //   (DCNv2/dcn_v2.py:64-70, dcn_v2_func.py:22-38, src/dcn_v2_cuda.c:10-102): per sample a bias
@@ -16,22 +16,6 @@
 // per 64-pixel tile and 32-channel chunk; on 64->64@128^2 that is 17 TB/s of L2 -> L1 traffic at
 // 108 TFLOP/s with the matrix pipe 15 % busy: every (tap, chunk) step is a dependent chain
 // record -> four gathers -> blend -> LDS -> barrier -> MFMA of ~2.4 us.
-//
-// dcn_win_kernel (the first design):
-//   * a workgroup owns an 8 x 8 block of output pixels of one image and stages, per 32-channel
-//     chunk, the (8 + 2 + 2R)^2 input WINDOW around it ONCE (37 KB at R = 3: 8x less L2 traffic;
-//     NHWC, so the copy is whole 128-byte lines); the four bilinear corners of every sample are
-//     then LDS reads (LDS: 256 B/clk/CU against ~64 B/clk of L1);
-//   * waves 0-3 SAMPLE: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask per (pixel, 4 channels) into the
-//     A tile of step k+1 (a two-tile ring), and stage the weight tile of step k+1;
-//     waves 4-7 MULTIPLY step k: fragments from LDS, three fp16 MFMAs per product (f32s).
-//     One barrier per step; the two halves never wait for each other's memory latency;
-//   * a sample whose corners leave the window (offset beyond the reach) takes its four corners
-//     from global memory instead -- requested one step ahead -- so unbounded offsets
-//     (dcn_v2.py:65-67: raw conv output) stay exact;
-//   * sampling records (bilinear fractions, modulation factor with the sigmoid of dcn_v2.py:67
-//     and the f32s input exponent folded in, top-left corner) are computed once per (pixel, tap)
-//     in the prologue: 16 bytes each, all nine taps resident.
 // Epilogue as everywhere: y = relu?((acc + bias) * scale + shift), plain fp32 or f32s, range words.
 #include "cn_common.h"
 
@@ -40,11 +24,7 @@ int cn_tune_dcn_bn64 = 0;      // cn_set_tuning key 35: 64-wide N tiles for Cout
 
 namespace {
 
-constexpr int NT = 512;        // 8 waves
-constexpr int NS = 256;        // sampling threads (waves 0-3); waves 4-7 multiply
-constexpr int TS = 8;          // output tile is TS x TS pixels
-constexpr int BM = TS * TS;    // 64
-constexpr int LDT = 36;        // floats per LDS row of the A / weight tiles (128 B + 16 B pad)
+constexpr int TS = 8;          // tiles are TS pixel rows high
 
 struct Dcn2Args {
     const float *x;            // (B, H, W, Cin) plain fp32
@@ -56,7 +36,7 @@ struct Dcn2Args {
     float x_mul;
     uint32_t *range;
     int dbg;                   // debug switches (cn_set_tuning key 9)
-    int ksplit;                // register-sampling kernel: K-chunk ranges per tile (blockIdx.z), > 1: raw partial sums
+    int ksplit;                // K-chunk ranges per tile (blockIdx.z), > 1: raw partial sums
     float *partial;            // [ksplit][B*H*W][cout_pad] fp32 (splitk_reduce_kernel applies the epilogue)
 };
 
@@ -68,359 +48,11 @@ typedef __attribute__((address_space(1))) cn_f32x4 d2_glb_f32x4;
 
 __device__ __forceinline__ float d2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int BN, int WD>
-constexpr size_t dcn2_lds_bytes()
-{
-    return (size_t)WD * WD * 128 + (size_t)2 * BM * LDT * 4 + (size_t)2 * BN * LDT * 4 + (size_t)9 * BM * 16;
-}
-
-// WD: window side; reach = (WD - TS - 2) / 2 pixels of offset on either side
-template <int BN, int WD>
-__global__ __launch_bounds__(NT, BN == 64 ? 4 : 2) void dcn_win_kernel(const Dcn2Args a)
-{
-    constexpr int RCH = (WD - TS - 2) / 2;
-    constexpr int WPIX = WD * WD;
-    constexpr int NPW = (WPIX * 8 + NT - 1) / NT;     // window pieces (16 B) per thread
-    constexpr int NB = BN / 64;                        // 32-wide N blocks per multiplying wave
-    constexpr int PBW = BN * 8 / NS;                   // weight pieces per sampling thread
-    static_assert(BN == 64 || BN == 128, "N tile");
-    static_assert((size_t)32 * (BN + 4) * 4 <= (size_t)2 * BM * LDT * 4 + (size_t)2 * BN * LDT * 4, "epilogue staging");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *Win = reinterpret_cast<float *>(smem);                  // [WPIX][32] plain fp32
-    float *As = Win + WPIX * 32;                                   // [2][BM][LDT] f32s rows
-    float *Bs = As + 2 * BM * LDT;                                 // [2][BN][LDT] f32s rows
-    cn_i32x4 *Rec = reinterpret_cast<cn_i32x4 *>(Bs + 2 * BN * LDT);  // [9][BM] {lh, lw, mask' (float bits), yl | xl << 16}
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool sampler = wave < 4;
-    const int H = a.H, W = a.W;
-    // XCD-aware tile order: contiguous tile ranges per XCD (block b runs on XCD b % 8)
-    int bx = blockIdx.x;
-    {
-        const int q8 = gridDim.x >> 3;
-        if (bx < (q8 << 3)) bx = (bx & 7) * q8 + (bx >> 3);
-    }
-    const int tiles = a.tiles_x * a.tiles_y;
-    const int b = bx / tiles;
-    const int tr = bx - b * tiles;
-    const int ty0 = (tr / a.tiles_x) * TS, tx0 = (tr % a.tiles_x) * TS;
-    const int wy0 = ty0 - 1 - RCH, wx0 = tx0 - 1 - RCH;     // window origin in the image
-    const int n0 = blockIdx.y * BN;
-    const float a_x_mul = a.x_mul;
-    const cn_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const char *xb = reinterpret_cast<const char *>(a.x);
-    const unsigned pix_bytes = (unsigned)a.Cin * 4u;
-
-    // ---- sampling records of all nine taps (dcn_v2_im2col_cuda.cu:151-176): 576 over 512 threads
-    for (int i = tid; i < 9 * BM; i += NT) {
-        const int tap = i / BM, m = i - tap * BM;
-        const int oy = ty0 + (m >> 3), ox = tx0 + (m & 7);
-        const float *om = a.om + (size_t)((b * H + oy) * W + ox) * a.om_pitch;
-        const float off_h = om[2 * tap], off_w = om[2 * tap + 1];
-        float mk = om[18 + tap];
-        if (a.mask_sigmoid) mk = d2_sigmoid(mk);   // dcn_v2.py:67
-        mk *= a_x_mul;                              // plain input -> stored units (a power of two)
-        const int ki = tap / 3, kj = tap - ki * 3;
-        const float h_im = (float)(oy - 1 + ki) + off_h;
-        const float w_im = (float)(ox - 1 + kj) + off_w;
-        cn_i32x4 rec = {0, 0, 0, 0};
-        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {   // :165
-            const float hf = floorf(h_im), wf = floorf(w_im);
-            const int yl = (int)hf, xl = (int)wf;      // -1 .. H-1 / W-1: fit 16 bits
-            rec[0] = __builtin_bit_cast(int, h_im - hf);
-            rec[1] = __builtin_bit_cast(int, w_im - wf);
-            rec[2] = __builtin_bit_cast(int, mk);
-            rec[3] = (yl & 0xffff) | (int)((uint32_t)(xl & 0xffff) << 16);
-        } else {
-            // outside the sampling domain (:165): the sample is 0 (mask' = 0); the pixel's own
-            // position as "corner" keeps the reads inside the window
-            rec[3] = (oy & 0xffff) | (int)((uint32_t)(ox & 0xffff) << 16);
-        }
-        Rec[i] = rec;
-    }
-
-    // ---- window staging: piece = (window pixel, 16-byte channel quad); by all 512 threads
-    cn_f32x4 rw[NPW];
-    unsigned woff[NPW];       // byte offset of the pixel's chunk-0 piece in x, or ~0u (zero fill)
-#pragma unroll
-    for (int p = 0; p < NPW; ++p) {
-        const int i = p * NT + tid;
-        const int wp = i >> 3, q = i & 7;
-        const int wy = wp / WD, wx = wp - wy * WD;
-        const int iy = wy0 + wy, ix = wx0 + wx;
-        woff[p] = (wp < WPIX && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                      ? (unsigned)((b * H + iy) * W + ix) * pix_bytes + 16u * q : 0xffffffffu;
-    }
-    auto load_win = [&](int chunk) {
-        const unsigned cb = (unsigned)chunk * 128u;
-#pragma unroll
-        for (int p = 0; p < NPW; ++p) {
-            const bool ok = woff[p] != 0xffffffffu && !(a.dbg & 2);
-            const cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(xb + (ok ? woff[p] + cb : 0u));
-            rw[p] = ok ? v : zero4;
-        }
-    };
-    auto store_win = [&]() {
-#pragma unroll
-        for (int p = 0; p < NPW; ++p) {
-            const int i = p * NT + tid;
-            if (i < WPIX * 8) *reinterpret_cast<cn_f32x4 *>(Win + i * 4) = rw[p];
-        }
-    };
-
-    // ---- weight tile of one (tap, chunk): BN rows of 128 bytes, by the sampling threads
-    cn_f32x4 rb[PBW];
-    const char *wb = reinterpret_cast<const char *>(a.w);
-    auto load_B = [&](int step) {
-        const int c = step / 9, t = step - c * 9;
-#pragma unroll
-        for (int p = 0; p < PBW; ++p) {
-            const int i = p * NS + tid, row = i >> 3, q = i & 7;
-            const int n = min(n0 + row, a.cout_pad - 1);
-            rb[p] = (a.dbg & 4) ? zero4 : *reinterpret_cast<const cn_f32x4 *>(
-                wb + ((size_t)(t * a.cout_pad + n) * a.cin_pad + (size_t)c * 32) * 4 + 16 * q);
-        }
-    };
-    auto store_B = [&](int buf) {
-        float *Bd = Bs + buf * BN * LDT;
-#pragma unroll
-        for (int p = 0; p < PBW; ++p) {
-            const int i = p * NS + tid, row = i >> 3, q = i & 7;
-            *reinterpret_cast<cn_f32x4 *>(Bd + row * LDT + 4 * q) = rb[p];
-        }
-    };
-
-    // ---- sampling: this thread's two (pixel, channel quad) items per step
-    const int sq = tid & 7, srow = (tid >> 3) & 31;    // sampling threads: rows srow, srow + 32
-    float rng_in = 0.f, rng_out = 0.f;
-    cn_f32x4 fb[2][4];          // corners fetched from global memory for the NEXT step's items
-    unsigned fbmask = 0u;       // bit p: item p of the next step samples outside the window
-    struct Item { float lh, lw, mk; int yl, xl; };
-    auto item_of = [&](int step, int p) -> Item {
-        const int t = step % 9;
-        const cn_i32x4 r = Rec[t * BM + p * 32 + srow];
-        const uint32_t pk = (uint32_t)r[3];
-        Item it;
-        // by value through locals: __builtin_bit_cast on a vector ELEMENT expression reads
-        // element 0 whatever the index (hipcc 7.2) -- seen as lh == lw == mask' in the ISA
-        const int r0 = r[0], r1 = r[1], r2 = r[2];
-        it.lh = __int_as_float(r0);
-        it.lw = __int_as_float(r1);
-        it.mk = __int_as_float(r2);
-        it.yl = (int)(short)(pk & 0xffffu);
-        it.xl = (int)(short)(pk >> 16);
-        return it;
-    };
-    auto in_window = [&](const Item &it) -> bool {
-        return (unsigned)(it.yl - wy0) <= (unsigned)(WD - 2) && (unsigned)(it.xl - wx0) <= (unsigned)(WD - 2);
-    };
-    // request the four corners of the out-of-window items of `step` (chunk of that step)
-    auto prefetch_far = [&](int step) {
-        const unsigned cb = (unsigned)(step / 9) * 128u + 16u * sq;
-        fbmask = 0u;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const Item it = item_of(step, p);
-            if (!in_window(it) && !(a.dbg & 1)) {
-                fbmask |= 1u << p;
-                const int y0 = max(it.yl, 0), y1 = min(it.yl + 1, H - 1);
-                const int x0 = max(it.xl, 0), x1 = min(it.xl + 1, W - 1);
-                const unsigned base = (unsigned)(b * H) * (unsigned)W;
-                fb[p][0] = *reinterpret_cast<const cn_f32x4 *>(xb + (base + y0 * W + x0) * pix_bytes + cb);
-                fb[p][1] = *reinterpret_cast<const cn_f32x4 *>(xb + (base + y0 * W + x1) * pix_bytes + cb);
-                fb[p][2] = *reinterpret_cast<const cn_f32x4 *>(xb + (base + y1 * W + x0) * pix_bytes + cb);
-                fb[p][3] = *reinterpret_cast<const cn_f32x4 *>(xb + (base + y1 * W + x1) * pix_bytes + cb);
-            }
-        }
-    };
-    // A tile of `step` into ring slot `buf`: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask'
-    // (dcn_v2_im2col_cuda.cu:43-45,174; corner weights zeroed per :30-41)
-    auto sample = [&](int step, int buf) {
-        float *Ad = As + buf * BM * LDT;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const Item it = item_of(step, p);
-            const float hh = 1.f - it.lh, hw = 1.f - it.lw;
-            const bool yl_ok = it.yl >= 0, xl_ok = it.xl >= 0;
-            const bool yh_ok = it.yl + 1 <= H - 1, xh_ok = it.xl + 1 <= W - 1;
-            const float w1 = (yl_ok && xl_ok) ? hh * hw : 0.f;
-            const float w2 = (yl_ok && xh_ok) ? hh * it.lw : 0.f;
-            const float w3 = (yh_ok && xl_ok) ? it.lh * hw : 0.f;
-            const float w4 = (yh_ok && xh_ok) ? it.lh * it.lw : 0.f;
-            cn_f32x4 v1, v2, v3, v4;
-            if (fbmask & (1u << p)) {
-                v1 = fb[p][0]; v2 = fb[p][1]; v3 = fb[p][2]; v4 = fb[p][3];
-            } else {
-                const float *c0 = Win + ((it.yl - wy0) * WD + (it.xl - wx0)) * 32 + 4 * sq;
-                v1 = *reinterpret_cast<const cn_f32x4 *>(c0);
-                v2 = *reinterpret_cast<const cn_f32x4 *>(c0 + 32);
-                v3 = *reinterpret_cast<const cn_f32x4 *>(c0 + WD * 32);
-                v4 = *reinterpret_cast<const cn_f32x4 *>(c0 + WD * 32 + 32);
-            }
-            cn_f32x4 v = v1 * w1 + v2 * w2 + v3 * w3 + v4 * w4;
-            v = v * it.mk;
-            if (a.dbg & 64) { v[0] = v[1] = v[2] = v[3] = 1.0f; }
-            if (a.dbg & 128) v = v1;
-            if (a.dbg & 256) { v[0] = it.lh; v[1] = it.mk; v[2] = (float)it.yl; v[3] = (float)it.xl; }
-            cn_rng_upd4(rng_in, v);
-            cn_f16x4v hi, lo;
-            cn_split4(v, hi, lo);
-            char *row = reinterpret_cast<char *>(Ad + (p * 32 + srow) * LDT);
-            *reinterpret_cast<cn_f16x4v *>(row + 8 * sq) = hi;
-            *reinterpret_cast<cn_f16x4v *>(row + 64 + 8 * sq) = lo;
-        }
-    };
-
-    // ---- multiplying waves: 2 x 2 over the 64 x BN tile, wave tile 32 x BN/2
-    const int cw = wave & 3, wm = cw >> 1, wn = cw & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-    cn_f32x16 acc[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    auto multiply = [&](int buf) {
-        const float *Ab = As + buf * BM * LDT + (wm * 32 + l31) * LDT + 4 * lh;
-        const float *Bb = Bs + buf * BN * LDT + (wn * (BN / 2) + l31) * LDT + 4 * lh;
-        d2_f16x8 af[4], bf[4][NB];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            af[kk] = *reinterpret_cast<const d2_f16x8 *>(Ab + kk * 8);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) bf[kk][j] = *reinterpret_cast<const d2_f16x8 *>(Bb + j * 32 * LDT + kk * 8);
-        }
-        // every fragment read is issued before the first MFMA and stays there (operand hazard
-        // note in cn_conv.hip)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int term = 0; term < 3; ++term)     // lo*hi, hi*lo, hi*hi
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int ka = (term == 0) ? 2 + s2 : s2;
-                    const int kb = (term == 1) ? 2 + s2 : s2;
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ka], bf[kb][j], acc[j], 0, 0, 0);
-                }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // ---- prologue: window of chunk 0, weights of step 0, then the A tile of step 0
-    const int total = a.nchunk * 9;
-    load_win(0);
-    if (sampler) load_B(0);
-    store_win();
-    if (sampler) store_B(0);
-    __syncthreads();                     // records, window, weights of step 0 visible
-    if (sampler) {
-        fbmask = 0u;
-        prefetch_far(0);
-        sample(0, 0);
-        if (total > 1) { load_B(1); prefetch_far(1); }
-    }
-    __syncthreads();                     // A tile of step 0 ready
-
-    // ---- main loop: in the span of step k the sampling waves build step k+1 and the multiplying
-    // waves consume step k.  A chunk boundary (step k+1 opens a new chunk) first replaces the
-    // window: an extra barrier separates the window write from its first readers.
-    for (int k = 0; k < total; ++k) {
-        const int t = k % 9;
-        const bool more = (k + 1) < total;
-        const bool new_chunk = more && t == 8;
-        if (t == 0 && (k / 9 + 1) < a.nchunk) load_win(k / 9 + 1);   // lands during the chunk's nine steps
-        if (new_chunk) {
-            store_win();                 // nobody reads the old window any more (its last reader ran in step k-1's span)
-            __syncthreads();
-        }
-        if (sampler) {
-            if (more) {
-                store_B((k + 1) & 1);    // requested in the previous span
-                sample(k + 1, (k + 1) & 1);
-                if (k + 2 < total) { load_B(k + 2); prefetch_far(k + 2); }
-            }
-        } else {
-            multiply(k & 1);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: y = relu?((acc + bias) * scale + shift); the 64 x BN tile goes through LDS one
-    // 32-row half at a time so that stores are 16-byte accesses along Cout (all 512 threads store)
-    constexpr int LDC = BN + 4;
-    float *Cs = As;                      // A / weight rings are free after the loop's last barrier
-    constexpr int C4 = BN / 4;
-    constexpr int RPI = NT / C4;         // rows per pass of the block (32 for BN = 64, 16 for 128)
-    constexpr int ITERS = 32 / RPI;
-    const int c4 = tid % C4, r0 = tid / C4;
-    const int n = n0 + c4 * 4;
-    float bs[4], sc[4], sf[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const bool ok = (n + e) < a.Cout;
-        bs[e] = (a.bias && ok) ? a.bias[n + e] : 0.f;
-        sc[e] = (a.scale && ok) ? a.scale[n + e] : 1.f;
-        sf[e] = (a.shift && ok) ? a.shift[n + e] : 0.f;
-    }
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass) __syncthreads();
-        if (!sampler && wm == pass) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    Cs[row * LDC + wn * (BN / 2) + j * 32 + l31] = acc[j][r];
-                }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int lr = it * RPI + r0;                 // row inside the 32-row half
-            const int m = pass * 32 + lr;
-            const size_t off = (size_t)((b * H + ty0 + (m >> 3)) * W + tx0 + (m & 7));
-            if (n + 4 <= a.Cout && !(a.dbg & 8)) {
-                cn_f32x4 v = *reinterpret_cast<const cn_f32x4 *>(Cs + lr * LDC + c4 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float tt = (v[e] + bs[e]) * sc[e] + sf[e];
-                    v[e] = a.relu ? fmaxf(tt, 0.f) : tt;
-                    if (a.dbg & 32) v[e] = 7.0f;
-                }
-                if (a.out_plain)
-                    *reinterpret_cast<cn_f32x4 *>(reinterpret_cast<float *>(a.y) + off * a.out_pitch + n) = v;
-                else {
-                    cn_rng_upd4(rng_out, v);
-                    cn_store4_f32s(a.y, off, a.out_pitch, n, v);
-                }
-            }
-        }
-    }
-    if (a.range && !(a.dbg & 16)) {
-        if (!a.out_plain) cn_rng_commit(a.range, 0, rng_out);
-        cn_rng_commit(a.range, 1, rng_in);
-    }
-}
-
-template <int BN, int WD>
-int launch_dcn2(const Dcn2Args &a, hipStream_t st)
-{
-    constexpr size_t lds = dcn2_lds_bytes<BN, WD>();
-    CN_SET_MAX_LDS_ONCE((dcn_win_kernel<BN, WD>), lds);
-    dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), cn_cdiv(a.Cout, BN));
-    hipLaunchKernelGGL((dcn_win_kernel<BN, WD>), grid, dim3(NT), lds, st, a);
-    CN_CHECK_LAUNCH();
-    return CN_OK;
-}
-
-
 // ======================================================================================
-// Register-sampling form (round 3, second design).  The wave-specialised kernel above lost to
+// Register-sampling form (round 3, second design).  The wave-specialised first design lost to
 // the global-gather form (70-97 against 100-155 TFLOP/s at B = 32): its A tile and weight tile
-// cross LDS once more than the window reads themselves, and each (tap, chunk) step of a 64-pixel
-// tile is far shorter than the one-step-ahead global loads and the barrier that close it.  Here
+// crossed LDS once more than the window reads themselves, and each (tap, chunk) step of a 64-pixel
+// tile was far shorter than the one-step-ahead global loads and the barrier that closed it.  Here
 //   * a workgroup of four waves owns 8 x 16 output pixels; the (8 + 8) x (16 + 8) input window
 //     of one 32-channel chunk sits in LDS (144-byte pixels, 3584-byte rows: bank-conflict free
 //     for undisplaced samples, see R_WLINE);
@@ -816,27 +448,23 @@ int launch_dcn_reg(const Dcn2Args &a, hipStream_t st)
 
 }  // namespace
 
-// Shapes these kernels take (the caller falls back to the global-gather form otherwise): maps of
-// whole pixel blocks (8 x 16 register-sampling form, 8 x 8 wave-specialised form), whole
-// 32-channel chunks, Cout a multiple of 4 and >= 33, and at least `min_wgs` workgroups (the
-// tap-split gather form serves the small grids).  variant: 0 = register-sampling form,
-// 1 = wave-specialised form (kept for comparison; slower, see the note above dcn_reg_kernel).
+// Shapes this kernel takes (the caller falls back to the global-gather form otherwise): maps of
+// whole 8 x 16 pixel blocks, whole 32-channel chunks, Cout a multiple of 4 and >= 33, and at least
+// `min_wgs` workgroups (the tap-split gather form serves the small grids).
 int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, const float *om,
                        int om_pitch, const float *scale, const float *shift, void *y, int out_pitch,
                        int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
-                       float x_mul, uint32_t *range, int min_wgs, int variant, int dbg, float *partial,
+                       float x_mul, uint32_t *range, int min_wgs, int dbg, float *partial,
                        size_t partial_bytes, int *ksplit_out, hipStream_t st)
 {
     if (ksplit_out) *ksplit_out = 1;
-    if ((H & 7) || (W & 7) || (Cin & 31) || (Cout & 3) || Cout <= 32) return CN_ERR_UNSUPPORTED;
-    if (variant == 0 && (W & 15)) return CN_ERR_UNSUPPORTED;
+    if ((H & 7) || (W & 15) || (Cin & 31) || (Cout & 3) || Cout <= 32) return CN_ERR_UNSUPPORTED;
     if (H > 32767 || W > 32767 || (out_pitch & 3) || !cn_aligned16(y) || !cn_aligned16(x)) return CN_ERR_UNSUPPORTED;
     if ((om_pitch & 1) || (((uintptr_t)om) & 7u)) return CN_ERR_UNSUPPORTED;   // (offset pairs are 8-byte loads)
     if ((size_t)B * H * W * Cin * 4 >= ((size_t)1 << 32)) return CN_ERR_UNSUPPORTED;   // 32-bit byte offsets
-    const int tsx = variant == 0 ? R_TX : TS;
     int bn = Cout > 64 ? 128 : 64;
-    if (variant == 0 && bn == 128 && (long)B * (H / TS) * (W / tsx) * cn_cdiv(Cout, 128) < cn_tune_dcn_bn64) bn = 64;
-    const long wgs = (long)B * (H / TS) * (W / tsx) * cn_cdiv(Cout, bn);
+    if (bn == 128 && (long)B * (H / TS) * (W / R_TX) * cn_cdiv(Cout, 128) < cn_tune_dcn_bn64) bn = 64;
+    const long wgs = (long)B * (H / TS) * (W / R_TX) * cn_cdiv(Cout, bn);
     // Too few tiles for the chip but a deep K (512 -> 256 @ 16^2): split the 32-channel chunks over
     // 2 / 4 / 8 workgroups per tile -- raw fp32 partial sums in the caller's workspace, summed in a
     // fixed order by splitk_reduce_kernel (deterministic) -- when that yields >= 256 workgroups
@@ -845,7 +473,7 @@ int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, 
         // the smallest split that reaches the workgroup target, else the deepest one that fits
         const int nchunk = (Cin + 31) / 32;
         const int cout_pad = (Cout + 31) / 32 * 32;
-        for (int s2 = 2; s2 <= 8 && variant == 0 && partial && wgs * ksplit < cn_tune_dcn_wgs; s2 *= 2)
+        for (int s2 = 2; s2 <= 8 && partial && wgs * ksplit < cn_tune_dcn_wgs; s2 *= 2)
             if (nchunk % s2 == 0 && nchunk / s2 >= 2 &&
                 (size_t)s2 * B * H * W * cout_pad * sizeof(float) <= partial_bytes)
                 ksplit = s2;
@@ -858,18 +486,12 @@ int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, 
     a.cin_pad = (Cin + 31) / 32 * 32;
     a.cout_pad = (Cout + 31) / 32 * 32;
     a.nchunk = a.cin_pad / 32;
-    a.tiles_x = W / tsx;
+    a.tiles_x = W / R_TX;
     a.tiles_y = H / TS;
     a.x_mul = x_mul; a.range = range; a.dbg = dbg;
     a.ksplit = ksplit;
     a.partial = ksplit > 1 ? partial : nullptr;
     if (ksplit_out) *ksplit_out = ksplit;
-    if (variant == 0) {
-        if (bn == 64) return launch_dcn_reg<64>(a, st);
-        return launch_dcn_reg<128>(a, st);
-    }
-    // 64-wide N tiles: window of reach 3 (32 KB) -> 77 KB of LDS, two workgroups per CU;
-    // 128-wide: one workgroup per CU anyway, window of reach 4
-    if (bn == 64) return launch_dcn2<64, 16>(a, st);
-    return launch_dcn2<128, 18>(a, st);
+    if (bn == 64) return launch_dcn_reg<64>(a, st);
+    return launch_dcn_reg<128>(a, st);
 }

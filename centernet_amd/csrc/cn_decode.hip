@@ -200,14 +200,7 @@ __device__ __forceinline__ void collect_and_sort(ForEach &&for_each, u64 prefix,
     __syncthreads();
 }
 
-__device__ __forceinline__ float sigmoidf_ref(float x)
-{
-    // 1 / (1 + exp(-x)) (detectors/ctdet.py:31): v_exp_f32 + v_rcp_f32 (1 ulp each), within 2e-7 of
-    // torch's value.  The reciprocal is the hardware approximation, not the IEEE division (11
-    // instructions per cell, the largest single item of the one-launch decode); every decode form
-    // uses this one definition, so the forms stay bit-identical among themselves.
-    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
+// (sigmoidf_ref: cn_common.h -- one definition of the logistic for every decode form and the flip average)
 
 constexpr int CAND_CAP = 4096;  // compacted positive peaks per band (uint16 tile offsets)
 
@@ -1561,6 +1554,23 @@ ImgPlan make_img_plan(int B, int C, int H, int W, int K, const BandPlan &bp)
     return p;
 }
 
+}  // namespace
+// Where the one-launch image-level decode keeps its per-image state words inside the workspace of
+// cn_ctdet_decode_f32 / cn_topk_f32 (byte offset and size; 0 bytes when the shape takes another form).
+// They are zero between calls: a caller that owns its workspace (CN_DECODE_STATE_CLEAN) can check or
+// re-zero exactly this region after a failed call instead of trusting it.
+extern "C" int cn_decode_state_region(int B, int C, int H, int W, int K, size_t *offset, size_t *bytes)
+{
+    if (!offset || !bytes) return CN_ERR_NULL;
+    *offset = 0; *bytes = 0;
+    BandPlan bp;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return CN_ERR_SHAPE;
+    if (!make_band_plan(B, C, H, W, K, &bp)) return CN_ERR_UNSUPPORTED;
+    const ImgPlan ip = make_img_plan(B, C, H, W, K, bp);
+    if (ip.use && ip.one_pass) { *offset = ip.counts; *bytes = ip.state_bytes; }
+    return CN_OK;
+}
+namespace {
 // the image-level decode: TWO launches (group maxima; threshold + candidates + select + outputs)
 template <int MODE>
 int launch_image_topk(const float *heat, int B, int C, int H, int W, int K, int flags, const ImgPlan &ip,
@@ -2167,13 +2177,34 @@ extern "C" int cn_exct_aggregate_f32(const float *heat, float *out, int B, int C
     return CN_OK;
 }
 
+namespace {
+// decode.py:297-305 for one edge map: heat * (max_pool2d(heat, 3, 1, 1) == heat), then values > 1 set
+// to 1.  (Clamping BEFORE the peak test would turn every plateau of clamped cells into peaks.)
+__global__ void exct_nms_clamp_kernel(const float *__restrict__ heat, float *__restrict__ out, int H, int W,
+                                      size_t total)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const float v = heat[i];
+        float m = v;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, heat[i + (long)dy * W + dx]);
+            }
+        out[i] = (m == v) ? fminf(v, 1.0f) : 0.0f;
+    }
+}
+}  // namespace
+
 extern "C" size_t cn_exct_decode_workspace_bytes(int B, int C, int H, int W, int K)
 {
     const size_t base = cn_ctdet_decode_workspace_bytes(B, C, H, W, K);
     if (!base) return 0;
     const size_t lists = 4 * 3 * cn_align_up((size_t)B * K * 4, 256);
     const size_t cand = cn_align_up((size_t)B * K * K * K * K * sizeof(float), 256);
-    return base + lists + cand;
+    const size_t map = cn_align_up((size_t)B * C * H * W * sizeof(float), 256);   // CN_EXCT_CLAMP_ONE: one peak-tested, clamped edge map
+    return base + lists + cand + map;
 }
 
 extern "C" int cn_exct_decode_f32(const float *t_heat, const float *l_heat, const float *b_heat,
@@ -2188,7 +2219,8 @@ extern "C" int cn_exct_decode_f32(const float *t_heat, const float *l_heat, cons
     if (num_dets <= 0 || K <= 0) return CN_ERR_SHAPE;
     if (K > 64 || num_dets > EXCT_MAX_DETS) return CN_ERR_UNSUPPORTED;  // K^4 must fit 32 bits / LDS sort
     if ((long)num_dets > (long)K * K * K * K) return CN_ERR_SHAPE;      // torch.topk: k out of range
-    if (apply_sigmoid) return CN_ERR_UNSUPPORTED;  // the centre map is gathered, not scanned
+    if (apply_sigmoid & ~CN_EXCT_CLAMP_ONE) return CN_ERR_UNSUPPORTED;  // the centre map is gathered, not scanned
+    const bool clamp_one = (apply_sigmoid & CN_EXCT_CLAMP_ONE) != 0;
     const size_t base = cn_ctdet_decode_workspace_bytes(B, C, H, W, K);
     if (!base) return CN_ERR_UNSUPPORTED;
     if (workspace_bytes < cn_exct_decode_workspace_bytes(B, C, H, W, K)) return CN_ERR_WORKSPACE;
@@ -2201,7 +2233,20 @@ extern "C" int cn_exct_decode_f32(const float *t_heat, const float *l_heat, cons
         float *s = (float *)p; p += slot;
         int32_t *i = (int32_t *)p; p += slot;
         int32_t *c = (int32_t *)p; p += slot;
-        const int rc = cn_topk_f32(heats[e], B, C, H, W, K, 0, s, i, c, workspace, base, stream);
+        int rc;
+        if (clamp_one) {
+            // peak test on the raw map, survivors clamped to 1 (decode.py:297-305), then the plain _topk
+            // over every cell of the result (zeros of the suppressed cells take part, as in the reference)
+            const size_t cells = (size_t)B * C * H * W;
+            float *tmp = (float *)((char *)workspace + base + 4 * 3 * slot +
+                                   cn_align_up((size_t)B * K * K * K * K * sizeof(float), 256));
+            hipLaunchKernelGGL(exct_nms_clamp_kernel, dim3((unsigned)((cells + 255) / 256 < 8192 ? (cells + 255) / 256 : 8192)),
+                               dim3(256), 0, (hipStream_t)stream, heats[e], tmp, H, W, cells);
+            CN_CHECK_LAUNCH();
+            rc = cn_topk_f32(tmp, B, C, H, W, K, CN_DECODE_NO_PEAK_TEST, s, i, c, workspace, base, stream);
+        } else {
+            rc = cn_topk_f32(heats[e], B, C, H, W, K, 0, s, i, c, workspace, base, stream);
+        }
         if (rc != CN_OK) return rc;
         L.score[e] = s; L.ind[e] = i; L.cls[e] = c;
     }

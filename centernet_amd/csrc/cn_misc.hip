@@ -790,8 +790,8 @@ __global__ void flip_average_kernel(float *__restrict__ x, float *__restrict__ o
         const size_t j = total + ((size_t)cs * H + y) * W + (W - 1 - xx);
         float a = x[i], b = x[j];
         if (apply_sigmoid) {
-            a = 1.0f / (1.0f + __expf(-a));
-            b = 1.0f / (1.0f + __expf(-b));
+            a = sigmoidf_ref(a);      // the decode kernels' definition (cn_common.h)
+            b = sigmoidf_ref(b);
             x[i] = a;
             x[j] = b;
         }

@@ -26,6 +26,7 @@ def _workspace(nbytes, device):
 
 _STATE_CLEAN = 4096    # CN_DECODE_STATE_CLEAN: the workspace's image state words are zero (see below)
 _own_ws = {}
+_verify_state = __import__("os").environ.get("CN_DECODE_VERIFY_STATE") == "1"
 
 
 def _own_workspace(entry, nbytes, device, shape):
@@ -91,11 +92,26 @@ def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=Fal
                                  int(bool(cat_spec_wh)), flags,
                                  native.ptr(dets), native.ptr(inds), native.ptr(ws), ws.numel(),
                                  native.stream_ptr())
+    if rc:
+        # a failed call may have left the image state words of an owned workspace dirty: never reuse it
+        _own_ws.clear()
     native.check(rc, "cn_ctdet_decode_f32")
+    if _verify_state and not _debug_flags:
+        # debug mode (CN_DECODE_VERIFY_STATE=1): synchronise and look at the state words the kernel
+        # promises to leave at zero (cn_decode_state_region)
+        import ctypes
+        off, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        native.check(lib.cn_decode_state_region(B, C, H, W, K, ctypes.byref(off), ctypes.byref(nb)),
+                     "cn_decode_state_region")
+        words = ws[off.value:off.value + nb.value].view(torch.int32)
+        if nb.value and int(words.abs().max().item()) != 0:
+            _own_ws.clear()
+            raise native.NativeError("cn_ctdet_decode_f32 left its workspace state words dirty")
     return (dets, inds.long()) if return_inds else dets
 
 
 _NO_PEAK_TEST = 512   # flag bit of the decode entry points: rank every cell (plain topk)
+_EXCT_CLAMP_ONE = 2   # CN_EXCT_CLAMP_ONE (cn_exct_decode_f32): clamp the peak-tested edge maps to 1
 
 
 def _topk_channel(scores, K=40, apply_sigmoid=False, nms=False):
@@ -242,7 +258,9 @@ def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=Non
     rc = lib.cn_exct_decode_f32(native.ptr(t_heat), native.ptr(l_heat), native.ptr(b_heat),
                                 native.ptr(r_heat), native.ptr(ct_heat), native.ptr(t_regr),
                                 native.ptr(l_regr), native.ptr(b_regr), native.ptr(r_regr), B, C, H,
-                                W, K, scores_thresh, center_thresh, num_dets, 0, native.ptr(dets),
+                                W, K, scores_thresh, center_thresh, num_dets,
+                                # aggregated edge maps exceed 1: clamp behind the peak test (decode.py:302-305)
+                                _EXCT_CLAMP_ONE if aggr_weight > 0 else 0, native.ptr(dets),
                                 native.ptr(ws), ws.numel(), native.stream_ptr())
     native.check(rc, "cn_exct_decode_f32")
     return dets

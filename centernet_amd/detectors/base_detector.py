@@ -322,6 +322,10 @@ class BaseDetector(object):
     def _pipe_for(self, frames, depth):
         if len(self.scales) != 1 or self.opt.flip_test:
             raise ValueError("run_frames is single-scale, no flip")
+        if getattr(self.opt, "nms", False):
+            # merge_outputs applies soft-NMS under --nms (detectors/ctdet.py:63-64); the batched tail
+            # does not: refuse rather than return something else than run(frame)['results']
+            raise ValueError("run_frames does not apply --nms (soft-NMS): use run(frame)")
         shapes = {tuple(f.shape) for f in frames}
         if len(shapes) != 1:
             raise ValueError("run_frames needs frames of one size")
@@ -332,7 +336,7 @@ class BaseDetector(object):
         pipes = self.__dict__.setdefault("_pipes", {})
         if key not in pipes:
             if len(pipes) >= 4:
-                pipes.pop(next(iter(pipes)))
+                pipes.pop(next(iter(pipes))).pool.shutdown(wait=False)
             pipes[key] = _FramePipe(self, len(frames), H, W, self.scales[0], depth)
         return pipes[key]
 

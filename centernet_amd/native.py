@@ -191,6 +191,8 @@ def _declare(lib):
     lib.cn_nhwc_to_nchw_f32.argtypes = [vp, vp, i, i, i, i, i, vp]
     lib.cn_ctdet_decode_workspace_bytes.restype = sz
     lib.cn_ctdet_decode_workspace_bytes.argtypes = [i] * 5
+    lib.cn_decode_state_region.restype = i
+    lib.cn_decode_state_region.argtypes = [i] * 5 + [ctypes.POINTER(ctypes.c_size_t)] * 2
     lib.cn_ctdet_decode_f32.restype = i
     lib.cn_ctdet_decode_f32.argtypes = [vp, vp, vp] + [i] * 7 + [vp, vp, vp, sz, vp]
     lib.cn_nms_topk_channel_f32.restype = i

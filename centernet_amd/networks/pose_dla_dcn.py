@@ -86,7 +86,10 @@ class Tree(nn.Module):
         # member exists: the buffer is allocated first and tree1 / tree2 / the max-pool write their
         # results into their slices (Root.forward's torch.cat, pose_dla_dcn.py:159, without the copies)
         buf = slots = None
-        if self.levels == 1 and self.downsample is not None:
+        # (not with a residual Root, DLA(residual_root=True): its 1x1 convolution would take children[0]
+        # -- a slice of the buffer, at the buffer's pitch -- as residual, and the 1x1 kernels want the
+        # residual at the output's pitch; those trees keep the copying concatenation)
+        if self.levels == 1 and self.downsample is not None and not self.root.residual:
             oc = self.tree1.conv2.weight.shape[0]
             widths = [oc, oc] + [c.C for c in children] + ([x.C] if self.level_root else [])
             Ho, Wo = x.H // self.stride, x.W // self.stride

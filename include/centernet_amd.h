@@ -552,6 +552,10 @@ int cn_ctdet_decode_f32(const float *heat, const float *wh, const float *reg,
  * form for larger planes) and 2048 the per-(class, band) select, for comparison; all forms are
  * bit-identical. */
 #define CN_DECODE_STATE_CLEAN 4096
+/* Byte offset and size, inside the workspace of cn_ctdet_decode_f32 / cn_topk_f32, of the per-image state
+ * words of the one-launch form (0 bytes when the shape takes another form).  A CN_DECODE_STATE_CLEAN caller
+ * re-zeroes (or checks) exactly this region after a failed or aborted call instead of trusting it. */
+int cn_decode_state_region(int B, int C, int H, int W, int K, size_t *offset, size_t *bytes);
 #define CN_DECODE_TWO_LAUNCHES 8192
 #define CN_DECODE_PER_BAND 2048
 /* (A/B only) the one-launch form walks its (image, class) planes image by image instead of class by
@@ -599,7 +603,12 @@ int cn_exct_aggregate_f32(const float *heat, float *out, int B, int C, int H, in
  * for aggr_weight == 0: dets (B, num_dets, 14) = [l_x, t_y, r_x, b_y, score, t_x, t_y, l_x, l_y,
  * b_x, b_y, r_x, r_y, cls].  The four regression maps are used only when all are given
  * (decode.py:372-373).  Heat-maps are post-sigmoid.  K <= 64, num_dets <= 1024.
- * Tie order of equal scores (unspecified by torch.topk): candidate index ascending. */
+ * Tie order of equal scores (unspecified by torch.topk): candidate index ascending.
+ * The `apply_sigmoid` argument carries flags: bit 0 (the logistic) is not supported here;
+ * CN_EXCT_CLAMP_ONE = the edge maps may exceed 1 (they are aggregated maps, cn_exct_aggregate_f32):
+ * after the 3x3 peak test the surviving values are clamped to 1 before the top-K, as the reference
+ * does (decode.py:302-305: `t_heat[t_heat > 1] = 1` behind `_nms`); runs one more pass per edge map. */
+#define CN_EXCT_CLAMP_ONE 2
 size_t cn_exct_decode_workspace_bytes(int B, int C, int H, int W, int K);
 int cn_exct_decode_f32(const float *t_heat, const float *l_heat, const float *b_heat,
                        const float *r_heat, const float *ct_heat, const float *t_regr,

@@ -27,6 +27,12 @@ EXCT_CASES = {
 AGGR_CASES = {
     "exct_aggr": ("exct_small", 0.1),
     "exct_aggr_k40": ("exct_k40", 0.25),
+    # aggregated peaks well above 1: the clamp behind the peak test (decode.py:302-305) decides scores,
+    # ranks and the scores_thresh rule.  Weights chosen so that every (image, edge map) holds FEWER than K
+    # clamped peaks: a run of scores == 1 that the K boundary cuts would make the reference's result depend
+    # on torch.topk's unspecified tie order
+    "exct_aggr_hot": ("exct_small", 2.5),
+    "exct_aggr_hot_k40": ("exct_k40", 3.0),
 }
 
 

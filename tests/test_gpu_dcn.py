@@ -236,9 +236,11 @@ def test_lds_window_variant_matches_oracle(dev):
 
 # ---- the kernel the benchmark runs: cn_dcn_v2_forward_nhwc with CN_DTYPE_F32S (NHWC input,
 # f32s-packed weight, tap split 1 / 3 / 9), entered with explicit offsets and masks
-def _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain, form=1):
+def _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain, form=1, msig=False):
     """x (B,C,H,W), off (B,18,H,W), mask (B,9,H,W) numpy -> (B,Cout,H,W) numpy through
-    PlanBuilder.dcn(om=...) = cn_dcn_v2_forward_nhwc(dtype = CN_DTYPE_F32S)."""
+    PlanBuilder.dcn(om=...) = cn_dcn_v2_forward_nhwc(dtype = CN_DTYPE_F32S).  msig: hand the mask
+    over as logits and let the kernel apply the sigmoid (dcn_v2.py:67: the instantiation the
+    networks run)."""
     from centernet_amd import native
     from centernet_amd.dcn_v2 import DCNv2
     from centernet_amd.engine import PlanBuilder, Act, exponent_for
@@ -252,17 +254,20 @@ def _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain, form=1):
     om = np.zeros((B, H, W, 32), np.float32)
     om[..., :18] = off.transpose(0, 2, 3, 1)
     om[..., 18:27] = mask.transpose(0, 2, 3, 1)
+    if msig:
+        m64 = om[..., 18:27].astype(np.float64)
+        om[..., 18:27] = np.log(m64 / (1.0 - m64)).astype(np.float32)
     want_scale = float(np.abs(x).max())
     lib = native.lib()
     lib.cn_set_tuning(13, tap_split)
-    lib.cn_set_tuning(23, form)    # 1 = global-gather form, 2 / 3 = LDS-window forms, 0 = by grid size
+    lib.cn_set_tuning(23, form)    # 1 = global-gather form, 2 = register-sampling window form, 4 / 5 = team form (T / N mode), 0 = by shape
     try:
         pb = PlanBuilder(dev, B, H, W, split=True,
                          exps={"x": exponent_for(want_scale), "t1": exponent_for(4.0 * want_scale)})
         xa = Act(torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).to(dev), B, H, W, C,
                  exp=pb._exp("x"), lid="x")
         oma = Act(torch.from_numpy(om).to(dev), B, H, W, 27, pitch=32)
-        y = pb.dcn(xa, m, om=oma, mask_sigmoid=False, out_plain=out_plain)
+        y = pb.dcn(xa, m, om=oma, mask_sigmoid=bool(msig), out_plain=out_plain)
         assert y.fmt == ("f32" if out_plain else "f32s")
         for op in pb.ops:
             op()
@@ -308,7 +313,7 @@ def test_f32s_nhwc_kernel_stress_offsets(dev):
         _check(_dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, False), want)
 
 
-@pytest.mark.parametrize("form", [0, 1])
+@pytest.mark.parametrize("form", [0, 1, 4, 5])
 @pytest.mark.parametrize("shape", [(512, 16, 256), (256, 32, 128), (128, 64, 64),     # resdcn_18
                                    (64, 128, 64), (128, 64, 128), (256, 32, 256),      # dla_34
                                    (256, 32, 64)])
@@ -327,13 +332,15 @@ def test_f32s_nhwc_kernel_at_benchmark_batch(dev, shape, form):
         _check(y[i:i + 1], want)
 
 
-# ---- the LDS-window forms (csrc/cn_dcn2.hip: input window in LDS; form 2 = every lane samples its
-# own MFMA operand, 8 x 16 pixel tiles; form 3 = sampling + multiplying waves, 8 x 8 tiles)
-WINDOW_FORMS = [2, 3]
+# ---- the LDS-window forms (input window in LDS, every lane samples its own MFMA operand, 8 x 16 pixel
+# tiles): form 2 = csrc/cn_dcn2.hip dcn_reg_kernel (four waves per tile), forms 4 / 5 = csrc/cn_dcn3.hip
+# dcn_team_kernel (eight waves per tile in two teams: T mode = the teams split the (tap, chunk) steps
+# of a 64-channel block and add up, N mode = each takes 64 of 128 output channels; window by LDS-DMA)
+WINDOW_FORMS = [2, 4, 5]
 
 
 def _window_takes(form, Cin, H, W, Cout):
-    return Cin % 32 == 0 and H % 8 == 0 and W % (16 if form == 2 else 8) == 0 and Cout > 32 and Cout % 4 == 0
+    return Cin % 32 == 0 and H % 8 == 0 and W % 16 == 0 and Cout > 32 and Cout % 4 == 0
 
 
 @pytest.mark.parametrize("form", WINDOW_FORMS)
@@ -375,6 +382,21 @@ def test_f32s_window_kernel_vs_oracle(dev, shape, off_std, form):
 
 
 @pytest.mark.parametrize("form", WINDOW_FORMS)
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16, 64), (1, 128, 24, 48, 128), (1, 512, 16, 16, 256),
+                                   (2, 96, 32, 32, 68)])
+@pytest.mark.parametrize("off_std", [1.0, 5.0])
+def test_f32s_window_kernel_with_the_sigmoid_inside(dev, shape, off_std, form):
+    """The instantiation the networks run: mask logits in, sigmoid in the kernel (dcn_v2.py:67); the
+    team form folds sigmoid(mask) * 2^-e into the four corner weights and neither clamps nor tracks
+    per sample."""
+    B, Cin, H, W, Cout = shape
+    x, off, mask, w, b = _case(B, Cin, H, W, Cout, 700 + Cin + H, off_std=off_std)
+    want = cref.dcn_v2_forward(x, off, mask, w, b)
+    for out_plain in (False, True):
+        _check(_dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, out_plain, form=form, msig=True), want)
+
+
+@pytest.mark.parametrize("form", WINDOW_FORMS)
 def test_f32s_window_kernel_stress_offsets(dev, form):
     """Offsets ~ U(-H, H) and exactly -1 / H / integers (dcn_v2_im2col_cuda.cu:165, :30-41): every
     sample takes the fallback or lies on a rule boundary."""
@@ -390,6 +412,7 @@ def test_f32s_window_kernel_stress_offsets(dev, form):
     want = ref.dcn_v2_forward(x, off, mask, w, b) if ref.available() else \
         cref.dcn_v2_forward(x, off, mask, w, b)
     _check(_dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, False, form=form), want)
+    _check(_dcn_f32s_nhwc(dev, x, off, mask, w, b, 0, False, form=form, msig=True), want)
 
 
 @pytest.mark.parametrize("form", WINDOW_FORMS)

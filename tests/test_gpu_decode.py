@@ -59,7 +59,7 @@ def test_fused_sigmoid_matches_oracle(dev):
     ids = np.stack([inds, dets[..., 5].astype(np.int64)], -1)
     rids = np.stack([ref_inds, ref[..., 5].astype(np.int64)], -1)
     r = compare_topk(dets, ref, tie=1e-6, got_ids=ids, ref_ids=rids)
-    assert r["paired"] >= 0.99 and r["in_place"] >= 0.9, r
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.995 and r["safe"] >= 0.9, r   # (the per-rank rules are asserted inside compare_topk)
 
 
 def test_ties_and_degenerate_maps(dev):

@@ -200,12 +200,16 @@ def _dcn_ref64(x, dy, dx, mask, w, bias):
     return out + bias.view(1, -1, 1, 1)
 
 
+@pytest.mark.parametrize("form", [0, 4])
 @pytest.mark.parametrize("scale", SCALES)
-def test_deformable_kernel_at_every_activation_scale(dev, scale):
+def test_deformable_kernel_at_every_activation_scale(dev, scale, form):
     """The f32s deformable kernel (gather + blend in fp32, the blended sample split with the
     input's exponent folded into the modulation factor) with fractional offsets, every tap split
     (1 / 3 / 9 workgroups per tile) -- offsets and mask logits constant per tap, so that the
-    offset convolution is exact (zero weights) and both sides sample the same positions."""
+    offset convolution is exact (zero weights) and both sides sample the same positions.
+    form 0 = the library's choice for the shape (gather form on these small grids), 4 = the team
+    form (cn_dcn3.hip: LDS-DMA window, exponent inside the corner weights, range word fed by
+    reading the window back)."""
     from centernet_amd import native
     from centernet_amd.dcn_v2 import DCN
     from centernet_amd.engine import PlanBuilder
@@ -231,6 +235,7 @@ def test_deformable_kernel_at_every_activation_scale(dev, scale):
             ref = F.relu(_dcn_ref64(x, dy, dx, mask, m.weight.double(), m.bias.double()))
         exps = {"x": _exp(x), "t1": _exp(ref)}
         lib.cn_set_tuning(13, split)
+        lib.cn_set_tuning(23, form)
         try:
             pb32 = PlanBuilder(dev, B, H, W, split=False)
             y32 = pb32.dcn(_act(x, dev, pb32, "x"), m, relu=True)
@@ -240,10 +245,11 @@ def test_deformable_kernel_at_every_activation_scale(dev, scale):
             _run(pb)
         finally:
             lib.cn_set_tuning(13, 0)
+            lib.cn_set_tuning(23, 0)
         err = _rel(y.to_float().permute(0, 3, 1, 2).cpu(), ref)
         err32 = _rel(y32.to_float().permute(0, 3, 1, 2).cpu(), ref)
         wd = _words(pb)
-        _report(test="dcn", shape=[B, C, H, W, Co], tap_split=split, scale=scale, f32s=err, fp32_mfma=err32)
+        _report(test="dcn", shape=[B, C, H, W, Co], tap_split=split, form=form, scale=scale, f32s=err, fp32_mfma=err32)
         assert err <= _bar(err32), (err, err32, split)
         # blended samples never exceed the input maximum (convex combination x mask <= 1)
         assert 0 < wd["t1"][1] <= float(x.float().abs().max()) * 2.0 ** -exps["x"] * (1 + 1e-6)
@@ -424,7 +430,7 @@ def test_network_with_feature_maps_at_any_scale(dev, arch, log2_scale):
     r = compare_topk(got, ref, got_ids=ids, ref_ids=rids)
     _report(test="network", arch=arch, log2_scale=log2_scale, paired=r["paired"],
             in_place=r["in_place"], **errs)
-    assert r["paired"] >= 0.999 and r["in_place"] >= 0.98, r
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.995 and r["safe"] >= 0.9, r   # (the per-rank rules are asserted inside compare_topk)
     # internal tensors really sit at the requested scale
     e = m.exponents
     assert e is not None and len(e) > 20

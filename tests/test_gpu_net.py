@@ -21,7 +21,7 @@ def _report_fracs(r):
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "parity_fractions.jsonl"), "a") as f:
             f.write(json.dumps({"test": inspect.stack()[1].function, "paired": r["paired"],
-                                "in_place": r["in_place"]}) + "\n")
+                                "in_place": r["in_place"], "safe": r.get("safe"), "eps": r.get("eps")}) + "\n")
     except OSError:
         pass
 
@@ -86,7 +86,7 @@ def test_end_to_end_boxes_512(dev, arch, B):
     r = compare_topk(dets, ref, got_ids=ids, ref_ids=rids)
     print("%s B=%d: paired %.4f, same rank %.4f" % (arch, B, r["paired"], r["in_place"]))
     _report_fracs(r)
-    assert r["paired"] >= 0.999 and r["in_place"] >= 0.98, r
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.995 and r["safe"] >= 0.9, r   # (the per-rank rules are asserted inside compare_topk)
 
 
 def _safe_positions(scores, gap_min=2e-6):
@@ -132,7 +132,7 @@ def test_end_to_end_boxes_at_benchmark_batch(dev, arch, B):
     print("%s B=%d: paired %.4f, same rank %.4f, heat-map max err %.2e, score max err %.2e" % (
         arch, B, r["paired"], r["in_place"], hm_err, np.abs(dets[..., 4] - ref[..., 4]).max()))
     _report_fracs(r)
-    assert r["paired"] >= 0.999 and r["in_place"] >= 0.98, r
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.995 and r["safe"] >= 0.9, r   # (the per-rank rules are asserted inside compare_topk)
 
 
 @pytest.mark.slow
@@ -155,7 +155,7 @@ def test_end_to_end_pose_at_benchmark_batch(dev):
     r = compare_topk(dets, ref, box_tol=1e-4)
     print("dla_34 multi_pose B=32: paired %.4f, same rank %.4f" % (r["paired"], r["in_place"]))
     _report_fracs(r)
-    assert r["paired"] >= 0.999 and r["in_place"] >= 0.95, r   # one class: scores crowd more
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.995 and r["safe"] >= 0.9, r   # (the per-rank rules are asserted inside compare_topk)
     safe = _safe_positions(ref[..., 4])
     # keypoints: regression branch to 1e-3 grid cells; the heat-map-snapped ones are discrete
     # choices that may flip where the reject rule sits on its threshold
@@ -190,7 +190,7 @@ def test_end_to_end_hourglass_512_batch8(dev):
     r = compare_topk(dets, ref, got_ids=ids, ref_ids=rids)
     print("hourglass fp32 B=8 512^2: paired %.4f, same rank %.4f" % (r["paired"], r["in_place"]))
     _report_fracs(r)
-    assert r["paired"] >= 0.999 and r["in_place"] >= 0.98, r
+    assert r["paired"] >= 0.999 and r["in_place"] >= 0.995 and r["safe"] >= 0.9, r   # (the per-rank rules are asserted inside compare_topk)
     m.half_compute()
     with torch.no_grad():
         o16 = m(x.to(dev))[-1]

@@ -13,12 +13,12 @@ dev = torch.device("cuda:0")
 lib = native.lib()
 KNOB = int(os.environ.get("KNOB", "22"))
 VALUES = [int(v) for v in os.environ.get("VALUES", "0,1").split(",")]
-# DBG=0,2,4: columns are probe builds of the register-sampling kernel (key 23 = 2, key 9 = value)
+# DBG=0,8,128: columns are probe builds of a window kernel (key 23 = FORM, default 2; key 9 = value)
 DBG = [int(v) for v in os.environ["DBG"].split(",")] if os.environ.get("DBG") else None
 ZERO_OFF = os.environ.get("ZERO_OFF") == "1"     # zero offsets (no LDS bank conflicts, nothing beyond the window)
 if DBG:
     KNOB, VALUES = 9, DBG
-    lib.cn_set_tuning(23, 2)
+    lib.cn_set_tuning(23, int(os.environ.get("FORM", "2")))
 SHAPES = [(512, 16, 16, 256), (256, 32, 32, 128), (128, 64, 64, 64), (64, 128, 128, 64), (256, 32, 32, 64),
           (128, 64, 64, 128), (256, 32, 32, 256)]
 for B in [int(b) for b in os.environ.get("B", "32").split(",")]:
