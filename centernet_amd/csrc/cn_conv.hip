@@ -866,8 +866,12 @@ __global__ void pack_weight_f32s_kernel(const float *__restrict__ w, _Float16 *_
         wp[g + 32 + (c & 31)] = (_Float16)(v - (float)hi);
     }
 }
-// Fragment-ordered f32s copy for the register-streamed form of the LDS-halo kernel
-// (cn_conv3x3.hip, NBUFB = 0): [tap][chunk][cout block of 32][lane 64][quarter 4][8 fp16].
+// Fragment-ordered f32s copy for the kernels that stream weights straight into MFMA operand registers
+// (cn_dcn2.hip / cn_dcn3.hip; the register-streamed form of the LDS-halo kernel, cn_conv3x3.hip NBUFB = 0):
+// [tap][chunk][cout block of 32][quarter 4][lane 64][8 fp16] -- a wave's load of one quarter is 1 KiB of
+// CONTIGUOUS memory, eight whole cache lines (round 5; the round-2 order [lane][quarter] made every load
+// instruction touch 32 lines for a quarter of their bytes, and the deformable kernels are bound by this
+// stream through the vector L1).
 // Lane (l31 = lane & 31, h = lane >> 5) of a 32 x 32 x 16 MFMA holds, for quarter kk, the
 // channels 16 * (kk & 1) + 8 * h .. + 7 of output channel 32 * block + l31 -- high parts for
 // kk < 2, low parts for kk >= 2 -- i.e. exactly what it would ds_read_b128 from the row form.
@@ -878,8 +882,8 @@ __global__ void pack_weight_f32s_frag_kernel(const float *__restrict__ w, _Float
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(i & 7);
-        const int kk = (int)((i >> 3) & 3);
-        const int lane = (int)((i >> 5) & 63);
+        const int lane = (int)((i >> 3) & 63);
+        const int kk = (int)((i >> 9) & 3);
         size_t r = i >> 11;
         const int nb = (int)(r % ncb); r /= ncb;
         const int chunk = (int)(r % nchunk);
@@ -1479,7 +1483,7 @@ extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weigh
                                   output_nhwc, out_pitch, (flags & CN_CONV_Y_PLAIN) ? 1 : 0, B, Cin, H, W, Cout,
                                   mask_sigmoid, relu, (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f,
                                   ctl ? ctl->range : nullptr,
-                                  (g_tune_dcn_form == 5 || (team_auto && cn_tune_dcn_team == 3)) ? 1 : 0, g_tune_dbgskip,
+                                  g_tune_dcn_form == 5 ? 2 : ((team_auto && cn_tune_dcn_team == 3) ? 1 : 0), g_tune_dbgskip,
                                   ws_ok ? (float *)workspace : nullptr, ws_ok ? workspace_bytes : 0, &ks,
                                   (hipStream_t)stream);
         if (rc == CN_ERR_UNSUPPORTED && g_tune_dcn_form < 4)
@@ -1804,7 +1808,7 @@ extern "C" int cn_set_tuning(int key, int value)
         g_tune_setprio = value;
         return CN_OK;
     }
-    if (key == 9 && value >= 0 && value <= 1023) {
+    if (key == 9 && value >= 0 && value <= 2047) {
         g_tune_dbgskip = value;
         return CN_OK;
     }

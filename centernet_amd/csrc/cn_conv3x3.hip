@@ -468,8 +468,8 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
     auto main_loop = [&]() {
     if constexpr (WREG) {
         // ---- register-streamed weights, software-pipelined one tap ahead.  A lane's four
-        // 16-byte quarter fragments of (tap, chunk, 32-channel output block) are 64 contiguous
-        // bytes of the fragment-ordered weight copy.  Both operand sets (A from the LDS halo, B
+        // 16-byte quarter fragments of (tap, chunk, 32-channel output block) sit 1 KiB apart in the
+        // fragment-ordered weight copy (a wave's load of one quarter is 1 KiB of contiguous memory).  Both operand sets (A from the LDS halo, B
         // from global) are double-buffered in registers and the set a load targets was last read
         // by MFMAs issued a full term earlier -- never by the MFMA just issued (see the operand
         // hazard note in cn_conv.hip).
@@ -482,10 +482,10 @@ __device__ __forceinline__ void conv3x3s1_body(const C3Args &a, const C3Heads &h
         auto load_Bf = [&](c3_f16x8 (*dst)[NB], int chunk, int tap) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const char *src = wf + ((((size_t)tap * a.nchunk + chunk) * a.ncb + nbk[j]) * 64 + lane) * 64;
+                const char *src = wf + (((size_t)tap * a.nchunk + chunk) * a.ncb + nbk[j]) * 4096 + lane * 16;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
-                    dst[kk][j] = *reinterpret_cast<const c3_f16x8 *>(src + kk * 16);
+                    dst[kk][j] = *reinterpret_cast<const c3_f16x8 *>(src + kk * 1024);
             }
         };
         auto load_Af = [&](c3_f16x8 (*dst)[MB], int tap) {

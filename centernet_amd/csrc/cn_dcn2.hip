@@ -61,7 +61,7 @@ __device__ __forceinline__ float d2_sigmoid(float x) { return 1.0f / (1.0f + exp
 //     four bilinear corners each (16 ds_read_b128), blended in fp32, modulated, split into
 //     (high, low) fp16 and used directly as the 32x32x16 MFMA's B operand.  No A tile in LDS;
 //   * the weights are the MFMA's A operand, read from the FRAGMENT-ordered packed copy
-//     (cn_conv.hip pack_weight_f32s_frag_kernel: 64 bytes per lane per (tap, chunk, 32 rows)),
+//     (cn_conv.hip pack_weight_f32s_frag_kernel: four 1 KiB quarters per (tap, chunk, 32 rows)),
 //     global -> registers, requested at the top of the step and landed under the sampling;
 //   * no barrier inside a chunk: waves run free over the nine taps; two barriers per chunk
 //     swap the window.  Two workgroups per CU (74 KB of LDS each) overlap each other's swaps.
@@ -286,9 +286,9 @@ __global__ __launch_bounds__(R_NT, 2) void dcn_reg_kernel(const Dcn2Args a)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int nb = min(nb0 + j, ncb - 1);
-                const char *g = wfrag + ((size_t)((t * a.nchunk + chunk) * ncb + nb) * 64 + lane) * 64;
+                const char *g = wfrag + (size_t)((t * a.nchunk + chunk) * ncb + nb) * 4096 + lane * 16;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) wf[j][kk] = *reinterpret_cast<const d2_f16x8 *>(g + kk * 16);
+                for (int kk = 0; kk < 4; ++kk) wf[j][kk] = *reinterpret_cast<const d2_f16x8 *>(g + kk * 1024);
             }
             if (!PIPE) {
                 cur = decode(Rec[t * R_PM + m]);

@@ -35,8 +35,8 @@
 // 1-2 ulp in fp32, far below the 2^-22 of the f32s split), bias then accumulate (dcn_v2_cuda.c:61-97).
 #include "cn_common.h"
 
-int cn_tune_dcn_team = 0;       // cn_set_tuning key 36: 0 = off, 1 = layers with <= 64 output channels, 2 = every layer it takes (T mode),
-                                // 3 = every layer, N mode where Cout is a multiple of 128
+int cn_tune_dcn_team = 3;       // cn_set_tuning key 36: 0 = off, 1 = layers with <= 64 output channels, 2 = every layer it takes (T mode),
+                                // 3 = every layer, N mode where Cout is a multiple of 128 and that still fills the chip
 int cn_tune_dcn_team_wgs = 512; // cn_set_tuning key 37: K split until a launch has this many workgroups
 
 // one 128-byte line of zeros: the DMA source of window pixels outside the image
@@ -55,8 +55,8 @@ constexpr int T_ROWB = T_WX * T_PIXB;          // 3072 = 12 x 256: a row starts 
 constexpr int T_WBYTES = T_WPIX * T_PIXB;      // 49152
 constexpr int T_NP = T_WPIX * 8 / T_NT;        // 6 DMA pieces (16 B) per thread and chunk
 constexpr int T_RECW = T_WBYTES;               // float4 [9][128]: corner weights (mask, exponent, validity folded in)
-constexpr int T_RECP = T_RECW + 9 * T_PM * 16; // uint32 [9][128]: swizzled LDS offsets of corners 1 and 2, or ~0 (beyond the window)
-constexpr int T_LDS_MAIN = T_RECP + 9 * T_PM * 4;          // 72192
+constexpr int T_RECP = T_RECW + 9 * T_PM * 16; // uint2 [9][128]: swizzled LDS offsets of corners 1 and 2 | beyond-the-window flag + corner
+constexpr int T_LDS_MAIN = T_RECP + 9 * T_PM * 8;          // 76800
 constexpr int T_LDC = 68;                      // floats per staged pixel row (64 + 4)
 constexpr int T_STG = 32 * T_LDC * 4;          // 8704 bytes per wave
 constexpr int T_LDS = T_LDS_MAIN > 8 * T_STG ? T_LDS_MAIN : 8 * T_STG;
@@ -109,7 +109,14 @@ __device__ __forceinline__ unsigned d3_enc(int wy, int wx)
 // MSIG:  the mask is sigmoid(conv output) (dcn_v2.py:67), hence in [0, 1]: a sample is a convex blend
 //        of window values times <= 1 and needs neither clamp nor range tracking of its own;
 //        false = caller-supplied mask of any size (clamp + track per sample)
-// DBG:   probe build
+// DBG:   probe build (D3Args.dbg)
+//
+// Counters of the first build of this kernel (profiles/r05_dcn_team_counters.txt): 171 VALU instructions per
+// (tap, chunk) wave-step at 4.4 cycles each against twelve MFMAs -- the vector ALU, not the matrix pipe, LDS or
+// the weight stream, is what a step costs (v_fma_mixlo_f16 7.5 cycles, v_pk_fma_f32 4.6, v_cvt_pk_f16_f32 4,
+// plain fp32 / integer 2.5-2.8: tools/ubench/valu_rates.hip).  The loop below is therefore written for
+// instruction count: corner weights and window addresses come ready from the records, the rare global path
+// keeps ALL its arithmetic inside its branch, the weight fragments are scalar-base + lane-offset loads.
 template <bool NMODE, bool MSIG, bool DBG>
 __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
 {
@@ -174,7 +181,10 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
 
     // ---- prologue: offsets / masks of the tile (1152 records over 512 threads, every load requested
     // before the first record is formed), the window of the first chunk behind them, then the records
-    // (dcn_v2_im2col_cuda.cu:151-176)
+    // (dcn_v2_im2col_cuda.cu:151-176).  A record = the four corner weights (validity rule :30-41, mask
+    // (:174), sigmoid (dcn_v2.py:67) and the f32s input exponent folded in) + two words: the swizzled LDS
+    // offsets of corners 1 and 2 (always valid window addresses) and, for a sample beyond the window's
+    // reach, bit 31 + the top-left corner (yl + 1, xl + 1) in 15 bits each.
     {
         constexpr int NR = (9 * T_PM + T_NT - 1) / T_NT;   // 3 (the last trip a quarter full)
         float off_h[NR], off_w[NR], mkv[NR];
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
             const int tap = i >> 7, m = i & (T_PM - 1);
             const int oy = ty0 + (m >> 4), ox = tx0 + (m & 15);
             float mk = mkv[p];
-            if (MSIG) mk = d3_sigmoid(mk);              // dcn_v2.py:67
+            if (MSIG) mk = sigmoidf_ref(mk);            // dcn_v2.py:67 (v_exp + v_rcp: within 2e-7 of the IEEE form)
             mk *= a.x_mul;                              // plain input -> stored units (a power of two)
             const int ki = tap / 3, kj = tap - ki * 3;
             const float h_im = (float)(oy - 1 + ki) + off_h[p];
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
             cn_f32x4 wv = {0.f, 0.f, 0.f, 0.f};
             // outside the sampling domain (:165): the sample is 0; the pixel's own position as
             // "corner" keeps the reads inside the window
-            unsigned pp = d3_enc((m >> 4) + 1 + T_RCH, (m & 15) + 1 + T_RCH);
+            unsigned p0 = d3_enc((m >> 4) + 1 + T_RCH, (m & 15) + 1 + T_RCH), p1 = 0u;
             if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {   // :165
                 const float hf = floorf(h_im), wf = floorf(w_im);
                 const int yl = (int)hf, xl = (int)wf;
@@ -217,22 +227,23 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
                 wv[3] = (yh_ok && xh_ok) ? lh * lw * mk : 0.f;
                 const int wyl = yl - wy0, wxl = xl - wx0;
                 const bool inwin = (unsigned)wyl <= (unsigned)(T_WY - 2) && (unsigned)wxl <= (unsigned)(T_WX - 2);
-                pp = (inwin && !(dbg & 1)) ? d3_enc(wyl, wxl) : 0xffffffffu;
+                if (inwin && !(dbg & 1)) p0 = d3_enc(wyl, wxl);
+                else p1 = 0x80000000u | ((unsigned)(yl + 1) << 15) | (unsigned)(xl + 1);
             }
             if (i < 9 * T_PM) {
                 *reinterpret_cast<cn_f32x4 *>(smem + T_RECW + i * 16) = wv;
-                *reinterpret_cast<unsigned *>(smem + T_RECP + i * 4) = pp;
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2 *>(smem + T_RECP + i * 8) = u32x2{p0, p1};
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (MSIG && a.range) track();
-    d3_barrier();                                  // records and the window of the first chunk visible
+    __syncthreads();                               // records and the window of the first chunk visible
 
     const int m = pb * 32 + l31;                   // this lane's pixel of the tile
-    const int oy = ty0 + (m >> 4), ox = tx0 + (m & 15);
-    const unsigned own_pp = d3_enc((m >> 4) + 1 + T_RCH, (m & 15) + 1 + T_RCH);
     const unsigned hx = (unsigned)h << 5;
+    const unsigned laneoff = (unsigned)lane * 16u;
     const char *wfrag = reinterpret_cast<const char *>(a.w) + (size_t)9 * a.cout_pad * a.cin_pad * 4;
     const int ncb = a.cout_pad >> 5;
     const int nb0 = min(n0 >> 5, ncb - 1), nb1 = min((n0 >> 5) + 1, ncb - 1);
@@ -241,50 +252,71 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    typedef float d3_f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned d3_u32x2 __attribute__((ext_vector_type(2)));
+
+    // Weight fragments, software-pipelined one K half ahead: set A serves K half 0 of a step, set B K half 1.
+    // Each set is requested right behind the blend of the K half BEFORE its own (the corner registers
+    // are dead there), so that the ~1000 cycles a fragment takes from L2 pass under a whole MFMA block,
+    // the next window reads and the next blend (probe: requested at the top of their own K half the
+    // fragments arrived ~300 cycles after the blend was done, every K half of every wave).
+    d3_f16x8 wAh0, wAl0, wAh1, wAl1, wBh0, wBl0, wBh1, wBl1;
+    auto wptr = [&](int t, int chunk) { return wfrag + (size_t)(t * a.nchunk + chunk) * ncb * 4096; };
+    auto first_tap = [&](int chunk) { return NMODE ? 0 : ((team ^ (chunk - c_lo)) & 1); };
+    auto load_A = [&](const char *sw) {
+        wAh0 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb0 * 4096 + laneoff);
+        wAl0 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb0 * 4096 + 2048 + laneoff);
+        wAh1 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb1 * 4096 + laneoff);
+        wAl1 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb1 * 4096 + 2048 + laneoff);
+    };
+    auto load_B = [&](const char *sw) {
+        wBh0 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb0 * 4096 + 1024 + laneoff);
+        wBl0 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb0 * 4096 + 3072 + laneoff);
+        wBh1 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb1 * 4096 + 1024 + laneoff);
+        wBl1 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb1 * 4096 + 3072 + laneoff);
+    };
+    load_A(wptr(first_tap(c_lo), c_lo));
+    constexpr int TSTEP = NMODE ? 1 : 2;
 
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
         if (chunk != c_lo) {
-            d3_barrier();                          // every wave is done with the previous window
+            __syncthreads();                       // every wave is done with the previous window
             dma(chunk);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (MSIG && a.range) track();
-            d3_barrier();
+            __syncthreads();
         }
-        const unsigned cb = (unsigned)chunk * 128u;
-        const int t0 = NMODE ? 0 : ((team ^ (chunk - c_lo)) & 1);
+        // byte offset, in x, of channel 8 h of this chunk in pixel 0 of the image (global path)
+        const unsigned far_base = img_base * pix_bytes + (unsigned)chunk * 128u + hx;
+        const int t0 = first_tap(chunk);
 #pragma unroll 1
-        for (int t = t0; t < ((dbg & 128) ? 0 : 9); t += (NMODE ? 1 : 2)) {
+        for (int t = t0; t < ((dbg & 128) ? 0 : 9); t += TSTEP) {
             const cn_f32x4 wv = *reinterpret_cast<const d3_lds_f32x4 *>(lds + T_RECW + (t * T_PM + m) * 16);
-            const unsigned pp = *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(lds + T_RECP + (t * T_PM + m) * 4);
-            const float w1 = wv[0], w2 = wv[1], w3 = wv[2], w4 = wv[3];
-            const bool far = pp == 0xffffffffu;
-            const unsigned ps = far ? own_pp : pp;
-            const unsigned A1 = (ps & 0xffffu) ^ hx, A2 = (ps >> 16) ^ hx;
-            const char *g0 = wfrag + ((size_t)((t * a.nchunk + chunk) * ncb + nb0) * 64 + lane) * 64;
-            const char *g1 = wfrag + ((size_t)((t * a.nchunk + chunk) * ncb + nb1) * 64 + lane) * 64;
+            const d3_u32x2 pp = *reinterpret_cast<const __attribute__((address_space(3))) d3_u32x2 *>(lds + T_RECP + (t * T_PM + m) * 8);
+            // fragment copy of this (tap, chunk) and of the K half that follows this step (uniform bases)
+            const char *sw = wptr(t, chunk);
+            const bool last_tap = t + TSTEP >= 9;
+            const int cn = last_tap ? min(chunk + 1, c_hi - 1) : chunk;
+            const char *sn = wptr(last_tap ? first_tap(cn) : t + TSTEP, cn);
+            const d3_f32x2 w1 = {wv[0], wv[0]}, w2 = {wv[1], wv[1]}, w3 = {wv[2], wv[2]}, w4 = {wv[3], wv[3]};
+            const unsigned A1 = (pp[0] & 0xffffu) ^ hx, A2 = (pp[0] >> 16) ^ hx;
+            const bool far = (int)pp[1] < 0;
             unsigned o1 = 0, o2 = 0, o3 = 0, o4 = 0;
             if (far) {
-                // beyond the window's reach: recompute the corner positions from the offsets
-                // (rare; clamped addresses -- off-map corners carry zero weight)
-                const float *om = a.om + (size_t)((b * H + oy) * W + ox) * a.om_pitch;
-                const int ki = t / 3, kj = t - ki * 3;
-                const float h_im = (float)(oy - 1 + ki) + om[2 * t];
-                const float w_im = (float)(ox - 1 + kj) + om[2 * t + 1];
-                const int yl = (int)floorf(h_im), xl = (int)floorf(w_im);
-                const int y0 = min(max(yl, 0), H - 1), y1 = max(min(yl + 1, H - 1), 0);
-                const int x0 = min(max(xl, 0), W - 1), x1 = max(min(xl + 1, W - 1), 0);
-                o1 = (img_base + (unsigned)(y0 * W + x0)) * pix_bytes + cb + hx;
-                o2 = (img_base + (unsigned)(y0 * W + x1)) * pix_bytes + cb + hx;
-                o3 = (img_base + (unsigned)(y1 * W + x0)) * pix_bytes + cb + hx;
-                o4 = (img_base + (unsigned)(y1 * W + x1)) * pix_bytes + cb + hx;
+                // beyond the window's reach: the four corners from global memory (clamped addresses --
+                // off-map corners carry zero weight); 24-bit integer multiplies (pixel index and pixel
+                // pitch are below 2^24, checked by the launcher)
+                const int yl = (int)((pp[1] >> 15) & 0x7fffu) - 1, xl = (int)(pp[1] & 0x7fffu) - 1;
+                const int y0 = max(yl, 0), y1 = min(yl + 1, H - 1);
+                const int x0 = max(xl, 0), x1 = min(xl + 1, W - 1);
+                const unsigned r0 = __umul24((unsigned)y0, (unsigned)W), r1 = __umul24((unsigned)y1, (unsigned)W);
+                o1 = __umul24(r0 + (unsigned)x0, pix_bytes) + far_base;
+                o2 = __umul24(r0 + (unsigned)x1, pix_bytes) + far_base;
+                o3 = __umul24(r1 + (unsigned)x0, pix_bytes) + far_base;
+                o4 = __umul24(r1 + (unsigned)x1, pix_bytes) + far_base;
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                // weights of this (tap, chunk, K half): the MFMA's A operand, straight from the fragment copy
-                const d3_f16x8 wh0 = *reinterpret_cast<const d3_f16x8 *>(g0 + kk * 16);
-                const d3_f16x8 wl0 = *reinterpret_cast<const d3_f16x8 *>(g0 + (2 + kk) * 16);
-                const d3_f16x8 wh1 = *reinterpret_cast<const d3_f16x8 *>(g1 + kk * 16);
-                const d3_f16x8 wl1 = *reinterpret_cast<const d3_f16x8 *>(g1 + (2 + kk) * 16);
                 // channels 16 kk + 8 h .. + 7 of the four corners: eight window reads
                 const unsigned B1 = A1 ^ ((unsigned)kk << 6), B2 = A2 ^ ((unsigned)kk << 6);
                 cn_f32x4 c1a = *reinterpret_cast<const d3_lds_f32x4 *>(lds + B1);
@@ -309,9 +341,19 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
                     // join, these loads would sit in front of every later weight fragment)
                     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
                 }
-                // w1*v1 + w2*v2 + w3*v3 + w4*v4 (dcn_v2_im2col_cuda.cu:43-45; mask and exponent inside the weights)
-                const cn_f32x4 va = c1a * w1 + c2a * w2 + c3a * w3 + c4a * w4;
-                const cn_f32x4 vb = c1b * w1 + c2b * w2 + c3b * w3 + c4b * w4;
+                // w1*v1 + w2*v2 + w3*v3 + w4*v4 (dcn_v2_im2col_cuda.cu:43-45; mask and exponent inside the
+                // weights), two channels per instruction (v_pk_fma_f32)
+                cn_f32x4 va, vb;
+                {
+                    auto lo2 = [](cn_f32x4 v) { return d3_f32x2{v[0], v[1]}; };
+                    auto hi2 = [](cn_f32x4 v) { return d3_f32x2{v[2], v[3]}; };
+                    const d3_f32x2 a0 = lo2(c1a) * w1 + lo2(c2a) * w2 + lo2(c3a) * w3 + lo2(c4a) * w4;
+                    const d3_f32x2 a1 = hi2(c1a) * w1 + hi2(c2a) * w2 + hi2(c3a) * w3 + hi2(c4a) * w4;
+                    const d3_f32x2 b0 = lo2(c1b) * w1 + lo2(c2b) * w2 + lo2(c3b) * w3 + lo2(c4b) * w4;
+                    const d3_f32x2 b1 = hi2(c1b) * w1 + hi2(c2b) * w2 + hi2(c3b) * w3 + hi2(c4b) * w4;
+                    va = cn_f32x4{a0[0], a0[1], a1[0], a1[1]};
+                    vb = cn_f32x4{b0[0], b0[1], b1[0], b1[1]};
+                }
                 cn_f16x4v ha, la, hb, lb;
                 if (MSIG) {
                     cn_split4<false>(va, ha, la);        // |v| <= max |x'|, which the range word reports
@@ -324,11 +366,17 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
                 }
                 const d3_f16x8 shi = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
                 const d3_f16x8 slo = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+                // the operands of the K half after this one: requested here, the corner registers are dead
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk == 0) load_B(sw); else load_A(sn);
                 if (dbg & 8) {
-                    acc[0][0] += (float)shi[0] + (float)slo[0] + (float)wh0[0] + (float)wl0[0] + (float)wh1[0] + (float)wl1[0];
+                    acc[0][0] += (float)shi[0] + (float)slo[0] + (float)wAh0[0] + (float)wBl1[0];
                     continue;
                 }
                 // every operand is in registers before the first MFMA issues (operand hazard note, cn_conv.hip)
+                __builtin_amdgcn_sched_barrier(0);
+                const d3_f16x8 wh0 = kk ? wBh0 : wAh0, wl0 = kk ? wBl0 : wAl0, wh1 = kk ? wBh1 : wAh1, wl1 = kk ? wBl1 : wAl1;
+                asm volatile("" :: "v"(wh0), "v"(wl0), "v"(wh1), "v"(wl1));    // (this set has landed: waited for here)
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl0, shi, acc[0], 0, 0, 0);
@@ -345,7 +393,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
     // ---- epilogue: every wave stages its 32 pixels x 64 channels (the window and the records are
     // dead), the teams' sums are added on the way out (T mode), y = relu?((acc + bias) * scale + shift)
     // and whole lines are stored.  acc[j][r]: channel 32 j + (r & 3) + 8 (r >> 2) + 4 h of pixel l31.
-    d3_barrier();
+    __syncthreads();
     {
         float *Cs = reinterpret_cast<float *>(smem + wave * T_STG);
 #pragma unroll
@@ -356,7 +404,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
                 *reinterpret_cast<cn_f32x4 *>(Cs + l31 * T_LDC + 32 * j + 8 * g + 4 * h) = v;
             }
     }
-    d3_barrier();
+    __syncthreads();
     const int cq = lane & 15, rr = lane >> 4;     // 16 lanes per pixel row, four rows per pass
     const int n = n0 + cq * 4;
     float bs[4], sc[4], sf2[4];
@@ -422,7 +470,7 @@ int launch_dcn_team(const D3Args &a, int mask_sigmoid, hipStream_t st)
 }  // namespace
 
 // Shapes this kernel takes (the caller falls back to the other forms otherwise): maps of whole
-// 8 x 16 pixel tiles, whole 32-channel chunks, Cout a multiple of 4 and >= 33.  nmode: 1 = the teams
+// 8 x 16 pixel tiles, whole 32-channel chunks, Cout a multiple of 4 and >= 33.  nmode: 1 (2 = even on small grids) = the teams
 // split a 128-channel block (needs Cout % 128 == 0), 0 = they split the steps of a 64-channel block.
 int cn_dcn_team_f32s(const float *x, const void *w_packed, const float *bias, const float *om,
                      int om_pitch, const float *scale, const float *shift, void *y, int out_pitch,
@@ -434,7 +482,13 @@ int cn_dcn_team_f32s(const float *x, const void *w_packed, const float *bias, co
     if ((H & 7) || (W & 15) || (Cin & 31) || (Cout & 3) || Cout <= 32) return CN_ERR_UNSUPPORTED;
     if (H > 32767 || W > 32767 || (out_pitch & 3) || !cn_aligned16(y) || !cn_aligned16(x)) return CN_ERR_UNSUPPORTED;
     if ((size_t)B * H * W * Cin * 4 >= ((size_t)1 << 32)) return CN_ERR_UNSUPPORTED;   // 32-bit byte offsets
+    // global path: 15-bit corner coordinates, 24-bit integer multiplies (pixel index, bytes per pixel)
+    if (H > 16383 || W > 16383 || (size_t)B * H * W >= ((size_t)1 << 24) || (size_t)Cin * 4 >= ((size_t)1 << 24)) return CN_ERR_UNSUPPORTED;
     if (nmode && (Cout & 127)) nmode = 0;
+    // N mode halves the workgroup count: only where two workgroups per CU remain (measured: 256 -> 128 @ 32^2 at
+    // B = 32 has 256 tiles: 0.093 ms in T mode, 0.109 in N mode; 128 -> 128 @ 64^2 and 256 -> 256 @ 32^2: 0.179 /
+    // 0.172 against 0.195 / 0.209)
+    if (nmode == 1 && (long)B * (H / T_TY) * (W / T_TX) * (Cout / 128) < cn_tune_dcn_team_wgs) nmode = 0;
     const long wgs = (long)B * (H / T_TY) * (W / T_TX) * cn_cdiv(Cout, nmode ? 128 : 64);
     // Too few tiles for the chip but a deep K (512 -> 256 @ 16^2): split the 32-channel chunks over
     // 2 / 4 / 8 workgroups per tile -- raw fp32 partial sums in the caller's workspace, summed in a

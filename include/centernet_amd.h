@@ -133,6 +133,8 @@ const char *cn_arch(void);
  *         (default), 0 = one grid row per head. */
 int cn_set_tuning(int key, int value);
 
+
+
 /* ------------------------------------------------------------------------
  * Deformable convolution v2, forward.
  *

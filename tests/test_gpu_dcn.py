@@ -319,10 +319,11 @@ def test_f32s_nhwc_kernel_stress_offsets(dev):
                                    (256, 32, 64)])
 def test_f32s_nhwc_kernel_at_benchmark_batch(dev, shape, form):
     """B = 32, the layer shapes of resdcn_18 and dla_34: the launch the benchmark
-    times -- form 0 = the library's DEFAULT choice for the shape (the register-sampling window
-    kernel dcn_reg_kernel on these grids, K-split on the 16^2 map), form 1 = the global-gather
-    kernel -- default tap split; images 0, 13 and 31 against the C oracle (the operator is per
-    image, dcn_v2_cuda.c:61)."""
+    times -- form 0 = the library's DEFAULT choice for the shape (round 5: the team form of the
+    window kernel, csrc/cn_dcn3.hip, N mode where Cout is a multiple of 128 and the grid still fills
+    the chip, K-split on the 16^2 map), form 1 = the global-gather kernel, 4 / 5 = the team form
+    forced into T / N mode -- default tap split; images 0, 13 and 31 against the C oracle (the
+    operator is per image, dcn_v2_cuda.c:61)."""
     Cin, HW, Cout = shape
     B = 32
     x, off, mask, w, b = _case(B, Cin, HW, HW, Cout, 300 + Cin)

@@ -21,6 +21,8 @@ if DBG:
     lib.cn_set_tuning(23, int(os.environ.get("FORM", "2")))
 SHAPES = [(512, 16, 16, 256), (256, 32, 32, 128), (128, 64, 64, 64), (64, 128, 128, 64), (256, 32, 32, 64),
           (128, 64, 64, 128), (256, 32, 32, 256)]
+if os.environ.get("ONLY"):     # ONLY=2,3: a subset of the shapes (counter passes)
+    SHAPES = [SHAPES[int(i)] for i in os.environ["ONLY"].split(",")]
 for B in [int(b) for b in os.environ.get("B", "32").split(",")]:
     print("B=%d  %-22s" % (B, "Cin,H,W,Cout"), "   ".join("key%d=%-10d" % (KNOB, v) for v in VALUES))
     for ci, H, W, co in SHAPES:
