@@ -773,7 +773,6 @@ int g_tune_occ4 = 0;        // cn_set_tuning key 19: 4-workgroups-per-CU form of
 int g_tune_dcn_form = 0;   // cn_set_tuning key 23: f32s deformable kernel, 0 = by shape and grid (team form per key 36, else the register-sampling window form, else the gather form), 1 = global-gather form always, 2 = register-sampling form (cn_dcn2.hip) for every shape it takes, 4 / 5 = team form (cn_dcn3.hip) in T / N mode for every shape it takes
 int g_tune_stem16s = 1;     // cn_set_tuning key 27: f32s form of the stride-1 16-channel stem (DLA base_layer); 0 = fp32 kernel
 int g_tune_dcn_tile2d = 1; // cn_set_tuning key 22: deformable kernel, 1 = 8-wide pixel blocks as tiles (default), 0 = row segments
-int g_tune_dcn_window = 0; // cn_set_tuning key 11: 1 = LDS-window DCN (cn_dcn.hip); default global gather (faster, measured)
 int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip
 int g_tune_nostem = 0;   // cn_set_tuning key 6: 1 = generic implicit-GEMM stem instead of cn_stem.hip
 
@@ -924,9 +923,6 @@ int cn_stem_pool_f32s(const float *x, const float *w_packed, const float *scale,
                       float *y, int B, int H, int W, int Ho, int Wo, int Cout, int KH, int KW,
                       int stride, int pad, int relu, int out_pitch, int KP, int y_f32s, const cn_f32s_ctl *ctl,
                       hipStream_t st);
-int cn_dcn_window_f32(const float *x, const float *w_packed, const float *bias, const float *om,
-                      int om_pitch, const float *scale, const float *shift, float *y, int B, int Cin,
-                      int H, int W, int Cout, int mask_sigmoid, int relu, int setprio, hipStream_t st);
 int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, const float *om,
                        int om_pitch, const float *scale, const float *shift, void *y, int out_pitch,
                        int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
@@ -937,7 +933,7 @@ int cn_dcn_team_f32s(const float *x, const void *w_packed, const float *bias, co
                      int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
                      float x_mul, uint32_t *range, int nmode, int dbg, float *partial,
                      size_t partial_bytes, int *ksplit_out, hipStream_t st);
-extern int cn_tune_dcn_team, cn_tune_dcn_team_wgs;   // cn_dcn3.hip
+extern int cn_tune_dcn_team, cn_tune_dcn_team_wgs, cn_tune_dcn_team_stagger;   // cn_dcn3.hip
 bool cn_conv3x3s2p_takes(int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch);
 int cn_conv3x3s2_persist(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
                          int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch, int relu,
@@ -1458,15 +1454,6 @@ extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weigh
     if (!cn_aligned16(input_nhwc) || !cn_aligned16(weight_packed)) return CN_ERR_ALIGN;
     if (f32s && !(flags & CN_CONV_Y_PLAIN) && !aligned128(output_nhwc)) return CN_ERR_ALIGN;
     if ((long)B * H * W * (long)(Cin > out_pitch ? Cin : out_pitch) >= (1L << 30)) return CN_ERR_UNSUPPORTED;  // 32-bit byte offsets
-    // LDS-staged input window (cn_dcn.hip): measured 20-30 % SLOWER than the L1/L2-served
-    // gather below on every CenterNet shape (tools/bench_dcn.py), so it is opt-in only
-    if (!f32s && out_pitch == Cout && g_tune_dcn_window && Cout > 32) {
-        const int rc = cn_dcn_window_f32(input_nhwc, (const float *)weight_packed, bias,
-                                         offset_mask_nhwc, om_pitch, scale, shift,
-                                         (float *)output_nhwc, B, Cin, H, W, Cout,
-                                         mask_sigmoid, relu, g_tune_setprio, (hipStream_t)stream);
-        if (rc != CN_ERR_UNSUPPORTED) return rc;
-    }
     // f32s: the LDS-window forms (cn_dcn3.hip team form, cn_dcn2.hip register-sampling form) for every
     // shape they take and every grid that fills the chip; the gather form below (tap split) serves the rest
     if (f32s && g_tune_dcn_form != 1) {
@@ -1732,7 +1719,6 @@ extern "C" int cn_stem_f32s_supported(const cn_conv_desc *d)
 }
 
 extern int cn_tune_c3p, cn_tune_c3p_stagger, cn_tune_c3p_knobs, cn_tune_c3p_heads, cn_tune_c3p_deconv, cn_tune_c3p_s2;
-extern int cn_tune_dcn_wgs, cn_tune_dcn_bn64;   // cn_dcn2.hip
 extern "C" int cn_set_tuning(int key, int value)
 {
     if (key == 28 && value >= 0 && value <= 7) {
@@ -1759,10 +1745,7 @@ extern "C" int cn_set_tuning(int key, int value)
         cn_tune_c3p_s2 = value;
         return CN_OK;
     }
-    if (key == 34 && value >= 1 && value <= 4096) {
-        cn_tune_dcn_wgs = value;
-        return CN_OK;
-    }
+
     if (key == 36 && value >= 0 && value <= 3) {
         cn_tune_dcn_team = value;
         return CN_OK;
@@ -1771,15 +1754,16 @@ extern "C" int cn_set_tuning(int key, int value)
         cn_tune_dcn_team_wgs = value;
         return CN_OK;
     }
-    if (key == 35 && value >= 0 && value <= 4096) {
-        cn_tune_dcn_bn64 = value;
+    if (key == 38 && value >= 0 && value <= 1024) {
+        cn_tune_dcn_team_stagger = value;
         return CN_OK;
     }
+
     if (key == 20 && (value == 0 || value == 1)) {
         cn_tune_f32s_lds_weights = value;
         return CN_OK;
     }
-    if (key == 21 && value >= 0 && value <= 15) {
+    if (key == 21 && value >= 0 && value <= 7) {
         cn_tune_f32s_policy = value;
         return CN_OK;
     }
@@ -1816,10 +1800,7 @@ extern "C" int cn_set_tuning(int key, int value)
         g_tune_nohalo = value;
         return CN_OK;
     }
-    if (key == 11 && (value == 0 || value == 1)) {
-        g_tune_dcn_window = value;
-        return CN_OK;
-    }
+    if (key == 11 && value == 0) return CN_OK;   // fp32 LDS-window DCN kernel: retired in round 5 (20-30 % slower than the gather form)
     if (key == 7 && (value == 0 || value == 1 || value == 2)) {
         g_tune_swz = value;
         return CN_OK;

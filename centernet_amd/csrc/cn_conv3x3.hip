@@ -1282,14 +1282,8 @@ static int c3_dispatch(C3Args &a, int bn_class, hipStream_t st)
     if (kskip)
         return wide ? launch_c3<float, 32, 32, 4, 1, false, 128, true>(a, st)
                     : launch_c3<float, 16, 32, 4, 1, false, 128, true>(a, st);
-    if constexpr (std::is_same<T, cn_f32s>::value) {
-        // 32-wide N tiles (the 27-channel offset convolutions of the deformable modules): 256-pixel tiles,
-        // a wave owns 64 pixels -- the weight fragments serve two pixel blocks and the halo shrinks from
-        // 1.59 to 1.33 staged pixels per output pixel (cn_set_tuning key 21 bit 3, A/B)
-        const long wgs256 = (long)a.B * cn_cdiv(a.H, 8) * cn_cdiv(a.W, 32);
-        if (wide && a.H >= 8 && (cn_tune_f32s_policy & 8) && wgs256 >= 512)
-            return launch_c3<T, 32, 32, 4, 1, false, 256>(a, st);
-    }
+    // (32-wide N tiles -- the 27-channel offset convolutions -- on 256-pixel tiles: +0.3 %, removed in round 5;
+    // profiles/r04_offset_conv_tile_ab.txt)
     return wide ? launch_c3<T, 32, 32, 4, 1>(a, st) : launch_c3<T, 16, 32, 4, 1>(a, st);
 }
 

@@ -19,8 +19,10 @@
 // Epilogue as everywhere: y = relu?((acc + bias) * scale + shift), plain fp32 or f32s, range words.
 #include "cn_common.h"
 
-int cn_tune_dcn_wgs = 256;     // cn_set_tuning key 34: the register-sampling form splits K until a launch has this many workgroups
-int cn_tune_dcn_bn64 = 0;      // cn_set_tuning key 35: 64-wide N tiles for Cout > 64 when 128-wide ones give fewer workgroups than this
+// K is split until a launch has this many workgroups (round-4 sweep of 256 / 512 / 1024 and of 64-wide N tiles
+// for Cout > 64, cn_set_tuning keys 34 / 35: within +-5 % on every layer shape, profiles/r04_dcn_split_sweep.txt;
+// the keys were removed in round 5)
+constexpr int cn_tune_dcn_wgs = 256;
 
 namespace {
 
@@ -462,8 +464,7 @@ int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, 
     if (H > 32767 || W > 32767 || (out_pitch & 3) || !cn_aligned16(y) || !cn_aligned16(x)) return CN_ERR_UNSUPPORTED;
     if ((om_pitch & 1) || (((uintptr_t)om) & 7u)) return CN_ERR_UNSUPPORTED;   // (offset pairs are 8-byte loads)
     if ((size_t)B * H * W * Cin * 4 >= ((size_t)1 << 32)) return CN_ERR_UNSUPPORTED;   // 32-bit byte offsets
-    int bn = Cout > 64 ? 128 : 64;
-    if (bn == 128 && (long)B * (H / TS) * (W / R_TX) * cn_cdiv(Cout, 128) < cn_tune_dcn_bn64) bn = 64;
+    const int bn = Cout > 64 ? 128 : 64;
     const long wgs = (long)B * (H / TS) * (W / R_TX) * cn_cdiv(Cout, bn);
     // Too few tiles for the chip but a deep K (512 -> 256 @ 16^2): split the 32-channel chunks over
     // 2 / 4 / 8 workgroups per tile -- raw fp32 partial sums in the caller's workspace, summed in a

@@ -38,6 +38,7 @@
 int cn_tune_dcn_team = 3;       // cn_set_tuning key 36: 0 = off, 1 = layers with <= 64 output channels, 2 = every layer it takes (T mode),
                                 // 3 = every layer, N mode where Cout is a multiple of 128 and that still fills the chip
 int cn_tune_dcn_team_wgs = 512; // cn_set_tuning key 37: K split until a launch has this many workgroups
+int cn_tune_dcn_team_stagger = 32; // cn_set_tuning key 38: start delay of the second resident workgroup of every CU, in units of 256 cycles (sweep 0 .. 128 at B = 32: 32-64 is 5-9 % faster on the multi-round shapes, nothing on the others; profiles/r05_dcn_team_stagger.txt)
 
 // one 128-byte line of zeros: the DMA source of window pixels outside the image
 __device__ __attribute__((aligned(128))) unsigned char cn_d3_zero_line[128];
@@ -72,6 +73,7 @@ struct D3Args {
     int cin_pad, cout_pad, nchunk, tiles_x, tiles_y, out_pitch, out_plain;
     float x_mul;
     uint32_t *range;
+    int stagger;               // start delay of workgroups 256 .. 511 (the second occupant of every CU), units of 256 cycles
     int dbg;                   // probe build (cn_set_tuning key 9): 1 = every sample takes the global path, 8 = no MFMAs, 128 = no taps
     int ksplit;                // K-chunk ranges per tile (blockIdx.z); > 1: raw partial sums
     float *partial;            // [ksplit][B*H*W][cout_pad] fp32 (splitk_reduce_kernel applies the epilogue)
@@ -127,6 +129,15 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
     const int pb = wave & 3, team = wave >> 2;
     const int H = a.H, W = a.W;
     int bx = blockIdx.x;
+    if (a.stagger) {
+        // two workgroups share a CU and do the same work: started together they reach their window swaps,
+        // prologues and epilogues together and nothing covers them.  One-off phase shift of the second occupant.
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin >= 256u && lin < 512u) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < (unsigned long long)a.stagger * 256u) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     {   // XCD-aware tile order: contiguous tile ranges per XCD (block b runs on XCD b % 8)
         const int q8 = gridDim.x >> 3;
         if (bx < (q8 << 3)) bx = (bx & 7) * q8 + (bx >> 3);
@@ -512,6 +523,7 @@ int cn_dcn_team_f32s(const float *x, const void *w_packed, const float *bias, co
     a.tiles_x = W / T_TX;
     a.tiles_y = H / T_TY;
     a.x_mul = x_mul; a.range = range; a.dbg = dbg;
+    a.stagger = cn_tune_dcn_team_stagger;
     a.ksplit = ksplit;
     a.partial = ksplit > 1 ? partial : nullptr;
     if (ksplit_out) *ksplit_out = ksplit;

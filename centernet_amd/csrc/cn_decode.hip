@@ -1252,27 +1252,11 @@ __global__ __launch_bounds__(OP_NT, CN_PSM_WAVES) void plane_select_merge_kernel
     const int lane = tid & (CN_WAVE - 1);
     const int hl = lane & 31, hw = tid >> 5;
     int b, c;
-    if (flags & CN_DECODE_IMAGE_MAJOR) {
-        b = (int)(blockIdx.x / (unsigned)C);
-        c = (int)blockIdx.x - b * C;
-    } else if (flags & CN_DECODE_BLOCK_MAJOR) {
-        // (A/B) class-major in blocks of eight classes: eight consecutive workgroups read 512 KB of ONE
-        // image back to back (one or two translations instead of eight), an image's planes still spread
-        // over the launch; the classes beyond the last whole block come last, image by image
-        const int full = C & ~7, pid = (int)blockIdx.x;
-        if (pid < B * full) {
-            const int chi = pid / (B * 8), r = pid - chi * (B * 8);
-            b = r >> 3;
-            c = chi * 8 + (r & 7);
-        } else {
-            const int t = C - full, q = pid - B * full;
-            b = q / t;
-            c = full + (q - b * t);
-        }
-    } else {
-        c = (int)(blockIdx.x / (unsigned)B);
-        b = (int)blockIdx.x - c * B;
-    }
+    // planes class by class (all images' plane 0, then plane 1, ...): an image's planes are spread over the
+    // launch and most of them find a floor.  (Round 4 A/B, removed in round 5: image by image +40 % time;
+    // class-major in blocks of eight classes +9 % warm, -19 % cold -- DESIGN.md 3.4.)
+    c = (int)(blockIdx.x / (unsigned)B);
+    b = (int)blockIdx.x - c * B;
     const size_t plane_id = (size_t)b * C + c;
     const bool sig = (flags & 1) != 0;
     const bool nonms = (flags & CN_DECODE_NO_PEAK_TEST) != 0;

@@ -560,11 +560,6 @@ int cn_ctdet_decode_f32(const float *heat, const float *wh, const float *reg,
 int cn_decode_state_region(int B, int C, int H, int W, int K, size_t *offset, size_t *bytes);
 #define CN_DECODE_TWO_LAUNCHES 8192
 #define CN_DECODE_PER_BAND 2048
-/* (A/B only) the one-launch form walks its (image, class) planes image by image instead of class by
- * class -- same results, the image floor finds less to prune. */
-#define CN_DECODE_IMAGE_MAJOR 32768
-/* (A/B only) class-major in blocks of eight classes: neighbouring workgroups read neighbouring planes. */
-#define CN_DECODE_BLOCK_MAJOR 131072
 
 /* _nms + _topk_channel (models/decode.py:9-15, 92-101) as one kernel: per
  * (b,c) plane the K best peaks; scores (B,C,K) desc, inds (B,C,K) int32. */

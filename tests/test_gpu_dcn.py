@@ -216,24 +216,6 @@ def test_full_size_linearity(dev):
     assert float((ym - 0.5 * y1).abs().max()) < 1e-5
 
 
-def test_lds_window_variant_matches_oracle(dev):
-    """The opt-in LDS-window kernel (cn_dcn.hip, cn_set_tuning key 11) against the oracle,
-    including offsets far beyond its window (global fallback per corner)."""
-    from centernet_amd import native
-    from centernet_amd.dcn_v2 import dcn_v2_forward
-    lib = native.lib()
-    try:
-        assert lib.cn_set_tuning(11, 1) == 0
-        for (B, Cin, H, W, Cout, std) in [(2, 64, 16, 16, 64, 2.0), (1, 128, 20, 12, 128, 6.0),
-                                          (1, 36, 9, 11, 40, 1.0)]:
-            x, off, mask, w, b = _case(B, Cin, H, W, Cout, 50 + Cin, off_std=std)
-            want = cref.dcn_v2_forward(x, off, mask, w, b)
-            y = dcn_v2_forward(*[torch.from_numpy(a).to(dev) for a in (x, off, mask, w, b)])
-            _check(y.cpu().numpy(), want)
-    finally:
-        lib.cn_set_tuning(11, 0)
-
-
 # ---- the kernel the benchmark runs: cn_dcn_v2_forward_nhwc with CN_DTYPE_F32S (NHWC input,
 # f32s-packed weight, tap split 1 / 3 / 9), entered with explicit offsets and masks
 def _dcn_f32s_nhwc(dev, x, off, mask, w, b, tap_split, out_plain, form=1, msig=False):

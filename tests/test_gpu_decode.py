@@ -301,9 +301,7 @@ def test_one_launch_form_equals_the_other_forms(dev, shape, sig):
     f, i_f = ctdet_decode(*args, K=K, apply_sigmoid=sig, return_inds=True, _debug_flags=16384)   # one launch + fill
     t, it = ctdet_decode(*args, K=K, apply_sigmoid=sig, return_inds=True, _debug_flags=8192)
     p, ip_ = ctdet_decode(*args, K=K, apply_sigmoid=sig, return_inds=True, _debug_flags=2048)
-    g, ig = ctdet_decode(*args, K=K, apply_sigmoid=sig, return_inds=True, _debug_flags=32768)   # planes image by image
-    h, ih = ctdet_decode(*args, K=K, apply_sigmoid=sig, return_inds=True, _debug_flags=131072)  # blocks of 8 classes
-    for d, i in ((f, i_f), (t, it), (p, ip_), (g, ig), (h, ih)):
+    for d, i in ((f, i_f), (t, it), (p, ip_)):
         assert torch.equal(ia, i) and torch.equal(a, d)
     if not sig:
         ref, ref_inds = cref.ctdet_decode(heat, wh, reg, K=K, return_inds=True)

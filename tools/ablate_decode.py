@@ -47,5 +47,5 @@ print("lib:", native.LIB_PATH, "heat:", kind)
 for sig in (1,):
     for st, name in ((1, "loads"), (2, "+keys"), (3, "+threshold"), (4, "+list"), (5, "+plane select / hand-on"),
                      (6, "+arrival"), (0, "everything"), (0 | 8, "everything, image-major")):
-        ms = min(run(sig | ((st & 7) << 16) | (32768 if st & 8 else 0)) for _ in range(3))
+        ms = min(run(sig | ((st & 7) << 16)) for _ in range(3))
         print("sigmoid=%d  stage %d %-26s %7.3f ms" % (sig, st, name, ms))

@@ -70,7 +70,7 @@ zws = torch.zeros(n, device=dev, dtype=torch.uint8)     # owned + zeroed once: C
 def check_forms():
     """all forms bit-identical on this map before anything is timed"""
     outs = []
-    for flags, w in ((1 | 4096, zws), (1, ws), (1 | 131072, ws), (1 | 32768, ws), (1 | 8192, ws), (1 | 2048, ws)):
+    for flags, w in ((1 | 4096, zws), (1, ws), (1 | 8192, ws), (1 | 2048, ws)):
         rc = lib.cn_ctdet_decode_f32(native.ptr(logits), native.ptr(wh), native.ptr(reg), B, C, H, W, K, 0,
                                      flags, native.ptr(dets), native.ptr(inds), native.ptr(w), n,
                                      native.stream_ptr())
@@ -85,8 +85,6 @@ check_forms()
 for name, flags, w in (("one launch, owned workspace (default product path)", 1 | 4096, zws),
                        ("one launch + state fill (any caller)", 1, ws),
                        ("one launch, post-sigmoid in", 4096, zws),
-                       ("one launch, planes image by image (flag 32768)", 1 | 32768, ws),
-                       ("one launch, blocks of 8 classes (flag 131072)", 1 | 131072, ws),
                        ("two launches (flag 8192; round-4 first form)", 1 | 8192, ws),
                        ("per-band select of round 1 (flag 2048)", 1 | 2048, ws)):
     ws_cur = w
@@ -118,8 +116,7 @@ if os.environ.get("COLD") == "1":
     big = torch.empty((1 << 30) // 4, device=dev)
     big2 = torch.empty_like(big)
     src = logits.clone()
-    for cname, cflags in (("class-major (default)", 1 | 4096), ("blocks of 8 classes", 1 | 4096 | 131072),
-                          ("image-major", 1 | 4096 | 32768)):
+    for cname, cflags in (("class-major (default)", 1 | 4096),):
         times = []
         for it in range(12):
             big2.copy_(big)
