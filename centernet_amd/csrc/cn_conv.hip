@@ -928,6 +928,11 @@ int cn_dcn_window_f32s(const float *x, const void *w_packed, const float *bias, 
                        int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
                        float x_mul, uint32_t *range, int min_wgs, int dbg, float *partial,
                        size_t partial_bytes, int *ksplit_out, hipStream_t st);
+bool cn_offconv_takes(int B, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch, int ksplit);
+int cn_offconv_f32s(const float *x, const void *w_packed, const float *scale, const float *shift, float *y,
+                    int B, int H, int W, int Cin, int Cout, int out_pitch, int relu, const cn_f32s_ctl *ctl,
+                    int ksplit, float *partial, hipStream_t st);
+extern int cn_tune_offconv, cn_tune_offconv_teams1;   // cn_offconv.hip
 int cn_dcn_team_f32s(const float *x, const void *w_packed, const float *bias, const float *om,
                      int om_pitch, const float *scale, const float *shift, void *y, int out_pitch,
                      int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
@@ -1336,6 +1341,20 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
                              d->Ho, d->Wo, d->Cin, d->Cout, d->stride, d->in_pitch, d->out_pitch,
                              d->relu, &d->ctl, st);
         if (rc != CN_ERR_UNSUPPORTED) return rc;
+    }
+    // <= 32 output channels on a plain fp32 tensor, plain output (the offset / mask convolution of the deformable
+    // modules): cn_offconv.hip, with or without the K split
+    if (f32s && (d->flags & CN_CONV_X_PLAIN) && (d->flags & CN_CONV_Y_PLAIN) && !residual && is_3x3s1(d) &&
+        d->in_layout == CN_LAYOUT_NHWC && d->out_layout == CN_LAYOUT_NHWC && a.vec_out &&
+        cn_offconv_takes(d->B, d->H, d->W, d->Cin, d->Cout, d->in_pitch, d->out_pitch, a.ksplit)) {
+        rc = cn_offconv_f32s((const float *)x, w_packed, scale, shift, (float *)y, d->B, d->H, d->W, d->Cin, d->Cout,
+                             d->out_pitch, d->relu, &d->ctl, a.ksplit, a.partial, st);
+        if (rc != CN_OK || a.ksplit == 1) return rc;
+        const size_t tot = (size_t)a.M * (a.cout_pad >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel<cn_f32s>, dim3((unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192)),
+                           dim3(256), 0, st, a);
+        CN_CHECK_LAUNCH();
+        return CN_OK;
     }
     // 3x3 / stride 1 / pad 1: the LDS-halo kernel (cn_conv3x3.hip) unless split-K applies
     const int res_pitch = d->res_pitch > 0 ? d->res_pitch : d->out_pitch;
@@ -1752,6 +1771,14 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 37 && value >= 1 && value <= 4096) {
         cn_tune_dcn_team_wgs = value;
+        return CN_OK;
+    }
+    if (key == 39 && (value == 0 || value == 1)) {
+        cn_tune_offconv = value;
+        return CN_OK;
+    }
+    if (key == 40 && value >= 0 && value <= 1000000) {
+        cn_tune_offconv_teams1 = value;
         return CN_OK;
     }
     if (key == 38 && value >= 0 && value <= 1024) {

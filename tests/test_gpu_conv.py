@@ -713,3 +713,41 @@ def test_f32s_halo_weight_forms(dev, lds_weights):
         _conv_case(dev, (16, 64, 64, 64, 192, 3, 1, 1, True, False, True, False), split=True)
     finally:
         lib.cn_set_tuning(20, 1)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-4, 3e3])
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 27, False), (1, 128, 24, 32, 27, False), (2, 512, 16, 16, 27, False),
+                                 (1, 32, 8, 16, 18, True), (3, 96, 16, 48, 32, False), (32, 128, 64, 64, 27, False)])
+def test_offset_conv_kernel(dev, cfg, scale):
+    """The `conv_offset_mask` launch of the deformable modules (DCNv2/dcn_v2.py:52-62: Conv2d(Cin, 27, 3, 1, 1)
+    on the plain fp32 tensor the sampler reads, 27 channels at pitch 32, plain output) on its own kernel
+    (csrc/cn_offconv.hip: LDS-DMA halo, split in registers, eight waves in two teams; K split on the deep
+    small map) against torch -- and against the LDS-halo kernel it replaces (cn_set_tuning key 39 = 0) --
+    at activation scales the f32s exponents must absorb; the input-side range word reports max |x'|."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder, Act, exponent_for
+    B, Cin, H, W, Cout, relu = cfg
+    x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 21)) * scale
+    w = torch.from_numpy(synth.normal((Cout, Cin, 3, 3), (2.0 / (Cin * 9)) ** 0.5, 22))
+    bias = torch.from_numpy(synth.normal((Cout,), 0.3, 23)) * scale
+    ref = F.conv2d(x.double(), w.double(), bias.double(), 1, 1)
+    if relu:
+        ref = F.relu(ref)
+    lib = native.lib()
+    outs = []
+    for key39 in (1, 0):
+        assert lib.cn_set_tuning(39, key39) == 0
+        try:
+            pb = PlanBuilder(dev, B, H, W, split=True, exps={"x": exponent_for(float(x.abs().max()))})
+            xa = Act(x.permute(0, 2, 3, 1).contiguous().to(dev), B, H, W, Cin, exp=pb._exp("x"), lid="x")
+            om = pb._new(B, H, W, Cout, pitch=32, lid="om")
+            y = pb.conv(xa, w, bias=bias, relu=relu, stride=1, padding=1, out=om, lid="om")
+            assert y.fmt == "f32"
+            _run(pb)
+        finally:
+            lib.cn_set_tuning(39, 1)
+        got = y.t[..., :Cout].permute(0, 3, 1, 2).double().cpu()
+        err = ((got - ref).abs() / (scale + ref.abs())).max()
+        assert float(err) < TOL, (key39, float(err))
+        outs.append(got)
+    assert float(((outs[0] - outs[1]).abs() / (scale + ref.abs())).max()) < TOL

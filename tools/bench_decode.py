@@ -38,6 +38,10 @@ def heat_map(kind):
 
 KIND = os.environ.get("HEAT", "iid")
 logits = heat_map(KIND).contiguous()
+# the reference-contract entry: ctdet_decode(heat) takes POST-sigmoid maps (models/decode.py:464).  (Round 4's
+# "post-sigmoid in" line passed the raw logits with the sigmoid switched off -- negative "scores", every
+# suppressed cell a zero ABOVE them: a plateau input, not a heat-map; its 0.125 / 0.487 ms were that.)
+scores = torch.sigmoid(logits).contiguous()
 print("heat map:", KIND)
 dets = torch.empty((B, K, 6), device=dev)
 inds = torch.empty((B, K), device=dev, dtype=torch.int32)
@@ -84,14 +88,17 @@ def check_forms():
 check_forms()
 for name, flags, w in (("one launch, owned workspace (default product path)", 1 | 4096, zws),
                        ("one launch + state fill (any caller)", 1, ws),
-                       ("one launch, post-sigmoid in", 4096, zws),
+                       ("one launch, post-sigmoid map in (reference contract)", 4096 | (1 << 30), zws),
                        ("two launches (flag 8192; round-4 first form)", 1 | 8192, ws),
                        ("per-band select of round 1 (flag 2048)", 1 | 2048, ws)):
     ws_cur = w
 
     def run_w(flags, iters=30, w=w):
+        src = scores if flags & (1 << 30) else logits     # (bit 30: tool-side marker, not a library flag)
+        flags &= ~(1 << 30)
+
         def call():
-            rc = lib.cn_ctdet_decode_f32(native.ptr(logits), native.ptr(wh), native.ptr(reg), B, C, H, W, K, 0,
+            rc = lib.cn_ctdet_decode_f32(native.ptr(src), native.ptr(wh), native.ptr(reg), B, C, H, W, K, 0,
                                          flags, native.ptr(dets), native.ptr(inds), native.ptr(w), n,
                                          native.stream_ptr())
             assert rc == 0, rc
