@@ -23,7 +23,10 @@ DCN_FORM_DEFAULT = 0     # cn_set_tuning key 23 as the library starts (csrc/cn_c
 
 def _check(y, ref):
     err = np.abs(y - ref) / (1 + np.abs(ref))
-    assert err.max() < TOL, err.max()
+    if not err.max() < TOL:      # say where and how many: a lost tile looks different from a rounding excursion
+        idx = np.unravel_index(np.argmax(err), err.shape)
+        raise AssertionError("max err %.3e at %s (got %r, want %r); %d of %d cells beyond the bar"
+                             % (err.max(), idx, float(y[idx]), float(ref[idx]), int((err >= TOL).sum()), err.size))
 
 
 def _case(B, Cin, H, W, Cout, seed, off_std=2.0):
