@@ -266,28 +266,17 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
     typedef float d3_f32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned d3_u32x2 __attribute__((ext_vector_type(2)));
 
-    // Weight fragments, software-pipelined one K half ahead: set A serves K half 0 of a step, set B K half 1.
-    // Each set is requested right behind the blend of the K half BEFORE its own (the corner registers
-    // are dead there), so that the ~1000 cycles a fragment takes from L2 pass under a whole MFMA block,
-    // the next window reads and the next blend (probe: requested at the top of their own K half the
-    // fragments arrived ~300 cycles after the blend was done, every K half of every wave).
-    d3_f16x8 wAh0, wAl0, wAh1, wAl1, wBh0, wBl0, wBh1, wBl1;
-    auto wptr = [&](int t, int chunk) { return wfrag + (size_t)(t * a.nchunk + chunk) * ncb * 4096; };
-    auto first_tap = [&](int chunk) { return NMODE ? 0 : ((team ^ (chunk - c_lo)) & 1); };
-    auto load_A = [&](const char *sw) {
-        wAh0 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb0 * 4096 + laneoff);
-        wAl0 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb0 * 4096 + 2048 + laneoff);
-        wAh1 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb1 * 4096 + laneoff);
-        wAl1 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb1 * 4096 + 2048 + laneoff);
-    };
-    auto load_B = [&](const char *sw) {
-        wBh0 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb0 * 4096 + 1024 + laneoff);
-        wBl0 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb0 * 4096 + 3072 + laneoff);
-        wBh1 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb1 * 4096 + 1024 + laneoff);
-        wBl1 = *reinterpret_cast<const d3_f16x8 *>(sw + (size_t)nb1 * 4096 + 3072 + laneoff);
-    };
-    load_A(wptr(first_tap(c_lo), c_lo));
     constexpr int TSTEP = NMODE ? 1 : 2;
+    // MFMA operand hazard: an LDS read issued right behind an MFMA block must not land in
+    // the A / B source registers of its (dependent, possibly still queued) MFMAs -- a rare wrong tile otherwise
+    // (one launch in a few hundred at B = 32).  The record and window reads of the NEXT K half are issued
+    // right behind this K half's block, so its operands are kept alive (an empty asm that "uses" them) until
+    // those reads have been issued: the register allocator cannot hand them out as the reads' destinations.
+    // The weight fragments (global loads: hundreds of cycles away) are requested behind that point and may
+    // take the same registers.  No instruction is added.  (Requested one K half ahead through a second
+    // register set the fragments arrived no earlier in wall time -- 0.104 vs 0.105 ms -- and the set left no
+    // room for this guard.)
+    d3_f16x8 kp0 = {}, kp1 = {}, kp2 = {}, kp3 = {}, kp4 = {}, kp5 = {};
 
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
         if (chunk != c_lo) {
@@ -299,16 +288,14 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
         }
         // byte offset, in x, of channel 8 h of this chunk in pixel 0 of the image (global path)
         const unsigned far_base = img_base * pix_bytes + (unsigned)chunk * 128u + hx;
-        const int t0 = first_tap(chunk);
+        const int t0 = NMODE ? 0 : ((team ^ (chunk - c_lo)) & 1);
 #pragma unroll 1
         for (int t = t0; t < ((dbg & 128) ? 0 : 9); t += TSTEP) {
             const cn_f32x4 wv = *reinterpret_cast<const d3_lds_f32x4 *>(lds + T_RECW + (t * T_PM + m) * 16);
             const d3_u32x2 pp = *reinterpret_cast<const __attribute__((address_space(3))) d3_u32x2 *>(lds + T_RECP + (t * T_PM + m) * 8);
-            // fragment copy of this (tap, chunk) and of the K half that follows this step (uniform bases)
-            const char *sw = wptr(t, chunk);
-            const bool last_tap = t + TSTEP >= 9;
-            const int cn = last_tap ? min(chunk + 1, c_hi - 1) : chunk;
-            const char *sn = wptr(last_tap ? first_tap(cn) : t + TSTEP, cn);
+            // fragment copy of this (tap, chunk): uniform base, lane offset; quarter kk at + 1 KiB kk
+            const char *sw = wfrag + (size_t)(t * a.nchunk + chunk) * ncb * 4096;
+            const char *g0 = sw + (size_t)nb0 * 4096, *g1 = sw + (size_t)nb1 * 4096;
             const d3_f32x2 w1 = {wv[0], wv[0]}, w2 = {wv[1], wv[1]}, w3 = {wv[2], wv[2]}, w4 = {wv[3], wv[3]};
             const unsigned A1 = (pp[0] & 0xffffu) ^ hx, A2 = (pp[0] >> 16) ^ hx;
             const bool far = (int)pp[1] < 0;
@@ -338,6 +325,16 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
                 cn_f32x4 c3b = *reinterpret_cast<const d3_lds_f32x4 *>(lds + (B1 ^ 16u) + T_ROWB);
                 cn_f32x4 c4a = *reinterpret_cast<const d3_lds_f32x4 *>(lds + B2 + T_ROWB);
                 cn_f32x4 c4b = *reinterpret_cast<const d3_lds_f32x4 *>(lds + (B2 ^ 16u) + T_ROWB);
+                // the previous MFMA block's operands: alive until the reads above (and, through the loop,
+                // the record reads of the step) have been issued
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" :: "v"(kp0), "v"(kp1), "v"(kp2), "v"(kp3), "v"(kp4), "v"(kp5));
+                __builtin_amdgcn_sched_barrier(0);
+                // weights of this (tap, chunk, K half): the MFMA's A operand, straight from the fragment copy
+                const d3_f16x8 wh0 = *reinterpret_cast<const d3_f16x8 *>(g0 + kk * 1024 + laneoff);
+                const d3_f16x8 wl0 = *reinterpret_cast<const d3_f16x8 *>(g0 + (2 + kk) * 1024 + laneoff);
+                const d3_f16x8 wh1 = *reinterpret_cast<const d3_f16x8 *>(g1 + kk * 1024 + laneoff);
+                const d3_f16x8 wl1 = *reinterpret_cast<const d3_f16x8 *>(g1 + (2 + kk) * 1024 + laneoff);
                 if (far) {
                     const d3_glb_char *g = xg + 64u * kk;
                     c1a = *reinterpret_cast<const d3_glb_f32x4 *>(g + o1);
@@ -377,17 +374,11 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
                 }
                 const d3_f16x8 shi = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
                 const d3_f16x8 slo = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
-                // the operands of the K half after this one: requested here, the corner registers are dead
-                __builtin_amdgcn_sched_barrier(0);
-                if (kk == 0) load_B(sw); else load_A(sn);
                 if (dbg & 8) {
-                    acc[0][0] += (float)shi[0] + (float)slo[0] + (float)wAh0[0] + (float)wBl1[0];
+                    acc[0][0] += (float)shi[0] + (float)slo[0] + (float)wh0[0] + (float)wl0[0] + (float)wh1[0] + (float)wl1[0];
                     continue;
                 }
                 // every operand is in registers before the first MFMA issues (operand hazard note, cn_conv.hip)
-                __builtin_amdgcn_sched_barrier(0);
-                const d3_f16x8 wh0 = kk ? wBh0 : wAh0, wl0 = kk ? wBl0 : wAl0, wh1 = kk ? wBh1 : wAh1, wl1 = kk ? wBl1 : wAl1;
-                asm volatile("" :: "v"(wh0), "v"(wl0), "v"(wh1), "v"(wl1));    // (this set has landed: waited for here)
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl0, shi, acc[0], 0, 0, 0);
@@ -397,6 +388,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, shi, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, shi, acc[1], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
+                kp0 = wh0; kp1 = wl0; kp2 = wh1; kp3 = wl1; kp4 = shi; kp5 = slo;
             }
         }
     }

@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256 * TEAMS, 4) void offconv_kernel(const OcArgs a)
         constexpr int TS = TEAMS;                   // tap stride of a wave
         const int t0 = TEAMS == 2 ? ((team ^ (chunk - c_lo)) & 1) : 0;
         oc_f16x8 wq[2][4];
+        // (MFMA operand hazard, DESIGN.md 3.0: the halo reads of the next K half are issued right behind this K
+        // half's MFMAs and must not land in their source registers -- the operands are kept alive until then)
+        oc_f16x8 keep_a = {}, keep_b = {}, keep_c = {}, keep_d = {};
         if (chunk != c_lo) __syncthreads();            // every wave is done with the previous halo
         dma(chunk);
         load_w(wq[0], t0, chunk);
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256 * TEAMS, 4) void offconv_kernel(const OcArgs a)
                     const unsigned ad = a0 ^ ((unsigned)kk << 6);
                     cn_f32x4 va = *reinterpret_cast<const oc_lds_f32x4 *>(lds + ad);
                     cn_f32x4 vb = *reinterpret_cast<const oc_lds_f32x4 *>(lds + (ad ^ 16u));
+                    asm volatile("" :: "v"(keep_a), "v"(keep_b), "v"(keep_c), "v"(keep_d));
                     va = va * xm;                          // plain input -> stored units (a power of two)
                     vb = vb * xm;
                     cn_f16x4v ha, la, hb, lb;
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(256 * TEAMS, 4) void offconv_kernel(const OcArgs a)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xhi, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xlo, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xhi, acc, 0, 0, 0);
+                    keep_a = wh; keep_b = wl; keep_c = xhi; keep_d = xlo;
                 }
             }
         }
