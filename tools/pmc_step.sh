@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_step
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --config $CFG --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-leg"
+BENCH="python $R/bench.py --config $CFG --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-leg --no-secondary"
 pass() {
   name=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- $BENCH > $OUT/$name.log 2>&1 || echo "pass $name failed" >> $OUT/fail.log
