@@ -94,9 +94,9 @@ def pmc_traffic(tag):
         base, targs = short(k)
         if base == "igemm_kernel":
             c = "dcn" if len(targs) > 4 and targs[4] in (2, 3) else "conv"   # AMODE
-        elif base.startswith(("dcn_reg_kernel", "dcn_win_kernel")):   # LDS-window forms (cn_dcn2.hip)
+        elif base.startswith(("dcn_reg_kernel", "dcn_win_kernel", "dcn_team_kernel")):   # LDS-window forms (cn_dcn2 / cn_dcn3.hip)
             c = "dcn"
-        elif base.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_")):
+        elif base.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_", "offconv_kernel")):
             c = "conv"
         elif base.startswith(("nms_topk", "merge_topk", "peak_", "group_", "pose_match", "decode_", "collect_merge",
                               "plane_select_merge")):
@@ -183,7 +183,7 @@ def parse(argv=None):
     p.add_argument("--per-op", action="store_true", help="print per-launch timings to stderr")
     p.add_argument("--no-secondary", action="store_true",
                    help="skip the short runs of BASELINE configs[2..4] behind the headline loop")
-    p.add_argument("--secondary-steps", type=int, default=10)
+    p.add_argument("--secondary-steps", type=int, default=20)
     a = p.parse_args(argv)
     cfg = CONFIGS[a.config]
     for k, v in cfg.items():
@@ -393,7 +393,7 @@ def secondary_config(cfg_id, res, steps, dev):
         det.model.half_compute()
     B = c["batch"]
     images = synth.images(B, res, res, seed=100).to(dev)
-    for _ in range(3):
+    for _ in range(10):      # (a fresh detector's first steps carry plan building, workspace growth and lazy code loads)
         det.run_batch(images)
     torch.cuda.synchronize()
     if not c["fp16"]:
