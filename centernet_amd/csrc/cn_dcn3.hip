@@ -60,7 +60,8 @@ constexpr int T_RECP = T_RECW + 9 * T_PM * 16; // uint2 [9][128]: swizzled LDS o
 constexpr int T_LDS_MAIN = T_RECP + 9 * T_PM * 8;          // 76800
 constexpr int T_LDC = 68;                      // floats per staged pixel row (64 + 4)
 constexpr int T_STG = 32 * T_LDC * 4;          // 8704 bytes per wave
-constexpr int T_LDS = T_LDS_MAIN > 8 * T_STG ? T_LDS_MAIN : 8 * T_STG;
+constexpr int T_EPI = T_LDS_MAIN;              // float [3][128]: bias, scale, shift of the workgroup's output channels
+constexpr int T_LDS = T_EPI + 3 * 128 * 4;     // 78336 (the epilogue strips, 8 x 8704 = 69632, alias the window and the records)
 static_assert(2 * T_LDS <= 163840, "two workgroups per CU");
 static_assert(T_ROWB % 256 == 0, "window rows keep the bank-group phase");
 
@@ -209,7 +210,17 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
             off_w[p] = om[2 * tap + 1];
             mkv[p] = om[18 + tap];
         }
+        // bias / scale / shift of this workgroup's output channels: requested here, parked in LDS for the
+        // epilogue (loaded there, twelve dependent L2 round trips sat between the last MFMA and the first store)
+        float epv = 0.f;
+        if (tid < 384) {
+            const int which = tid >> 7, cn = (NMODE ? (int)blockIdx.y * 128 : (int)blockIdx.y * 64) + (tid & 127);
+            const float *src = which == 0 ? a.bias : (which == 1 ? a.scale : a.shift);
+            epv = which == 1 ? 1.f : 0.f;
+            if (src && cn < a.Cout) epv = src[cn];
+        }
         dma(c_lo);
+        if (tid < 384) reinterpret_cast<float *>(smem + T_EPI)[tid] = epv;
 #pragma unroll
         for (int p = 0; p < NR; ++p) {
             const int i = p * T_NT + tid;
@@ -410,14 +421,10 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
     __syncthreads();
     const int cq = lane & 15, rr = lane >> 4;     // 16 lanes per pixel row, four rows per pass
     const int n = n0 + cq * 4;
-    float bs[4], sc[4], sf2[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const bool ok = (n + e) < a.Cout;
-        bs[e] = (a.bias && ok) ? a.bias[n + e] : 0.f;
-        sc[e] = (a.scale && ok) ? a.scale[n + e] : 1.f;
-        sf2[e] = (a.shift && ok) ? a.shift[n + e] : 0.f;
-    }
+    const float *epl = reinterpret_cast<const float *>(smem + T_EPI) + (NMODE ? 64 * team : 0) + cq * 4;
+    const cn_f32x4 bs = *reinterpret_cast<const cn_f32x4 *>(epl);
+    const cn_f32x4 sc = *reinterpret_cast<const cn_f32x4 *>(epl + 128);
+    const cn_f32x4 sf2 = *reinterpret_cast<const cn_f32x4 *>(epl + 256);
     constexpr int PASSES = NMODE ? 8 : 4;
     const float *C0 = reinterpret_cast<const float *>(smem + (NMODE ? wave : pb) * T_STG);
     const float *C1 = reinterpret_cast<const float *>(smem + (pb + 4) * T_STG);
