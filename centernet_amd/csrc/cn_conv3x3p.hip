@@ -39,9 +39,10 @@
 #include <type_traits>
 
 int cn_tune_c3p = 1;        // cn_set_tuning key 28: 0 = off, 1 = on for the shapes it takes
-int cn_tune_c3p_stagger = 64; // cn_set_tuning key 29: start delay of the second resident workgroup, in units of 256 cycles
+int cn_tune_c3p_stagger = 0;  // cn_set_tuning key 29: start delay of the second resident workgroup, in units of 256 cycles
+                              // (64 was worth 1-2 % with the unpipelined schedule; with the pipelined one 0 is: r05_c3p_pipe.txt)
                               // (measured 0 ... 96: 48-64 is best on every trunk shape, +6 ... +13 % over none)
-int cn_tune_c3p_knobs = 0;    // cn_set_tuning key 30 (A/B): see P3Args.knobs
+int cn_tune_c3p_knobs = 2;    // cn_set_tuning key 30 (A/B): see P3Args.knobs
 int cn_tune_c3p_heads = 1;    // cn_set_tuning key 31: the fused heads (hidden width 64) on this kernel; 0 = halo kernel
 int cn_tune_c3p_deconv = 1;   // cn_set_tuning key 32: ConvTranspose2d(4, 2, 1) in parity form on this kernel; 0 = halo kernel
 int cn_tune_c3p_s2 = 1;       // cn_set_tuning key 33: 3x3 / stride 2 / pad 1 in parity-plane form on this kernel; 0 = implicit GEMM
@@ -96,6 +97,7 @@ struct P3Args {
     uint32_t *range;
     int stagger;
     int knobs;                // A/B switches (cn_set_tuning key 30): 1 = no s_setprio 1 around the consumers' MFMA block
+                              // (unpipelined forms), 2 = the pipelined fragment schedule (template PIPE)
                               // (with the loaders at priority 3 the raised priority measured 3-5 % faster)
     // instrumented instantiation only (DBG = true; cn_conv3x3p_probe): ablation switches and cycle counters
     int dbg;                  // 1: no MFMAs, 2: no fragment reads (and no MFMAs), 4: no weight DMA, 8: no halo DMA,
@@ -114,6 +116,11 @@ __device__ __forceinline__ void p3_barrier()
 // 155-177): output block nb of an item = head nb; its 64 hidden channels never leave the registers
 // of the consumer waves and go straight into the head's 1x1 convolution.
 constexpr int P_MAXH = 8;
+// pipelined fragment schedule (template PIPE): MFMAs of a six-MFMA block in front of the next block's reads
+#ifndef P3_SPLIT
+#define P3_SPLIT 4
+#endif
+static_assert(P3_SPLIT >= 4, "the front part of a block must reference all six fragments (see the fence in front of the barrier)");
 struct P3Heads {
     const char *wf[P_MAXH];       // 1x1 matrix as MFMA-ready (high, low) fragments (cn_pack_head_w2_f32s)
     const float *bias[P_MAXH];    // (cout) or null
@@ -155,9 +162,10 @@ __device__ constexpr int p3_s2_tap(int i)     // weight matrix (ky * 3 + kx) of 
     return i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 6 : i == 3 ? 8 : i == 4 ? 3 : i == 5 ? 5 : i == 6 ? 1 : i == 7 ? 7 : 4;
 }
 
-template <int RES, bool OUT_PLAIN, bool DBG = false, bool HEADS = false, int NTAP = 9, bool S2 = false>
+template <int RES, bool OUT_PLAIN, bool DBG = false, bool HEADS = false, int NTAP = 9, bool S2 = false, bool PIPE = false>
 __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const P3Heads hd)
 {
+    static_assert(!PIPE || !DBG, "pipelined fragment schedule: not in the instrumented instantiation");
     static_assert(!S2 || (NTAP == 9 && RES == 0 && !DBG && !HEADS), "stride 2: nine taps, no residual");
     // residual rows requested this many steps before an item's last step ends (0 .. 3 measured with
     // interleaved medians at B = 32: no difference on any trunk shape, so the shortest live range)
@@ -627,6 +635,141 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
             g += 9;
             ++sidx;
         };
+        if constexpr (PIPE) {
+            // pipelined fragment schedule (see the plain consumers below): two sets of six fragments, the
+            // next block's reads behind the fourth MFMA of the current one, the barrier of step t + 1 in
+            // the middle of block (t, 1); nothing carried across an item boundary
+            struct HFrag { p3_f16x8 wh[2], wl[2], xh, xl; };
+            HFrag F0, F1;
+            auto hload = [&](auto T, auto KH, int hb, int wb, HFrag &F) {
+                constexpr int t = decltype(T)::value, kh = decltype(KH)::value;
+                constexpr int ky = t / 3, kx = t % 3;
+                constexpr int tapoff = (ky * P_HW + kx) * 128;
+                constexpr int blk1 = 32 * 128;
+                int ax = arow + ((aswz >> (8 * kx)) & 0xff), bx = b0;
+                asm volatile("" : "+v"(ax), "+v"(bx));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) F.wh[j] = lds128(wb + j * blk1 + (bx ^ (kh << 5)));
+                F.xl = lds128(hb + tapoff + (ax ^ ((kh << 5) | 64)));
+                F.xh = lds128(hb + tapoff + (ax ^ (kh << 5)));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) F.wl[j] = lds128(wb + j * blk1 + (bx ^ ((kh << 5) | 64)));
+            };
+            auto hfront = [&](const HFrag &F) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wh[j], F.xl, acc[j], 0, 0, 0);
+                if constexpr (P3_SPLIT >= 4) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wl[j], F.xh, acc[j], 0, 0, 0);
+                }
+                if constexpr (P3_SPLIT >= 6) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wh[j], F.xh, acc[j], 0, 0, 0);
+                }
+            };
+            auto hback = [&](const HFrag &F) {
+                if constexpr (P3_SPLIT < 4) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wl[j], F.xh, acc[j], 0, 0, 0);
+                }
+                if constexpr (P3_SPLIT < 6) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wh[j], F.xh, acc[j], 0, 0, 0);
+                }
+            };
+            auto hkeep = [&](const HFrag &F) {
+                asm volatile("" :: "v"(F.wh[0]), "v"(F.wh[1]), "v"(F.wl[0]), "v"(F.wl[1]), "v"(F.xh), "v"(F.xl));
+            };
+            auto pstage = [&](auto LAST, int c, const P3Item &cur) {
+                constexpr bool last = decltype(LAST)::value;
+                const int hb = (sidx & 1) * P_HBYTES, hb1 = ((sidx + 1) & 1) * P_HBYTES;
+                auto WB = [&](int i) { return P_WOFF + ((g + i) & 3) * P_WSLOT; };
+                float sv = 1.f, hv = 0.f, ov[2] = {1.f, 1.f}, bv[2] = {0.f, 0.f};
+                if (c == 0) {
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    const unsigned o = (unsigned)(64 * cur.nb + ln) * 4u;
+                    if (a.scale) sv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.scale) + o);
+                    if (a.shift) hv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.shift) + o);
+                    const float *os2 = hd.oscale[cur.nb], *b2 = hd.bias[cur.nb];
+                    const int cout2 = hd.cout[cur.nb];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int co = ln + 64 * u;
+                        if (co < cout2) {
+                            if (os2) ov[u] = os2[co];
+                            if (b2) bv[u] = b2[co];
+                        }
+                    }
+                }
+                auto pstep = [&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+                    hfront(F0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    hload(T, P3_IC(1), hb, WB(t), F1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    hkeep(F0);
+                    hback(F0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    hfront(F1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(0);
+                    p3_lds_fence();              // (every read of tile t complete before its slot is handed back)
+                    p3_barrier();
+                    if constexpr (t + 1 < 9) hload(P3_IC(t + 1), P3_IC(0), hb, WB(t + 1), F0);
+                    else if constexpr (!last) hload(P3_IC(0), P3_IC(0), hb1, WB(9), F0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    hkeep(F1);
+                    hback(F1);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                pstep(P3_IC(0));
+                pstep(P3_IC(1));
+                pstep(P3_IC(2));
+                if (c == 0) {
+                    *reinterpret_cast<float *>(smem + P_SSOFF + lane * 4) = sv;
+                    *reinterpret_cast<float *>(smem + P_SSOFF + 256 + lane * 4) = hv;
+                    *reinterpret_cast<float *>(smem + P_SSOFF + 512 + lane * 4) = ov[0];
+                    *reinterpret_cast<float *>(smem + P_SSOFF + 896 + lane * 4) = bv[0];
+                    if (lane < 32) {
+                        *reinterpret_cast<float *>(smem + P_SSOFF + 512 + (64 + lane) * 4) = ov[1];
+                        *reinterpret_cast<float *>(smem + P_SSOFF + 896 + (64 + lane) * 4) = bv[1];
+                    }
+                }
+                pstep(P3_IC(3));
+                pstep(P3_IC(4));
+                pstep(P3_IC(5));
+                pstep(P3_IC(6));
+                if constexpr (last) {
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_w2(wfa, hd.wf[cur.nb], 0, 0, ln);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                pstep(P3_IC(7));
+                pstep(P3_IC(8));
+                g += 9;
+                ++sidx;
+            };
+            p3_barrier();                        // barrier 0 of the first stage
+            for (int k = 0; k < nit; ++k) {
+                const P3Item cur = p3_decode(a, first + k * nx);
+                __builtin_amdgcn_sched_barrier(0);
+                hload(P3_IC(0), P3_IC(0), (sidx & 1) * P_HBYTES, P_WOFF + (g & 3) * P_WSLOT, F0);
+                __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < a.nchunk - 1; ++c) pstage(std::false_type{}, c, cur);
+                pstage(std::true_type{}, a.nchunk - 1, cur);
+                // (behind barrier 0 of the next item: the stash is rewritten behind its barrier 3 at the
+                // earliest, which no wave passes before every wave has left this epilogue)
+                if (a.nchunk == 1) p3_lds_fence();
+                epilogue(cur);
+                zero_acc();
+                lane_consts();
+            }
+        } else {
         for (int k = 0; k < nit; ++k) {
             const P3Item cur = p3_decode(a, first + k * nx);
             for (int c = 0; c < a.nchunk - 1; ++c) stage(std::false_type{}, c, cur);
@@ -639,6 +782,7 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
             lane_consts();
         }
         p3_barrier();
+        }
 #undef P3_IC
         if (a.range) cn_rng_commit(a.range, 0, rng_out);
         return;
@@ -864,6 +1008,143 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
         if (DBG) pf_bar += now() - c0;
     };
 #define P3_IC(v) std::integral_constant<int, (v)>{}
+    if constexpr (PIPE) {
+        // ---- pipelined fragment schedule.  A step is two blocks of six MFMAs (K halves 0 and 1), each on
+        // its own set of six fragments.  The reads of the NEXT block go out in the middle of the current
+        // one -- behind its fourth MFMA, into the set of the block BEFORE it (whose MFMAs have all left
+        // the queue by then: the operand hazard of DESIGN 3.0 wants four MFMAs between a set's last use
+        // and its refill) -- so the matrix pipe has work queued while fragments are in flight, and the
+        // wave reaches a barrier with four MFMAs still to run.  The barrier of step t + 1 sits in the
+        // middle of block (t, 1), in front of the reads of (t + 1, 0): the loaders' protocol (tile t + 1
+        // and the stage's halo landed before it; every read of tile t - 1 complete before it) is the
+        // unpipelined one.  Nothing is carried across an item boundary (the epilogue wants the registers).
+        struct Frag { p3_f16x8 wh, wl, xh[2], xl[2]; };
+        Frag F0, F1;
+        auto load_half = [&](auto T, auto KH, int hb, int wb, Frag &F) {
+            constexpr int t = decltype(T)::value, kh = decltype(KH)::value;
+            const int ky = S2 ? p3_s2_oy(t) : (DECONV ? t / 2 + par_y : t / 3);
+            const int kx = S2 ? p3_s2_ox(t) : (DECONV ? t % 2 + par_x : t % 3);
+            const int tapoff = (ky * P_HW + kx) * 128;
+            int ax = arow + ((aswz >> (8 * kx)) & 0xff) + (DECONV ? tapoff : 0), bx = b0;
+            asm volatile("" : "+v"(ax), "+v"(bx));
+            const int tapimm = DECONV ? 0 : tapoff;
+            constexpr int blk1 = 2 * P_HW * 128;
+            F.wh = lds128(wb + (bx ^ (kh << 5)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) F.xl[i] = lds128(hb + tapimm + i * blk1 + (ax ^ ((kh << 5) | 64)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) F.xh[i] = lds128(hb + tapimm + i * blk1 + (ax ^ (kh << 5)));
+            F.wl = lds128(wb + (bx ^ ((kh << 5) | 64)));
+        };
+        // (same order of the products as the unpipelined step: smallest terms first)
+        auto mfma_front = [&](const Frag &F) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wh, F.xl[i], acc[i], 0, 0, 0);
+            if constexpr (P3_SPLIT >= 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wl, F.xh[i], acc[i], 0, 0, 0);
+            }
+            if constexpr (P3_SPLIT >= 6) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wh, F.xh[i], acc[i], 0, 0, 0);
+            }
+        };
+        auto mfma_back = [&](const Frag &F) {
+            if constexpr (P3_SPLIT < 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wl, F.xh[i], acc[i], 0, 0, 0);
+            }
+            if constexpr (P3_SPLIT < 6) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.wh, F.xh[i], acc[i], 0, 0, 0);
+            }
+        };
+        auto keep = [&](const Frag &F) {
+            asm volatile("" :: "v"(F.wh), "v"(F.wl), "v"(F.xh[0]), "v"(F.xh[1]), "v"(F.xl[0]), "v"(F.xl[1]));
+        };
+        bar();                                   // barrier 0 of stage 0
+        int s = 0;                               // stage counter of the workgroup (halo buffer parity)
+        for (k = 0; k < nit; ++k) {              // an item is entered behind barrier 0 of its first stage
+            cur = p3_decode(a, first + k * nx);
+            par_y = cur.par >> 1; par_x = cur.par & 1;
+            // this lane's scale (lanes 0-31) or shift (32-63) value of the wave's 32 channels: requested
+            // here, parked in the wave's LDS stash three steps later
+            float ssv;
+            {
+                const int grp = 2 * cur.nb + wn;
+                const int ln = opaque_lane();
+                const unsigned o = (unsigned)(32 * grp + (ln & 31)) * 4u;
+                float sv = 1.f, hv = 0.f;
+                if (grp < a.ngroups) {
+                    sv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.scale) + o);
+                    if (a.shift) hv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.shift) + o);
+                }
+                ssv = (ln >> 5) ? hv : sv;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(P3_IC(0), P3_IC(0), S2 ? 0 : (s & 1) * P_HBYTES, P_WOFF + (g & 3) * P_WSLOT, F0);
+            __builtin_amdgcn_sched_barrier(0);
+            for (c = 0; c < a.nchunk; ++c, ++s) {
+                const int hb0 = (s & 1) * P_HBYTES, hb1 = ((s + 1) & 1) * P_HBYTES;
+                auto HB = [&](int i) { return S2 ? p3_s2_buf(i) * P_HBYTES : hb0; };
+                auto WB = [&](int i) { return P_WOFF + ((g + i) & 3) * P_WSLOT; };
+                const bool more = (c + 1 < a.nchunk);     // another stage of this item follows
+                auto pstep = [&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+                    mfma_front(F0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_half(T, P3_IC(1), HB(t), WB(t), F1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    keep(F0);
+                    mfma_back(F0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_front(F1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(0);
+                    // every fragment read of tile t is complete before its slot is handed back (the front
+                    // MFMAs reference all six fragments, so this wait is already behind us: it is here to
+                    // say so -- a front part that left fragments to the back part, P3_SPLIT = 2, was measured
+                    // losing words of tile t to the DMA of tile t + 4 on the layers with the hottest weights)
+                    p3_lds_fence();
+                    p3_barrier();                // barrier t + 1 (t = NTAP - 1: barrier 0 of the next stage)
+                    if constexpr (t + 1 < NTAP) {
+                        load_half(P3_IC(t + 1), P3_IC(0), HB(t + 1), WB(t + 1), F0);
+                    } else {
+                        if (more) load_half(P3_IC(0), P3_IC(0), S2 ? 0 : hb1, WB(NTAP), F0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    keep(F1);
+                    mfma_back(F1);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                pstep(P3_IC(0));
+                pstep(P3_IC(1));
+                pstep(P3_IC(2));
+                if (c == 0) *reinterpret_cast<float *>(smem + P_SSOFF + wave * 256 + lane * 4) = ssv;
+                pstep(P3_IC(3));
+                if constexpr (!DECONV) {
+                    pstep(P3_IC(4));
+                    pstep(P3_IC(5));
+                    pstep(P3_IC(6));
+                    pstep(P3_IC(7));
+                    pstep(P3_IC(8));
+                }
+                g += NTAP;
+            }
+            // behind barrier 0 of the next item's first stage (or the last barrier of all): the item's
+            // last stage used buffer (s - 1) & 1, dead until the loader refills it behind the next barrier
+            if constexpr (RES != 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_residual(cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            epilogue(cur, S2 ? P_HBYTES : ((s - 1) & 1) * P_HBYTES);
+            zero_acc();
+            lane_consts();
+        }
+    } else
     for (int s = 0;; ++s) {
         bar();
         if (s > 0 && c == 0) {
@@ -1006,13 +1287,17 @@ int cn_deconv4x4s2_persist(const void *x, const void *w_packed, const float *sca
     int per_xcd = cn_cdiv(a.items, 8);
     if (per_xcd > 64) per_xcd = 64;
     const dim3 grid(8 * per_xcd), block(384);
-    if (out_plain) {
-        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, true, false, false, 4>), P_LDS);
-        hipLaunchKernelGGL((conv3x3p_kernel<0, true, false, false, 4>), grid, block, P_LDS, st, a, P3Heads{});
+#define P3_LAUNCH4(OP, PIPE)                                                                                     \
+    do {                                                                                                         \
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, OP, false, false, 4, false, PIPE>), P_LDS);                       \
+        hipLaunchKernelGGL((conv3x3p_kernel<0, OP, false, false, 4, false, PIPE>), grid, block, P_LDS, st, a, P3Heads{}); \
+    } while (0)
+    if (a.knobs & 2) {
+        if (out_plain) P3_LAUNCH4(true, true); else P3_LAUNCH4(false, true);
     } else {
-        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, false, false, 4>), P_LDS);
-        hipLaunchKernelGGL((conv3x3p_kernel<0, false, false, false, 4>), grid, block, P_LDS, st, a, P3Heads{});
+        if (out_plain) P3_LAUNCH4(true, false); else P3_LAUNCH4(false, false);
     }
+#undef P3_LAUNCH4
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -1060,13 +1345,17 @@ int cn_conv3x3s2_persist(const void *x, const void *w_packed, const float *scale
     int per_xcd = cn_cdiv(a.items, 8);
     if (per_xcd > 64) per_xcd = 64;
     const dim3 grid(8 * per_xcd), block(384);
-    if (out_plain) {
-        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, true, false, false, 9, true>), P_LDS);
-        hipLaunchKernelGGL((conv3x3p_kernel<0, true, false, false, 9, true>), grid, block, P_LDS, st, a, P3Heads{});
+#define P3_LAUNCHS2(OP, PIPE)                                                                                    \
+    do {                                                                                                         \
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, OP, false, false, 9, true, PIPE>), P_LDS);                        \
+        hipLaunchKernelGGL((conv3x3p_kernel<0, OP, false, false, 9, true, PIPE>), grid, block, P_LDS, st, a, P3Heads{}); \
+    } while (0)
+    if (a.knobs & 2) {
+        if (out_plain) P3_LAUNCHS2(true, true); else P3_LAUNCHS2(false, true);
     } else {
-        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, false, false, 9, true>), P_LDS);
-        hipLaunchKernelGGL((conv3x3p_kernel<0, false, false, false, 9, true>), grid, block, P_LDS, st, a, P3Heads{});
+        if (out_plain) P3_LAUNCHS2(true, false); else P3_LAUNCHS2(false, false);
     }
+#undef P3_LAUNCHS2
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -1132,10 +1421,14 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
     int per_xcd = cn_cdiv(a.items, 8);
     if (per_xcd > 64) per_xcd = 64;
     const dim3 grid(8 * per_xcd), block(384);
-#define P3_LAUNCH(R, OP)                                                                   \
-    do {                                                                                   \
-        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<R, OP>), P_LDS);                               \
-        hipLaunchKernelGGL((conv3x3p_kernel<R, OP>), grid, block, P_LDS, st, a, P3Heads{}); \
+#define P3_LAUNCH_(R, OP, PIPE)                                                                                  \
+    do {                                                                                                         \
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<R, OP, false, false, 9, false, PIPE>), P_LDS);                       \
+        hipLaunchKernelGGL((conv3x3p_kernel<R, OP, false, false, 9, false, PIPE>), grid, block, P_LDS, st, a, P3Heads{}); \
+    } while (0)
+#define P3_LAUNCH(R, OP)                                                    \
+    do {                                                                    \
+        if (a.knobs & 2) P3_LAUNCH_(R, OP, true); else P3_LAUNCH_(R, OP, false); \
     } while (0)
     const int rmode = !residual ? 0 : (res_plain ? 2 : 1);
     if ((p3_probe_dbg || p3_probe_prof) && !out_plain && rmode < 2) {
@@ -1157,6 +1450,7 @@ int cn_conv3x3s1_persist(const void *x, const void *w_packed, const float *scale
         if (rmode == 0) P3_LAUNCH(0, false); else if (rmode == 1) P3_LAUNCH(1, false); else P3_LAUNCH(2, false);
     }
 #undef P3_LAUNCH
+#undef P3_LAUNCH_
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -1210,8 +1504,13 @@ int cn_heads3x3p(const void *x, int B, int H, int W, int Cin, int in_pitch, cons
     int per_xcd = cn_cdiv(a.items, 8);
     if (per_xcd > 64) per_xcd = 64;
     const dim3 grid(8 * per_xcd), block(384);
-    CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, false, true>), P_LDS);
-    hipLaunchKernelGGL((conv3x3p_kernel<0, false, false, true>), grid, block, P_LDS, st, a, hd);
+    if (a.knobs & 2) {
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, false, true, 9, false, true>), P_LDS);
+        hipLaunchKernelGGL((conv3x3p_kernel<0, false, false, true, 9, false, true>), grid, block, P_LDS, st, a, hd);
+    } else {
+        CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, false, false, true>), P_LDS);
+        hipLaunchKernelGGL((conv3x3p_kernel<0, false, false, true>), grid, block, P_LDS, st, a, hd);
+    }
     CN_CHECK_LAUNCH();
     return CN_OK;
 }

@@ -392,6 +392,63 @@ def test_conv3x3_stride2_on_the_persistent_kernel(dev, cfg):
         lib.cn_set_tuning(33, 1)
 
 
+@pytest.mark.parametrize("form", ["conv", "conv_res", "conv_plain_res", "deconv", "s2", "heads"])
+def test_persistent_kernel_pipelined_schedule_is_bit_identical(dev, form):
+    """The pipelined fragment schedule of the persistent kernel (cn_conv3x3p.hip, template PIPE: key 30
+    bit 2, the default) sums every output in the order of the unpipelined one: the raw output tensors
+    are BIT-identical, launch after launch, in every form -- 3x3 / s1 without / with an f32s residual,
+    plain output with a residual, the transposed convolution, stride 2, the fused heads -- on forced
+    small shapes with edge tiles and at the benchmark batch (where two workgroups share a CU and a
+    fragment lost to an early DMA refill or a late LDS read would show as a rare differing tile)."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder
+    lib = native.lib()
+    shapes = {"conv": [(2, 96, 20, 24, 96), (32, 64, 128, 128, 64), (32, 256, 32, 32, 256)],
+              "conv_res": [(3, 64, 17, 40, 64), (32, 64, 128, 128, 64), (32, 512, 16, 16, 512)],
+              "conv_plain_res": [(2, 128, 16, 32, 128), (32, 128, 64, 64, 128)],
+              "deconv": [(2, 128, 37, 45, 96), (32, 128, 64, 64, 64)],
+              "s2": [(1, 96, 17, 23, 96), (32, 64, 128, 128, 128)],
+              "heads": [(1, 64, 20, 24, 0), (32, 64, 128, 128, 0)]}[form]
+    try:
+        for (B, Cin, H, W, Cout) in shapes:
+            assert lib.cn_set_tuning(28, 2 if B < 32 else 1) == 0
+            x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 1)).relu_()
+            xa = _nhwc_act(x, dev)
+            res = _nhwc_act(torch.from_numpy(synth.normal((B, Cout, H, W), 1.0, 5)), dev) if "res" in form else None
+            pairs = _heads_case(Cin, 64, {"hm": 80, "wh": 2, "reg": 2}, seed=B) if form == "heads" else None
+            raws = {}
+            for knobs in (0, 2):
+                assert lib.cn_set_tuning(30, knobs) == 0
+                pb = PlanBuilder(dev, B, H, W, split=True)
+                xin = pb.packed(xa)
+                if form == "heads":
+                    outs = pb.heads_from_convs(xin, pairs)
+                    ts = [outs[n].t for n in ("hm", "wh", "reg")]
+                elif form == "deconv":
+                    w = torch.from_numpy(synth.normal((Cin, Cout, 4, 4), (2.0 / (Cin * 4)) ** 0.5, 2))
+                    ts = [pb.conv_transpose4x4s2(xin, w, bn=_bn(Cout, 3), relu=True).t]
+                else:
+                    w = torch.from_numpy(synth.normal((Cout, Cin, 3, 3), (2.0 / (Cin * 9)) ** 0.5, 2))
+                    r = None
+                    if res is not None:
+                        r = pb.packed(res) if form == "conv_res" else pb.plain(res)
+                    ts = [pb.conv(xin, w, bn=_bn(Cout, 3), relu=True, stride=2 if form == "s2" else 1, padding=1,
+                                  residual=r, out_plain=(form == "conv_plain_res")).t]
+                reps = 6 if B == 32 else 2
+                for rep in range(reps):
+                    for t in ts:
+                        t.zero_()
+                    _run(pb)
+                    if knobs == 0 and rep == 0:
+                        raws = [t.clone() for t in ts]
+                        assert all(float(t.abs().max()) > 0 for t in raws)
+                    for t, r0 in zip(ts, raws):
+                        assert torch.equal(t, r0), (form, (B, Cin, H, W, Cout), knobs, rep)
+    finally:
+        lib.cn_set_tuning(28, 1)
+        lib.cn_set_tuning(30, 2)
+
+
 @pytest.mark.parametrize("persistent", [1, 0])
 def test_concat_members_written_in_place(dev, persistent):
     """Root.forward's torch.cat (pose_dla_dcn.py:157-165) without copies: the concatenation buffer is

@@ -126,6 +126,7 @@ def check(case, nb=None, label=""):
 
 
 allok = True
+lib.cn_set_tuning(30, int(os.environ.get("CHECK_KNOBS", "0")))     # key 30 for the correctness pass
 print("== correctness (error relative to the rms of the fp64 reference)")
 CASES = [
     ("B2 64->64 @32x32", dict(B=2, ci=64, H=32, W=32, co=64)),
@@ -153,6 +154,30 @@ print("ALL OK" if allok else "SOME FAILED")
 
 if os.environ.get("QUICK"):
     sys.exit(0 if allok else 1)
+
+# the pipelined fragment schedule (key 30 bit 2) sums in the order of the unpipelined one: bit-identical
+# outputs, launch after launch (EQ = launches per shape; a fragment overwritten under a queued MFMA --
+# the operand hazard of DESIGN 3.0 -- shows up here as a rare differing tile)
+EQ = int(os.environ.get("EQ", "0"))
+if EQ:
+    print("== pipelined vs unpipelined schedule, bit equality over %d launches per shape" % EQ)
+    lib.cn_set_tuning(28, 1)
+    for (ci, H, W, co, res) in [(64, 128, 128, 64, 1), (128, 64, 64, 128, 0), (256, 32, 32, 256, 1), (512, 16, 16, 512, 0)]:
+        c = Case(32, ci, H, W, co, res=res)
+        lib.cn_set_tuning(30, 0)
+        c.launch()
+        base = c.y.clone()
+        lib.cn_set_tuning(30, 2)
+        bad = 0
+        for _ in range(EQ):
+            c.y.zero_()
+            c.launch()
+            bad += int(not torch.equal(c.y, base))
+        print("%-24s res %d: %d of %d launches differ" % (str((ci, H, W, co)), res, bad, EQ))
+        allok &= bad == 0
+        del c
+    lib.cn_set_tuning(30, 0)
+    print("ALL OK" if allok else "SOME FAILED")
 
 print("== timing, B = 32 (ms per launch, effective TFLOP/s)")
 SHAPES = [(64, 128, 128, 64), (128, 64, 64, 128), (256, 32, 32, 256), (512, 16, 16, 512)]
