@@ -120,6 +120,7 @@ constexpr int P_MAXH = 8;
 #ifndef P3_SPLIT
 #define P3_SPLIT 4
 #endif
+
 static_assert(P3_SPLIT >= 4, "the front part of a block must reference all six fragments (see the fence in front of the barrier)");
 struct P3Heads {
     const char *wf[P_MAXH];       // 1x1 matrix as MFMA-ready (high, low) fragments (cn_pack_head_w2_f32s)
