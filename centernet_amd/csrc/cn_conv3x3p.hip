@@ -163,8 +163,18 @@ __device__ constexpr int p3_s2_tap(int i)     // weight matrix (ky * 3 + kx) of 
     return i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 6 : i == 3 ? 8 : i == 4 ? 3 : i == 5 ? 5 : i == 6 ? 1 : i == 7 ? 7 : 4;
 }
 
+// Halo loader waves: the stride-2 form stages four halos per chunk (one per parity plane) and the transposed form
+// one per four steps -- 10 and 6 DMA pieces per step against 2.6 of the nine-tap form, more than one wave issues
+// in a step's time (matrix pipe 30 % / 40 % busy with one loader: profiles/r05_sq_counters_v3_cfg1.txt) -- so
+// those two forms run TWO halo loader waves (448 threads), each taking every other piece.
+#ifndef P3_HALO2
+#define P3_HALO2 1
+#endif
+constexpr int p3_halo_loaders(int ntap, bool s2) { return (P3_HALO2 && (s2 || ntap == 4)) ? 2 : 1; }
+constexpr int p3_threads(int ntap, bool s2) { return 320 + 64 * p3_halo_loaders(ntap, s2); }
+
 template <int RES, bool OUT_PLAIN, bool DBG = false, bool HEADS = false, int NTAP = 9, bool S2 = false, bool PIPE = false>
-__global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const P3Heads hd)
+__global__ __launch_bounds__(p3_threads(NTAP, S2), 4) void conv3x3p_kernel(const P3Args a, const P3Heads hd)
 {
     static_assert(!PIPE || !DBG, "pipelined fragment schedule: not in the instrumented instantiation");
     static_assert(!S2 || (NTAP == 9 && RES == 0 && !DBG && !HEADS), "stride 2: nine taps, no residual");
@@ -268,15 +278,21 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
         } else {
             // ---- halos: piece k covers halo rows 8k .. 8k+7; lane = (row in piece, 16-byte slot s);
             // slot s of row r receives source column s ^ key(r), key = (halo column >> 1) & 7
-            int poff[P_HP];          // byte offset of the lane's source relative to pixel (ty0, tx0) of the tile
-            int pyx[P_HP];           // hy | hx << 8, or -1: row beyond the halo
+            // (two loader waves: wave 5 + h takes pieces 2 j + h -- one copy of this code per h, so that every
+            // piece index stays a compile-time constant)
+            auto halo_loader = [&](auto HW) {
+            constexpr int NHL = p3_halo_loaders(NTAP, S2), NPW = (P_HP + NHL - 1) / NHL;
+            constexpr int hw = decltype(HW)::value;
+            int poff[NPW];           // byte offset of the lane's source relative to pixel (ty0, tx0) of the tile
+            int pyx[NPW];            // hy | hx << 8, or -1: row beyond the halo
 #pragma unroll
-            for (int k = 0; k < P_HP; ++k) {
+            for (int j = 0; j < NPW; ++j) {
+                const int k = j * NHL + hw;
                 const int r = 8 * k + prow;
                 const int hy = r / P_HW, hx = r - hy * P_HW;
                 const int col = ps ^ ((hx >> 1) & 7);
-                poff[k] = (S2 ? 2 : 1) * ((hy - 1) * a.Wi + (hx - 1)) * a.in_pitchB + col * 16;
-                pyx[k] = (r < P_HR) ? (hy | (hx << 8)) : -1;
+                poff[j] = (S2 ? 2 : 1) * ((hy - 1) * a.Wi + (hx - 1)) * a.in_pitchB + col * 16;
+                pyx[j] = (r < P_HR) ? (hy | (hx << 8)) : -1;
             }
             const char *zero = reinterpret_cast<const char *>(cn_p3_zero_line) + ps * 16;
             int hk = 0, hc = 0, hj = 0;   // cursor: the stage whose halo goes out next (hj: parity plane, S2)
@@ -299,12 +315,14 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
                 char *dst = smem + buf * P_HBYTES;
                 if (DBG && (a.dbg & 8)) return;
 #pragma unroll
-                for (int k = k0; k < k1; ++k) {
-                    const int hy = pyx[k] & 255, hx = pyx[k] >> 8;
+                for (int j = k0 / NHL; j < (k1 + NHL - 1) / NHL; ++j) {
+                    const int k = j * NHL + hw;
+                    if (NHL == 2 && (k < k0 || k >= k1)) continue;     // (wave-uniform)
+                    const int hy = pyx[j] & 255, hx = pyx[j] >> 8;
                     const int iy = S2 ? 2 * (hit.ty0 - 1 + hy) + hp : hit.ty0 - 1 + hy;
                     const int ix = S2 ? 2 * (hit.tx0 - 1 + hx) + hq : hit.tx0 - 1 + hx;
-                    const bool ok = pyx[k] >= 0 && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-                    const char *src = ok ? hbase + poff[k] : zero;
+                    const bool ok = pyx[j] >= 0 && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+                    const char *src = ok ? hbase + poff[j] : zero;
                     __builtin_amdgcn_global_load_lds((p3_gl_void *)src, (p3_lds_void *)(dst + k * 1024), 16, 0, 0);
                 }
             };
@@ -395,6 +413,9 @@ __global__ __launch_bounds__(384, 4) void conv3x3p_kernel(const P3Args a, const 
                 if (s == S) break;
                 if (!last) advance_H();
             }
+            };
+            if (p3_halo_loaders(NTAP, S2) == 1 || wave == 5) halo_loader(P3_IC(0));
+            else halo_loader(P3_IC(1));
         }
 #undef P3_IC
         if (DBG && a.prof && lane == 0) {
@@ -1287,7 +1308,7 @@ int cn_deconv4x4s2_persist(const void *x, const void *w_packed, const float *sca
     a.knobs = cn_tune_c3p_knobs;
     int per_xcd = cn_cdiv(a.items, 8);
     if (per_xcd > 64) per_xcd = 64;
-    const dim3 grid(8 * per_xcd), block(384);
+    const dim3 grid(8 * per_xcd), block(p3_threads(4, false));
 #define P3_LAUNCH4(OP, PIPE)                                                                                     \
     do {                                                                                                         \
         CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, OP, false, false, 4, false, PIPE>), P_LDS);                       \
@@ -1345,7 +1366,7 @@ int cn_conv3x3s2_persist(const void *x, const void *w_packed, const float *scale
     a.knobs = cn_tune_c3p_knobs;
     int per_xcd = cn_cdiv(a.items, 8);
     if (per_xcd > 64) per_xcd = 64;
-    const dim3 grid(8 * per_xcd), block(384);
+    const dim3 grid(8 * per_xcd), block(p3_threads(9, true));
 #define P3_LAUNCHS2(OP, PIPE)                                                                                    \
     do {                                                                                                         \
         CN_SET_MAX_LDS_ONCE((conv3x3p_kernel<0, OP, false, false, 9, true, PIPE>), P_LDS);                        \
