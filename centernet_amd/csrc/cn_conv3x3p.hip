@@ -170,6 +170,7 @@ __device__ constexpr int p3_s2_tap(int i)     // weight matrix (ky * 3 + kx) of 
 #ifndef P3_HALO2
 #define P3_HALO2 1
 #endif
+
 constexpr int p3_halo_loaders(int ntap, bool s2) { return (P3_HALO2 && (s2 || ntap == 4)) ? 2 : 1; }
 constexpr int p3_threads(int ntap, bool s2) { return 320 + 64 * p3_halo_loaders(ntap, s2); }
 
@@ -363,12 +364,12 @@ __global__ __launch_bounds__(p3_threads(NTAP, S2), 4) void conv3x3p_kernel(const
                         if (s == ST) { done = true; return; }
                         if (!last) {
                             if constexpr (n == 4) {
-                                if (t == 1) issue_H(P3_IC(0), P3_IC(8), nbuf);
-                                if (t == 2) issue_H(P3_IC(8), P3_IC(16), nbuf);
-                                if (t == 3) issue_H(P3_IC(16), P3_IC(P_HP), nbuf);
+                                // (two loader waves: twelve pieces each in two slices / at once -- the halo has a
+                                // step more to land than with three / two slices: stride-2 layers another -6 %)
+                                if (t == 1) issue_H(P3_IC(0), P3_IC(12), nbuf);
+                                if (t == 2) issue_H(P3_IC(12), P3_IC(P_HP), nbuf);
                             } else if constexpr (n == 2) {
-                                if (t == 0) issue_H(P3_IC(0), P3_IC(12), nbuf);
-                                if (t == 1) issue_H(P3_IC(12), P3_IC(P_HP), nbuf);
+                                if (t == 0) issue_H(P3_IC(0), P3_IC(P_HP), nbuf);
                             } else {
                                 issue_H(P3_IC(0), P3_IC(P_HP), nbuf);
                             }
@@ -396,10 +397,9 @@ __global__ __launch_bounds__(p3_threads(NTAP, S2), 4) void conv3x3p_kernel(const
                     if (DBG) { pf_wait += c1 - c0; pf_bar += now() - c1; }
                     if (s == S) break;
                     if (!last) {
-                        if constexpr (DECONV) {     // four steps per stage: the halo goes out behind steps 1 .. 3
-                            if (t == 1) issue_H(P3_IC(0), P3_IC(8), nbuf);
-                            if (t == 2) issue_H(P3_IC(8), P3_IC(16), nbuf);
-                            if (t == 3) issue_H(P3_IC(16), P3_IC(P_HP), nbuf);
+                        if constexpr (DECONV) {     // four steps per stage: the halo goes out behind steps 1 and 2
+                            if (t == 1) issue_H(P3_IC(0), P3_IC(12), nbuf);
+                            if (t == 2) issue_H(P3_IC(12), P3_IC(P_HP), nbuf);
                         } else {
                             if (t == 1) issue_H(P3_IC(0), P3_IC(4), nbuf);
                             if (t == 2) issue_H(P3_IC(4), P3_IC(8), nbuf);
