@@ -861,13 +861,24 @@ class PlanBuilder:
         w = torch.cat([c.weight.detach() for c in firsts], 0)
         b = torch.cat([c.bias.detach() for c in firsts], 0)
         k = firsts[0].kernel_size[0]
-        if (self.fuse_heads and self.dtype == torch.float32 and k == 3 and len(names) <= 8 and
+        if (self.fuse_heads and self.dtype == torch.float32 and k == 3 and
                 not x.nchw and x.c_off == 0 and
                 self._fusable_hidden([c.weight.shape[0] for c in firsts],
                                      [pairs[n][1].weight.shape[0] for n in names]) and
                 all(c.padding[0] == 1 and c.stride[0] == 1 for c in firsts) and
                 all(tuple(pairs[n][1].kernel_size) == (1, 1) for n in names)):
-            return self._heads_fused(x, names, pairs, w, b, lid)
+            if len(names) <= 8:
+                return self._heads_fused(x, names, pairs, w, b, lid)
+            # more heads than one launch takes (the exdet task's nine, opts.py:299-306): groups of up
+            # to six (head counts the kernel is exercised with: 3 and 6), each its own fused launch
+            # over the same feature map; one hidden exponent (lid)
+            outs = {}
+            for g in range(0, len(names), 6):
+                sub = names[g:g + 6]
+                outs.update(self._heads_fused(
+                    x, sub, pairs, torch.cat([pairs[n][0].weight.detach() for n in sub], 0),
+                    torch.cat([pairs[n][0].bias.detach() for n in sub], 0), lid))
+            return {n: outs[n] for n in names}
         hcs = [c.weight.shape[0] for c in firsts]
         # an f32s tensor is addressable in whole 32-channel groups only: hidden widths that are
         # not a multiple of 32 keep the hidden layer in plain floats (slices then start anywhere

@@ -5,14 +5,16 @@ Training / dataset / debug-visualisation flags are accepted so that existing com
 lines parse, but only the inference-relevant ones are consumed by this package:
 task, --arch, --head_conv, --down_ratio, --input_res/_h/_w, --load_model, --gpus, --K,
 --flip_test, --test_scales, --nms, --keep_res/--fix_res, --cat_spec_wh, --not_reg_offset,
---not_hm_hp, --not_reg_hp_offset, --debug, --vis_thresh.
+--not_hm_hp, --not_reg_hp_offset, --debug, --vis_thresh; for the ddd task --not_reg_bbox and
+--peak_thresh, for exdet --scores_thresh, --center_thresh, --aggr_weight (--agnostic_ex sets the
+heads as the reference does, the class-agnostic decoder itself is not built).
 """
 import argparse
 import os
 
 # (flag, kwargs) -- table form; names and defaults as in opts.py:13-225
 _FLAGS = [
-    ("task", dict(default="ctdet", nargs="?", help="ctdet | multi_pose (ddd, exdet: not on the MI355X hot path)")),
+    ("task", dict(default="ctdet", nargs="?", help="ctdet | multi_pose | ddd | exdet")),
     ("--dataset", dict(default="coco")), ("--exp_id", dict(default="default")),
     ("--test", dict(action="store_true")), ("--debug", dict(type=int, default=0)),
     ("--demo", dict(default="")), ("--load_model", dict(default="")),
@@ -68,6 +70,10 @@ _DATASET_DEFAULTS = {  # opts.py:337-353
                        std=[0.289, 0.274, 0.278], dataset="coco_hp", num_joints=17,
                        flip_idx=[[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14],
                                  [15, 16]]),
+    "exdet": dict(default_resolution=[512, 512], num_classes=80, mean=[0.408, 0.447, 0.470],
+                  std=[0.289, 0.274, 0.278], dataset="coco"),
+    "ddd": dict(default_resolution=[384, 1280], num_classes=3, mean=[0.485, 0.456, 0.406],
+                std=[0.229, 0.224, 0.225], dataset="kitti"),
 }
 
 
@@ -151,17 +157,27 @@ class opts(object):
                 opt.heads.update({'hm_hp': 17})
             if opt.reg_hp_offset:
                 opt.heads.update({'hp_offset': 2})
+        elif opt.task == 'ddd':
+            opt.heads = {'hm': opt.num_classes, 'dep': 1, 'rot': 8, 'dim': 3}
+            if opt.reg_bbox:
+                opt.heads.update({'wh': 2})
+            if opt.reg_offset:
+                opt.heads.update({'reg': 2})
+        elif opt.task == 'exdet':
+            edge_maps = 1 if opt.agnostic_ex else opt.num_classes
+            opt.heads = {'hm_t': edge_maps, 'hm_l': edge_maps, 'hm_b': edge_maps, 'hm_r': edge_maps,
+                         'hm_c': opt.num_classes}
+            if opt.reg_offset:
+                opt.heads.update({'reg_t': 2, 'reg_l': 2, 'reg_b': 2, 'reg_r': 2})
         else:
-            raise NotImplementedError(
-                "task '%s' is outside the MI355X hot path (ctdet, multi_pose)" % opt.task)
+            raise NotImplementedError("task '%s' is not defined (ctdet, multi_pose, ddd, exdet)" % opt.task)
         return opt
 
     def init(self, args=''):
         # opts.py:336-362
         opt = self.parse(args)
         if opt.task not in _DATASET_DEFAULTS:
-            raise NotImplementedError(
-                "task '%s' is outside the MI355X hot path (ctdet, multi_pose)" % opt.task)
+            raise NotImplementedError("task '%s' is not defined (ctdet, multi_pose, ddd, exdet)" % opt.task)
         dataset = _Struct(_DATASET_DEFAULTS[opt.task])
         opt.dataset = dataset.dataset
         opt = self.update_dataset_info_and_set_heads(opt, dataset)

@@ -1,7 +1,8 @@
-"""Host tail of the path (mirror of src/lib/utils/post_process.py:83-114): map
-detections from the output grid back to image coordinates and split per class."""
+"""Host tail of the path (mirror of src/lib/utils/post_process.py:83-114, and :10-81 for the ddd
+task): map detections from the output grid back to image coordinates and split per class."""
 import numpy as np
 
+from .ddd_utils import ddd2locrot
 from .image import transform_preds
 
 
@@ -41,6 +42,67 @@ def multi_pose_post_process(dets, c, s, h, w):
                                moved[:, 2:].reshape(K, 34)], axis=1).astype(np.float32)
         ret.append({1: rows.tolist()})
     return ret
+
+
+def get_alpha(rot):
+    """(n, 8) orientation head [bin 1: 2 class logits, sin, cos | bin 2: the same] -> observation
+    angle (utils/post_process.py:13-21): the bin whose second logit is larger wins; bin 1 is centred
+    on -pi / 2, bin 2 on +pi / 2.  The blend is written with the reference's 0 / 1 products (a float64
+    result, as there)."""
+    first = rot[:, 1] > rot[:, 5]
+    a1 = np.arctan2(rot[:, 2], rot[:, 3]) + (-0.5 * np.pi)
+    a2 = np.arctan2(rot[:, 6], rot[:, 7]) + (0.5 * np.pi)
+    return a1 * first + a2 * (1 - first)
+
+
+def ddd_post_process_2d(dets, c, s, opt):
+    """(B, K, 16 | 18) rows of ``ddd_decode`` [x, y, score, rot 8, depth, dim 3, (w, h), class] ->
+    per image {1-based class: (n, 8 | 10) float32 [x, y, score, alpha, depth, h, w, l, (w, h)]} with
+    the centre in source pixels (utils/post_process.py:24-51).  The reference sends the (w, h) pair
+    through the same point map as the centre -- translation included; so does this.  Writes the
+    moved centres into ``dets`` (callers pass a copy, as the reference's detector does)."""
+    out = []
+    has_wh = dets.shape[2] > 16
+    grid = (opt.output_w, opt.output_h)
+    for i in range(dets.shape[0]):
+        dets[i, :, :2] = transform_preds(dets[i, :, 0:2], c[i], s[i], grid)
+        cls = dets[i, :, -1]
+        per_class = {}
+        for j in range(opt.num_classes):
+            rows = dets[i, cls == j]
+            cols = [rows[:, :3].astype(np.float32),
+                    get_alpha(rows[:, 3:11])[:, np.newaxis].astype(np.float32),
+                    rows[:, 11:12].astype(np.float32), rows[:, 12:15].astype(np.float32)]
+            if has_wh:
+                cols.append(transform_preds(rows[:, 15:17], c[i], s[i], grid).astype(np.float32))
+            per_class[j + 1] = np.concatenate(cols, axis=1)
+        out.append(per_class)
+    return out
+
+
+def ddd_post_process_3d(dets, calibs):
+    """The 2-D stage's rows -> per image {class: (n, 13) float32 [alpha, x1, y1, x2, y2, h, w, l,
+    x, y, z, rotation_y, score]}, an EMPTY class being a (0,) array (utils/post_process.py:53-79).
+    Every image is lifted with ``calibs[0]``, as in the reference (its detector is single-image)."""
+    out = []
+    for per_class in dets:
+        lifted = {}
+        for cls, rows in per_class.items():
+            preds = []
+            for r in rows:
+                center, score, alpha, depth, dims, wh = r[:2], r[2], r[3], r[4], r[5:8], r[8:10]
+                location, rotation_y = ddd2locrot(center, alpha, dims, depth, calibs[0])
+                box = [center[0] - wh[0] / 2, center[1] - wh[1] / 2,
+                       center[0] + wh[0] / 2, center[1] + wh[1] / 2]
+                preds.append([alpha] + box + dims.tolist() + location.tolist() + [rotation_y, score])
+            lifted[cls] = np.array(preds, dtype=np.float32)
+        out.append(lifted)
+    return out
+
+
+def ddd_post_process(dets, c, s, calibs, opt):
+    """utils/post_process.py:81-86."""
+    return ddd_post_process_3d(ddd_post_process_2d(dets, c, s, opt), calibs)
 
 
 def ctdet_results_batch(dets, metas, num_classes, scale=1, max_per_image=100):

@@ -329,3 +329,26 @@ def multi_pose_process(arch, sd, images, heads, K=100, flip_test=False, flip_idx
     dets = cref.multi_pose_decode(out["hm"].numpy(), out["wh"].numpy(), out["hps"].numpy(),
                                   reg.numpy(), hm_hp.numpy(), hp_offset.numpy(), K=K)
     return out, dets
+
+
+def ddd_process(arch, sd, images, heads, K=100, reg_bbox=True, reg_offset=True):
+    """DddDetector.process (detectors/ddd.py:56-73): returns (output, dets (B, K, 16 | 18))."""
+    out = forward(arch, sd, images, heads)
+    out["hm"] = out["hm"].sigmoid_()
+    out["dep"] = 1. / (out["dep"].sigmoid() + 1e-6) - 1.
+    wh = out["wh"].numpy() if reg_bbox else None
+    reg = out["reg"].numpy() if reg_offset else None
+    dets = cref.ddd_decode(out["hm"].numpy(), out["rot"].numpy(), out["dep"].numpy(), out["dim"].numpy(),
+                           wh=wh, reg=reg, K=K)
+    return out, dets
+
+
+def exdet_process(arch, sd, images, heads, K=40, scores_thresh=0.1, center_thresh=0.1, aggr_weight=0.0,
+                  reg_offset=True):
+    """ExdetDetector.process (detectors/exdet.py:28-55): returns (output, dets (B, 1000, 14))."""
+    out = forward(arch, sd, images, heads)
+    heats = [out[n].sigmoid_().numpy() for n in ("hm_t", "hm_l", "hm_b", "hm_r", "hm_c")]
+    regs = [out[n].numpy() for n in ("reg_t", "reg_l", "reg_b", "reg_r")] if reg_offset else [None] * 4
+    dets = cref.exct_decode(*(heats + regs), K=K, scores_thresh=scores_thresh, center_thresh=center_thresh,
+                            aggr_weight=aggr_weight)
+    return out, dets

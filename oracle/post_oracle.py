@@ -202,3 +202,103 @@ def ctdet_merge_outputs(detections, num_classes, n_scales, nms=False, max_per_im
             keep_inds = (results[j][:, 4] >= thresh)
             results[j] = results[j][keep_inds]
     return results
+
+
+# ---------------------------------------------------------------------------------------------
+# ddd task: utils/post_process.py:10-86 + utils/ddd_utils.py:68-114, detectors/ddd.py:75-88
+# ---------------------------------------------------------------------------------------------
+def ddd_alpha(rot):
+    """get_alpha, utils/post_process.py:13-21."""
+    idx = rot[:, 1] > rot[:, 5]
+    alpha1 = np.arctan2(rot[:, 2], rot[:, 3]) + (-0.5 * np.pi)
+    alpha2 = np.arctan2(rot[:, 6], rot[:, 7]) + (0.5 * np.pi)
+    return alpha1 * idx + alpha2 * (1 - idx)
+
+
+def ddd_unproject(pt_2d, depth, P):
+    """unproject_2d_to_3d, utils/ddd_utils.py:68-78."""
+    z = depth - P[2, 3]
+    x = (pt_2d[0] * depth - P[0, 3] - P[0, 2] * z) / P[0, 0]
+    y = (pt_2d[1] * depth - P[1, 3] - P[1, 2] * z) / P[1, 1]
+    return np.array([x, y, z], dtype=np.float32)
+
+
+def ddd_rot_y(alpha, x, cx, fx):
+    """alpha2rot_y, utils/ddd_utils.py:80-92."""
+    rot_y = alpha + np.arctan2(x - cx, fx)
+    if rot_y > np.pi:
+        rot_y -= 2 * np.pi
+    if rot_y < -np.pi:
+        rot_y += 2 * np.pi
+    return rot_y
+
+
+def ddd_results(dets, meta, num_classes, out_w, out_h):
+    """DddDetector.post_process (detectors/ddd.py:75-80) for one image: ddd_post_process_2d then
+    ddd_post_process_3d, statement by statement.  dets (1, K, 18) as ddd_decode returns them."""
+    d = dets.reshape(1, -1, dets.shape[2]).copy()
+    c, s, calib = meta['c'], meta['s'], meta['calib']
+    d[0, :, :2] = transform_preds(d[0, :, 0:2], c, s, (out_w, out_h))
+    classes = d[0, :, -1]
+    out = {}
+    for j in range(num_classes):
+        inds = (classes == j)
+        rows = np.concatenate([
+            d[0, inds, :3].astype(np.float32), ddd_alpha(d[0, inds, 3:11])[:, np.newaxis].astype(np.float32),
+            d[0, inds, 11:12].astype(np.float32), d[0, inds, 12:15].astype(np.float32),
+            transform_preds(d[0, inds, 15:17], c, s, (out_w, out_h)).astype(np.float32)], axis=1)
+        preds = []
+        for r in rows:
+            center, score, alpha, depth, dimensions, wh = r[:2], r[2], r[3], r[4], r[5:8], r[8:10]
+            locations = ddd_unproject(center, depth, calib)                       # ddd2locrot, ddd_utils.py:109-114
+            locations[1] += dimensions[0] / 2
+            rotation_y = ddd_rot_y(alpha, center[0], calib[0, 2], calib[0, 0])
+            bbox = [center[0] - wh[0] / 2, center[1] - wh[1] / 2, center[0] + wh[0] / 2, center[1] + wh[1] / 2]
+            preds.append([alpha] + bbox + dimensions.tolist() + locations.tolist() + [rotation_y, score])
+        out[j + 1] = np.array(preds, dtype=np.float32)
+    return out
+
+
+def ddd_merge_outputs(detections, num_classes, peak_thresh):
+    """DddDetector.merge_outputs, detectors/ddd.py:82-88."""
+    results = detections[0]
+    for j in range(1, num_classes + 1):
+        if len(results[j]) > 0:
+            results[j] = results[j][results[j][:, -1] > peak_thresh]
+    return results
+
+
+# ---------------------------------------------------------------------------------------------
+# exdet task: detectors/exdet.py:86-123
+# ---------------------------------------------------------------------------------------------
+def exdet_post_process(dets, meta, scale=1):
+    """ExdetDetector.post_process, detectors/exdet.py:86-97: the rows of [frame, mirrored frame]."""
+    out_width, out_height = meta['out_width'], meta['out_height']
+    d = np.array(dets, dtype=np.float32).reshape(2, -1, 14)
+    d[1, :, [0, 2]] = out_width - d[1, :, [2, 0]]
+    d = d.reshape(1, -1, 14)
+    d[0, :, 0:2] = transform_preds(d[0, :, 0:2], meta['c'], meta['s'], (out_width, out_height))
+    d[0, :, 2:4] = transform_preds(d[0, :, 2:4], meta['c'], meta['s'], (out_width, out_height))
+    d[:, :, 0:4] /= scale
+    return d[0]
+
+
+def exdet_merge_outputs(detections, num_classes, max_per_image=100):
+    """ExdetDetector.merge_outputs, detectors/exdet.py:99-123 (soft_nms: this file's restatement of
+    external/nms.pyx, pinned to the cython build in tests/test_oracle_ref.py)."""
+    detections = np.concatenate([d for d in detections], axis=0).astype(np.float32)
+    classes = detections[..., -1]
+    keep = detections[:, 4] > 0
+    detections, classes = detections[keep], classes[keep]
+    results = {}
+    for j in range(num_classes):
+        results[j + 1] = detections[classes == j][:, 0:7].astype(np.float32)
+        soft_nms(results[j + 1], Nt=0.5, method=2)
+        results[j + 1] = results[j + 1][:, 0:5]
+    scores = np.hstack([results[j][:, -1] for j in range(1, num_classes + 1)])
+    if len(scores) > max_per_image:
+        kth = len(scores) - max_per_image
+        thresh = np.partition(scores, kth)[kth]
+        for j in range(1, num_classes + 1):
+            results[j] = results[j][results[j][:, -1] >= thresh]
+    return results

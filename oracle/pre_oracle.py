@@ -284,3 +284,20 @@ def pre_process(image, scale, mean, std, fix_res=True, input_h=512, input_w=512,
         images = np.concatenate((images, images[:, :, :, ::-1]), axis=0)
     meta = {'c': c, 's': s, 'out_height': inp_height // down_ratio, 'out_width': inp_width // down_ratio}
     return np.ascontiguousarray(images), meta
+
+
+def ddd_pre_process(image, mean, std, input_h=384, input_w=1280, keep_res=False, down_ratio=4, calib=None):
+    """DddDetector.pre_process, detectors/ddd.py:30-54: no resize, the frame warped straight onto the
+    fixed input, FLOAT32 normalisation ``(x.astype(float32) / 255. - mean) / std`` -> (images
+    (1, 3, H, W) float32, meta without the detector's default calib filled in)."""
+    height, width = image.shape[0:2]
+    c = np.array([width / 2, height / 2], dtype=np.float32)
+    s = np.array([input_w, input_h], dtype=np.int32) if keep_res else np.array([width, height], dtype=np.int32)
+    trans = get_affine_transform(c, s, 0, [input_w, input_h])
+    inp = cv_warp_affine_u8(image, trans, (input_w, input_h))
+    inp = inp.astype(np.float32) / 255.
+    inp = (inp - np.asarray(mean, np.float32).reshape(1, 1, 3)) / np.asarray(std, np.float32).reshape(1, 1, 3)
+    images = inp.transpose(2, 0, 1)[np.newaxis, ...]
+    meta = {'c': c, 's': s, 'out_height': input_h // down_ratio, 'out_width': input_w // down_ratio,
+            'calib': None if calib is None else np.array(calib, dtype=np.float32)}
+    return np.ascontiguousarray(images), meta

@@ -19,8 +19,20 @@ def test_opts_init_ctdet_defaults():
     o = opts().init(["multi_pose", "--arch", "hourglass", "--keep_res", "--test_scales", "0.5,1,2"])
     assert o.heads == {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
     assert o.pad == 127 and o.num_stacks == 2 and not o.fix_res and o.test_scales == [0.5, 1.0, 2.0]
+    # the ddd / exdet tasks (opts.py:299-312,341-353): kitti geometry, the 3-D heads, the five extreme-point maps
+    o = opts().init(["ddd"])
+    assert o.heads == {"hm": 3, "dep": 1, "rot": 8, "dim": 3, "wh": 2, "reg": 2} and o.arch == "dla_34"
+    assert (o.input_h, o.input_w, o.output_h, o.output_w) == (384, 1280, 96, 320) and o.dataset == "kitti"
+    assert o.mean == [0.485, 0.456, 0.406] and o.std == [0.229, 0.224, 0.225] and o.peak_thresh == 0.2
+    assert opts().init(["ddd", "--not_reg_bbox", "--not_reg_offset"]).heads == {"hm": 3, "dep": 1, "rot": 8, "dim": 3}
+    o = opts().init(["exdet", "--arch", "hourglass"])
+    assert o.heads == {"hm_t": 80, "hm_l": 80, "hm_b": 80, "hm_r": 80, "hm_c": 80,
+                       "reg_t": 2, "reg_l": 2, "reg_b": 2, "reg_r": 2}
+    assert (o.scores_thresh, o.center_thresh, o.aggr_weight) == (0.1, 0.1, 0.0)
+    o = opts().init(["exdet", "--agnostic_ex", "--not_reg_offset"])
+    assert o.heads == {"hm_t": 1, "hm_l": 1, "hm_b": 1, "hm_r": 1, "hm_c": 80}
     with pytest.raises(NotImplementedError):
-        opts().init(["ddd"])
+        opts().init(["segmentation"])
 
 
 def test_affine_identity_for_benchmark_configuration():
