@@ -2024,9 +2024,11 @@ struct ExctRegr {
 };
 
 // one 1024-thread workgroup per image
+// ``cls_map`` (B, H, W) or null: the class-agnostic form (agnex_ct_decode, decode.py:171-187,262-263) takes a
+// detection's class from the centre map's arg-max at the box centre instead of from the top point's list
 __global__ __launch_bounds__(NTM) void exct_select_kernel(
     const float *__restrict__ cand, const ExctLists L, const ExctRegr R, float *__restrict__ dets,
-    int K, int H, int W, int num_dets)
+    int K, int H, int W, int num_dets, const int32_t *__restrict__ cls_map)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     SelShared &sh = *reinterpret_cast<SelShared *>(smem);
@@ -2078,11 +2080,13 @@ __global__ __launch_bounds__(NTM) void exct_select_kernel(
     const int o = b * K;
     const int HW = H * W;
     const int sel[4] = {it, il, ib, ir};
-    float xs[4], ys[4];
+    float xs[4], ys[4], gx[4], gy[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int ind = L.ind[e][o + sel[e]];
         float x = (float)(ind % W), y = (float)(ind / W);
+        gx[e] = x;
+        gy[e] = y;
         if (R.r[0]) {  // decode.py:372-390 (all four regression maps given)
             x = x + R.r[e][((size_t)b * 2 + 0) * HW + ind];
             y = y + R.r[e][((size_t)b * 2 + 1) * HW + ind];
@@ -2098,7 +2102,35 @@ __global__ __launch_bounds__(NTM) void exct_select_kernel(
     d[4] = score;
     d[5] = xs[0]; d[6] = ys[0]; d[7] = xs[1]; d[8] = ys[1];
     d[9] = xs[2]; d[10] = ys[2]; d[11] = xs[3]; d[12] = ys[3];
-    d[13] = (float)L.cls[0][o + it];                          // clses = t_clses
+    if (cls_map) {   // decode.py:171-172: the box centre on the grid, from the points BEFORE their offsets
+        const int cx = (int)((gx[1] + gx[3] + 0.5f) / 2.0f);
+        const int cy = (int)((gy[0] + gy[2] + 0.5f) / 2.0f);
+        d[13] = (float)cls_map[(size_t)b * HW + (size_t)cy * W + cx];
+    } else {
+        d[13] = (float)L.cls[0][o + it];                      // clses = t_clses
+    }
+}
+
+// agnex_ct_decode's `torch.max(ct_heat, dim=1)` (decode.py:164): per cell the largest value over the classes and
+// the FIRST class that holds it
+__global__ void channel_max_kernel(const float *__restrict__ heat, float *__restrict__ vmax,
+                                   int32_t *__restrict__ imax, int C, int HW, size_t cells)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, p = i - b * HW;
+        const float *src = heat + b * (size_t)C * HW + p;
+        float best = src[0];
+        int arg = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = src[(size_t)c * HW];
+            if (v > best) {
+                best = v;
+                arg = c;
+            }
+        }
+        vmax[i] = best;
+        imax[i] = arg;
+    }
 }
 
 }  // namespace
@@ -2191,13 +2223,13 @@ extern "C" size_t cn_exct_decode_workspace_bytes(int B, int C, int H, int W, int
     return base + lists + cand + map;
 }
 
-extern "C" int cn_exct_decode_f32(const float *t_heat, const float *l_heat, const float *b_heat,
-                                  const float *r_heat, const float *ct_heat, const float *t_regr,
-                                  const float *l_regr, const float *b_regr, const float *r_regr,
-                                  int B, int C, int H, int W, int K, float scores_thresh,
-                                  float center_thresh, int num_dets, int apply_sigmoid,
-                                  float *dets, void *workspace, size_t workspace_bytes,
-                                  void *stream)
+static int exct_decode_impl(const float *t_heat, const float *l_heat, const float *b_heat,
+                            const float *r_heat, const float *ct_heat, const float *t_regr,
+                            const float *l_regr, const float *b_regr, const float *r_regr,
+                            int B, int C, int H, int W, int K, float scores_thresh,
+                            float center_thresh, int num_dets, int apply_sigmoid,
+                            float *dets, void *workspace, size_t workspace_bytes,
+                            void *stream, const int32_t *cls_map)
 {
     if (!t_heat || !l_heat || !b_heat || !r_heat || !ct_heat || !dets || !workspace) return CN_ERR_NULL;
     if (num_dets <= 0 || K <= 0) return CN_ERR_SHAPE;
@@ -2246,7 +2278,55 @@ extern "C" int cn_exct_decode_f32(const float *t_heat, const float *l_heat, cons
     R.r[2] = all_regr ? b_regr : nullptr; R.r[3] = all_regr ? r_regr : nullptr;
     const size_t lds = sizeof(SelShared) + EXCT_MAX_DETS * sizeof(u64);
     hipLaunchKernelGGL(exct_select_kernel, dim3(B), dim3(NTM), lds, st, cand, L, R, dets, K, H, W,
-                       num_dets);
+                       num_dets, cls_map);
     CN_CHECK_LAUNCH();
     return CN_OK;
+}
+
+extern "C" int cn_exct_decode_f32(const float *t_heat, const float *l_heat, const float *b_heat,
+                                  const float *r_heat, const float *ct_heat, const float *t_regr,
+                                  const float *l_regr, const float *b_regr, const float *r_regr,
+                                  int B, int C, int H, int W, int K, float scores_thresh,
+                                  float center_thresh, int num_dets, int apply_sigmoid,
+                                  float *dets, void *workspace, size_t workspace_bytes,
+                                  void *stream)
+{
+    return exct_decode_impl(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr, l_regr, b_regr, r_regr, B, C, H, W, K,
+                            scores_thresh, center_thresh, num_dets, apply_sigmoid, dets, workspace,
+                            workspace_bytes, stream, nullptr);
+}
+
+// agnex_ct_decode (models/decode.py:121-271): the class-agnostic form -- ONE top / left / bottom / right map per
+// image, the centre map over C classes.  The grouping is exct_decode's over single-channel maps (every point is
+// "class 0": the class rule never fires and subtracts an exact 0) against the per-cell maximum of the centre map;
+// a detection's class is that map's arg-max at the box centre.  Workspace: the single-class exct workspace + the
+// (B, H, W) maximum and arg-max planes.
+extern "C" size_t cn_agnex_ct_decode_workspace_bytes(int B, int C, int H, int W, int K)
+{
+    const size_t base = cn_exct_decode_workspace_bytes(B, 1, H, W, K);
+    if (!base || C <= 0) return 0;
+    return base + 2 * cn_align_up((size_t)B * H * W * 4, 256);
+}
+
+extern "C" int cn_agnex_ct_decode_f32(const float *t_heat, const float *l_heat, const float *b_heat,
+                                      const float *r_heat, const float *ct_heat, const float *t_regr,
+                                      const float *l_regr, const float *b_regr, const float *r_regr,
+                                      int B, int C, int H, int W, int K, float scores_thresh,
+                                      float center_thresh, int num_dets, int flags, float *dets,
+                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!t_heat || !l_heat || !b_heat || !r_heat || !ct_heat || !dets || !workspace) return CN_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CN_ERR_SHAPE;
+    const size_t base = cn_exct_decode_workspace_bytes(B, 1, H, W, K);
+    if (!base) return CN_ERR_UNSUPPORTED;
+    if (workspace_bytes < cn_agnex_ct_decode_workspace_bytes(B, C, H, W, K)) return CN_ERR_WORKSPACE;
+    const size_t cells = (size_t)B * H * W;
+    float *vmax = (float *)((char *)workspace + base);
+    int32_t *imax = (int32_t *)((char *)workspace + base + cn_align_up(cells * 4, 256));
+    const unsigned grid = (unsigned)((cells + 255) / 256 < 8192 ? (cells + 255) / 256 : 8192);
+    hipLaunchKernelGGL(channel_max_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ct_heat, vmax, imax, C,
+                       H * W, cells);
+    CN_CHECK_LAUNCH();
+    return exct_decode_impl(t_heat, l_heat, b_heat, r_heat, vmax, t_regr, l_regr, b_regr, r_regr, B, 1, H, W, K,
+                            scores_thresh, center_thresh, num_dets, flags, dets, workspace, base, stream, imax);
 }

@@ -226,9 +226,20 @@ def ddd_decode(heat, rot, depth, dim, wh=None, reg=None, K=40, apply_sigmoid=Fal
     return dets
 
 
+def agnex_ct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=None, b_regr=None,
+                    r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, aggr_weight=0.0,
+                    num_dets=1000):
+    """decode.py:121-271 -> (B, num_dets, 14): the class-agnostic ``exct_decode`` -- single-channel edge
+    maps, the centre map over the classes; groupings are scored against the centre map's per-cell maximum
+    and take its arg-max at the box centre as their class (``cn_agnex_ct_decode_f32``)."""
+    return exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr, l_regr, b_regr, r_regr, K=K,
+                       scores_thresh=scores_thresh, center_thresh=center_thresh, aggr_weight=aggr_weight,
+                       num_dets=num_dets, _agnostic=True)
+
+
 def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=None, b_regr=None,
                 r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, aggr_weight=0.0,
-                num_dets=1000):
+                num_dets=1000, _agnostic=False):
     """decode.py:273-424 -> (B, num_dets, 14).  Heat-maps post-sigmoid (values <= 1).
     ``aggr_weight > 0``: the edge aggregation of decode.py:17-90,136-140 runs in front
     (``cn_exct_aggregate_f32``: rows of t / b, columns of l / r)."""
@@ -236,6 +247,8 @@ def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=Non
         t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr, l_regr, b_regr, r_regr)
     lib = native.lib()
     B, C, H, W = t_heat.shape
+    if _agnostic and C != 1:
+        raise RuntimeError("agnex_ct_decode takes single-channel edge maps, got %d channels" % C)
     if aggr_weight > 0:
         for name, t in (("l_heat", l_heat), ("b_heat", b_heat), ("r_heat", r_heat)):
             _expect(name, t, B, C, H, W, t_heat.device)
@@ -247,13 +260,30 @@ def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=Non
                          "cn_exct_aggregate_f32")
             agg.append(o)
         t_heat, l_heat, b_heat, r_heat = agg
-    for name, t in (("l_heat", l_heat), ("b_heat", b_heat), ("r_heat", r_heat), ("ct_heat", ct_heat)):
+    for name, t in (("l_heat", l_heat), ("b_heat", b_heat), ("r_heat", r_heat)):
         _expect(name, t, B, C, H, W, t_heat.device)
+    if _agnostic:
+        if ct_heat.dim() != 4 or ct_heat.shape[0] != B or tuple(ct_heat.shape[2:]) != (H, W) or \
+                ct_heat.device != t_heat.device:
+            raise RuntimeError("ct_heat must be (B, classes, H, W) on the device of the edge maps")
+    else:
+        _expect("ct_heat", ct_heat, B, C, H, W, t_heat.device)
     for name, t in (("t_regr", t_regr), ("l_regr", l_regr), ("b_regr", b_regr), ("r_regr", r_regr)):
         _expect(name, t, B, 2, H, W, t_heat.device)
     if K > H * W or num_dets > K ** 4:
         raise RuntimeError("selected index k out of range")
     dets = torch.empty((B, num_dets, 14), device=t_heat.device, dtype=torch.float32)
+    if _agnostic:
+        Cc = int(ct_heat.shape[1])
+        ws = _workspace(lib.cn_agnex_ct_decode_workspace_bytes(B, Cc, H, W, K), t_heat.device)
+        rc = lib.cn_agnex_ct_decode_f32(native.ptr(t_heat), native.ptr(l_heat), native.ptr(b_heat),
+                                        native.ptr(r_heat), native.ptr(ct_heat), native.ptr(t_regr),
+                                        native.ptr(l_regr), native.ptr(b_regr), native.ptr(r_regr), B, Cc, H,
+                                        W, K, scores_thresh, center_thresh, num_dets,
+                                        _EXCT_CLAMP_ONE if aggr_weight > 0 else 0, native.ptr(dets),
+                                        native.ptr(ws), ws.numel(), native.stream_ptr())
+        native.check(rc, "cn_agnex_ct_decode_f32")
+        return dets
     ws = _workspace(lib.cn_exct_decode_workspace_bytes(B, C, H, W, K), t_heat.device)
     rc = lib.cn_exct_decode_f32(native.ptr(t_heat), native.ptr(l_heat), native.ptr(b_heat),
                                 native.ptr(r_heat), native.ptr(ct_heat), native.ptr(t_regr),

@@ -1,6 +1,7 @@
 """exdet task -- ExtremeNet-style detection (public behaviour of src/lib/detectors/exdet.py:23-118):
 four extreme-point heat-maps + a centre map per class on the HIP network, grouped into boxes by
-``cn_exct_decode_f32`` (K^4 candidate scoring with the edge aggregation of --aggr_weight in front).
+``cn_exct_decode_f32`` (K^4 candidate scoring with the edge aggregation of --aggr_weight in front);
+--agnostic_ex: one extreme-point map per edge for all classes, ``cn_agnex_ct_decode_f32``.
 
 Two things the reference's class does are kept as they are, because they ARE its results:
 * ``post_process`` reads the decode's rows as TWO images -- the frame and its mirror image -- and
@@ -16,7 +17,7 @@ import time
 import numpy as np
 import torch
 
-from ..decode import exct_decode
+from ..decode import agnex_ct_decode, exct_decode
 from ..image import transform_preds
 from ..soft_nms import soft_nms
 from .base_detector import BaseDetector
@@ -27,13 +28,12 @@ EDGE_OFFSETS = ('reg_t', 'reg_l', 'reg_b', 'reg_r')
 
 class ExdetDetector(BaseDetector):
     def __init__(self, opt):
-        if opt.agnostic_ex:
-            raise NotImplementedError("--agnostic_ex (agnex_ct_decode, models/decode.py:126-271) is not built")
         if opt.K > 64:
             # the reference would score K^4 = 10^8 groupings per image at the --K default of 100; the
             # kernel takes K <= 64 (cn_exct_decode_f32), ExtremeNet's own setting is 40
             raise ValueError("the exdet task needs --K <= 64 (K^4 candidate groupings per image); use --K 40")
         super(ExdetDetector, self).__init__(opt)
+        self.decode = agnex_ct_decode if opt.agnostic_ex else exct_decode      # exdet.py:26
 
     def process(self, images, return_time=False):
         """exdet.py:28-55: the five maps post-sigmoid (in place, as there), then ``exct_decode`` with
@@ -44,7 +44,7 @@ class ExdetDetector(BaseDetector):
             torch.cuda.synchronize()
             forward_time = time.time()
             offsets = [output[n] for n in EDGE_OFFSETS] if self.opt.reg_offset else []
-            dets = exct_decode(*(heats + offsets), K=self.opt.K, scores_thresh=self.opt.scores_thresh,
+            dets = self.decode(*(heats + offsets), K=self.opt.K, scores_thresh=self.opt.scores_thresh,
                                center_thresh=self.opt.center_thresh, aggr_weight=self.opt.aggr_weight)
         return (output, dets, forward_time) if return_time else (output, dets)
 

@@ -212,6 +212,11 @@ def _declare(lib):
     lib.cn_exct_decode_f32.restype = i
     lib.cn_exct_decode_f32.argtypes = [vp] * 9 + [i] * 5 + [ctypes.c_float, ctypes.c_float, i, i,
                                                         vp, vp, sz, vp]
+    lib.cn_agnex_ct_decode_workspace_bytes.restype = sz
+    lib.cn_agnex_ct_decode_workspace_bytes.argtypes = [i] * 5
+    lib.cn_agnex_ct_decode_f32.restype = i
+    lib.cn_agnex_ct_decode_f32.argtypes = [vp] * 9 + [i] * 5 + [ctypes.c_float, ctypes.c_float, i, i,
+                                                            vp, vp, sz, vp]
     lib.cn_multi_pose_decode_workspace_bytes.restype = sz
     lib.cn_multi_pose_decode_workspace_bytes.argtypes = [i] * 6
     lib.cn_multi_pose_decode_f32.restype = i

@@ -6,8 +6,7 @@ lines parse, but only the inference-relevant ones are consumed by this package:
 task, --arch, --head_conv, --down_ratio, --input_res/_h/_w, --load_model, --gpus, --K,
 --flip_test, --test_scales, --nms, --keep_res/--fix_res, --cat_spec_wh, --not_reg_offset,
 --not_hm_hp, --not_reg_hp_offset, --debug, --vis_thresh; for the ddd task --not_reg_bbox and
---peak_thresh, for exdet --scores_thresh, --center_thresh, --aggr_weight (--agnostic_ex sets the
-heads as the reference does, the class-agnostic decoder itself is not built).
+--peak_thresh, for exdet --scores_thresh, --center_thresh, --aggr_weight, --agnostic_ex.
 """
 import argparse
 import os

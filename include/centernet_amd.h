@@ -613,6 +613,20 @@ int cn_exct_decode_f32(const float *t_heat, const float *l_heat, const float *b_
                        int H, int W, int K, float scores_thresh, float center_thresh, int num_dets,
                        int apply_sigmoid, float *dets, void *workspace, size_t workspace_bytes,
                        void *stream);
+/* agnex_ct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr.., K=40, scores_thresh=0.1,
+ *                 center_thresh=0.1, aggr_weight=0.0, num_dets=1000)   (models/decode.py:121-271), the
+ * class-agnostic form behind --agnostic_ex (detectors/exdet.py:26): the four edge maps are (B, 1, H, W), the
+ * centre map (B, C, H, W); a grouping is scored against the per-cell MAXIMUM of the centre map over the classes
+ * (torch.max(ct_heat, dim=1), decode.py:164), there is no class rule, and a detection's class is the arg-max
+ * (first on ties) at the box centre.  Same row layout, limits, tie order and `flags` (CN_EXCT_CLAMP_ONE) as
+ * cn_exct_decode_f32; the scores are that function's over single-channel maps, bit for bit. */
+size_t cn_agnex_ct_decode_workspace_bytes(int B, int C, int H, int W, int K);
+int cn_agnex_ct_decode_f32(const float *t_heat, const float *l_heat, const float *b_heat,
+                           const float *r_heat, const float *ct_heat, const float *t_regr,
+                           const float *l_regr, const float *b_regr, const float *r_regr, int B, int C,
+                           int H, int W, int K, float scores_thresh, float center_thresh, int num_dets,
+                           int flags, float *dets, void *workspace, size_t workspace_bytes,
+                           void *stream);
 
 /* ------------------------------------------------------------------------
  * multi_pose decode.

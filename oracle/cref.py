@@ -237,8 +237,19 @@ def v_aggregate(heat, aggr_weight=0.1):
     return _edge_aggregate(heat, 2, aggr_weight)
 
 
+def agnex_ct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=None, b_regr=None,
+                    r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, num_dets=1000, aggr_weight=0.0):
+    """models/decode.py:121-271, the class-agnostic form: the statements of exct_decode with (B, 1, H, W)
+    edge maps, ``torch.max(ct_heat, dim=1)`` as the centre map (:164), no class rule (:202-215) and the
+    arg-max class at the box centre (:175-177,262-263)."""
+    return exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr, l_regr, b_regr, r_regr, K=K,
+                       scores_thresh=scores_thresh, center_thresh=center_thresh, num_dets=num_dets,
+                       aggr_weight=aggr_weight, agnostic=True)
+
+
 def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=None, b_regr=None,
-                r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, num_dets=1000, aggr_weight=0.0):
+                r_regr=None, K=40, scores_thresh=0.1, center_thresh=0.1, num_dets=1000, aggr_weight=0.0,
+                agnostic=False):
     """models/decode.py:273-424, statement by statement in float32 numpy (aggr_weight > 0: the edge
     aggregation of :136-140 in front).  Ties of the final top-k are ordered by candidate index (torch
     leaves that unspecified)."""
@@ -262,9 +273,16 @@ def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=Non
     full = (B, K, K, K, K)
     box_ct_xs = (((l_xs + r_xs) + f32(0.5)) / f32(2)).astype(np.int64)          # :331
     box_ct_ys = (((t_ys + b_ys) + f32(0.5)) / f32(2)).astype(np.int64)          # :332
-    ct_inds = CL[0].astype(np.int64) * (H * W) + box_ct_ys * W + box_ct_xs      # :333
-    ct_inds = np.broadcast_to(ct_inds, full).reshape(B, -1)
-    ct_flat = np.ascontiguousarray(ct_heat, f32).reshape(B, -1)
+    if agnostic:                                                                 # :164,173-177
+        ct_all = np.ascontiguousarray(ct_heat, f32)
+        ct_clses = np.argmax(ct_all, axis=1).reshape(B, -1)                      # first maximum, as torch.max
+        ct_flat = np.max(ct_all, axis=1).reshape(B, -1)
+        ct_inds = np.broadcast_to(box_ct_ys * W + box_ct_xs, full).reshape(B, -1)
+        agn_clses = np.take_along_axis(ct_clses, ct_inds, axis=1).reshape(full)
+    else:
+        ct_inds = CL[0].astype(np.int64) * (H * W) + box_ct_ys * W + box_ct_xs  # :333
+        ct_inds = np.broadcast_to(ct_inds, full).reshape(B, -1)
+        ct_flat = np.ascontiguousarray(ct_heat, f32).reshape(B, -1)
     ct_scores = np.take_along_axis(ct_flat, ct_inds, axis=1).reshape(full)      # :334-336
     scores = ((((S[0] + S[1]) + S[2]) + S[3]) + f32(2) * ct_scores) / f32(6)    # :343
     cls_inds = (CL[0] != CL[1]) | (CL[0] != CL[2]) | (CL[0] != CL[3])           # :346-348
@@ -275,7 +293,9 @@ def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=Non
     th, cth = f32(scores_thresh), f32(center_thresh)
     sc_inds = (S[0] < th) | (S[1] < th) | (S[2] < th) | (S[3] < th) | (ct_scores < cth)  # :359-362
     scores = scores.astype(f32)
-    for flag in (sc_inds, cls_inds, top_inds, left_inds, bottom_inds, right_inds):        # :364-369
+    rules = (sc_inds, top_inds, left_inds, bottom_inds, right_inds) if agnostic else \
+        (sc_inds, cls_inds, top_inds, left_inds, bottom_inds, right_inds)
+    for flag in rules:                                                                    # :364-369 (:217-221)
         scores = scores - np.broadcast_to(flag, full).astype(f32)
     scores = scores.reshape(B, -1)
     order = np.lexsort((np.broadcast_to(np.arange(scores.shape[1]), scores.shape), -scores), axis=1)
@@ -297,5 +317,5 @@ def exct_decode(t_heat, l_heat, b_heat, r_heat, ct_heat, t_regr=None, l_regr=Non
     cols = [pick(XS[1]), pick(YS[0]), pick(XS[3]), pick(YS[2]), top_scores]       # bboxes :403
     for e in range(4):
         cols += [pick(XS[e]), pick(YS[e])]
-    cols.append(pick(CL[0]).astype(f32))
+    cols.append(pick(agn_clses if agnostic else CL[0]).astype(f32))
     return np.concatenate(cols, axis=2).astype(f32)

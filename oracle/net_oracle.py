@@ -344,11 +344,13 @@ def ddd_process(arch, sd, images, heads, K=100, reg_bbox=True, reg_offset=True):
 
 
 def exdet_process(arch, sd, images, heads, K=40, scores_thresh=0.1, center_thresh=0.1, aggr_weight=0.0,
-                  reg_offset=True):
-    """ExdetDetector.process (detectors/exdet.py:28-55): returns (output, dets (B, 1000, 14))."""
+                  reg_offset=True, agnostic=False):
+    """ExdetDetector.process (detectors/exdet.py:28-55): returns (output, dets (B, 1000, 14));
+    ``agnostic``: agnex_ct_decode instead of exct_decode (exdet.py:26)."""
     out = forward(arch, sd, images, heads)
     heats = [out[n].sigmoid_().numpy() for n in ("hm_t", "hm_l", "hm_b", "hm_r", "hm_c")]
     regs = [out[n].numpy() for n in ("reg_t", "reg_l", "reg_b", "reg_r")] if reg_offset else [None] * 4
-    dets = cref.exct_decode(*(heats + regs), K=K, scores_thresh=scores_thresh, center_thresh=center_thresh,
-                            aggr_weight=aggr_weight)
+    decode = cref.agnex_ct_decode if agnostic else cref.exct_decode
+    dets = decode(*(heats + regs), K=K, scores_thresh=scores_thresh, center_thresh=center_thresh,
+                  aggr_weight=aggr_weight)
     return out, dets

@@ -202,3 +202,68 @@ def test_exdet_detector_matches_the_oracle_pipeline(dev):
     from centernet_amd.detectors import detector_factory
     with pytest.raises(ValueError):
         detector_factory["exdet"](opts().init(["exdet", "--arch", "hourglass"]))      # --K 100 > 64
+
+
+# ------------------------------------------------------------------------------------------------
+# --agnostic_ex: agnex_ct_decode (models/decode.py:121-271) through cn_agnex_ct_decode_f32
+# ------------------------------------------------------------------------------------------------
+from test_oracle_agnex import GEN as AGEN, GOLD as AGOLD      # noqa: E402
+from test_oracle_exct import assert_same                      # noqa: E402
+
+
+def _t(a, dev):
+    return None if a is None else torch.from_numpy(a).to(dev)
+
+
+@pytest.mark.parametrize("name", sorted(AGEN.AGNEX_CASES))
+def test_agnex_ct_decode_matches_reference_golden(dev, name):
+    from centernet_amd import decode as D
+    from oracle import cref
+    heats, regs, K, num_dets = AGEN.agnex_inputs(name)
+    dets = D.agnex_ct_decode(*[_t(h, dev) for h in heats], *[_t(r, dev) for r in regs], K=K,
+                             num_dets=num_dets).cpu().numpy()
+    assert_same(dets, AGOLD[name + "/dets"])
+    ref = cref.agnex_ct_decode(*heats, *regs, K=K, num_dets=num_dets)
+    assert np.array_equal(dets.view(np.uint32), ref.view(np.uint32))     # same tie rule: fully bit-exact
+    if name == "agnex_small":
+        with pytest.raises(RuntimeError):        # edge maps with classes belong to exct_decode
+            D.agnex_ct_decode(*[_t(np.repeat(h, 2, axis=1) if i < 4 else h, dev) for i, h in enumerate(heats)], K=K,
+                              num_dets=num_dets)
+        # with the edge aggregation in front (the shared cn_exct_aggregate_f32 + clamp path)
+        got = D.agnex_ct_decode(*[_t(h, dev) for h in heats], *[_t(r, dev) for r in regs], K=K,
+                                num_dets=num_dets, aggr_weight=0.1).cpu().numpy()
+        ref = cref.agnex_ct_decode(*heats, *regs, K=K, num_dets=num_dets, aggr_weight=0.1)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_exdet_agnostic_detector_matches_the_oracle_pipeline(dev):
+    """--agnostic_ex end to end: one extreme-point map per edge, classes from the centre map's arg-max."""
+    det, opt = _detector(["exdet", "--arch", "hourglass", "--agnostic_ex", "--flip_test", "--input_res", "256",
+                          "--K", "40", "--scores_thresh", "0", "--center_thresh", "0"])
+    assert [opt.heads[n] for n in ("hm_t", "hm_l", "hm_b", "hm_r", "hm_c")] == [1, 1, 1, 1, 80]
+    image = np.random.RandomState(13).randint(0, 256, (256, 256, 3)).astype(np.uint8)
+    images, meta = det.pre_process(image, 1.0)
+    _, ref_dets = net_oracle.exdet_process("hourglass", det.model.state_dict(), images, list(opt.heads), K=opt.K,
+                                           scores_thresh=0.0, center_thresh=0.0, agnostic=True)
+    _, dets = det.process(images.to(dev))
+    got = dets.cpu().numpy()
+    assert got.shape == ref_dets.shape == (2, 1000, 14)
+    tol = np.array([2e-3] * 4 + [1e-4] + [2e-3] * 8 + [0.0])
+    fr = []
+    for b in range(2):
+        m = match_rows(got[b][:320], ref_dets[b][:320], list(range(14)), tol, window=20)
+        fr.append(float((m[:300] >= 0).mean()))
+    valid = int((ref_dets[..., 4] > 0).sum())
+    classes = len(set(ref_dets[..., 13].reshape(-1).tolist()))
+    _note("exdet_agnostic_raw", paired=fr, valid_rows=valid, classes=classes)
+    assert min(fr) >= 0.95 and valid >= 1000 and classes >= 1, (fr, valid, classes)
+    res = det.run(image)["results"]
+    ref = post_oracle.exdet_merge_outputs([post_oracle.exdet_post_process(ref_dets, meta, 1.0)], opt.num_classes)
+    n_ref = sum(len(v) for v in ref.values())
+    same = 0
+    for j in range(1, 81):
+        if len(ref[j]) and len(res[j]):
+            d = np.abs(res[j][:, None, :].astype(np.float64) - ref[j][None, :, :]).max(axis=2)
+            same += int((d.min(axis=0) < 5e-3).sum())
+    _note("exdet_agnostic_results", rows=n_ref, same=same)
+    assert n_ref > 0 and same >= 0.9 * n_ref, (same, n_ref)

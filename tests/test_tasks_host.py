@@ -199,7 +199,10 @@ def test_exdet_second_half_is_unmirrored_and_only_the_box_is_moved():
     assert np.array_equal(rows[:, 4:], d.reshape(-1, 14)[:, 4:])        # score, extreme points, class: untouched
 
 
-def test_exdet_refuses_the_class_agnostic_decoder():
+def test_exdet_guard_rails():
+    """--K above what the K^4 grouping kernel takes is refused before any device work."""
     from centernet_amd.opts import opts
-    with pytest.raises(NotImplementedError):
-        ExdetDetector(opts().init(["exdet", "--agnostic_ex"]))
+    with pytest.raises(ValueError):
+        ExdetDetector(opts().init(["exdet", "--arch", "hourglass"]))             # the --K default of 100
+    with pytest.raises(ValueError):
+        ExdetDetector(opts().init(["exdet", "--agnostic_ex", "--K", "65"]))
