@@ -1,4 +1,5 @@
-"""COCO result writer -- the on-disk format AP is computed from.
+"""Result writers -- the on-disk formats the benchmarks' evaluators read: COCO json for
+ctdet / exdet / multi_pose, KITTI label files for ddd.
 
 Mirror of ``COCO.convert_eval_format / save_results`` (src/lib/datasets/dataset/coco.py:86-112)
 and ``COCOHP.convert_eval_format / save_results`` (src/lib/datasets/dataset/coco_hp.py:70-103):
@@ -50,3 +51,30 @@ def convert_eval_format(all_bboxes, task="ctdet", valid_ids=None):
 def save_results(results, save_dir, task="ctdet", valid_ids=None):
     with open('{}/results.json'.format(save_dir), 'w') as f:
         json.dump(convert_eval_format(results, task, valid_ids), f)
+
+
+KITTI_CLASS_NAMES = ['__background__', 'Pedestrian', 'Car', 'Cyclist']      # datasets/dataset/kitti.py:35-36
+
+
+def kitti_result_lines(per_class, class_names=None):
+    """One image's ddd results ``{class (1-based): (n, 13) rows [alpha, x1, y1, x2, y2, h, w, l, x, y, z,
+    rotation_y, score]}`` -> the lines of its KITTI label file: ``<type> 0.0 0`` (truncation, occlusion) and
+    the 13 values with two decimals (datasets/dataset/kitti.py:74-81)."""
+    names = KITTI_CLASS_NAMES if class_names is None else class_names
+    lines = []
+    for cls_ind in per_class:
+        for row in per_class[cls_ind]:
+            lines.append('{} 0.0 0'.format(names[cls_ind]) + ''.join(' {:.2f}'.format(v) for v in row))
+    return lines
+
+
+def save_results_kitti(results, save_dir, class_names=None):
+    """``{image id: run()['results']}`` -> ``<save_dir>/results/<image id, six digits>.txt`` for the KITTI
+    object evaluator (datasets/dataset/kitti.py:68-82)."""
+    import os
+    results_dir = os.path.join(save_dir, 'results')
+    os.makedirs(results_dir, exist_ok=True)
+    for img_id in results:
+        with open(os.path.join(results_dir, '{:06d}.txt'.format(img_id)), 'w') as f:
+            for line in kitti_result_lines(results[img_id], class_names):
+                f.write(line + '\n')

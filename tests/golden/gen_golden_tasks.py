@@ -103,6 +103,12 @@ def exdet_inputs(name):
     return d, meta, scale
 
 
+def kitti_results_inputs(gold):
+    """{image id: run()['results']} for the KITTI writer, from the ddd goldens (an image with an empty class)"""
+    return {7: {j: np.asarray(gold["ddd/kitti_default_calib/merged/%d" % j]) for j in (1, 2, 3)},
+            123: {j: np.asarray(gold["ddd/kitti_p2/merged/%d" % j]) for j in (1, 2, 3)}}
+
+
 def _import_reference_detectors():
     import importlib
     from oracle import pre_oracle, ref
@@ -177,6 +183,27 @@ def main():
     for j, v in merged.items():
         if len(v):
             out["exdet/two_scales/merged/%d" % j] = v
+    # the KITTI result files (datasets/dataset/kitti.py:68-82): one text file per image, written by the reference's
+    # own KITTI.save_results from the ddd results above
+    import importlib.util
+    import json
+    import tempfile
+    stub = types.ModuleType("pycocotools")
+    stub.coco = types.ModuleType("pycocotools.coco")
+    sys.modules.update({"pycocotools": stub, "pycocotools.coco": stub.coco})
+    spec = importlib.util.spec_from_file_location("ref_kitti", "/root/reference/src/lib/datasets/dataset/kitti.py")
+    kitti = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kitti)
+    results = kitti_results_inputs(out)
+    me = types.SimpleNamespace(class_name=['__background__', 'Pedestrian', 'Car', 'Cyclist'])       # kitti.py:35-36
+    files = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        kitti.KITTI.save_results(me, results, tmp)
+        for name in sorted(os.listdir(os.path.join(tmp, "results"))):
+            files[name] = open(os.path.join(tmp, "results", name)).read()
+    with open(os.path.join(HERE, "tasks_kitti_golden.json"), "w") as f:
+        json.dump(files, f)
+    print("kitti files:", {k: v.count("\n") for k, v in files.items()})
     np.savez_compressed(os.path.join(HERE, "tasks_golden.npz"), **out)
     print(len(out), "arrays;", {k: v.shape for k, v in list(out.items())[:8]})
 

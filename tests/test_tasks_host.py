@@ -206,3 +206,17 @@ def test_exdet_guard_rails():
         ExdetDetector(opts().init(["exdet", "--arch", "hourglass"]))             # the --K default of 100
     with pytest.raises(ValueError):
         ExdetDetector(opts().init(["exdet", "--agnostic_ex", "--K", "65"]))
+
+
+def test_kitti_result_files_equal_the_reference(tmp_path):
+    """datasets/dataset/kitti.py:68-82 (KITTI.save_results run on the ddd goldens): same files, same bytes."""
+    import json
+    from centernet_amd import results as R
+    golden = json.load(open(os.path.join(HERE, "golden", "tasks_kitti_golden.json")))
+    inp = GEN.kitti_results_inputs(GOLD)
+    R.save_results_kitti(inp, str(tmp_path))
+    got = {n: open(tmp_path / "results" / n).read() for n in sorted(os.listdir(tmp_path / "results"))}
+    assert got == golden and sorted(got) == ["000007.txt", "000123.txt"]
+    first = got["000007.txt"].splitlines()[0].split()
+    assert first[0] in R.KITTI_CLASS_NAMES[1:] and first[1:3] == ["0.0", "0"] and len(first) == 3 + 13
+    assert all(len(v.split(".")[1]) == 2 for v in first[3:])
