@@ -39,6 +39,14 @@ def _detector(args):
     return det, opt
 
 
+def _favour_one_class(model, cls=17, by=3.0):
+    """the last layer of the five exdet maps (the only 80-wide biases of those heads) gets one strong class"""
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.split(".")[0] in ("hm_t", "hm_l", "hm_b", "hm_r", "hm_c") and k.endswith("bias") and v.numel() == 80:
+                v[cls] += by
+
+
 def _paired_fraction(got, ref, cols, atol, rtol, window):
     """share of the oracle's rows that have a partner among the produced rows at most ``window`` ranks away
     with every column of ``cols`` within atol + rtol * |ref|"""
@@ -150,11 +158,7 @@ def test_exdet_detector_matches_the_oracle_pipeline(dev):
     assert list(opt.heads) == ["hm_t", "hm_l", "hm_b", "hm_r", "hm_c", "reg_t", "reg_l", "reg_b", "reg_r"]
     # random heads never agree on a class (every grouping would carry the class rejection, score < 0):
     # one class is favoured in the last layer of the five maps, as a trained net's dominant object would be
-    import re
-    with torch.no_grad():
-        for k, v in det.model.state_dict().items():
-            if k.split(".")[0] in ("hm_t", "hm_l", "hm_b", "hm_r", "hm_c") and re.search(r"\.1\.bias$", k) and v.numel() == 80:
-                v[17] += 3.0
+    _favour_one_class(det.model)
     image = np.random.RandomState(12).randint(0, 256, (256, 256, 3)).astype(np.uint8)
     images, meta = det.pre_process(image, 1.0)
     assert tuple(images.shape) == (2, 3, 256, 256)
@@ -267,3 +271,28 @@ def test_exdet_agnostic_detector_matches_the_oracle_pipeline(dev):
             same += int((d.min(axis=0) < 5e-3).sum())
     _note("exdet_agnostic_results", rows=n_ref, same=same)
     assert n_ref > 0 and same >= 0.9 * n_ref, (same, n_ref)
+
+
+@pytest.mark.parametrize("arch", ["resdcn_18", "dla_34"])
+def test_exdet_on_the_other_backbones(dev, arch):
+    """The zoo also carries exdet on DLA-34; head_conv = 64 (resdcn_18) puts the nine heads on the persistent
+    kernel's fused-heads form, 256 (dla_34) on the wide form -- both as two launches of six and three heads."""
+    det, opt = _detector(["exdet", "--arch", arch, "--flip_test", "--input_res", "256", "--K", "40",
+                          "--scores_thresh", "0", "--center_thresh", "0"])
+    _favour_one_class(det.model)
+    image = np.random.RandomState(14).randint(0, 256, (256, 256, 3)).astype(np.uint8)
+    images, meta = det.pre_process(image, 1.0)
+    out_ref, ref_dets = net_oracle.exdet_process(arch, det.model.state_dict(), images, list(opt.heads), K=opt.K,
+                                                 scores_thresh=0.0, center_thresh=0.0)
+    output, dets = det.process(images.to(dev))
+    for n in opt.heads:
+        r = out_ref[n].numpy()
+        assert np.abs(output[n].cpu().numpy() - r).max() < 1e-4 * max(1.0, float(np.abs(r).max())), n
+    got = dets.cpu().numpy()
+    tol = np.array([2e-3] * 4 + [1e-4] + [2e-3] * 8 + [0.0])
+    fr = []
+    for b in range(2):
+        m = match_rows(got[b][:320], ref_dets[b][:320], list(range(14)), tol, window=20)
+        fr.append(float((m[:300] >= 0).mean()))
+    _note("exdet_" + arch, paired=fr, valid_rows=int((ref_dets[..., 4] > 0).sum()))
+    assert min(fr) >= 0.95, fr
