@@ -770,7 +770,7 @@ int g_tune_dcn_split = 0;   // cn_set_tuning key 13: 0 = auto, 1 = never, 3 / 9 
 int g_tune_bm256 = 0;       // cn_set_tuning key 14: 1 = 256-pixel tiles for 64-wide layers in the halo kernel (no gain, measured)
 int g_tune_waves8 = 1;      // cn_set_tuning key 15: 8-wave workgroups for the 128-wide halo tiles
 int g_tune_occ4 = 0;        // cn_set_tuning key 19: 4-workgroups-per-CU form of the 64-wide halo tiles: 0 = by rounds rule, 1 = always, 2 = never
-int g_tune_dcn_form = 0;   // cn_set_tuning key 23: f32s deformable kernel, 0 = by shape and grid (team form per key 36, else the register-sampling window form, else the gather form), 1 = global-gather form always, 2 = register-sampling form (cn_dcn2.hip) for every shape it takes, 4 / 5 = team form (cn_dcn3.hip) in T / N mode for every shape it takes
+int g_tune_dcn_form = 0;   // cn_set_tuning key 23: f32s deformable kernel, 0 = by shape and grid (team form per key 36, else the register-sampling window form, else the gather form), 1 = global-gather form always, 2 = register-sampling form (cn_dcn2.hip) for every shape it takes, 4 / 5 = team form (cn_dcn3.hip) in T / N mode for every shape it takes, 6 / 7 = wide form (cn_dcn4.hip; 7: four blocks per workgroup) for every shape it takes
 int g_tune_stem16s = 1;     // cn_set_tuning key 27: f32s form of the stride-1 16-channel stem (DLA base_layer); 0 = fp32 kernel
 int g_tune_dcn_tile2d = 1; // cn_set_tuning key 22: deformable kernel, 1 = 8-wide pixel blocks as tiles (default), 0 = row segments
 int g_tune_nohalo = 0;   // cn_set_tuning key 10: 1 = generic implicit GEMM for 3x3/s1 instead of cn_conv3x3.hip
@@ -939,6 +939,12 @@ int cn_dcn_team_f32s(const float *x, const void *w_packed, const float *bias, co
                      float x_mul, uint32_t *range, int nmode, int dbg, float *partial,
                      size_t partial_bytes, int *ksplit_out, hipStream_t st);
 extern int cn_tune_dcn_team, cn_tune_dcn_team_wgs, cn_tune_dcn_team_stagger;   // cn_dcn3.hip
+int cn_dcn_wide_f32s(const float *x, const void *w_packed, const float *bias, const float *om,
+                     int om_pitch, const float *scale, const float *shift, void *y, int out_pitch,
+                     int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
+                     float x_mul, uint32_t *range, int nb, int dbg, float *partial, size_t partial_bytes,
+                     int *ksplit_out, hipStream_t st);
+extern int cn_tune_dcn_wide, cn_tune_dcn_wide_wgs;   // cn_dcn4.hip
 bool cn_conv3x3s2p_takes(int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch);
 int cn_conv3x3s2_persist(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
                          int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch, int relu,
@@ -1484,7 +1490,16 @@ extern "C" int cn_dcn_v2_forward_nhwc(const float *input_nhwc, const void *weigh
         const long tiles128 = (long)B * (H / 8) * (W / 16);
         const bool team_auto = g_tune_dcn_form == 0 && tiles128 >= 64 &&
                                ((cn_tune_dcn_team == 1 && Cout <= 64) || cn_tune_dcn_team >= 2);
-        if (g_tune_dcn_form == 4 || g_tune_dcn_form == 5 || team_auto)
+        // wide form (cn_dcn4.hip): every sample once per tile for ALL output channels; Cout % 128 == 0
+        const bool wide_auto = g_tune_dcn_form == 0 && cn_tune_dcn_wide && tiles128 >= 64 && (Cout & 127) == 0 && !g_tune_dbgskip;
+        if (g_tune_dcn_form == 6 || g_tune_dcn_form == 7 || wide_auto)
+            rc = cn_dcn_wide_f32s(input_nhwc, weight_packed, bias, offset_mask_nhwc, om_pitch, scale, shift,
+                                  output_nhwc, out_pitch, (flags & CN_CONV_Y_PLAIN) ? 1 : 0, B, Cin, H, W, Cout,
+                                  mask_sigmoid, relu, (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f,
+                                  ctl ? ctl->range : nullptr, g_tune_dcn_form == 7 ? 4 : 0, g_tune_dbgskip,
+                                  ws_ok ? (float *)workspace : nullptr, ws_ok ? workspace_bytes : 0, &ks,
+                                  (hipStream_t)stream);
+        if (rc == CN_ERR_UNSUPPORTED && (g_tune_dcn_form == 4 || g_tune_dcn_form == 5 || team_auto))
             rc = cn_dcn_team_f32s(input_nhwc, weight_packed, bias, offset_mask_nhwc, om_pitch, scale, shift,
                                   output_nhwc, out_pitch, (flags & CN_CONV_Y_PLAIN) ? 1 : 0, B, Cin, H, W, Cout,
                                   mask_sigmoid, relu, (ctl && ctl->x_mul != 0.f) ? ctl->x_mul : 1.f,
@@ -1880,7 +1895,15 @@ extern "C" int cn_set_tuning(int key, int value)
         cn_tune_heads_remap = value;
         return CN_OK;
     }
-    if (key == 23 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 5)) {
+    if (key == 41 && (value == 0 || value == 1)) {
+        cn_tune_dcn_wide = value;
+        return CN_OK;
+    }
+    if (key == 42 && value >= 1 && value <= 4096) {
+        cn_tune_dcn_wide_wgs = value;
+        return CN_OK;
+    }
+    if (key == 23 && (value == 0 || value == 1 || value == 2 || (value >= 4 && value <= 7))) {
         g_tune_dcn_form = value;
         return CN_OK;
     }
