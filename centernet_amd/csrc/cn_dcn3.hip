@@ -364,7 +364,14 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
                 // weights), two channels per instruction (v_pk_fma_f32)
                 cn_f32x4 va, vb;
                 {
-                    auto lo2 = [](cn_f32x4 v) { return d3_f32x2{v[0], v[1]}; };
+    #ifdef CN_DCN_SCALAR_FMA
+                #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    va[e] = __builtin_fmaf(c4a[e], w4[0], __builtin_fmaf(c3a[e], w3[0], __builtin_fmaf(c2a[e], w2[0], c1a[e] * w1[0])));
+                    vb[e] = __builtin_fmaf(c4b[e], w4[0], __builtin_fmaf(c3b[e], w3[0], __builtin_fmaf(c2b[e], w2[0], c1b[e] * w1[0])));
+                }
+                #else
+                auto lo2 = [](cn_f32x4 v) { return d3_f32x2{v[0], v[1]}; };
                     auto hi2 = [](cn_f32x4 v) { return d3_f32x2{v[2], v[3]}; };
                     const d3_f32x2 a0 = lo2(c1a) * w1 + lo2(c2a) * w2 + lo2(c3a) * w3 + lo2(c4a) * w4;
                     const d3_f32x2 a1 = hi2(c1a) * w1 + hi2(c2a) * w2 + hi2(c3a) * w3 + hi2(c4a) * w4;
@@ -372,6 +379,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
                     const d3_f32x2 b1 = hi2(c1b) * w1 + hi2(c2b) * w2 + hi2(c3b) * w3 + hi2(c4b) * w4;
                     va = cn_f32x4{a0[0], a0[1], a1[0], a1[1]};
                     vb = cn_f32x4{b0[0], b0[1], b1[0], b1[1]};
+                #endif
                 }
                 cn_f16x4v ha, la, hb, lb;
                 if (MSIG) {

@@ -110,6 +110,11 @@ __global__ __launch_bounds__(W_NT, 2) void dcn_wide_kernel(const D4Args a)
 {
     extern __shared__ __attribute__((aligned(128))) char smem[];
     constexpr int SLOT = NB * 4096;                // bytes of one step's weight fragments
+    // NB = 4 leaves room for a SECOND window behind the ring: the next chunk's window is copied one piece per
+    // thread and step while the current one is sampled, and a chunk boundary costs one barrier instead of a
+    // barrier + 48 KiB DMA round trip + barrier
+    constexpr bool WDB = (NB == 4);
+    constexpr int W_WIN1 = W_RING + 2 * SLOT;
     constexpr int NPW = NB / 2;                    // 1 KiB DMA pieces per wave and step
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,18 +156,32 @@ __global__ __launch_bounds__(W_NT, 2) void dcn_wide_kernel(const D4Args a)
         doff[p] = ok ? (img_base + (unsigned)(iy * W + ix)) * pix_bytes + 16u * (unsigned)lq : 0xffffffffu;
     }
     const d4_glb_char *zline = (const d4_glb_char *)cn_d4_zero_line + 16 * (lane & 7);
-    auto dma = [&](int chunk) {
+    unsigned wbase = 0;             // byte offset of the window being sampled (0 or W_WIN1)
+    auto dma1 = [&](int chunk, int p, unsigned base) {
         const unsigned cb = (unsigned)chunk * 128u;
+        const d4_glb_char *src = (doff[p] != 0xffffffffu) ? xg + (doff[p] + cb) : zline;
+        __builtin_amdgcn_global_load_lds((d4_glb_void *)src, (d4_lds_void *)(smem + base + (p * W_NT + wave * 64) * 16), 16, 0, 0);
+    };
+    auto dma = [&](int chunk) {
 #pragma unroll
-        for (int p = 0; p < W_NP; ++p) {
-            const d4_glb_char *src = (doff[p] != 0xffffffffu) ? xg + (doff[p] + cb) : zline;
-            __builtin_amdgcn_global_load_lds((d4_glb_void *)src, (d4_lds_void *)(smem + (p * W_NT + wave * 64) * 16), 16, 0, 0);
+        for (int p = 0; p < W_NP; ++p) dma1(chunk, p, wbase);
+    };
+    auto dma_piece = [&](int chunk, int t, unsigned base) {   // piece t (uniform): scalar branches, doff stays in registers
+        static_assert(W_NP == 6, "six pieces per thread");
+        switch (t) {
+        case 0: dma1(chunk, 0, base); break;
+        case 1: dma1(chunk, 1, base); break;
+        case 2: dma1(chunk, 2, base); break;
+        case 3: dma1(chunk, 3, base); break;
+        case 4: dma1(chunk, 4, base); break;
+        case 5: dma1(chunk, 5, base); break;
+        default: break;
         }
     };
     auto track = [&]() {
 #pragma unroll
         for (int p = 0; p < W_NP; ++p) {
-            const cn_f32x4 v = *reinterpret_cast<const d4_lds_f32x4 *>(lds + (p * W_NT + tid) * 16);
+            const cn_f32x4 v = *reinterpret_cast<const d4_lds_f32x4 *>(lds + wbase + (p * W_NT + tid) * 16);
             cn_rng_upd4(rng_in, v);
         }
     };
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(W_NT, 2) void dcn_wide_kernel(const D4Args a)
         wv = wv_n;
         const d4_u32x2 pp = pp_n;
         if (t < 8) record(t + 1);
-        const unsigned B1 = (pp[0] & 0xffffu) ^ hx ^ kx, B2 = (pp[0] >> 16) ^ hx ^ kx;
+        const unsigned B1 = ((pp[0] & 0xffffu) ^ hx ^ kx) + wbase, B2 = ((pp[0] >> 16) ^ hx ^ kx) + wbase;
         if ((int)pp[1] < 0 && !(dbg & 16)) {
             // beyond the window's reach: the four corners from global memory (clamped addresses --
             // off-map corners carry zero weight); 24-bit integer multiplies (checked by the launcher)
@@ -338,14 +357,13 @@ __global__ __launch_bounds__(W_NT, 2) void dcn_wide_kernel(const D4Args a)
         const d4_f32x2 w1 = {wv[0], wv[0]}, w2 = {wv[1], wv[1]}, w3 = {wv[2], wv[2]}, w4 = {wv[3], wv[3]};
         cn_f32x4 va, vb;
         {
-            auto lo2 = [](cn_f32x4 v) { return d4_f32x2{v[0], v[1]}; };
-            auto hi2 = [](cn_f32x4 v) { return d4_f32x2{v[2], v[3]}; };
-            const d4_f32x2 a0 = lo2(c1a) * w1 + lo2(c2a) * w2 + lo2(c3a) * w3 + lo2(c4a) * w4;
-            const d4_f32x2 a1 = hi2(c1a) * w1 + hi2(c2a) * w2 + hi2(c3a) * w3 + hi2(c4a) * w4;
-            const d4_f32x2 b0 = lo2(c1b) * w1 + lo2(c2b) * w2 + lo2(c3b) * w3 + lo2(c4b) * w4;
-            const d4_f32x2 b1 = hi2(c1b) * w1 + hi2(c2b) * w2 + hi2(c3b) * w3 + hi2(c4b) * w4;
-            va = cn_f32x4{a0[0], a0[1], a1[0], a1[1]};
-            vb = cn_f32x4{b0[0], b0[1], b1[0], b1[1]};
+// plain v_fma_f32 (this file is built with -fno-slp-vectorize): v_pk_fma_f32 issues through the matrix pipe's
+            // slot and does not overlap the partner wave's MFMAs (5 % on every shape, profiles/r06_dcn_wide.txt)
+            #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                va[e] = __builtin_fmaf(c4a[e], w4[0], __builtin_fmaf(c3a[e], w3[0], __builtin_fmaf(c2a[e], w2[0], c1a[e] * w1[0])));
+                vb[e] = __builtin_fmaf(c4b[e], w4[0], __builtin_fmaf(c3b[e], w3[0], __builtin_fmaf(c2b[e], w2[0], c1b[e] * w1[0])));
+            }
         }
         cn_f16x4v ha, la, hb, lb;
         if (MSIG) {
@@ -364,11 +382,18 @@ __global__ __launch_bounds__(W_NT, 2) void dcn_wide_kernel(const D4Args a)
     int step = 0;                                  // linear (chunk, tap) step: ring slot = step & 1
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
         if (chunk != c_lo && !(dbg & 64)) {
-            __syncthreads();                       // every wave is done with the previous window
-            dma(chunk);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window and this step's weights (issued a step ago)
-            if (MSIG && a.range) track();
-            __syncthreads();
+            if (WDB) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of this chunk's window (copied under the previous chunk)
+                __syncthreads();                   // everybody's; every wave is done with the previous window
+                wbase ^= (unsigned)W_WIN1;
+                if (MSIG && a.range) track();
+            } else {
+                __syncthreads();                   // every wave is done with the previous window
+                dma(chunk);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window and this step's weights (issued a step ago)
+                if (MSIG && a.range) track();
+                __syncthreads();
+            }
         }
         // byte offset, in x, of channel 16 kk + 8 h of this chunk in pixel 0 of the image (global path)
         far_base = img_base * pix_bytes + (unsigned)chunk * 128u + hx + kx;
@@ -397,7 +422,9 @@ __global__ __launch_bounds__(W_NT, 2) void dcn_wide_kernel(const D4Args a)
                 if (tr_on) ts[3] = __builtin_readcyclecounter();
                 if (t < 8 && !(dbg & 4)) request(t + 1);
                 if (tr_on) ts[5] = __builtin_readcyclecounter();
+                if (WDB && chunk + 1 < c_hi && !(dbg & 64)) dma_piece(chunk + 1, t, wbase ^ (unsigned)W_WIN1);
             } else {
+                if (WDB && chunk + 1 < c_hi && !(dbg & 64)) dma_piece(chunk + 1, t, wbase ^ (unsigned)W_WIN1);
                 // next step's weights into the other slot (its last readers are behind this step's barrier)
                 int tn = t + 1, cnx = chunk;
                 if (tn == 9) { tn = 0; cnx = chunk + 1; }
@@ -510,7 +537,7 @@ __global__ __launch_bounds__(W_NT, 2) void dcn_wide_kernel(const D4Args a)
 template <int NB>
 int launch_dcn_wide(const D4Args &a, int mask_sigmoid, hipStream_t st)
 {
-    constexpr int LDS = W_RING + 2 * NB * 4096;
+    constexpr int LDS = W_RING + 2 * NB * 4096 + (NB == 4 ? W_WBYTES : 0);
     static_assert(LDS <= 163840, "one workgroup per CU");
     dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y), (unsigned)(a.Cout / (32 * NB)), (unsigned)a.ksplit);
     if (a.dbg && mask_sigmoid) {

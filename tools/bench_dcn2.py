@@ -33,6 +33,7 @@ for B in [int(b) for b in os.environ.get("B", "32").split(",")]:
                 m.conv_offset_mask.weight.zero_(); m.conv_offset_mask.bias.zero_()
         xt = torch.randn((B, H, W, ci), device=dev).relu_()
         row = []
+        plans = []
         for v in VALUES:
             lib.cn_set_tuning(KNOB, v)
             pb = PlanBuilder(dev, B, H, W, exps={"x": exponent_for(float(xt.max())), "t1": exponent_for(8.0)})
@@ -40,15 +41,23 @@ for B in [int(b) for b in os.environ.get("B", "32").split(",")]:
             pb.dcn(x, m, relu=True)
             for op in pb.ops:        # offset conv -> real offsets (sigma ~ 1.4 px), then the DCN
                 op()
-            op = pb.ops[-1]
-            for _ in range(3): op()
-            torch.cuda.synchronize()
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(20): op()
-            e.record(); torch.cuda.synchronize()
-            ms = s.elapsed_time(e) / 20
-            row.append("%.3fms %5.1fTF" % (ms, pb.meta[-1]["flops"] / ms / 1e9))
+            plans.append(pb)
+        # interleaved rounds (ROUNDS, default 5), median per column: boxes drift by several per cent within seconds
+        times = [[] for _ in VALUES]
+        for _ in range(int(os.environ.get("ROUNDS", "5"))):
+            for k, v in enumerate(VALUES):
+                lib.cn_set_tuning(KNOB, v)
+                op = plans[k].ops[-1]
+                for _ in range(3): op()
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(20): op()
+                e.record(); torch.cuda.synchronize()
+                times[k].append(s.elapsed_time(e) / 20)
+        for k in range(len(VALUES)):
+            ms = sorted(times[k])[len(times[k]) // 2]
+            row.append("%.3fms %5.1fTF" % (ms, plans[k].meta[-1]["flops"] / ms / 1e9))
         print("      %-22s" % str((ci, H, W, co)), "   ".join("%-16s" % r for r in row))
 lib.cn_set_tuning(KNOB, 1 if KNOB in (22, 23) else 0)
 lib.cn_set_tuning(23, 0)

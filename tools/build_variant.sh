@@ -9,7 +9,7 @@ src=$root/centernet_amd/csrc
 obj=/tmp/cn_variant_$name
 mkdir -p "$obj" "$root/centernet_amd/variants"
 objs=""
-for f in cn_conv cn_decode cn_misc cn_stem cn_conv3x3 cn_conv3x3p cn_dcn cn_dcn2 cn_pre cn_conv16 cn_dcn_general; do
+for f in $(sed -n "s/^SRCS *:= *//p" "$src/Makefile" | sed "s/\.hip//g"); do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra -c "$src/$f.hip" -o "$obj/$f.o" &
   objs="$objs $obj/$f.o"
 done
