@@ -945,6 +945,7 @@ int cn_dcn_wide_f32s(const float *x, const void *w_packed, const float *bias, co
                      float x_mul, uint32_t *range, int nb, int dbg, float *partial, size_t partial_bytes,
                      int *ksplit_out, hipStream_t st);
 extern int cn_tune_dcn_wide, cn_tune_dcn_wide_wgs;   // cn_dcn4.hip
+extern int cn_tune_stem_stagger, cn_tune_stem_dbg;                         // cn_stem.hip (probe instantiation of the stem + max-pool kernel)
 bool cn_conv3x3s2p_takes(int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch);
 int cn_conv3x3s2_persist(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
                          int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch, int relu,
@@ -1893,6 +1894,14 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 24 && value >= 0 && value <= 3) {
         cn_tune_heads_remap = value;
+        return CN_OK;
+    }
+    if (key == 44 && value >= 0 && value <= 1024) {
+        cn_tune_stem_stagger = value;
+        return CN_OK;
+    }
+    if (key == 43 && value >= 0 && value <= 31) {
+        cn_tune_stem_dbg = value;
         return CN_OK;
     }
     if (key == 41 && (value == 0 || value == 1)) {

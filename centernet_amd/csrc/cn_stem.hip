@@ -18,6 +18,9 @@
 #include "cn_common.h"
 #include <type_traits>
 
+int cn_tune_stem_stagger = 0;   // cn_set_tuning key 44: start delay of the second resident workgroup of the stem + max-pool kernel, units of 256 cycles
+int cn_tune_stem_dbg = 0;   // cn_set_tuning key 43: probe switches of the stem + max-pool kernel (StemArgs.dbg)
+
 namespace {
 
 constexpr int NT = 256;
@@ -33,6 +36,9 @@ struct StemArgs {
     float x_mul;      // f32s kernels: the image is multiplied by this (2^-e) before it is split
     uint32_t *range;  // f32s kernels: [1] receives max |x * x_mul| (cn_f32s_ctl), may be null
     int y_f32s;       // stem + max-pool kernel: y is an f32s tensor (CN_CONV_STEM_Y_F32S), range side 0 = max |y|
+    int stagger;      // stem + max-pool kernel: start delay of workgroups >= 256 (the second occupant of every CU), units of 256 cycles
+    int dbg;          // stem + max-pool kernel, probe instantiation (cn_set_tuning key 43): 1 = no MFMAs, 2 = no window
+                      // stores, 4 = no image loads, 8 = no pooling / output stores, 16 = no barriers
 };
 
 template <int BN>
@@ -405,9 +411,21 @@ __global__ __launch_bounds__(NT) void stem_persist_f32_kernel(const StemArgs a, 
 // weights (and read the next pixel / the zeroed spare row).  A lane's eight kx of a row are
 // eight consecutive fp16 of the window -- 4-byte aligned at stride 2 -- fetched as four
 // ds_read_b32 with immediate offsets.  Output stays plain fp32 (the max-pool reads it).
-constexpr int SKS = 11;            // 16-deep K steps (22 window rows incl. the zero row)
+constexpr int SKS = 11;            // 16-deep K steps (22 (c, kx) groups of 8 incl. the zero group)
 constexpr int SKP = 16 * SKS;      // 176 K values per part
 constexpr int SLDW = SKP + 8;      // fp16 per LDS weight row (368 bytes: conflict-free b128 reads)
+// Round 6: the window is COLUMN-major.  K order: step s, lane half h, element j  <->  group g = 2s + h =
+// (c, kx) = (g / 7, g % 7), ky = j; j = 7 and g = 21 carry zero weights.  A plane holds, per channel and
+// window column, the column's seven ky values + a zero as one 16-byte group: a lane's A fragment of a step
+// is ONE ds_read_b128 per plane (was four ds_read_b32), a staging thread writes its column's channel as
+// ONE ds_write_b128 per plane (was seven ds_write_b16), conversions run on pairs.  Columns are XOR-swizzled
+// (slot = col ^ ((col >> 4) & 1)) so that the 16-lane groups of a ds_read_b128 -- lanes two columns
+// apart at stride 2 -- hit 16 distinct bank groups.  Counters of the row-major form at B = 32: 14.7 VALU
+// instructions per MFMA, matrix pipe 26 % busy (profiles/r05_sq_counters_v3_cfg1.txt).
+constexpr int CM_WXC = 264;                 // window columns per channel (261 carry data)
+constexpr int CM_CH = CM_WXC * 16;          // bytes per channel of a plane
+constexpr int CM_PLANE = 3 * CM_CH;         // 12672 bytes per plane (high / low)
+__device__ __forceinline__ int cm_swz(int col) { return col ^ ((col >> 4) & 1); }
 typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t st_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -420,15 +438,12 @@ __global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a,
     constexpr int TM = BM / WM;
     constexpr int MB = TM / 32;
     constexpr int WX = (BM - 1) * S + PKW;           // 261 columns carry data
-    constexpr int WXH = 262;                          // fp16 per window row: even, = 2 mod 4
-    static_assert(WXH >= WX + 1 && (WXH & 3) == 2, "window pitch");
-    constexpr int PLANE = (PROWS + 1) * WXH;          // + the zero row
+    static_assert(WX <= CM_WXC - 3, "window columns");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16 *winH = reinterpret_cast<_Float16 *>(smem);            // [22][WXH]
-    _Float16 *winL = winH + PLANE;
-    _Float16 *WsH = winL + PLANE + 8;                                // [BN][SLDW], 16-byte aligned
+    char *winH = smem;                                               // [3][CM_WXC][8] fp16: high parts
+    char *winL = smem + CM_PLANE;                                    // low parts
+    _Float16 *WsH = reinterpret_cast<_Float16 *>(smem + 2 * CM_PLANE);   // [BN][SLDW], 16-byte aligned
     _Float16 *WsL = WsH + BN * SLDW;
-    static_assert(((2 * PLANE + 8) * 2) % 16 == 0, "weight tile alignment");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -438,77 +453,103 @@ __global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a,
 
     // ---- once per workgroup: zero both planes (the spare row and column 261 stay zero), and
     // the weights of this N tile, split and permuted into the (step, half, kx) K order
-    for (int i = tid; i < 2 * PLANE; i += NT) winH[i] = (_Float16)0.f;
+    for (int i = tid; i < 2 * CM_PLANE / 4; i += NT) reinterpret_cast<uint32_t *>(smem)[i] = 0u;
     for (int i = tid; i < BN * SKP; i += NT) {
         const int nrow = i / SKP, k = i - nrow * SKP;
         const int st = k >> 4, h = (k >> 3) & 1, j = k & 7;
-        const int r = 2 * st + h;
-        const int c = r / PKH, ky = r - c * PKH;
+        const int r = 2 * st + h;                  // group (c, kx); element j = ky
+        const int c = r / PKW, kx = r - c * PKW;
         const int nn = min(n0 + nrow, a.cout_pad - 1);
         float w = 0.f;
-        if (r < PROWS && j < PKW) w = a.w[(size_t)nn * a.KP + (ky * PKW + j) * 3 + c];
+        if (r < 3 * PKW && j < PKH) w = a.w[(size_t)nn * a.KP + (j * PKW + kx) * 3 + c];
         const _Float16 hi = (_Float16)w;
         WsH[nrow * SLDW + k] = hi;
         WsL[nrow * SLDW + k] = (_Float16)(w - (float)hi);
     }
     __syncthreads();
 
-    const int trow = tid >> 3, tcol = NT + (tid & 7);
-    const bool tail_ok = trow < PROWS && tcol < WX;
-    const bool col_ok = tid < WX;
-    const int tc = trow / PKH, twy = trow - tc * PKH;
+    // staging: thread t owns window column t (all 21 (c, ky) values); columns 256 .. 260 are taken by
+    // threads 128 .. 142 as one (c, column) group of seven rows each
+    constexpr int NTAIL = 3 * (WX - NT);
+    const int tt = tid - 128;
+    const bool tail_thr = tt >= 0 && tt < NTAIL;
+    const int tc = tail_thr ? tt / (WX - NT) : 0, tcol = NT + (tail_thr ? tt % (WX - NT) : 0);
 
-    float v[PROWS], vt;
-    unsigned vmask = 0;
+    float v[PROWS], vt[PKH];
+    unsigned vrow = 0;          // bit u: window row u = (c, ky) lies inside the image (uniform)
+    unsigned vcol = 0, vtcol = 0;   // all ones: this thread's column / tail column lies inside the image
     auto prefetch = [&](int tile) {
         const int xt = tile % tpr;
         const int rowid = tile / tpr;  // b*Ho + oy
         const int b = rowid / a.Ho, oy = rowid - b * a.Ho;
         const int iy_min = oy * S - a.pad, ix_min = xt * BM * S - a.pad;
         const float *xb = a.x + (size_t)b * 3 * a.H * a.W;
-        const int ix = ix_min + tid;
-        const bool cok = col_ok && ix >= 0 && ix < a.W;
+        const int ix = ix_min + tid, jx = ix_min + tcol;
+        const bool cok = ix >= 0 && ix < a.W;
+        const bool tok = tail_thr && jx >= 0 && jx < a.W;
+        const int ixc = cok ? ix : 0, jxc = tok ? jx : 0;
         unsigned mk = 0;
 #pragma unroll
         for (int u = 0; u < PROWS; ++u) {
             const int c = u / PKH, wy = u % PKH;
             const int iy = iy_min + wy;
-            const bool ok = cok && iy >= 0 && iy < a.H;
-            v[u] = xb[ok ? ((size_t)(c * a.H + iy) * a.W + ix) : 0];
-            mk |= ok ? (1u << u) : 0u;
+            const bool rok = iy >= 0 && iy < a.H;            // uniform
+            const float *rowp = xb + (size_t)(c * a.H + (rok ? iy : 0)) * a.W;
+            v[u] = rowp[ixc];
+            mk |= rok ? (1u << u) : 0u;
         }
-        {
-            const int iy = iy_min + twy, jx = ix_min + tcol;
-            const bool ok = tail_ok && iy >= 0 && iy < a.H && jx >= 0 && jx < a.W;
-            vt = xb[ok ? ((size_t)(tc * a.H + iy) * a.W + jx) : 0];
-            mk |= ok ? (1u << PROWS) : 0u;
+        if (tail_thr) {
+#pragma unroll
+            for (int wy = 0; wy < PKH; ++wy) {
+                const int iy = iy_min + wy;
+                const bool rok = iy >= 0 && iy < a.H;
+                vt[wy] = xb[(size_t)(tc * a.H + (rok ? iy : 0)) * a.W + jxc];
+            }
         }
-        vmask = mk;
+        vrow = mk;
+        vcol = cok ? 0xffffffffu : 0u;
+        vtcol = tok ? 0xffffffffu : 0u;
     };
-    float rng_in = 0.f;
-    auto put = [&](int idx, float xr) {
-        const float xs = xr * a.x_mul;
-        cn_rng_upd1_in(rng_in, xs);
-        const float x = __builtin_fminf(__builtin_fmaxf(xs, -65504.0f), 65504.0f);
-        const _Float16 hi = (_Float16)x;
-        winH[idx] = hi;
-        winL[idx] = (_Float16)(x - (float)hi);
+    uint32_t rng_bits = 0;      // max |x| as a bit pattern; a NaN reads above +inf's pattern and stays
+    // one (channel, column) group: seven rows -> (x * x_mul) split into 8 + 8 fp16 (ky = 7: zero), two 16-byte stores
+    auto put7 = [&](int c, int col, const float *src, unsigned cmask, unsigned rowbits) {
+        float x[8];
+#pragma unroll
+        for (int ky = 0; ky < PKH; ++ky) {
+            const uint32_t keep = cmask & (((rowbits >> ky) & 1u) ? 0xffffffffu : 0u);
+            const float xs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, src[ky]) & keep) * a.x_mul;
+            const uint32_t ab = __builtin_bit_cast(uint32_t, xs) & 0x7fffffffu;
+            rng_bits = rng_bits > ab ? rng_bits : ab;
+            x[ky] = __builtin_amdgcn_fmed3f(xs, -65504.0f, 65504.0f);
+        }
+        x[7] = 0.f;
+        st_u32x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t h2, l2;
+            cn_split2_bits(x[2 * e], x[2 * e + 1], h2, l2);
+            hi[e] = h2; lo[e] = l2;
+        }
+        const int off = c * CM_CH + cm_swz(col) * 16;
+        *reinterpret_cast<st_u32x4 *>(winH + off) = hi;
+        *reinterpret_cast<st_u32x4 *>(winL + off) = lo;
     };
     auto store_window = [&]() {
-        if (col_ok) {
 #pragma unroll
-            for (int u = 0; u < PROWS; ++u) put(u * WXH + tid, ((vmask >> u) & 1u) ? v[u] : 0.f);
-        }
-        if (tail_ok) put(trow * WXH + tcol, ((vmask >> PROWS) & 1u) ? vt : 0.f);
+        for (int c = 0; c < 3; ++c) put7(c, tid, v + c * PKH, vcol, vrow >> (c * PKH));
+        if (tail_thr) put7(tc, tcol, vt, vtcol, vrow >> (tc * PKH));
     };
 
-    // 32-bit views: a lane's 8 kx of a window row are words (2*pixel + 0..3) of the row
-    const uint32_t *aH[MB], *aL[MB];
+    // A fragment of step st, block i: group g = 2 st + lh = (c, kx), this lane's pixel's window column
+    // 2 * pixel + kx -- one 16-byte read per plane; the byte offsets do not depend on the tile
+    int aoff[SKS][MB];
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        const int off = (wm * TM + i * 32 + l31) * S + lh * WXH;   // fp16 index: even
-        aH[i] = reinterpret_cast<const uint32_t *>(winH + off);
-        aL[i] = reinterpret_cast<const uint32_t *>(winL + off);
+    for (int st = 0; st < SKS; ++st) {
+        const int g = min(2 * st + lh, 3 * PKW - 1);      // group 21 has zero weights: any valid address
+        const int c = g / PKW, kx = g - c * PKW;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+            aoff[st][i] = c * CM_CH + cm_swz((wm * TM + i * 32 + l31) * S + kx) * 16;
     }
     const _Float16 *wH = WsH + (wn * 32 + l31) * SLDW + 8 * lh;
     const _Float16 *wL = WsL + (wn * 32 + l31) * SLDW + 8 * lh;
@@ -535,14 +576,11 @@ __global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a,
         st_u32x4 fa[2][2][MB];      // [set][hi / lo][block]
         st_f16x8 fb[2][2];          // [set][hi / lo]
         auto load_step = [&](int set, int st) {
-            constexpr int RW = WXH / 2;   // words per window row
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    fa[set][0][i][j] = aH[i][2 * st * RW + j];
-                    fa[set][1][i][j] = aL[i][2 * st * RW + j];
-                }
+            for (int i = 0; i < MB; ++i) {
+                fa[set][0][i] = *reinterpret_cast<const st_u32x4 *>(winH + aoff[st][i]);
+                fa[set][1][i] = *reinterpret_cast<const st_u32x4 *>(winL + aoff[st][i]);
+            }
             fb[set][0] = *reinterpret_cast<const st_f16x8 *>(wH + 16 * st);
             fb[set][1] = *reinterpret_cast<const st_f16x8 *>(wL + 16 * st);
         };
@@ -585,7 +623,7 @@ __global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a,
         }
         __syncthreads();  // every wave is done reading the window
     }
-    if (a.range) cn_rng_commit(a.range, 1, rng_in);
+    if (a.range) cn_rng_commit(a.range, 1, rng_bits > 0x7f800000u ? __builtin_inff() : __builtin_bit_cast(float, rng_bits));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -602,19 +640,25 @@ __global__ __launch_bounds__(NT) void stem_persist_f32s_kernel(const StemArgs a,
 //     joins it, an odd row 2p+1 completes pooled row p -- which is stored -- and starts p+1.
 // The strip's first row (2*p0 - 1) is computed only to start the running maximum: one extra row
 // per 2R (6 % at R = 8).  max() is exact, so the result equals stem -> max-pool bit for bit.
-template <int TPR>
+template <int TPR, bool DBG>
 __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, int nstrips, int R)
 {
+    const int dbg = DBG ? (a.dbg & 255) : 0;
+    if (a.stagger && blockIdx.x >= 256u) {
+        // two workgroups share a CU and walk identical strips: started together they sit in their MFMA
+        // loops -- and in their staging / pooling phases -- at the same time and nothing overlaps.  One-off
+        // phase shift of the second occupant.
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)a.stagger * 256u) __builtin_amdgcn_s_sleep(32);
+    }
     constexpr int BN = 64;
     constexpr int S = 2;
     constexpr int WN = 2, WM = 2, TM = BM / WM, MB = TM / 32;
     constexpr int WX = (BM - 1) * S + PKW;
-    constexpr int WXH = 262;
-    constexpr int PLANE = (PROWS + 1) * WXH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16 *winH = reinterpret_cast<_Float16 *>(smem);
-    _Float16 *winL = winH + PLANE;
-    _Float16 *WsH = winL + PLANE + 8;
+    char *winH = smem;                                               // column-major planes, see stem_persist_f32s_kernel
+    char *winL = smem + CM_PLANE;
+    _Float16 *WsH = reinterpret_cast<_Float16 *>(smem + 2 * CM_PLANE);
     _Float16 *WsL = WsH + BN * SLDW;
     float *bnd = reinterpret_cast<float *>(WsL + BN * SLDW);   // [2 parity][2 wm][64]
 
@@ -625,73 +669,101 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
     const int spi = PH / R;                  // strips per image
     const float NEG_INF = -__builtin_huge_valf();
 
-    for (int i = tid; i < 2 * PLANE; i += NT) winH[i] = (_Float16)0.f;
+    for (int i = tid; i < 2 * CM_PLANE / 4; i += NT) reinterpret_cast<uint32_t *>(smem)[i] = 0u;
     for (int i = tid; i < BN * SKP; i += NT) {
         const int nrow = i / SKP, k = i - nrow * SKP;
         const int st = k >> 4, h = (k >> 3) & 1, j = k & 7;
-        const int r = 2 * st + h;
-        const int c = r / PKH, ky = r - c * PKH;
+        const int r = 2 * st + h;                  // group (c, kx); element j = ky
+        const int c = r / PKW, kx = r - c * PKW;
         const int nn = min(nrow, a.cout_pad - 1);
         float w = 0.f;
-        if (r < PROWS && j < PKW) w = a.w[(size_t)nn * a.KP + (ky * PKW + j) * 3 + c];
+        if (r < 3 * PKW && j < PKH) w = a.w[(size_t)nn * a.KP + (j * PKW + kx) * 3 + c];
         const _Float16 hi = (_Float16)w;
         WsH[nrow * SLDW + k] = hi;
         WsL[nrow * SLDW + k] = (_Float16)(w - (float)hi);
     }
     __syncthreads();
 
-    const int trow = tid >> 3, tcol = NT + (tid & 7);
-    const bool tail_ok = trow < PROWS && tcol < WX;
-    const bool col_ok = tid < WX;
-    const int tc = trow / PKH, twy = trow - tc * PKH;
+    // staging: thread t owns window column t (all 21 (c, ky) values); columns 256 .. 260 are taken by
+    // threads 128 .. 142 as one (c, column) group of seven rows each
+    constexpr int NTAIL = 3 * (WX - NT);
+    const int tt = tid - 128;
+    const bool tail_thr = tt >= 0 && tt < NTAIL;
+    const int tc = tail_thr ? tt / (WX - NT) : 0, tcol = NT + (tail_thr ? tt % (WX - NT) : 0);
 
-    float v[PROWS], vt;
-    unsigned vmask = 0;
+    float v[PROWS], vt[PKH];
+    unsigned vrow = 0;          // bit u: window row u = (c, ky) lies inside the image (uniform)
+    unsigned vcol = 0, vtcol = 0;   // all ones: this thread's column / tail column lies inside the image
     auto prefetch = [&](int b, int oy, int xt) {
         const int iy_min = oy * S - a.pad, ix_min = xt * BM * S - a.pad;
         const float *xb = a.x + (size_t)b * 3 * a.H * a.W;
-        const int ix = ix_min + tid;
-        const bool cok = col_ok && ix >= 0 && ix < a.W;
+        const int ix = ix_min + tid, jx = ix_min + tcol;
+        const bool cok = ix >= 0 && ix < a.W;
+        const bool tok = tail_thr && jx >= 0 && jx < a.W;
+        const int ixc = cok ? ix : 0, jxc = tok ? jx : 0;
         unsigned mk = 0;
 #pragma unroll
         for (int u = 0; u < PROWS; ++u) {
             const int c = u / PKH, wy = u % PKH;
             const int iy = iy_min + wy;
-            const bool ok = cok && iy >= 0 && iy < a.H;
-            v[u] = xb[ok ? ((size_t)(c * a.H + iy) * a.W + ix) : 0];
-            mk |= ok ? (1u << u) : 0u;
+            const bool rok = iy >= 0 && iy < a.H;            // uniform
+            const float *rowp = xb + (size_t)(c * a.H + (rok ? iy : 0)) * a.W;
+            v[u] = rowp[ixc];
+            mk |= rok ? (1u << u) : 0u;
         }
-        {
-            const int iy = iy_min + twy, jx = ix_min + tcol;
-            const bool ok = tail_ok && iy >= 0 && iy < a.H && jx >= 0 && jx < a.W;
-            vt = xb[ok ? ((size_t)(tc * a.H + iy) * a.W + jx) : 0];
-            mk |= ok ? (1u << PROWS) : 0u;
+        if (tail_thr) {
+#pragma unroll
+            for (int wy = 0; wy < PKH; ++wy) {
+                const int iy = iy_min + wy;
+                const bool rok = iy >= 0 && iy < a.H;
+                vt[wy] = xb[(size_t)(tc * a.H + (rok ? iy : 0)) * a.W + jxc];
+            }
         }
-        vmask = mk;
+        vrow = mk;
+        vcol = cok ? 0xffffffffu : 0u;
+        vtcol = tok ? 0xffffffffu : 0u;
     };
-    float rng_in = 0.f, rng_out = 0.f;
-    auto put = [&](int idx, float xr) {
-        const float xs = xr * a.x_mul;
-        cn_rng_upd1_in(rng_in, xs);
-        const float x = __builtin_fminf(__builtin_fmaxf(xs, -65504.0f), 65504.0f);
-        const _Float16 hi = (_Float16)x;
-        winH[idx] = hi;
-        winL[idx] = (_Float16)(x - (float)hi);
+    uint32_t rng_bits = 0;      // max |x| as a bit pattern; a NaN reads above +inf's pattern and stays
+    float rng_out = 0.f;
+    // one (channel, column) group: seven rows -> (x * x_mul) split into 8 + 8 fp16 (ky = 7: zero), two 16-byte stores
+    auto put7 = [&](int c, int col, const float *src, unsigned cmask, unsigned rowbits) {
+        float x[8];
+#pragma unroll
+        for (int ky = 0; ky < PKH; ++ky) {
+            const uint32_t keep = cmask & (((rowbits >> ky) & 1u) ? 0xffffffffu : 0u);
+            const float xs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, src[ky]) & keep) * a.x_mul;
+            const uint32_t ab = __builtin_bit_cast(uint32_t, xs) & 0x7fffffffu;
+            rng_bits = rng_bits > ab ? rng_bits : ab;
+            x[ky] = __builtin_amdgcn_fmed3f(xs, -65504.0f, 65504.0f);
+        }
+        x[7] = 0.f;
+        st_u32x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t h2, l2;
+            cn_split2_bits(x[2 * e], x[2 * e + 1], h2, l2);
+            hi[e] = h2; lo[e] = l2;
+        }
+        const int off = c * CM_CH + cm_swz(col) * 16;
+        *reinterpret_cast<st_u32x4 *>(winH + off) = hi;
+        *reinterpret_cast<st_u32x4 *>(winL + off) = lo;
     };
     auto store_window = [&]() {
-        if (col_ok) {
 #pragma unroll
-            for (int u = 0; u < PROWS; ++u) put(u * WXH + tid, ((vmask >> u) & 1u) ? v[u] : 0.f);
-        }
-        if (tail_ok) put(trow * WXH + tcol, ((vmask >> PROWS) & 1u) ? vt : 0.f);
+        for (int c = 0; c < 3; ++c) put7(c, tid, v + c * PKH, vcol, vrow >> (c * PKH));
+        if (tail_thr) put7(tc, tcol, vt, vtcol, vrow >> (tc * PKH));
     };
 
-    const uint32_t *aH[MB], *aL[MB];
+    // A fragment of step st, block i: group g = 2 st + lh = (c, kx), this lane's pixel's window column
+    // 2 * pixel + kx -- one 16-byte read per plane; the byte offsets do not depend on the tile
+    int aoff[SKS][MB];
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        const int off = (wm * TM + i * 32 + l31) * S + lh * WXH;
-        aH[i] = reinterpret_cast<const uint32_t *>(winH + off);
-        aL[i] = reinterpret_cast<const uint32_t *>(winL + off);
+    for (int st = 0; st < SKS; ++st) {
+        const int g = min(2 * st + lh, 3 * PKW - 1);      // group 21 has zero weights: any valid address
+        const int c = g / PKW, kx = g - c * PKW;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+            aoff[st][i] = c * CM_CH + cm_swz((wm * TM + i * 32 + l31) * S + kx) * 16;
     }
     const _Float16 *wH = WsH + (wn * 32 + l31) * SLDW + 8 * lh;
     const _Float16 *wL = WsL + (wn * 32 + l31) * SLDW + 8 * lh;
@@ -717,14 +789,14 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
 #pragma unroll
                 for (int e = 0; e < 8 * MB; ++e) cur[t][e] = NEG_INF;
         }
-        store_window();
-        __syncthreads();  // window visible
+        if (!(dbg & 2)) store_window();
+        if (!(dbg & 16)) __syncthreads();  // window visible
         // the tile after this one (possibly the first of the next strip): in flight during the MFMAs
         int ns = s, ny = y, ncb = cb + 1;
         if (ncb == TPR) { ncb = 0; ny = y + 1; }
         if (ny > ylast) { ns = s + gridDim.x; ny = ns < nstrips ? first_row(ns) : 0; }
         const bool more = ns < nstrips;
-        if (more) prefetch(ns / spi, ny, ncb);
+        if (more && !(dbg & 4)) prefetch(ns / spi, ny, ncb);
 
         cn_f32x16 acc[MB];
 #pragma unroll
@@ -734,20 +806,18 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
         st_u32x4 fa[2][2][MB];
         st_f16x8 fb[2][2];
         auto load_step = [&](int set, int st) {
-            constexpr int RW = WXH / 2;
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    fa[set][0][i][j] = aH[i][2 * st * RW + j];
-                    fa[set][1][i][j] = aL[i][2 * st * RW + j];
-                }
+            for (int i = 0; i < MB; ++i) {
+                fa[set][0][i] = *reinterpret_cast<const st_u32x4 *>(winH + aoff[st][i]);
+                fa[set][1][i] = *reinterpret_cast<const st_u32x4 *>(winL + aoff[st][i]);
+            }
             fb[set][0] = *reinterpret_cast<const st_f16x8 *>(wH + 16 * st);
             fb[set][1] = *reinterpret_cast<const st_f16x8 *>(wL + 16 * st);
         };
-        load_step(0, 0);
+        if (!(dbg & 1)) load_step(0, 0);
 #pragma unroll
         for (int st = 0; st < SKS; ++st) {
+            if (dbg & 1) break;
             const int cs = st & 1;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -777,7 +847,13 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
             }
         // this wave pair's last pixel (63 / 127) goes to the LDS line of this tile's parity
         if (lh == 1) bnd[(par * 2 + wm) * BN + n] = acc[MB - 1][15];
-        __syncthreads();   // also: every wave is done reading the window
+        if (!(dbg & 16)) __syncthreads();   // also: every wave is done reading the window
+        if (dbg & 8) {
+            if (!more) break;
+            par ^= 1;
+            s = ns; y = ny; cb = ncb;
+            continue;
+        }
         float lastp[MB][4];   // the partner lane's pixel 4g' + 3 of every group it holds
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -806,54 +882,94 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
             if (odd && y > first_row(s)) {
                 // completes pooled row (y - 1) / 2
                 const int pr = (y - 1) >> 1;
-                float *yb = a.y + ((size_t)(b * PH + pr) * PW + (size_t)cb * (BM / 2)) * a.out_pitch + n;
+                if (a.y_f32s) {
+                    // f32s output: a pooled pixel's 32 channels are one 128-byte group (32 high halves, 32 low
+                    // halves) and a lane holds ONE channel of 16 pooled pixels -- 2-byte stores and a 64-bit address
+                    // per value were the largest item of this kernel (probe: 55 of 205 us).  The wave's 32 pixels x
+                    // 128 bytes go through a wave-private LDS strip instead -- four 1 KiB chunks of the window
+                    // columns this wave itself stages (the window is dead behind the barrier above; no other
+                    // wave writes them) -- and leave as 16-byte stores of whole groups.
+                    const uint32_t nkeep = n < a.Cout ? 0xffffffffu : 0u;
+                    char *strip[4] = {winH + wave * 1024, winH + CM_CH + wave * 1024, winH + 2 * CM_CH + wave * 1024,
+                                      winL + wave * 1024};
 #pragma unroll
-                for (int i = 0; i < MB; ++i)
+                    for (int i = 0; i < MB; ++i)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int h2 = 0; h2 < 2; ++h2) {
-                            const int pc = 2 * (2 * q + lh + 8 * i + 16 * wm) + h2;
-                            if (n < a.Cout) {
-                                const float v = fmaxf(cur[t][(i * 4 + q) * 2 + h2], hp[i][q][h2]);
-                                if (a.y_f32s) {   // (high, low) halves of channel n: 32 lanes = 64 contiguous bytes each
-                                    cn_rng_upd1(rng_out, v);
-                                    cn_store1_f32s(a.y, (size_t)(b * PH + pr) * PW + (size_t)cb * (BM / 2) + pc,
-                                                   a.out_pitch, n, v);
-                                } else {
-                                    yb[(size_t)pc * a.out_pitch] = v;
-                                }
-                            }
+                        for (int q = 0; q < 4; ++q) {
+                            float v0 = fmaxf(cur[t][(i * 4 + q) * 2], hp[i][q][0]);
+                            float v1 = fmaxf(cur[t][(i * 4 + q) * 2 + 1], hp[i][q][1]);
+                            cn_rng_upd1(rng_out, v0);
+                            cn_rng_upd1(rng_out, v1);
+                            uint32_t hb, lb;
+                            cn_split2_bits(__builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f),
+                                           __builtin_amdgcn_fmed3f(v1, -65504.0f, 65504.0f), hb, lb);
+                            hb &= nkeep;             // pad channels of the last group: zero
+                            lb &= nkeep;
+                            // local pooled pixel 16 i + 4 q + 2 lh + h2: chunk 2 i + (q >> 1), row 4 (q & 1) + 2 lh + h2
+                            char *dst = strip[2 * i + (q >> 1)] + (4 * (q & 1) + 2 * lh) * 128 + l31 * 2;
+                            *reinterpret_cast<uint16_t *>(dst) = (uint16_t)hb;
+                            *reinterpret_cast<uint16_t *>(dst + 64) = (uint16_t)lb;
+                            *reinterpret_cast<uint16_t *>(dst + 128) = (uint16_t)(hb >> 16);
+                            *reinterpret_cast<uint16_t *>(dst + 192) = (uint16_t)(lb >> 16);
                         }
-            }
+                    // LDS operations of one wave complete in order: the reads below see the writes above
+                    const size_t pitchB = (size_t)a.out_pitch * 4;
+                    char *rowp = reinterpret_cast<char *>(a.y) + ((size_t)(b * PH + pr) * PW + (size_t)cb * (BM / 2)) * pitchB;
+                    const unsigned lane_off = (unsigned)(32 * wm + (lane >> 3)) * (unsigned)pitchB + (unsigned)wn * 128u + (unsigned)(lane & 7) * 16u;
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const int e = (i * 4 + q) * 2 + h2;
-                        cur[t][e] = odd ? hp[i][q][h2] : fmaxf(cur[t][e], hp[i][q][h2]);
+                    for (int k = 0; k < 4; ++k) {
+                        const st_u32x4 g = *reinterpret_cast<const st_u32x4 *>(strip[k] + lane * 16);
+                        *reinterpret_cast<st_u32x4 *>(rowp + lane_off + (unsigned)(8 * k) * (unsigned)pitchB) = g;
                     }
+                } else {
+                    float *yb = a.y + ((size_t)(b * PH + pr) * PW + (size_t)cb * (BM / 2)) * a.out_pitch + n;
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const int pc = 2 * (2 * q + lh + 8 * i + 16 * wm) + h2;
+                                if (n < a.Cout) yb[(size_t)pc * a.out_pitch] = fmaxf(cur[t][(i * 4 + q) * 2 + h2], hp[i][q][h2]);
+                            }
+                }
+            }
+            if (odd) {      // uniform: a branch, not sixteen selects
+#pragma unroll
+                for (int e = 0; e < 8 * MB; ++e) cur[t][e] = hp[e >> 3][(e >> 1) & 3][e & 1];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8 * MB; ++e) cur[t][e] = fmaxf(cur[t][e], hp[e >> 3][(e >> 1) & 3][e & 1]);
+            }
         }
         if (!more) break;
         par ^= 1;
         s = ns; y = ny; cb = ncb;
     }
     if (a.range) {
-        cn_rng_commit(a.range, 1, rng_in);
+        cn_rng_commit(a.range, 1, rng_bits > 0x7f800000u ? __builtin_inff() : __builtin_bit_cast(float, rng_bits));
         if (a.y_f32s) cn_rng_commit(a.range, 0, rng_out);
     }
 }
 
 template <int TPR>
-int launch_stem_pool_f32s(const StemArgs &a, int B, int R, hipStream_t st)
+int launch_stem_pool_f32s(const StemArgs &a0, int B, int R, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)(2 * (PROWS + 1) * 262 + 8 + 2 * 64 * SLDW) * 2 + 2 * 2 * 64 * 4;
+    constexpr size_t lds = (size_t)2 * CM_PLANE + (size_t)2 * 64 * SLDW * 2 + 2 * 2 * 64 * 4;
+    StemArgs a = a0;
+    a.dbg = cn_tune_stem_dbg & 255;
+    a.stagger = cn_tune_stem_stagger;
     const int nstrips = B * (a.Ho / 2 / R);
-    const int wgs = nstrips < 512 ? nstrips : 512;  // two resident workgroups per CU
-    CN_SET_MAX_LDS_ONCE((stem_pool_f32s_kernel<TPR>), lds);
-    hipLaunchKernelGGL((stem_pool_f32s_kernel<TPR>), dim3(wgs), dim3(NT), lds, st, a, nstrips, R);
+    int wgs = nstrips < 512 ? nstrips : 512;  // two resident workgroups per CU
+    if (a.stagger == 1000) { wgs = nstrips < 256 ? nstrips : 256; a.stagger = 0; }   // probe: one workgroup per CU
+    if (a.stagger == 1001) { wgs = nstrips < 768 ? nstrips : 768; a.stagger = 0; }
+    if (a.dbg) {
+        CN_SET_MAX_LDS_ONCE((stem_pool_f32s_kernel<TPR, true>), lds);
+        hipLaunchKernelGGL((stem_pool_f32s_kernel<TPR, true>), dim3(wgs), dim3(NT), lds, st, a, nstrips, R);
+    } else {
+        CN_SET_MAX_LDS_ONCE((stem_pool_f32s_kernel<TPR, false>), lds);
+        hipLaunchKernelGGL((stem_pool_f32s_kernel<TPR, false>), dim3(wgs), dim3(NT), lds, st, a, nstrips, R);
+    }
     CN_CHECK_LAUNCH();
     return CN_OK;
 }
@@ -861,7 +977,7 @@ int launch_stem_pool_f32s(const StemArgs &a, int B, int R, hipStream_t st)
 template <int BN>
 int launch_stem_persist_f32s(const StemArgs &a, int B, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)(2 * (PROWS + 1) * 262 + 8 + 2 * BN * SLDW) * 2;
+    constexpr size_t lds = (size_t)2 * CM_PLANE + (size_t)2 * BN * SLDW * 2;
     const long total = (long)B * a.tiles_per_image;
     const int wgs = (int)(total < 512 ? total : 512);  // two resident workgroups per CU
     dim3 grid(wgs, cn_cdiv(a.Cout, BN));
