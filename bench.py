@@ -46,10 +46,42 @@ CONFIGS = {
 }
 
 
-def pmc_traffic(tag):
+def device_identity(index, stub=False):
+    """What a rank says about the device it runs on: used to prove that N ranks sit on N GPUs."""
+    if stub:
+        # BENCH_FAKE_UUID: the shared-device refusal under test on a host without GPUs (tests/test_sharding.py)
+        return {"rank": int(os.environ.get("RANK", "0")), "device": "cpu",
+                "uuid": os.environ.get("BENCH_FAKE_UUID") or "cpu-%d" % os.getpid(), "name": "stub"}
+    import torch
+    pr = torch.cuda.get_device_properties(index)
+    uuid = getattr(pr, "uuid", None)
+    uuid = str(uuid) if uuid is not None else "%s/%s" % (getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", index))
+    return {"rank": int(os.environ.get("RANK", "0")), "device": "cuda:%d" % index, "uuid": uuid,
+            "name": pr.name, "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+
+
+def kernel_tree_sha():
+    """Fingerprint of everything a launch list depends on: the HIP sources, the C ABI header and the planner.
+    (.git does not travel to the GPU box, so a commit hash cannot be read there; this digest is what
+    tools/pmc_traffic.py records as a profile's `head` and what a run compares itself with.)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "centernet_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "centernet_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "centernet_amd.h"), os.path.join(ROOT, "centernet_amd", "engine.py")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(tag, check_head=True):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary of this
     configuration (tools/pmc_traffic.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), summed
-    per kernel class; {} when no profile of this configuration is committed."""
+    per kernel class; {} when no profile of this configuration is committed.  A profile whose recorded
+    `head` (kernel_tree_sha at the time it was taken) differs from the running tree is REFUSED:
+    {"_stale": (its head, this tree's)} -- the caller reports traffic null."""
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % tag)))
     if not hits and tag == "cfg1":
         hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
@@ -57,6 +89,10 @@ def pmc_traffic(tag):
         return {}, None
     with open(hits[-1]) as f:
         raw = json.load(f)
+    # a profile taken on OTHER kernels says nothing about this run's traffic: refuse it (traffic: null)
+    head = (raw.get("_meta") or {}).get("head")
+    if check_head and head != kernel_tree_sha():
+        return {"_stale": (head, kernel_tree_sha())}, os.path.basename(hits[-1])
     cls = {"conv": 0.0, "dcn": 0.0, "decode": 0.0, "maxpool": 0.0}
     n = {"conv": 0, "dcn": 0, "decode": 0, "maxpool": 0}
     def short(name):
@@ -94,7 +130,7 @@ def pmc_traffic(tag):
         base, targs = short(k)
         if base == "igemm_kernel":
             c = "dcn" if len(targs) > 4 and targs[4] in (2, 3) else "conv"   # AMODE
-        elif base.startswith(("dcn_reg_kernel", "dcn_win_kernel", "dcn_team_kernel")):   # LDS-window forms (cn_dcn2 / cn_dcn3.hip)
+        elif base.startswith(("dcn_reg_kernel", "dcn_win_kernel", "dcn_team_kernel", "dcn_wide_kernel")):   # LDS-window forms (cn_dcn2 / 3 / 4.hip)
             c = "dcn"
         elif base.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_", "offconv_kernel")):
             c = "conv"
@@ -178,7 +214,7 @@ def parse(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-fp32-leg", action="store_true",
                    help="skip the short fp32-MFMA leg that is reported next to the f32s headline")
-    p.add_argument("--cpu-seconds", type=float, default=15.0,
+    p.add_argument("--cpu-seconds", type=float, default=5.0,
                    help="bound of the CPU-baseline sample (seconds of CPU work)")
     p.add_argument("--per-op", action="store_true", help="print per-launch timings to stderr")
     p.add_argument("--no-secondary", action="store_true",
@@ -336,7 +372,11 @@ def cpu_baseline(task, arch, state_dict, heads, res, seconds):
     rec = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference_res18.json")))
     if rec:
         with open(rec[-1]) as f:
-            out["reference_res18_recorded"] = dict(json.load(f), file="profiles/" + os.path.basename(rec[-1]))
+            out["reference_res18_recorded"] = dict(
+                json.load(f), file="profiles/" + os.path.basename(rec[-1]), replay=True,
+                replay_note="NOT timed in this run: the record of an earlier run in the build container, where "
+                            "/root/reference exists (it does not on the GPU box); `reference_res18`, when present, IS "
+                            "this run's timing of the same code")
     ref_src = "/root/reference/src/lib"
     if os.path.isdir(ref_src):
         try:
@@ -564,6 +604,19 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s); launch with "
                          "`python bench.py --gpus N` (self-spawning) or torchrun --nproc-per-node N"
                          % (a.gpus, world))
+    # first contact with a multi-GPU node must not be able to pass silently on ONE device: every rank
+    # reports the device it really sits on, rank 0 refuses a world in which two ranks share one
+    rank_devices = None
+    if dist is not None:
+        mine = device_identity(dev_index, stub)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
+        ids = [d["uuid"] for d in rank_devices]
+        if len(set(ids)) != len(ids) and os.environ.get("BENCH_ALLOW_SHARED_DEVICE") != "1":
+            dist.destroy_process_group()
+            raise SystemExit("bench.py: %d ranks but only %d distinct devices %r -- two ranks share a GPU "
+                             "(check LOCAL_RANK / HIP_VISIBLE_DEVICES); refusing to report a scaling number"
+                             % (world, len(set(ids)), ids))
 
     from centernet_amd import synth, native
     for kv in a.tune:
@@ -785,6 +838,7 @@ def main():
         standard = (a.res == 512 and not a.tune and not a.fp32_mfma and
                     all(getattr(a, k) == v for k, v in CONFIGS[a.config].items()))
         pmc, pmc_file = pmc_traffic("cfg%d" % a.config) if standard else ({}, None)
+        pmc_stale = pmc.pop("_stale", None)
 
         def traffic(k):
             # measured HBM bytes per launch of this kernel class (committed PMC profile of the
@@ -841,6 +895,8 @@ def main():
                        "global_batch": B * world, "parallelism": "image-sharded x%d" % world,
                        "gflop_per_image": plan.flops / B / 1e9},
             "world_size_seen": world,
+            "rccl_ranks_seen": world if (dist is not None and backend == "nccl") else None,
+            "rank_devices": rank_devices,
             "backend": ("%s (RCCL over xGMI)" % backend if backend == "nccl" else backend) if dist is not None else None,
             "weight_broadcast_bytes": bcast_bytes, "weight_broadcast_ms": bcast_ms,
             "per_rank_img_s": per_rank_rate, "cross_rank_agreement": agreement,
@@ -859,7 +915,12 @@ def main():
                 F16_MFMA_PEAK_TF if a.fp16 else (F32_MFMA_PEAK_TF if a.fp32_mfma else F32S_MFMA_PEAK_TF),
                 a.config),
             "pmc_profile": pmc_file,
+            "pmc_profile_head": None if pmc_file is None else (pmc_stale[0] if pmc_stale else kernel_tree_sha()),
+            "kernel_tree_head": kernel_tree_sha(),
+            "pmc_profile_stale": bool(pmc_stale),
             "traffic_source": None if pmc_file is None else
+            ("REFUSED: profiles/%s was taken on kernel sources %s, this run is %s -- traffic is null until the "
+             "PMC passes are re-taken (tools/profile_round.sh)" % (pmc_file, pmc_stale[0], pmc_stale[1])) if pmc_stale else
             "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/%s "
             "(counters cannot be read from inside the run)" % pmc_file,
             "precision_check": precision_check(dev) if not (a.fp16 or stub) else None,
@@ -872,6 +933,27 @@ def main():
             "time_share": {k: round(v["ms"] / (dt * 1e3), 4) for k, v in kinds.items()},
         }
         if world == 1 and standard and a.config == 1 and not a.no_secondary and not stub:
+            # the reference's own operating point -- ONE image per step (src/test.py:60-62, MODEL_ZOO: 7 ms on a
+            # TITAN Xp for this network) -- on the headline's detector: det.run_batch on a batch of one, the same
+            # entry point, no markers inside the loop
+            try:
+                one = synth.images(1, a.res, a.res, seed=7).to(dev)
+                for _ in range(10):
+                    det.run_batch(one)
+                torch.cuda.synchronize()
+                assert det.range_ok(one), "f32s range check failed at batch 1"
+                n1 = 100
+                t1 = time.perf_counter()
+                for _ in range(n1):
+                    det.run_batch(one)
+                ok1 = det.range_ok()
+                torch.cuda.synchronize()
+                b1 = (time.perf_counter() - t1) / n1 * 1e3
+                res["batch_1"] = {"b1_ms_per_step": b1, "img_s": 1e3 / b1, "steps": n1, "range_clean": bool(ok1),
+                                  "what": "network + decode for ONE 512x512 image per step (device-resident input), "
+                                          "launches per step %d" % (len(det.model.plan_for(1, a.res, a.res, dev).b.ops) + 1)}
+            except Exception as e:
+                res["batch_1"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             # BASELINE configs[2..4], a few steps each, behind the headline loop (never inside it)
             sec = {}
             for cid in (2, 3, 4):

@@ -230,7 +230,7 @@ bool cn_offconv_takes(int B, int H, int W, int Cin, int Cout, int in_pitch, int 
     if (!cn_tune_offconv) return false;
     if (Cout > 32 || Cout < 1 || (Cin & 31) || in_pitch != Cin) return false;
     if ((H & 7) || (W & 15)) return false;
-    if (out_pitch < 32 || (out_pitch & 3)) return false;       // whole 16-byte groups of the 32-channel block
+    if (out_pitch != 32) return false;     // the epilogue stores the whole 32-channel block (zeros behind Cout): the output must own it
     if ((size_t)B * H * W * Cin * 4 >= ((size_t)1 << 32)) return false;
     if (ksplit < 1 || (Cin / 32) % ksplit) return false;
     return true;

@@ -670,6 +670,7 @@ __global__ __launch_bounds__(NT) void stem_pool_f32s_kernel(const StemArgs a, in
     const float NEG_INF = -__builtin_huge_valf();
 
     for (int i = tid; i < 2 * CM_PLANE / 4; i += NT) reinterpret_cast<uint32_t *>(smem)[i] = 0u;
+    if (!(dbg & 1 && dbg & 2 && dbg & 4 && dbg & 8 && dbg & 16))
     for (int i = tid; i < BN * SKP; i += NT) {
         const int nrow = i / SKP, k = i - nrow * SKP;
         const int st = k >> 4, h = (k >> 3) & 1, j = k & 7;

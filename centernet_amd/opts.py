@@ -91,6 +91,12 @@ class opts(object):
     def parse(self, args=''):
         # opts.py:227-282
         opt = self.parser.parse_args() if args == '' else self.parser.parse_args(args)
+        # exdet scores K^4 groupings per image; the kernel takes K <= 64 and ExtremeNet's own setting is 40.  A
+        # command line that does not pass --K (the reference default of 100) runs at 40 instead of failing.
+        import sys as _sys
+        argv = _sys.argv[1:] if args == '' else list(args)
+        if opt.task == 'exdet' and not any(a == '--K' or str(a).startswith('--K=') for a in argv):
+            opt.K = 40
         opt.gpus_str = opt.gpus
         opt.gpus = [int(g) for g in opt.gpus.split(',')]
         opt.gpus = [i for i in range(len(opt.gpus))] if opt.gpus[0] >= 0 else [-1]

@@ -79,7 +79,12 @@ int cn_version(void);
 const char *cn_status_string(int status);
 /* Architecture the device code was compiled for ("gfx950"). */
 const char *cn_arch(void);
-/* Kernel-selection knobs for benchmarking (process-wide; not needed for correctness).
+/* Kernel-selection knobs for benchmarking (not needed for correctness).
+ * THREADING: the knobs are plain process-global integers read by every launch.  cn_set_tuning is NOT
+ * thread-safe against concurrent launches: the "thread-safe per stream" rule of the entry points holds only
+ * while nobody calls cn_set_tuning.  Set knobs once, before the first launch (as bench.py --tune does), or
+ * with all streams of the process idle; a value changed under a running launch list gives a mix of forms
+ * (every form computes the same function, so results stay valid, timings do not).
  * key 1: LDS tile buffers of the dense implicit-GEMM kernels, 0 = default, 1 or 2.
  * key 2: 1 = never pick 64-wide N tiles for Cout > 64 (default 0 = pick them when they
  *        avoid a half-empty 128-wide tile).
@@ -130,7 +135,14 @@ const char *cn_arch(void);
  *         (default), 0 = staged through LDS; 2 = 128-wide slices (register-bound, A/B only),
  *         3 = the register form for 64-wide hidden layers too (slower there, A/B only).
  * key 24: fused heads: 1 = 1-D grid with the heads of a pixel tile dispatched together on one XCD
- *         (default), 0 = one grid row per head. */
+ *         (default), 0 = one grid row per head.
+ * key 23 (round 5 / 6 values): 4 / 5 = the team form (cn_dcn3.hip) in T / N mode, 6 / 7 = the wide form
+ *         (cn_dcn4.hip: a workgroup owns ALL output channels of its tile; 7 = four blocks per workgroup)
+ *         for every shape they take.
+ * key 41: 1 = layers with Cout % 128 == 0 take the wide deformable form (default), 0 = the team form.
+ * key 42: wide form: K split until a launch has this many workgroups (default 256).
+ * key 43 / 44: stem + max-pool kernel: probe switches of its instrumented instantiation / start delay of
+ *         the second resident workgroup (measurement only; defaults 0). */
 int cn_set_tuning(int key, int value);
 
 

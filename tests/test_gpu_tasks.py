@@ -205,7 +205,8 @@ def test_exdet_detector_matches_the_oracle_pipeline(dev):
     from centernet_amd.opts import opts
     from centernet_amd.detectors import detector_factory
     with pytest.raises(ValueError):
-        detector_factory["exdet"](opts().init(["exdet", "--arch", "hourglass"]))      # --K 100 > 64
+        detector_factory["exdet"](opts().init(["exdet", "--arch", "hourglass", "--K", "100"]))      # an explicit --K > 64
+    assert opts().init(["exdet", "--arch", "hourglass"]).K == 40     # no --K: ExtremeNet's own setting, not the 100 of the other tasks
 
 
 # ------------------------------------------------------------------------------------------------

@@ -166,6 +166,21 @@ def test_bench_rank_logic_end_to_end_two_ranks_gloo():
     # whole-job rate = images of ALL ranks / the slowest rank's time
     assert abs(r["value"] - 8 * 6 / (r["ms_per_step"] * 6e-3)) <= 1e-6 * r["value"]
     assert r["metric"].startswith("images/sec whole-node") and r["higher_is_better"] is True
+    # every rank says which device it sits on; the line carries one distinct identity per rank
+    assert [d["rank"] for d in r["rank_devices"]] == [0, 1]
+    assert len({d["uuid"] for d in r["rank_devices"]}) == 2
+    assert r["rccl_ranks_seen"] is None      # gloo here; an RCCL run reports the world it really formed
+
+
+def test_bench_refuses_two_ranks_on_one_device():
+    """Two ranks that report the SAME device identity (a wrong LOCAL_RANK -> device mapping on a real node):
+    no JSON line, non-zero exit, a message that names the cause -- a scaling number can never come from
+    ranks that shared a GPU."""
+    p, lines = _run_bench_stub(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--res", "64"],
+                               {"BENCH_FAKE_UUID": "GPU-same"})
+    assert p.returncode != 0
+    assert not lines
+    assert "two ranks share a GPU" in (p.stderr + p.stdout)
 
 
 def test_bench_config2_over_eight_ranks_is_global_batch_256():

@@ -202,8 +202,12 @@ def test_exdet_second_half_is_unmirrored_and_only_the_box_is_moved():
 def test_exdet_guard_rails():
     """--K above what the K^4 grouping kernel takes is refused before any device work."""
     from centernet_amd.opts import opts
+    # a command line that does not pass --K runs exdet at ExtremeNet's own K = 40 (the reference default of 100
+    # means 10^8 groupings per image; ADVICE r05) -- an explicit --K is taken as given, and refused above 64
+    assert opts().init(["exdet", "--arch", "hourglass"]).K == 40
+    assert opts().init(["exdet", "--K", "100"]).K == 100 and opts().init(["ctdet"]).K == 100
     with pytest.raises(ValueError):
-        ExdetDetector(opts().init(["exdet", "--arch", "hourglass"]))             # the --K default of 100
+        ExdetDetector(opts().init(["exdet", "--arch", "hourglass", "--K", "100"]))
     with pytest.raises(ValueError):
         ExdetDetector(opts().init(["exdet", "--agnostic_ex", "--K", "65"]))
 

@@ -106,7 +106,14 @@ def analyse(lines, first, last):
                 if mm:  # raw immediate: lgkmcnt is bits 11:8
                     n = (int(mm.group(1), 0) >> 8) & 15
             if n is not None and n < len(queue):
-                queue = queue[len(queue) - n:] if n else ()
+                if n == 0:
+                    queue = ()
+                elif any(q[1].startswith("s_") for q in queue):
+                    # scalar-memory returns are OUT of order: with an s_load / s_buffer_load in the queue a
+                    # counted wait proves nothing about the older LDS reads -- only lgkmcnt(0) retires them
+                    pass
+                else:
+                    queue = queue[len(queue) - n:]
             return queue
         if l.strip().startswith("s_barrier"):
             pend = tuple(q for q in queue if q[1].startswith("ds_read") or q[1].startswith("ds_load"))
@@ -115,7 +122,14 @@ def analyse(lines, first, last):
             return queue
         m = LGKM_RE.match(l)
         if m:
-            queue = (queue + ((i, m.group(1), l.strip()),))[-CAP:]
+            queue = queue + ((i, m.group(1), l.strip()),)
+            if len(queue) > CAP:
+                # the counter saturates at CAP entries in the model: drop the oldest NON-read entries first, an
+                # outstanding ds_read is never forgotten (it stays flagged until a wait retires it)
+                keep = [q for q in queue if q[1].startswith("ds_read") or q[1].startswith("ds_load")]
+                rest = [q for q in queue if not (q[1].startswith("ds_read") or q[1].startswith("ds_load"))]
+                rest = rest[max(0, len(rest) - max(0, CAP - len(keep))):]
+                queue = tuple(sorted(keep + rest))
         return queue
 
     inq = {0: ()}

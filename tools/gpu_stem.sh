@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 6: stem kernels (column-major window): their tests, then the per-op listing of config 1
+# the stem kernels (cn_stem.hip): their tests, then the per-op listing of config 1
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r6stem; mkdir -p $O
+O=gpurun_out/stem; mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_conv.py tests/test_gpu_f32s_range.py -q -x --timeout 600 -p no:cacheprovider -k "stem" 2>&1 | tail -15 > $O/pytest_stem.log
 tail -5 $O/pytest_stem.log
 python bench.py --config 1 --per-op --no-cpu-baseline --no-secondary > $O/bench.json 2> $O/per_op.txt

@@ -41,7 +41,15 @@ for k in sorted(set(fetch) | set(write)):
                      "write_bytes_per_launch": w / max(nw, 1) * 1024}
     out[short(k)]["hbm_bytes_per_launch"] = (out[short(k)]["read_bytes_per_launch_corrected"] +
                                              out[short(k)]["write_bytes_per_launch"])
+# the kernel sources this profile was taken on (bench.py refuses a profile whose head differs from the run's)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["_meta"] = {"head": bench.kernel_tree_sha(),
+                "what": "sha256/16 of centernet_amd/csrc/*.hip, *.h, include/centernet_amd.h, centernet_amd/engine.py"}
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 for k, v in out.items():
+    if k == "_meta":
+        continue
     print("%-60s launches %4d  read %9.1f MB  write %9.1f MB" % (
         k[:60], v["launches"], v["read_bytes_per_launch_corrected"] / 1e6, v["write_bytes_per_launch"] / 1e6))
