@@ -944,7 +944,12 @@ int cn_dcn_wide_f32s(const float *x, const void *w_packed, const float *bias, co
                      int out_plain, int B, int Cin, int H, int W, int Cout, int mask_sigmoid, int relu,
                      float x_mul, uint32_t *range, int nb, int dbg, float *partial, size_t partial_bytes,
                      int *ksplit_out, hipStream_t st);
-extern int cn_tune_dcn_wide, cn_tune_dcn_wide_wgs;   // cn_dcn4.hip
+extern int cn_tune_dcn_wide, cn_tune_dcn_wide_wgs, cn_tune_dcn_wide_prefetch;   // cn_dcn4.hip
+bool cn_proj1x1_takes(int B, int H, int W, int Cin, int Cout, int stride, int in_pitch, int out_pitch);
+int cn_proj1x1_f32s(const void *x, const void *w_packed, const float *scale, const float *shift, void *y, int B, int H,
+                    int W, int Cin, int Cout, int stride, int in_pitch, int out_pitch, int relu, int out_plain,
+                    const cn_f32s_ctl *ctl, hipStream_t st);
+extern int cn_tune_proj;   // cn_proj.hip
 extern int cn_tune_stem_stagger, cn_tune_stem_dbg;                         // cn_stem.hip (probe instantiation of the stem + max-pool kernel)
 bool cn_conv3x3s2p_takes(int B, int Hi, int Wi, int Cin, int Cout, int in_pitch, int out_pitch);
 int cn_conv3x3s2_persist(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
@@ -1073,10 +1078,10 @@ extern "C" size_t cn_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW
 
 extern "C" size_t cn_packed_conv_weight_elems(int Cout, int Cin, int KH, int KW, int dtype)
 {
-    // f32s: counted in 4-byte units like fp32 (the stem keeps plain fp32 weights); 3x3 kernels
+    // f32s: counted in 4-byte units like fp32 (the stem keeps plain fp32 weights); 3x3 and 1x1 kernels
     // carry a second, fragment-ordered copy of the same size behind the row-ordered one
     const size_t n = packed_elems(Cout, Cin, KH, KW, dtype == CN_DTYPE_F16 ? 64 : 32);
-    return (dtype == CN_DTYPE_F32S && KH == 3 && KW == 3 && Cin != 3) ? 2 * n : n;
+    return (dtype == CN_DTYPE_F32S && ((KH == 3 && KW == 3) || (KH == 1 && KW == 1)) && Cin != 3) ? 2 * n : n;
 }
 
 template <typename T>
@@ -1117,7 +1122,7 @@ extern "C" int cn_pack_conv_weight(const float *w_oihw, void *w_packed, int Cout
         hipLaunchKernelGGL(pack_weight_f32s_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            w_oihw, (_Float16 *)w_packed, Cout, Cin, taps, cout_pad, cin_pad);
         CN_CHECK_LAUNCH();
-        if (KH == 3 && KW == 3) {
+        if ((KH == 3 && KW == 3) || (KH == 1 && KW == 1)) {
             hipLaunchKernelGGL(pack_weight_f32s_frag_kernel, dim3(blocks), dim3(256), 0,
                                (hipStream_t)stream, w_oihw, (_Float16 *)w_packed + 2 * total, Cout, Cin,
                                taps, cout_pad / 32, cin_pad / 32);
@@ -1382,6 +1387,15 @@ extern "C" int cn_conv2d(const cn_conv_desc *d, const void *x, const void *w_pac
         cn_conv3x3s2p_takes(d->B, d->H, d->W, d->Cin, d->Cout, d->in_pitch, d->out_pitch))
         return cn_conv3x3s2_persist(x, w_packed, scale, shift, y, d->B, d->H, d->W, d->Cin, d->Cout, d->in_pitch,
                                     d->out_pitch, d->relu, (d->flags & CN_CONV_Y_PLAIN) ? 1 : 0, &d->ctl, st);
+    // 1x1 (stride 1 or 2), f32s tensors, no residual -- the `downsample` projections: the direct-fragment kernel
+    // (cn_proj.hip), bound by the layer's HBM bytes instead of the implicit GEMM's fixed costs
+    if (f32s && !(d->flags & (CN_CONV_X_PLAIN | CN_CONV_R_PLAIN)) && !residual && scale && a.vec_out && d->KH == 1 &&
+        d->KW == 1 && d->pad_h == 0 && d->pad_w == 0 && d->dil == 1 && d->oy_mul == 1 && d->ox_mul == 1 &&
+        d->oy_add == 0 && d->ox_add == 0 && d->OH == d->Ho && d->OW == d->Wo && d->in_layout == CN_LAYOUT_NHWC &&
+        d->out_layout == CN_LAYOUT_NHWC && d->Ho == (d->H - 1) / d->stride + 1 && d->Wo == (d->W - 1) / d->stride + 1 &&
+        cn_proj1x1_takes(d->B, d->H, d->W, d->Cin, d->Cout, d->stride, d->in_pitch, d->out_pitch))
+        return cn_proj1x1_f32s(x, w_packed, scale, shift, y, d->B, d->H, d->W, d->Cin, d->Cout, d->stride, d->in_pitch,
+                               d->out_pitch, d->relu, (d->flags & CN_CONV_Y_PLAIN) ? 1 : 0, &d->ctl, st);
     if (f32s) {
         if (cls == 2)
             rc = bm64 ? launch_igemm_s<64, 128, 2, 2, A_DENSE, false>(a, st)
@@ -1894,6 +1908,14 @@ extern "C" int cn_set_tuning(int key, int value)
     }
     if (key == 24 && value >= 0 && value <= 3) {
         cn_tune_heads_remap = value;
+        return CN_OK;
+    }
+    if (key == 46 && (value == 0 || value == 1)) {
+        cn_tune_proj = value;
+        return CN_OK;
+    }
+    if (key == 45 && (value == 0 || value == 1)) {
+        cn_tune_dcn_wide_prefetch = value;
         return CN_OK;
     }
     if (key == 44 && value >= 0 && value <= 1024) {

@@ -32,6 +32,7 @@
 #include "cn_common.h"
 
 int cn_tune_dcn_wide = 1;        // cn_set_tuning key 41: 0 = off, 1 = layers with Cout % 128 == 0 that the form takes
+int cn_tune_dcn_wide_prefetch = 1;   // cn_set_tuning key 45: L2 prefetch of the weight slabs three steps ahead
 int cn_tune_dcn_wide_wgs = 256;  // cn_set_tuning key 42: K split until a launch has this many workgroups
 
 __device__ __attribute__((aligned(128))) unsigned char cn_d4_zero_line[128];
@@ -70,6 +71,7 @@ struct D4Args {
     uint32_t *range;
     int ksplit;                // K-chunk ranges per tile (blockIdx.z); > 1: raw partial sums
     float *partial;            // [ksplit][B*H*W][cout_pad] fp32 (splitk_reduce_kernel applies the epilogue)
+    int prefetch;              // 1 = L2 prefetch of the weights three steps ahead (cn_set_tuning key 45, default 1)
     int dbg;                   // probe build (cn_set_tuning key 9): 1 = no weight DMA, 2 = no MFMAs, 4 = no sampling, 8 = no per-step barrier, 16 = no far path, 32 = no steps, 64 = no window swaps, 128 = no epilogue
 };
 
@@ -379,6 +381,7 @@ __global__ __launch_bounds__(W_NT, 2) void dcn_wide_kernel(const D4Args a)
         slo = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
+    uint32_t pf = 0;                               // L2 prefetch word of team 1 (see the step loop)
     int step = 0;                                  // linear (chunk, tap) step: ring slot = step & 1
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
         if (chunk != c_lo && !(dbg & 64)) {
@@ -422,6 +425,18 @@ __global__ __launch_bounds__(W_NT, 2) void dcn_wide_kernel(const D4Args a)
                 if (tr_on) ts[3] = __builtin_readcyclecounter();
                 if (t < 8 && !(dbg & 4)) request(t + 1);
                 if (tr_on) ts[5] = __builtin_readcyclecounter();
+                // L2 prefetch of the weights three steps ahead: inside a network step 4 GB pass between two uses of
+                // a layer's weights, the slab's first touch is an HBM miss and the DMA runs only ONE step ahead of
+                // its use (cold: +13 % on the four-block form).  One dword per 128-byte line, by the team without
+                // DMA duty; the value is "used" a step later so that the compiler keeps the load.
+                if (a.prefetch) {
+                    asm volatile("" :: "v"(pf));
+                    int tp = t + 3, cp = chunk;
+                    if (tp >= 9) { tp -= 9; cp = chunk + 1; }
+                    if (cp < c_hi && pb * 64 < NB * 32)
+                        pf = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(
+                            wfrag + ((size_t)(tp * a.nchunk + cp) * ncb + (n0 >> 5)) * 4096 + (unsigned)(pb * 64 + lane) * 128u);
+                }
                 if (WDB && chunk + 1 < c_hi && !(dbg & 64)) dma_piece(chunk + 1, t, wbase ^ (unsigned)W_WIN1);
             } else {
                 if (WDB && chunk + 1 < c_hi && !(dbg & 64)) dma_piece(chunk + 1, t, wbase ^ (unsigned)W_WIN1);
@@ -603,6 +618,8 @@ int cn_dcn_wide_f32s(const float *x, const void *w_packed, const float *bias, co
     a.tiles_x = W / W_TX;
     a.tiles_y = H / W_TY;
     a.x_mul = x_mul; a.range = range; a.dbg = dbg;
+    // L2 prefetch: pays where the weight stream is long and cold (four-block form on deep K: +5 % cold); costs 1-4 % elsewhere
+    a.prefetch = (cn_tune_dcn_wide_prefetch && nb == 4 && Cin >= 256) ? 1 : 0;
     a.ksplit = ksplit;
     a.partial = ksplit > 1 ? partial : nullptr;
     if (ksplit_out) *ksplit_out = ksplit;

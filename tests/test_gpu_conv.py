@@ -808,3 +808,52 @@ def test_offset_conv_kernel(dev, cfg, scale):
         assert float(err) < TOL, (key39, float(err))
         outs.append(got)
     assert float(((outs[0] - outs[1]).abs() / (scale + ref.abs())).max()) < TOL
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, Cin, H, W, Cout, stride, bias, bn, relu
+    (32, 64, 128, 128, 128, 2, False, True, False),     # resdcn_18 layer2.0.downsample at the benchmark batch
+    (4, 256, 32, 32, 512, 2, False, True, False),       # layer4.0.downsample
+    (1, 64, 17, 19, 128, 2, False, True, False),        # odd map: (H - 1) / 2 + 1 rows, ragged last tile
+    (2, 128, 33, 31, 256, 2, True, False, True),
+    (3, 96, 9, 11, 160, 1, True, False, True),          # stride 1, three chunks, two channel groups of the second block row
+    (2, 64, 8, 8, 32, 1, False, True, False),           # one block of output channels
+    (1, 512, 16, 16, 512, 1, False, True, True),        # deep K: the four-chunk ring wraps
+])
+def test_projection_1x1_kernel(dev, cfg):
+    """1x1 convolutions on f32s tensors without a residual operand -- the `downsample` projections
+    (resnet_dcn.py:179-195, applied :52-56) -- on the direct-fragment kernel (csrc/cn_proj.hip): f32s and plain
+    output, against torch fp64, and against the implicit-GEMM kernel it replaces (cn_set_tuning key 46 = 0)."""
+    from centernet_amd import native
+    from centernet_amd.engine import PlanBuilder
+    B, Cin, H, W, Cout, s, use_bias, use_bn, relu = cfg
+    x = torch.from_numpy(synth.normal((B, Cin, H, W), 1.0, 31))
+    w = torch.from_numpy(synth.normal((Cout, Cin, 1, 1), (2.0 / Cin) ** 0.5, 32))
+    bias = torch.from_numpy(synth.normal((Cout,), 0.3, 33)) if use_bias else None
+    bn = _bn(Cout, 34) if use_bn else None
+    ref = F.conv2d(x.double(), w.double(), bias.double() if use_bias else None, s, 0)
+    if bn is not None:
+        ref = bn.double()(ref)
+        bn.float()
+    if relu:
+        ref = F.relu(ref)
+    ref = ref.detach()
+    lib = native.lib()
+    got = {}
+    try:
+        for key46 in (1, 0):
+            assert lib.cn_set_tuning(46, key46) == 0
+            for out_plain in (False, True):
+                pb = PlanBuilder(dev, B, H, W, split=True)
+                xs = pb.packed(_nhwc_act(x, dev))
+                y = pb.conv(xs, w, bias=bias, bn=bn, relu=relu, stride=s, padding=0, out_plain=out_plain)
+                assert y.fmt == ("f32" if out_plain else "f32s")
+                yp = pb.plain(y)
+                _run(pb)
+                got[key46, out_plain] = yp.t[..., :Cout].permute(0, 3, 1, 2).cpu().double()
+                err = (got[key46, out_plain] - ref).abs() / (1 + ref.abs())
+                assert float(err.max()) < TOL, (key46, out_plain, float(err.max()))
+    finally:
+        lib.cn_set_tuning(46, 1)
+    # the two kernels agree far inside the bar (same arithmetic, different summation order)
+    assert float((got[1, True] - got[0, True]).abs().max()) < 2e-5 * float(ref.abs().max())

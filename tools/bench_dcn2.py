@@ -16,6 +16,12 @@ VALUES = [int(v) for v in os.environ.get("VALUES", "0,1").split(",")]
 # DBG=0,8,128: columns are probe builds of a window kernel (key 23 = FORM, default 2; key 9 = value)
 DBG = [int(v) for v in os.environ["DBG"].split(",")] if os.environ.get("DBG") else None
 ZERO_OFF = os.environ.get("ZERO_OFF") == "1"     # zero offsets (no LDS bank conflicts, nothing beyond the window)
+# COLD=1: every timed launch runs behind a 1 GiB copy (weights and input gone from L2 / the Infinity Cache, as inside a
+# network step where 4 GB pass between two uses of a layer's weights) and is timed alone
+COLD = os.environ.get("COLD") == "1"
+if COLD:
+    _ca = torch.empty(256 << 20, dtype=torch.float32, device=dev)
+    _cb = torch.empty(256 << 20, dtype=torch.float32, device=dev)
 if DBG:
     KNOB, VALUES = 9, DBG
     lib.cn_set_tuning(23, int(os.environ.get("FORM", "2")))
@@ -50,6 +56,16 @@ for B in [int(b) for b in os.environ.get("B", "32").split(",")]:
                 op = plans[k].ops[-1]
                 for _ in range(3): op()
                 torch.cuda.synchronize()
+                if COLD:
+                    tot = 0.0
+                    for _ in range(8):
+                        _cb.copy_(_ca)
+                        plans[k].ops[-2]()       # the offset conv just in front, as in the network (it reads the input)
+                        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        s.record(); op(); e.record(); torch.cuda.synchronize()
+                        tot += s.elapsed_time(e)
+                    times[k].append(tot / 8)
+                    continue
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 for _ in range(20): op()
