@@ -75,7 +75,8 @@ struct D3Args {
     float x_mul;
     uint32_t *range;
     int stagger;               // start delay of workgroups 256 .. 511 (the second occupant of every CU), units of 256 cycles
-    int dbg;                   // probe build (cn_set_tuning key 9): 1 = every sample takes the global path, 8 = no MFMAs, 128 = no taps
+    int dbg;                   // probe build (cn_set_tuning key 9): 1 = every sample takes the global path, 8 = no MFMAs, 128 = no taps,
+                               // 16 = no offset / mask loads, 32 = no output stores, 64 = no window DMA
     int ksplit;                // K-chunk ranges per tile (blockIdx.z); > 1: raw partial sums
     float *partial;            // [ksplit][B*H*W][cout_pad] fp32 (splitk_reduce_kernel applies the epilogue)
 };
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
     const d3_glb_char *zline = (const d3_glb_char *)cn_d3_zero_line + 16 * (lane & 7);
     auto dma = [&](int chunk) {
         const unsigned cb = (unsigned)chunk * 128u;
+        if (DBG && (a.dbg & 64)) return;
 #pragma unroll
         for (int p = 0; p < T_NP; ++p) {
             const d3_glb_char *src = (doff[p] != 0xffffffffu) ? xg + (doff[p] + cb) : zline;
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
             const int tap = i >> 7, m = i & (T_PM - 1);
             const int oy = ty0 + (m >> 4), ox = tx0 + (m & 15);
             const float *om = a.om + (size_t)((b * H + oy) * W + ox) * a.om_pitch;
+            if (dbg & 16) { off_h[p] = 0.3f; off_w[p] = -0.2f; mkv[p] = 0.1f; continue; }
             off_h[p] = om[2 * tap];
             off_w[p] = om[2 * tap + 1];
             mkv[p] = om[18 + tap];
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
         if (a.partial) {   // K split: raw sums, one slab per split; the reduce kernel does the rest
             if (n < a.cout_pad)
                 *reinterpret_cast<cn_f32x4 *>(a.partial + ((size_t)blockIdx.z * ((size_t)a.B * H * W) + off) * a.cout_pad + n) = v;
-        } else if (n + 4 <= a.Cout) {
+        } else if (n + 4 <= a.Cout && !(dbg & 32)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float tt = (v[e] + bs[e]) * sc[e] + sf2[e];
