@@ -352,7 +352,10 @@ int cn_conv2d_f32(const cn_conv_desc *desc, const float *x, const float *w_packe
                   const float *scale, const float *shift, const float *residual,
                   float *y, void *stream);
 /* dtype-generic forms (desc->dtype selects fp32 / fp16; NCHW head outputs and the stem's
- * NCHW image are always fp32; scale/shift are always fp32). */
+ * NCHW image are always fp32; scale/shift are always fp32).
+ * CN_DTYPE_F32S: 3x3 and (round 6) 1x1 kernels carry a second, fragment-ordered copy of the matrix behind
+ * the row-ordered one ([tap][chunk][32-channel block][quarter][lane] x 16 bytes: what a lane of the
+ * 32x32x16 MFMA holds, one contiguous 1 KiB per wave-load); cn_packed_conv_weight_elems counts both. */
 size_t cn_packed_conv_weight_elems(int Cout, int Cin, int KH, int KW, int dtype);
 int cn_pack_conv_weight(const float *w_oihw, void *w_packed, int Cout, int Cin, int KH, int KW,
                         int dtype, void *stream);
