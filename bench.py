@@ -132,7 +132,7 @@ def pmc_traffic(tag, check_head=True):
             c = "dcn" if len(targs) > 4 and targs[4] in (2, 3) else "conv"   # AMODE
         elif base.startswith(("dcn_reg_kernel", "dcn_win_kernel", "dcn_team_kernel", "dcn_wide_kernel")):   # LDS-window forms (cn_dcn2 / 3 / 4.hip)
             c = "dcn"
-        elif base.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_", "offconv_kernel")):
+        elif base.startswith(("stem_", "splitk_reduce", "conv3x3", "conv16_kernel", "heads_", "offconv_kernel", "proj1x1_kernel")):
             c = "conv"
         elif base.startswith(("nms_topk", "merge_topk", "peak_", "group_", "pose_match", "decode_", "collect_merge",
                               "plane_select_merge")):
