@@ -42,6 +42,8 @@ int cn_tune_dcn_team_stagger = 32; // cn_set_tuning key 38: start delay of the s
 
 // one 128-byte line of zeros: the DMA source of window pixels outside the image
 __device__ __attribute__((aligned(128))) unsigned char cn_d3_zero_line[128];
+// probe build, key 9 bit 256: cycle stamps of wave 0 of every 64th workgroup (tile life: start, records, first window, taps, epilogue, end)
+__device__ unsigned long long cn_d3_trace[64 * 8];
 
 namespace {
 
@@ -76,7 +78,7 @@ struct D3Args {
     uint32_t *range;
     int stagger;               // start delay of workgroups 256 .. 511 (the second occupant of every CU), units of 256 cycles
     int dbg;                   // probe build (cn_set_tuning key 9): 1 = every sample takes the global path, 8 = no MFMAs, 128 = no taps,
-                               // 16 = no offset / mask loads, 32 = no output stores, 64 = no window DMA
+                               // 16 = no offset / mask loads, 32 = no output stores, 64 = no window DMA, 256 = cycle stamps of a tile's life (cn_dcn_team_trace)
     int ksplit;                // K-chunk ranges per tile (blockIdx.z); > 1: raw partial sums
     float *partial;            // [ksplit][B*H*W][cout_pad] fp32 (splitk_reduce_kernel applies the epilogue)
 };
@@ -150,6 +152,9 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
     const int ty0 = (tr / a.tiles_x) * T_TY, tx0 = (tr % a.tiles_x) * T_TX;
     const int wy0 = ty0 - 1 - T_RCH, wx0 = tx0 - 1 - T_RCH;
     const int dbg = DBG ? a.dbg : 0;
+    unsigned long long ts[8] = {};
+    const bool tr_on = DBG && (a.dbg & 256) && (blockIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && (blockIdx.x >> 6) < 64;
+    if (tr_on) ts[0] = __builtin_readcyclecounter();
     const int n0 = NMODE ? (int)blockIdx.y * 128 + 64 * team : (int)blockIdx.y * 64;
     const unsigned pix_bytes = (unsigned)a.Cin * 4u;
     const unsigned img_base = (unsigned)(b * H) * (unsigned)W;
@@ -262,9 +267,12 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
             }
         }
     }
+    if (tr_on) ts[1] = __builtin_readcyclecounter();          // records written (offset / mask loads waited for on the way)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tr_on) ts[2] = __builtin_readcyclecounter();          // first window landed
     if (MSIG && a.range) track();
     __syncthreads();                               // records and the window of the first chunk visible
+    if (tr_on) ts[3] = __builtin_readcyclecounter();
 
     const int m = pb * 32 + l31;                   // this lane's pixel of the tile
     const unsigned hx = (unsigned)h << 5;
@@ -415,6 +423,7 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
         }
     }
 
+    if (tr_on) ts[4] = __builtin_readcyclecounter();          // taps and window swaps done
     // ---- epilogue: every wave stages its 32 pixels x 64 channels (the window and the records are
     // dead), the teams' sums are added on the way out (T mode), y = relu?((acc + bias) * scale + shift)
     // and whole lines are stored.  acc[j][r]: channel 32 j + (r & 3) + 8 (r >> 2) + 4 h of pixel l31.
@@ -463,6 +472,13 @@ __global__ __launch_bounds__(T_NT, 4) void dcn_team_kernel(const D3Args a)
             }
         }
     }
+    if (tr_on) {
+        ts[5] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[6] = __builtin_readcyclecounter();      // stores drained
+        ts[7] = __builtin_amdgcn_s_memrealtime();  // 100 MHz wall clock: when this workgroup ended
+        for (int e = 0; e < 8; ++e) cn_d3_trace[(blockIdx.x >> 6) * 8 + e] = ts[e];
+    }
     if (a.range) {
         if (!a.out_plain && !a.partial) cn_rng_commit(a.range, 0, rng_out);
         // window values were tracked in the tensor's own units: x' = x * x_mul (a power of two)
@@ -489,6 +505,11 @@ int launch_dcn_team(const D3Args &a, int mask_sigmoid, hipStream_t st)
 }
 
 }  // namespace
+
+extern "C" int cn_dcn_team_trace(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cn_d3_trace), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? CN_OK : CN_ERR_LAUNCH;
+}
 
 // Shapes this kernel takes (the caller falls back to the other forms otherwise): maps of whole
 // 8 x 16 pixel tiles, whole 32-channel chunks, Cout a multiple of 4 and >= 33.  nmode: 1 (2 = even on small grids) = the teams
