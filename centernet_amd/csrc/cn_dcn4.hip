@@ -23,8 +23,12 @@
 //   * one barrier per step hands the ring slot over; the two teams add their accumulators in the
 //     epilogue;
 //   * window, records, far path, range tracking: as in the team form.
-// LDS: window 48 KiB + records 27 KiB + ring 2 x NB x 4 KiB = 109 / 142 KiB: one workgroup per CU,
-// two waves per SIMD, up to 256 registers (NB = 8: 128 accumulator registers).
+// LDS: window 48 KiB + records 27 KiB + ring 2 x NB x 4 KiB = 109 / 142 KiB (NB = 4 adds a second window:
+// 157 KiB): one workgroup per CU, two waves per SIMD, up to 256 registers (NB = 8: 128 accumulator
+// registers).  With two waves per SIMD nothing but the partner wave covers a round trip, so the step loop is a
+// written-out schedule: the two teams of a pixel block share a SIMD and run in anti-phase, every request
+// (record, window reads, far corners) is issued a whole MFMA phase before its blend, team 0 alone owns the
+// weight DMA (see the loop; DESIGN.md 3.2 "Round 6" has the measurements that led there).
 // Semantics held: sampling domain h_im > -1 && w_im > -1 && h_im < H && w_im < W
 // (dcn_v2_im2col_cuda.cu:165), corner rule (:30-41), weights hh*hw, hh*lw, lh*hw, lh*lw (:26-28,43),
 // value * mask (:174; the mask multiplies the four corner weights), bias then accumulate
